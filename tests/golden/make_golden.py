@@ -1,0 +1,351 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF on CPU.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden.py [--full]
+
+The reference (sh-Lin/DynamicScaler) has no tests or golden vectors of its own,
+so parity is pinned by what this script captures from the imported reference code:
+
+  G1 ring_segments.json      get_dimension_slices_and_sizes          utils/shift_window_utils.py:14-38
+  G2 ring_latent.npz         RingLatent get/set with wrap in F,H,W   utils/shift_window_utils.py:40-206
+  G3 mix.npz                 mix_latents_with_mask (3-D and 5-D)     utils/tensor_utils.py:19-39
+  G4 scheduler.npz           lvdm_DDIM_Scheduler tables, ddim_step, re_noise   pipeline/scheduler.py:18-110
+  G8 unet_tiny_{t2v,i2v}.npz UNetModel forward, toy config           lvdm/modules/networks/openaimodel3d.py:657-708
+  G9 loops_small.npz         t2v basic_sample + ring loops, toy geometry, tiny UNet and fake eps
+     loop_traces.json        window coordinates + final-panorama SHA-256 for BASELINE configs 2/3/5 (fake eps)
+  G10 unet_full_t2v.npz      (--full) full-size t2v UNet eps at tile [1,4,16,40,64] (2 forwards, ~2 min)
+
+Only data is written (inputs, expected outputs, seeds); no reference source text.
+"""
+import argparse
+import contextlib
+import hashlib
+import io
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from oracle.ref_import import import_reference, REFERENCE_ROOT  # noqa: E402
+
+import_reference()
+
+from utils.shift_window_utils import RingLatent, get_dimension_slices_and_sizes  # noqa: E402  (reference)
+from utils.tensor_utils import mix_latents_with_mask  # noqa: E402  (reference)
+from pipeline.scheduler import lvdm_DDIM_Scheduler  # noqa: E402  (reference)
+from pipeline.t2v_normal_pipeline import VC2_Pipeline_T2V  # noqa: E402  (reference)
+from pipeline.t2v_sphere_panorama_pipeline import VC2_Pipeline_T2V_SpherePano  # noqa: E402  (reference)
+from lvdm.models.ddpm3d import DDPM, DiffusionWrapper  # noqa: E402  (reference)
+from lvdm.modules.networks.openaimodel3d import UNetModel  # noqa: E402  (reference)
+
+from dynamicscaler_amd.unet_spec import param_shapes  # noqa: E402
+from dynamicscaler_amd.synth import synth_state_dict, synth_normal  # noqa: E402
+
+TINY = dict(in_channels=4, out_channels=4, model_channels=32, attention_resolutions=[2, 1], num_res_blocks=1,
+            channel_mult=[1, 2], num_head_channels=16, transformer_depth=1, context_dim=64, use_linear=True,
+            use_checkpoint=True, temporal_conv=True, temporal_attention=True, temporal_selfatt_only=True,
+            use_relative_position=False, use_causal_attention=False, temporal_length=4,
+            addition_attention=True, fps_cond=True)
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()
+
+
+def save_npz(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+class FakeLatentDiffusion(nn.Module):
+    """What the pipelines read from `pretrained_t2v`, with the reference's own
+    schedule registration (DDPM.register_schedule, ddpm3d.py:113-134) and DiffusionWrapper."""
+
+    def __init__(self, eps_module, cond_ctx, uncond_ctx, temporal_length=16):
+        super().__init__()
+        self.v_posterior = 0.0           # ctor defaults read by register_schedule (ddpm3d.py:60-75)
+        self.parameterization = "eps"
+        DDPM.register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000,
+                               linear_start=0.00085, linear_end=0.012)
+        self.model = eps_module
+        self.temporal_length = temporal_length
+        self.uncond_type = "empty_seq"
+        self.use_scale = False
+        self.first_stage_model = None
+        self.cond_stage_model = None
+        self.channels = 4
+        self._cond, self._uncond = cond_ctx, uncond_ctx
+
+    @property
+    def device(self):
+        return torch.device("cpu")
+
+    def get_learned_conditioning(self, prompts):
+        return self._uncond if prompts[0] == "" else self._cond
+
+
+class FakeEps(nn.Module):
+    """The survey's fake eps-model: 0.1*x + 0.01*mean(ctx)."""
+    diffusion_model = None
+
+    def forward(self, x, t, c_crossattn=None, fps=None, **kw):
+        return 0.1 * x + 0.01 * torch.cat(c_crossattn, 1).mean()
+
+
+def build_reference_unet(params, seed):
+    m = UNetModel(**params).eval()
+    shapes = param_shapes(params)
+    ref_shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert ref_shapes == {k: tuple(v) for k, v in shapes.items()}, "param spec != reference state dict"
+    m.load_state_dict(synth_state_dict(shapes, seed), strict=True)
+    return m
+
+
+class WrappedUNet(nn.Module):
+    """DiffusionWrapper(conditioning_key='crossattn') around an already-built reference UNetModel."""
+
+    def __init__(self, unet):
+        super().__init__()
+        self.diffusion_model = unet
+        self.conditioning_key = "crossattn"
+
+    def forward(self, *a, **k):
+        return DiffusionWrapper.forward(self, *a, **k)
+
+
+WIN_RE = re.compile(r"window_latent: f\[(\d+) - (\d+)\] h\[(-?\d+) - (-?\d+)\] w\[(\d+) - (\d+)\]")
+STEP_RE = re.compile(r"^i = (\d+), t = (\d+)")
+
+
+def parse_trace(text):
+    steps = []
+    for line in text.splitlines():
+        m = STEP_RE.match(line.strip())
+        if m:
+            steps.append({"i": int(m.group(1)), "t": int(m.group(2)), "windows": []})
+            continue
+        m = WIN_RE.search(line)
+        if m:
+            fb, fe, top, down, left, right = map(int, m.groups())
+            steps[-1]["windows"].append([left, right, top, down, fb, fe])
+    return steps
+
+
+def run_ring_pipeline(ld, unet_params, seed, **kw):
+    sched = lvdm_DDIM_Scheduler(ld)
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, sched, {"params": {"unet_config": {"params": unet_params}}})
+    buf = io.StringIO()
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(buf):
+        videos, denoised = pipe.basic_sample_shift_multi_windows(prompt="a prompt", output_type="latent", **kw)
+    return denoised, parse_trace(buf.getvalue())
+
+
+# ------------------------------------------------------------------------------------------------
+def g1_segments():
+    cases = [(456, 520, 512), (27, 67, 64), (500, 1100, 512), (0, 16, 16), (3, 19, 16), (0, 8, 16),
+             (15, 17, 16), (16, 32, 16), (5, 6, 7), (6, 20, 7), (0, 40, 64), (24, 64, 64), (45, 85, 64),
+             (1016, 1080, 1024), (8, 72, 512)]
+    out = []
+    for b, e, s in cases:
+        slices, sizes = get_dimension_slices_and_sizes(b, e, s)
+        out.append({"begin": b, "end": e, "size": s,
+                    "slices": [[sl.start, sl.stop] for sl in slices], "sizes": list(sizes)})
+    with open(os.path.join(HERE, "ring_segments.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote ring_segments.json")
+
+
+def g2_ring():
+    pano = synth_normal((1, 4, 6, 8, 16), seed=11)
+    windows = [  # (left, right, top, down, f_begin, f_end)
+        (0, 16, 0, 8, 0, 6), (3, 11, 2, 6, 1, 4), (12, 20, 5, 11, 4, 8), (15, 31, 7, 15, 5, 11),
+        (0, 4, 0, 2, 0, 1), (8, 24, 0, 8, 0, 6), (1, 9, 6, 10, 3, 7), (16, 32, 8, 16, 6, 12),
+    ]
+    arrays = {"pano": pano, "windows": np.array(windows, dtype=np.int64)}
+    handler = RingLatent(pano)
+    for i, (l, r, t, d, fb, fe) in enumerate(windows):
+        arrays[f"get_{i}"] = handler.get_window_latent(l, r, t, d, fb, fe)
+    # scatter sequence applied cumulatively (overwrite semantics, later windows win)
+    h2 = RingLatent(pano)
+    for i, (l, r, t, d, fb, fe) in enumerate(windows):
+        tile = synth_normal((1, 4, fe - fb, d - t, r - l), seed=100 + i)
+        h2.set_window_latent(tile, l, r, t, d, fb, fe)
+        arrays[f"set_after_{i}"] = h2.torch_latent.clone()
+    # multi-wrap gather is legal up to 2*size (shift_window_utils.py:73-75)
+    arrays["get_multiwrap"] = handler.get_window_latent(10, 32, 0, 16, 0, 12)
+    save_npz("ring_latent.npz", **arrays)
+
+
+def g3_mix():
+    l1 = synth_normal((1, 4, 4, 8, 16), 21)
+    l2 = synth_normal((1, 4, 4, 8, 16), 22)
+    g = torch.Generator().manual_seed(23)
+    m3 = (torch.rand((1, 8, 16), generator=g) > 0.5).float()
+    m5 = (torch.rand((1, 4, 4, 8, 16), generator=g) > 0.5).float()
+    arrays = {"l1": l1, "l2": l2, "m3": m3, "m5": m5}
+    for r in (1, 1.0, 0.5, 0.3):
+        arrays[f"out3_{r}"] = mix_latents_with_mask(l1, l2, m3, r)
+        arrays[f"out5_{r}"] = mix_latents_with_mask(l1, l2, m5, r)
+    save_npz("mix.npz", **arrays)
+
+
+def g4_scheduler():
+    ld = FakeLatentDiffusion(FakeEps(), None, None)
+    arrays = {"alphas_cumprod": ld.alphas_cumprod, "betas": ld.betas}
+    for n in (4, 48, 50):
+        s = lvdm_DDIM_Scheduler(ld)
+        with contextlib.redirect_stdout(io.StringIO()):
+            s.make_schedule(n)
+        arrays[f"ts_{n}"] = s.ddim_timesteps
+        arrays[f"alphas_{n}"] = s.ddim_alphas
+        arrays[f"alphas_prev_{n}"] = np.asarray(s.ddim_alphas_prev, dtype=np.float64)
+        arrays[f"sigmas_{n}"] = np.asarray(s.ddim_sigmas, dtype=np.float64)
+        arrays[f"sqrt1m_{n}"] = s.ddim_sqrt_one_minus_alphas
+    # ddim_step / re_noise with the global RNG seeded (draws are recorded implicitly by the seed)
+    for n, eta in ((50, 0.0), (4, 0.0), (50, 1.0)):
+        s = lvdm_DDIM_Scheduler(ld)
+        with contextlib.redirect_stdout(io.StringIO()):
+            s.make_schedule(n, ddim_eta=eta)
+        x = synth_normal((1, 4, 4, 8, 16), 31)
+        e = synth_normal((1, 4, 4, 8, 16), 32)
+        for index in (0, n // 2, n - 1):
+            torch.manual_seed(777)
+            xp, x0 = s.ddim_step(x, e, [index] * 4)
+            arrays[f"step_{n}_{eta}_{index}_xprev"] = xp
+            arrays[f"step_{n}_{eta}_{index}_x0"] = x0
+        for (a, b) in ((0, 1), (n - 2, n - 1), (n // 2 - 1, n // 2)):
+            torch.manual_seed(778)
+            arrays[f"renoise_{n}_{eta}_{a}_{b}"] = s.re_noise(x, a, b)
+    arrays["x"] = synth_normal((1, 4, 4, 8, 16), 31)
+    arrays["e"] = synth_normal((1, 4, 4, 8, 16), 32)
+    save_npz("scheduler.npz", **arrays)
+
+
+def g8_unet_tiny():
+    for name, img in (("t2v", False), ("i2v", True)):
+        p = dict(TINY)
+        p["use_image_attention"] = img
+        m = build_reference_unet(p, seed=5)
+        L = 77 + (16 if img else 0)
+        arrays = {}
+        for case, (shape, tval, fps) in enumerate([((1, 4, 4, 8, 16), 500, 8), ((1, 4, 4, 16, 8), 999, 16),
+                                                   ((1, 4, 6, 8, 8), 20, 24)]):
+            x = synth_normal(shape, 40 + case)
+            ctx = synth_normal((1, L, 64), 50 + case)
+            t = torch.tensor([tval])
+            with torch.no_grad():
+                eps = m(x, t, context=ctx, fps=fps)
+            arrays.update({f"x_{case}": x, f"ctx_{case}": ctx, f"t_{case}": t, f"fps_{case}": np.int64(fps),
+                           f"eps_{case}": eps})
+        arrays["weights_sha"] = np.frombuffer(bytes.fromhex(sha(torch.cat([v.flatten() for _, v in sorted(m.state_dict().items())]))), dtype=np.uint8)
+        arrays["params_json"] = np.frombuffer(json.dumps(p).encode(), dtype=np.uint8)
+        save_npz(f"unet_tiny_{name}.npz", **arrays)
+
+
+SMALL_GEOMS = {
+    "grid4x2": dict(height=64, width=128, frames=4, total_w=512, total_h=96, num_windows_w=4, num_windows_h=2,
+                    num_windows_f=1, loop_step=4, num_inference_steps=6),
+    "overlapw": dict(height=64, width=128, frames=4, total_w=512, total_h=96, num_windows_w=5, num_windows_h=2,
+                     num_windows_f=1, loop_step=4, num_inference_steps=5),
+    "frames2": dict(height=64, width=128, frames=4, total_w=512, total_h=96, num_windows_w=4, num_windows_h=2,
+                    num_windows_f=2, loop_step=4, num_inference_steps=5),
+    "dock": dict(height=64, width=128, frames=4, total_w=512, total_h=96, num_windows_w=4, num_windows_h=2,
+                 num_windows_f=1, loop_step=4, num_inference_steps=5, dock_at_h=True),
+}
+
+
+def g9_loops_small():
+    cond = synth_normal((1, 77, 64), 61)
+    uncond = synth_normal((1, 77, 64), 62)
+    unet = build_reference_unet(dict(TINY), seed=5)
+    arrays = {"cond": cond, "uncond": uncond}
+    traces = {}
+    for eps_name, eps_mod in (("fake", FakeEps()), ("tiny", WrappedUNet(unet))):
+        ld = FakeLatentDiffusion(eps_mod, cond, uncond, temporal_length=4)
+        # P1: single tile
+        sched = lvdm_DDIM_Scheduler(ld)
+        pipe = VC2_Pipeline_T2V(ld, sched, {"params": {"unet_config": {"params": dict(TINY)}}})
+        torch.manual_seed(2333333)
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, den = pipe.basic_sample(prompt="a prompt", height=64, width=128, frames=4, fps=8,
+                                       guidance_scale=7.5, num_inference_steps=4, output_type="latent")
+        arrays[f"basic_{eps_name}"] = den
+        for gname, geom in SMALL_GEOMS.items():
+            if eps_name == "tiny" and gname not in ("grid4x2", "overlapw"):
+                continue
+            den, trace = run_ring_pipeline(ld, dict(TINY), 2333333, fps=8, guidance_scale=7.5, **geom)
+            arrays[f"ring_{gname}_{eps_name}"] = den
+            traces[gname] = trace
+    save_npz("loops_small.npz", **arrays)
+    with open(os.path.join(HERE, "loops_small_traces.json"), "w") as f:
+        json.dump({"geoms": SMALL_GEOMS, "traces": traces}, f)
+    print("wrote loops_small_traces.json")
+
+
+BASELINE_GEOMS = {
+    "cfg2_2048x512": dict(height=320, width=512, frames=16, total_w=2048, total_h=512, num_windows_w=4,
+                          num_windows_h=2, num_windows_f=1, loop_step=8, num_inference_steps=50),
+    "cfg3_4096x512": dict(height=320, width=512, frames=16, total_w=4096, total_h=512, num_windows_w=8,
+                          num_windows_h=2, num_windows_f=1, loop_step=8, num_inference_steps=50),
+    "cfg3_overlap_nw10": dict(height=320, width=512, frames=16, total_w=4096, total_h=512, num_windows_w=10,
+                              num_windows_h=2, num_windows_f=1, loop_step=8, num_inference_steps=10),
+    "cfg5_8192x1024x24": dict(height=320, width=512, frames=24, total_w=8192, total_h=1024, num_windows_w=16,
+                              num_windows_h=4, num_windows_f=1, loop_step=8, num_inference_steps=10),
+}
+
+
+def g9_traces():
+    cond = synth_normal((1, 77, 64), 61)
+    uncond = synth_normal((1, 77, 64), 62)
+    ld = FakeLatentDiffusion(FakeEps(), cond, uncond)
+    out = {}
+    for name, geom in BASELINE_GEOMS.items():
+        den, trace = run_ring_pipeline(ld, {"in_channels": 4}, 2333333, fps=8, guidance_scale=7.5, **geom)
+        out[name] = {"geom": geom, "trace": trace, "denoised_sha256": sha(den), "shape": list(den.shape)}
+        print(name, "tiles/step:", sorted({len(s["windows"]) for s in trace}), out[name]["denoised_sha256"][:12])
+    with open(os.path.join(HERE, "loop_traces.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote loop_traces.json")
+
+
+def g10_unet_full():
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(os.cpu_count())
+    m = build_reference_unet(params, seed=0)
+    x = synth_normal((1, 4, 16, 40, 64), 2333333)
+    arrays = {"x": x, "t": np.int64(499), "fps": np.int64(8)}
+    for name, seed in (("cond", 1), ("uncond", 2)):
+        ctx = synth_normal((1, 77, 1024), seed)
+        with torch.no_grad():
+            eps = m(x, torch.tensor([499]), context=ctx, fps=8)
+        arrays[f"eps_{name}"] = eps
+        print(name, float(eps.abs().mean()), float(eps.std()))
+    save_npz("unet_full_t2v.npz", **arrays)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also run the full-size UNet fixture (minutes)")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
+             "g9": g9_loops_small, "g9t": g9_traces}
+    if args.full:
+        steps["g10"] = g10_unet_full
+    for k, fn in steps.items():
+        if args.only and k != args.only:
+            continue
+        fn()

@@ -1,0 +1,202 @@
+"""Pin the oracle (CPU restatement, oracle/) against golden vectors captured from the reference
+itself by tests/golden/make_golden.py.  CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ring as oring
+from oracle import ddim as oddim
+from oracle import loops as oloops
+from oracle.unet import unet_forward
+from dynamicscaler_amd.unet_spec import param_shapes
+from dynamicscaler_amd.synth import synth_state_dict
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def npz(name):
+    return np.load(os.path.join(G, name))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_g1_ring_segments():
+    for case in json.load(open(os.path.join(G, "ring_segments.json"))):
+        segs = oring.ring_segments(case["begin"], case["end"], case["size"])
+        assert [list(s) for s in segs] == case["slices"]
+        assert [b - a for a, b in segs] == case["sizes"]
+
+
+def test_g2_ring_gather_scatter_bit_exact():
+    z = npz("ring_latent.npz")
+    pano = T(z["pano"])
+    wins = z["windows"]
+    for i, (l, r, t, d, fb, fe) in enumerate(wins.tolist()):
+        got = oring.ring_gather(pano, l, r, t, d, fb, fe)
+        assert torch.equal(got, T(z[f"get_{i}"]))
+    assert torch.equal(oring.ring_gather(pano, 10, 32, 0, 16, 0, 12), T(z["get_multiwrap"]))
+    from dynamicscaler_amd.synth import synth_normal
+    p2 = pano.clone()
+    for i, (l, r, t, d, fb, fe) in enumerate(wins.tolist()):
+        tile = synth_normal((1, 4, fe - fb, d - t, r - l), seed=100 + i)
+        oring.ring_scatter(p2, tile, l, r, t, d, fb, fe)
+        assert torch.equal(p2, T(z[f"set_after_{i}"]))
+
+
+def test_g2_ring_asserts_like_reference():
+    pano = torch.zeros(1, 4, 6, 8, 16)
+    with pytest.raises(AssertionError):
+        oring.ring_gather(pano, 10, 42, 0, 8, 0, 6)      # > 2*W  (shift_window_utils.py:73)
+    with pytest.raises(AssertionError):
+        oring.ring_scatter(pano, torch.zeros(1, 4, 6, 8, 17), 0, 17, 0, 8, 0, 6)  # self-overlap (:145)
+    with pytest.raises(AssertionError):
+        oring.ring_scatter(pano, torch.zeros(1, 4, 6, 8, 3), 0, 4, 0, 8, 0, 6)    # shape mismatch (:190)
+
+
+def test_g3_mix_bit_exact():
+    z = npz("mix.npz")
+    l1, l2, m3, m5 = T(z["l1"]), T(z["l2"]), T(z["m3"]), T(z["m5"])
+    for r in (1, 1.0, 0.5, 0.3):
+        assert torch.equal(oddim.mix_latents_with_mask(l1, l2, m3, r), T(z[f"out3_{r}"]))
+        assert torch.equal(oddim.mix_latents_with_mask(l1, l2, m5, r), T(z[f"out5_{r}"]))
+
+
+def test_g4_scheduler_tables_and_steps_bit_exact():
+    z = npz("scheduler.npz")
+    tables = oddim.DiffusionTables()
+    assert torch.equal(tables.alphas_cumprod, T(z["alphas_cumprod"]))
+    assert torch.equal(tables.betas, T(z["betas"]))
+    for n in (4, 48, 50):
+        s = oddim.DDIMSchedule(tables, n)
+        assert np.array_equal(s.ddim_timesteps, z[f"ts_{n}"])
+        assert torch.equal(s.ddim_alphas, T(z[f"alphas_{n}"]))
+        assert np.array_equal(np.asarray(s.ddim_alphas_prev, dtype=np.float64), z[f"alphas_prev_{n}"])
+        assert np.array_equal(np.asarray(s.ddim_sigmas, dtype=np.float64), z[f"sigmas_{n}"])
+        assert torch.equal(torch.as_tensor(s.ddim_sqrt_one_minus_alphas), T(z[f"sqrt1m_{n}"]))
+    x, e = T(z["x"]), T(z["e"])
+    for n, eta in ((50, 0.0), (4, 0.0), (50, 1.0)):
+        s = oddim.DDIMSchedule(tables, n, eta=eta)
+        for index in (0, n // 2, n - 1):
+            torch.manual_seed(777)
+            xp, x0 = oddim.ddim_step(s, x, e, [index] * 4)
+            assert torch.equal(xp, T(z[f"step_{n}_{eta}_{index}_xprev"]))
+            assert torch.equal(x0, T(z[f"step_{n}_{eta}_{index}_x0"]))
+            # the scalar-coefficient form the HIP kernel consumes reproduces the same numbers (eta=0)
+            if eta == 0.0:
+                c = s.step_coefficients(index)
+                f = torch.float32
+                x0b = (x - torch.tensor(c["sqrt_one_minus_at"], dtype=f) * e) / torch.tensor(c["sqrt_at"], dtype=f)
+                xpb = torch.tensor(c["sqrt_a_prev"], dtype=f) * x0b + torch.tensor(c["dir_coef"], dtype=f) * e
+                assert torch.equal(x0b, x0)
+                assert torch.equal(xpb + 0.0, xp)
+        for (a, b) in ((0, 1), (n - 2, n - 1), (n // 2 - 1, n // 2)):
+            torch.manual_seed(778)
+            assert torch.equal(oddim.re_noise(s, x, a, b), T(z[f"renoise_{n}_{eta}_{a}_{b}"]))
+
+
+@pytest.mark.parametrize("name", ["t2v", "i2v"])
+def test_g8_unet_tiny(name):
+    z = npz(f"unet_tiny_{name}.npz")
+    params = json.loads(bytes(z["params_json"]).decode())
+    sd = synth_state_dict(param_shapes(params), seed=5)
+    flat = torch.cat([v.flatten() for _, v in sorted(sd.items())])
+    assert hashlib.sha256(flat.numpy().tobytes()).digest() == bytes(z["weights_sha"])
+    for case in range(3):
+        eps = unet_forward(sd, params, T(z[f"x_{case}"]), T(z[f"t_{case}"]), T(z[f"ctx_{case}"]),
+                           fps=int(z[f"fps_{case}"]))
+        ref = T(z[f"eps_{case}"])
+        assert eps.shape == ref.shape
+        err = float((eps - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-5, err  # fp32; differs only by summation order inside ATen
+
+
+def _tiny_setup():
+    z = npz("unet_tiny_t2v.npz")
+    params = json.loads(bytes(z["params_json"]).decode())
+    sd = synth_state_dict(param_shapes(params), seed=5)
+    return params, sd
+
+
+def _fake_eps(x, ts, ctx):
+    return 0.1 * x + 0.01 * ctx.mean()
+
+
+def test_g9_small_loops_fake_eps_bit_exact_and_traces():
+    z = npz("loops_small.npz")
+    meta = json.load(open(os.path.join(G, "loops_small_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    tables = oddim.DiffusionTables()
+    torch.manual_seed(2333333)
+    den, _ = oloops.t2v_basic_sample(_fake_eps, tables, cond, uncond, height=64, width=128, frames=4,
+                                     guidance_scale=7.5, num_inference_steps=4)
+    assert torch.equal(den, T(z["basic_fake"]))
+    for gname, geom in meta["geoms"].items():
+        trace = []
+        torch.manual_seed(2333333)
+        den, _, _ = oloops.t2v_ring_sample(_fake_eps, tables, cond, uncond, guidance_scale=7.5,
+                                           trace=trace, **geom)
+        assert torch.equal(den, T(z[f"ring_{gname}_fake"])), gname
+        ref_trace = meta["traces"][gname]
+        assert len(trace) == len(ref_trace)
+        for (i, t, wins), ref in zip(trace, ref_trace):
+            assert i == ref["i"] and t == ref["t"]
+            assert [list(w) for w in wins] == ref["windows"], (gname, i)
+
+
+def test_g9_small_loops_tiny_unet():
+    z = npz("loops_small.npz")
+    meta = json.load(open(os.path.join(G, "loops_small_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    params, sd = _tiny_setup()
+    tables = oddim.DiffusionTables()
+
+    def eps(x, ts, ctx):
+        return unet_forward(sd, params, x, ts, ctx, fps=8)
+
+    torch.manual_seed(2333333)
+    den, _ = oloops.t2v_basic_sample(eps, tables, cond, uncond, height=64, width=128, frames=4,
+                                     guidance_scale=7.5, num_inference_steps=4)
+    ref = T(z["basic_tiny"])
+    assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4
+    for gname in ("grid4x2", "overlapw"):
+        torch.manual_seed(2333333)
+        den, _, _ = oloops.t2v_ring_sample(eps, tables, cond, uncond, guidance_scale=7.5, **meta["geoms"][gname])
+        ref = T(z[f"ring_{gname}_tiny"])
+        assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4, gname
+
+
+def test_g9_baseline_geometry_traces():
+    """Window coordinates of BASELINE configs 2/3/5 (bit-exact index sequences) -- arithmetic only."""
+    data = json.load(open(os.path.join(G, "loop_traces.json")))
+    for name, rec in data.items():
+        geom = dict(rec["geom"])
+        n = geom.pop("num_inference_steps")
+        for step in rec["trace"]:
+            wins = oloops.t2v_ring_windows(step["i"], height=geom["height"], width=geom["width"],
+                                           frames=geom["frames"], total_h=geom["total_h"], total_w=geom["total_w"],
+                                           num_windows_h=geom["num_windows_h"], num_windows_w=geom["num_windows_w"],
+                                           num_windows_f=geom["num_windows_f"], loop_step=geom["loop_step"])
+            assert [list(w) for w in wins] == step["windows"], (name, step["i"])
+    # the probe of SURVEY.md 8-a R10: config-3 step 1
+    w = oloops.t2v_ring_windows(1, height=320, width=512, frames=16, total_h=512, total_w=4096,
+                                num_windows_h=2, num_windows_w=8, num_windows_f=1, loop_step=8)
+    assert w[0] == (8, 72, 3, 43, 0, 16) and w[1] == (8, 72, 27, 67, 0, 16) and w[-1] == (456, 520, 27, 67, 0, 16)
+
+
+@pytest.mark.parametrize("name", ["cfg3_overlap_nw10"])
+def test_g9_baseline_geometry_final_panorama_sha(name):
+    """Full-size panorama loop with the fake eps-model: final pred_x0 panorama hash equals the reference's."""
+    rec = json.load(open(os.path.join(G, "loop_traces.json")))[name]
+    z = npz("loops_small.npz")
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    torch.manual_seed(2333333)
+    den, _, _ = oloops.t2v_ring_sample(_fake_eps, oddim.DiffusionTables(), cond, uncond, guidance_scale=7.5,
+                                       **rec["geom"])
+    assert list(den.shape) == rec["shape"]
+    assert hashlib.sha256(den.numpy().tobytes()).hexdigest() == rec["denoised_sha256"]
