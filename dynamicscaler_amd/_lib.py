@@ -1,0 +1,93 @@
+"""ctypes binding of libdynscaler_hip.so (the C ABI declared in include/dynscaler_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol is absent this module
+raises at import of the first op (HipLibraryMissing), loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdynscaler_hip.so")
+
+DS_F16, DS_F32 = 0, 1
+DS_A_DENSE, DS_A_CONV3, DS_A_TCONV = 0, 1, 2
+DS_EPI_GEGLU, DS_EPI_SILU, DS_EPI_OUT_F32 = 1, 2, 4
+DS_MAX_WINDOWS = 64
+ABI_VERSION = 1
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class DsError(RuntimeError):
+    pass
+
+
+class RingGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("C", "F", "H", "W", "tf", "th", "tw", "dtype")]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "M", "N", "K", "a_mode", "lda", "cin", "nimg", "hin", "win", "hout", "wout", "stride", "upsample",
+        "t_len", "hw", "ldc", "ldr", "bias_rows", "ldbias", "epilogue")]
+
+
+_vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/dynscaler_hip.h one to one
+SIGNATURES = {
+    "ds_last_error": (C.c_char_p, []),
+    "ds_abi_version": (_i, []),
+    "ds_ring_gather": (_i, [_vp, _vp, _vp, _vp, C.POINTER(RingGeom), C.POINTER(C.c_int32), _i, _vp]),
+    "ds_ring_scatter3": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(RingGeom), C.POINTER(C.c_int32), _i, _vp]),
+    "ds_renoise_mix": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _i, _u64, _u64, C.POINTER(RingGeom), _i, _vp]),
+    "ds_cfg_ddim": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, C.POINTER(RingGeom), _i, _vp]),
+    "ds_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),
+    "ds_groupnorm_stats_workspace_floats": (_sz, [_i, _i, _i]),
+    "ds_groupnorm_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ds_groupnorm_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ds_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "ds_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "ds_temporal_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "ds_concat_channels": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ds_im2col_in": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ds_rows_to_ncthw": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ds_timestep_embedding": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ds_silu_f16": (_i, [_vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library once and bind every symbol of the ABI; raise HipLibraryMissing otherwise."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m dynamicscaler_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the DynamicScaler hot path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryMissing(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryMissing(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ds_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing(f"ABI version mismatch: library {lib.ds_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ds_last_error()
+        raise DsError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

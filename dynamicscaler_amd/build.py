@@ -1,0 +1,63 @@
+"""Build libdynscaler_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+    python -m dynamicscaler_amd.build [--force]
+
+Objects are rebuilt only when a source (or a header) is newer.  The .so stays next to this file so it
+travels to the GPU box with the repo snapshot (git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libdynscaler_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = ["error.cpp", "tile_ops.hip", "gemm.hip", "attention.hip", "norm.hip", "misc.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-fno-gpu-rdc", "-ffp-contract=on"]
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "dynscaler_hip.h")]
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _newer([src] + headers, obj):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return cmd, r
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        for cmd, r in ex.map(run, jobs):
+            if verbose and (r.stdout or r.stderr):
+                sys.stderr.write(r.stdout + r.stderr)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    if force or jobs or _newer(objs, LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("link failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,355 @@
+// Attention kernels for gfx950 (head_dim 64, fp16 in/out, fp32 softmax statistics and accumulation).
+//
+// 1) ds_attention_f16 -- flash-style softmax(q k^T * scale) v for the spatial self-attention (N = 2560 / 640 /
+//    160 / 40 tokens) and the cross-attention (77 text (+16 image) tokens) of SpatialTransformer
+//    (lvdm/modules/attention.py:76-127).  q/k/v are read in place from the fused projection outputs (row stride
+//    ld*, head h at column h*64), no head split / permute copies.
+//      * workgroup = 4 waves; a wave owns QB x 32 query rows; K/V tiles of 64 keys are staged through LDS
+//        (global -> VGPR -> LDS, next tile's loads in flight during the MFMAs).
+//      * S^T = K Q^T (v_mfma_f32_32x32x16_f16, K fragment as A operand): a lane then owns ONE query column and
+//        32 keys in registers -> the softmax max/sum are in-register plus one cross-half shuffle.
+//      * O^T += V^T P^T: the S^T accumulator registers, converted to fp16 in place, ARE the B operand of the
+//        second MFMA (k order of a 32x32 accumulator: key = 16s + 8(j>>2) + 4*half + (j&3)); V is transposed
+//        on the way into LDS so the matching A fragment is two 8-byte LDS reads.
+//      * O^T keeps the query on the lane as well, so the online-softmax rescale is a per-lane scalar.
+// 2) ds_temporal_attention_f16 -- self-attention over T (<= 32) frames per pixel (TemporalTransformer,
+//    attention.py:281-373): 0.1% of the FLOPs, pure HBM traffic; one wave per (pixel, head), VALU math.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int KT = 64;          // keys per LDS tile
+constexpr int VT_STRIDE = 68;   // halfs per V^T row (64 keys + 4 pad): 34-dword stride -> conflict-free b64 reads
+
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+template <int QB>
+__global__ void __launch_bounds__(256)
+attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v, f16* __restrict__ out,
+                 int heads, int nq, int nk, int ldq, int ldk, int ldv, int ldo, int kv_batch_div, float scale_log2,
+                 int accumulate, int q_tiles) {
+    __shared__ __attribute__((aligned(256))) f16 sK[KT * HD];
+    __shared__ __attribute__((aligned(16))) f16 sVT[HD * VT_STRIDE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int qt = blockIdx.x % q_tiles;
+    const int bh = blockIdx.x / q_tiles;
+    const int head = bh % heads, b = bh / heads;
+    const int kvb = b / kv_batch_div;
+    const int q_base = qt * (128 * QB) + wave * (32 * QB);
+
+    const f16* qp = q + (long)b * nq * ldq + head * HD;
+    const f16* kp = k + (long)kvb * nk * ldk + head * HD;
+    const f16* vp = v + (long)kvb * nk * ldv + head * HD;
+
+    // ---- Q fragments (B operand: lane = query column, 8 consecutive d per k-step half) ----
+    f16x8 qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = q_base + qb * 32 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (qi < nq) qf[qb][ks] = *reinterpret_cast<const f16x8*>(qp + (long)qi * ldq + ks * 16 + fh * 8);
+            else qf[qb][ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    f32x16 o[QB][2];
+    float mrun[QB], lrun[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        mrun[qb] = -1e30f; lrun[qb] = 0.0f;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[qb][db][j] = 0.0f;
+    }
+
+    // staging: thread -> (key row = tid/8 (+32), 16-byte chunk = tid%8)
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;
+    uint4 rk[2], rv[2];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto load_g = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = t * KT + ld_row + 32 * i;
+            if (key < nk) {
+                rk[i] = *reinterpret_cast<const uint4*>(kp + (long)key * ldk + ld_chunk * 8);
+                rv[i] = *reinterpret_cast<const uint4*>(vp + (long)key * ldv + ld_chunk * 8);
+            } else {
+                rk[i] = zero4; rv[i] = zero4;
+            }
+        }
+    };
+    auto store_l = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = ld_row + 32 * i;
+            *reinterpret_cast<uint4*>(sK + row * HD + swz_chunk(row, ld_chunk) * 8) = rk[i];
+            const f16* vv = reinterpret_cast<const f16*>(&rv[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sVT[(ld_chunk * 8 + j) * VT_STRIDE + row] = vv[j];
+        }
+    };
+
+    const int ntiles = (nk + KT - 1) / KT;
+    load_g(0);
+    store_l();
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) load_g(t + 1);
+
+        // K fragments for this tile are shared by the wave's QB query blocks
+        f16x8 kf[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int row = kb * 32 + fr;
+                kf[kb][ks] = *reinterpret_cast<const f16x8*>(sK + row * HD + swz_chunk(row, 2 * ks + fh) * 8);
+            }
+
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s[kb][j] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[qb][ks], s[kb], 0, 0, 0);
+            }
+            // scale, mask the keys past nk, running max
+            float mt = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int key = t * KT + kb * 32 + (j & 3) + 8 * (j >> 2) + 4 * fh;
+                    float sv = s[kb][j] * scale_log2;
+                    sv = key < nk ? sv : -1e30f;
+                    s[kb][j] = sv;
+                    mt = fmaxf(mt, sv);
+                }
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mnew = fmaxf(mrun[qb], mt);
+            const float alpha = exp2f(mrun[qb] - mnew);
+            mrun[qb] = mnew;
+            float lsum = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float p = exp2f(s[kb][j] - mnew);
+                    s[kb][j] = p;
+                    lsum += p;
+                }
+            lrun[qb] = lrun[qb] * alpha + lsum;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) o[qb][db][j] *= alpha;
+
+            // O^T[d][q] += V^T[d][key] * P^T[key][q]
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int sstep = 0; sstep < 2; ++sstep) {
+                    f16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (f16)s[kb][8 * sstep + j];
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const int drow = db * 32 + fr;
+                        const int key0 = kb * 32 + sstep * 16 + 4 * fh;
+                        const f16x4 v0 = *reinterpret_cast<const f16x4*>(sVT + drow * VT_STRIDE + key0);
+                        const f16x4 v1 = *reinterpret_cast<const f16x4*>(sVT + drow * VT_STRIDE + key0 + 8);
+                        const f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[qb][db], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            store_l();
+            __syncthreads();
+        }
+    }
+
+    // ---- normalise and store: lane owns query fr, d = 32*db + (j&3) + 8*(j>>2) + 4*fh ----
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l = lrun[qb] + __shfl_xor(lrun[qb], 32);
+        const float inv = 1.0f / l;
+        const int qi = q_base + qb * 32 + fr;
+        if (qi >= nq) continue;
+        f16* op = out + ((long)b * nq + qi) * ldo + head * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dcol = db * 32 + 8 * g + 4 * fh;
+                f16x4 w;
+                if (accumulate) {
+                    const f16x4 prev = *reinterpret_cast<const f16x4*>(op + dcol);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = (f16)((float)prev[j] + o[qb][db][4 * g + j] * inv);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = (f16)(o[qb][db][4 * g + j] * inv);
+                }
+                *reinterpret_cast<f16x4*>(op + dcol) = w;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Temporal attention: one wave per (batch, pixel, head); lane = (query frame t = lane & 15 | lane & 31, d-slice).
+// TPAD = 16 or 32 query slots; DS = 64 / (64 / TPAD) d values per lane.
+// ---------------------------------------------------------------------------------------------------------
+template <int TPAD>
+__global__ void __launch_bounds__(256)
+temporal_attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+                          f16* __restrict__ out, long nseq_total, int T, int hw, int heads, int ldq, int ldk, int ldv,
+                          int ldo, float scale) {
+    constexpr int NSL = 64 / TPAD;   // d-slices per query (4 for T<=16, 2 for T<=32)
+    constexpr int DS = HD / NSL;     // d values per lane (16 or 32)
+    __shared__ __attribute__((aligned(16))) f16 sKV[4][2][32 * HD];  // per wave: K and V tiles [T][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long item = (long)blockIdx.x * 4 + wave;     // (b, p, head)
+    const bool active = item < nseq_total;
+    const long it = active ? item : 0;
+    const int head = (int)(it % heads);
+    const long bp = it / heads;
+    const int p = (int)(bp % hw);
+    const long b = bp / hw;
+    const long row0 = b * T * hw + p;                  // row of frame 0; frame t is row0 + t*hw
+
+    f16* sK = sKV[wave][0];
+    f16* sV = sKV[wave][1];
+    // stage K, V: T rows x 128 bytes = T*8 chunks of 16 B
+    for (int c = lane; c < T * 8; c += 64) {
+        const int t = c >> 3, ch = c & 7;
+        const long row = row0 + (long)t * hw;
+        *reinterpret_cast<uint4*>(sK + t * HD + ch * 8) = *reinterpret_cast<const uint4*>(k + row * ldk + head * HD + ch * 8);
+        *reinterpret_cast<uint4*>(sV + t * HD + ch * 8) = *reinterpret_cast<const uint4*>(v + row * ldv + head * HD + ch * 8);
+    }
+    const int tq = lane % TPAD, sl = lane / TPAD;
+    const bool qvalid = tq < T;
+    float qr[DS];
+    {
+        const long row = row0 + (long)(qvalid ? tq : 0) * hw;
+        const f16* qp = q + row * ldq + head * HD + sl * DS;
+#pragma unroll
+        for (int c = 0; c < DS / 8; ++c) {
+            const f16x8 t8 = *reinterpret_cast<const f16x8*>(qp + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qr[c * 8 + j] = (float)t8[j];
+        }
+    }
+    __syncthreads();
+
+    // scores over all T keys (partial over this lane's d-slice), then reduce across the NSL slices
+    float sc[32];
+    float mx = -1e30f;
+#pragma unroll
+    for (int t2 = 0; t2 < 32; ++t2) {
+        if (t2 < T) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < DS / 8; ++c) {
+                const f16x8 k8 = *reinterpret_cast<const f16x8*>(sK + t2 * HD + sl * DS + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += qr[c * 8 + j] * (float)k8[j];
+            }
+#pragma unroll
+            for (int sh = TPAD; sh < 64; sh <<= 1) acc += __shfl_xor(acc, sh);
+            acc *= scale;
+            sc[t2] = acc;
+            mx = fmaxf(mx, acc);
+        } else {
+            sc[t2] = -1e30f;
+        }
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int t2 = 0; t2 < 32; ++t2) {
+        const float pz = t2 < T ? __expf(sc[t2] - mx) : 0.0f;
+        sc[t2] = pz;
+        sum += pz;
+    }
+    const float inv = 1.0f / sum;
+    float oacc[DS];
+#pragma unroll
+    for (int j = 0; j < DS; ++j) oacc[j] = 0.0f;
+#pragma unroll
+    for (int t2 = 0; t2 < 32; ++t2) {
+        if (t2 < T) {
+            const float pz = sc[t2] * inv;
+#pragma unroll
+            for (int c = 0; c < DS / 8; ++c) {
+                const f16x8 v8 = *reinterpret_cast<const f16x8*>(sV + t2 * HD + sl * DS + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) oacc[c * 8 + j] += pz * (float)v8[j];
+            }
+        }
+    }
+    if (active && qvalid) {
+        f16* op = out + (row0 + (long)tq * hw) * ldo + head * HD + sl * DS;
+#pragma unroll
+        for (int c = 0; c < DS / 8; ++c) {
+            f16x8 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (f16)oacc[c * 8 + j];
+            *reinterpret_cast<f16x8*>(op + c * 8) = w;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ds_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int heads, int nq,
+                                int nk, int ldq, int ldk, int ldv, int ldo, int kv_batch_div, float scale,
+                                int accumulate, void* stream) {
+    DS_CHECK_ARG(q && k && v && out, "ds_attention_f16: null argument");
+    DS_CHECK_ARG(batch > 0 && heads > 0 && nq > 0 && nk > 0, "ds_attention_f16: batch/heads/nq/nk must be positive");
+    DS_CHECK_ARG(kv_batch_div > 0 && batch % kv_batch_div == 0, "ds_attention_f16: batch %% kv_batch_div != 0");
+    DS_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "ds_attention_f16: row strides must be multiples of 8 (ldo: 4)");
+    DS_CHECK_ARG(ldq >= heads * HD && ldk >= heads * HD && ldv >= heads * HD && ldo >= heads * HD, "ds_attention_f16: row stride < heads*64");
+    hipStream_t st = (hipStream_t)stream;
+    const float scale_log2 = scale * 1.4426950408889634f;
+    if (nq >= 512) {
+        const int q_tiles = ds_cdiv(nq, 256);
+        attention_kernel<2><<<(long)batch * heads * q_tiles, 256, 0, st>>>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out,
+                                                                         heads, nq, nk, ldq, ldk, ldv, ldo, kv_batch_div, scale_log2, accumulate, q_tiles);
+    } else {
+        const int q_tiles = ds_cdiv(nq, 128);
+        attention_kernel<1><<<(long)batch * heads * q_tiles, 256, 0, st>>>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out,
+                                                                         heads, nq, nk, ldq, ldk, ldv, ldo, kv_batch_div, scale_log2, accumulate, q_tiles);
+    }
+    DS_CHECK_LAUNCH("ds_attention_f16");
+    return DS_OK;
+}
+
+extern "C" int ds_temporal_attention_f16(const void* q, const void* k, const void* v, void* out, int nseq_batches,
+                                         int T, int hw, int heads, int ldq, int ldk, int ldv, int ldo, float scale,
+                                         void* stream) {
+    DS_CHECK_ARG(q && k && v && out, "ds_temporal_attention_f16: null argument");
+    DS_CHECK_ARG(nseq_batches > 0 && hw > 0 && heads > 0, "ds_temporal_attention_f16: sizes must be positive");
+    DS_CHECK_ARG(T >= 1 && T <= 32, "ds_temporal_attention_f16: T=%d must be in [1,32]", T);
+    DS_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "ds_temporal_attention_f16: strides must be multiples of 8");
+    hipStream_t st = (hipStream_t)stream;
+    const long items = (long)nseq_batches * hw * heads;
+    const int grid = (int)((items + 3) / 4);
+    if (T <= 16)
+        temporal_attention_kernel<16><<<grid, 256, 0, st>>>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, items, T, hw, heads, ldq, ldk, ldv, ldo, scale);
+    else
+        temporal_attention_kernel<32><<<grid, 256, 0, st>>>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, items, T, hw, heads, ldq, ldk, ldv, ldo, scale);
+    DS_CHECK_LAUNCH("ds_temporal_attention_f16");
+    return DS_OK;
+}

@@ -1,0 +1,338 @@
+// Implicit-GEMM on the gfx950 matrix cores: out[M,N] = gatherA[M,K] * W[N,K]^T (+bias, +residual, GEGLU, SiLU).
+//
+// One kernel serves nn.Linear, Conv2d 1x1 / 3x3 (stride 1|2, nearest-x2 upsample folded into the gather)
+// and Conv3d (3,1,1): the modes differ only in how a row of the A tile is addressed (DS_A_*).
+//
+// Structure (CDNA4, wave64):
+//   * workgroup = 256 threads = 4 waves in a 2x2 grid; block tile BM x BN (128x128 or 128x64), K-step 64.
+//   * operands staged global -> VGPR -> LDS (the A rows are a gather with zero padding, so register staging;
+//     the next K-tile's global loads are issued before the MFMAs of the current one), double-buffered LDS,
+//     one barrier per K-step.
+//   * LDS tiles are [rows][64 halfs] (128-byte rows) with the 16-byte chunk index XOR-swizzled by
+//     ((row >> 1) & 7): every ds_read_b128 lane group of a 32-row fragment read hits 16 distinct 16-byte slots
+//     of the 256-byte bank row (conflict-free), and the staging ds_write_b128 (8 lanes per row) is too.
+//   * v_mfma_f32_32x32x16_f16 with the WEIGHT fragment as the A operand and the ACTIVATION fragment as B:
+//     D[i=n][j=m], so a lane owns one output row m (lane&31) and 4 consecutive columns n per register quad
+//     -> float4 LDS stores in the epilogue.
+//   * epilogue through LDS (fp32 tile, stride BN+4): rows are read back as 8-column chunks, bias / per-item
+//     bias (time-embedding add) / residual / SiLU / GEGLU applied in fp32, one rounding to fp16, 16-byte
+//     coalesced stores.
+//   * blockIdx is remapped so that the blocks that share an XCD (bid % 8) walk neighbouring N tiles of the same
+//     A row panel (L2 reuse; performance only).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;  // halfs per K-step (128-byte LDS rows, 8 chunks of 16 bytes)
+
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+struct RowInfo {   // per staged A row, computed once
+    long base;     // element offset of the row's "centre" source (DENSE/TCONV: m*lda)
+    int a, b, c;   // CONV3: img, oy, ox ; TCONV: t ; validity
+    bool valid;
+};
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, 2)
+gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const float* __restrict__ bias,
+                const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n) {
+    constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
+    constexpr int A_ROWS_PER_THREAD = BM / 32, B_ROWS_PER_THREAD = BN / 32;
+    constexpr int CS = BN + 4;                // fp32 epilogue tile stride
+
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    f16* sA = reinterpret_cast<f16*>(smem);                 // [2][BM][64]
+    f16* sB = sA + 2 * BM * BK;                             // [2][BN][64]
+    float* sC = reinterpret_cast<float*>(smem);             // [BM][CS] (reuses the staging space)
+
+    // ---- XCD-aware block remap (bijective for any grid size) ----
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = bid % tiles_n;
+    const int tile_m = bid / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ld_row = tid >> 3;   // 0..31
+    const int ld_chunk = tid & 7;  // 16-byte chunk within the 64-half K-step
+
+    // ---- per-row source bookkeeping for the A gather ----
+    RowInfo ri[A_ROWS_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
+        const int m = m0 + ld_row + 32 * i;
+        ri[i].valid = m < d.M;
+        const int mm = ri[i].valid ? m : 0;
+        if (d.a_mode == DS_A_CONV3) {
+            const int hw = d.hout * d.wout;
+            const int img = mm / hw, rem = mm - img * hw;
+            ri[i].a = img; ri[i].b = rem / d.wout; ri[i].c = rem - ri[i].b * d.wout;
+            ri[i].base = 0;
+        } else if (d.a_mode == DS_A_TCONV) {
+            ri[i].a = (mm / d.hw) % d.t_len; ri[i].b = 0; ri[i].c = 0;
+            ri[i].base = (long)mm * d.lda;
+        } else {
+            ri[i].a = ri[i].b = ri[i].c = 0;
+            ri[i].base = (long)mm * d.lda;
+        }
+    }
+    bool b_valid[B_ROWS_PER_THREAD];
+    long b_base[B_ROWS_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
+        const int n = n0 + ld_row + 32 * i;
+        b_valid[i] = n < d.N;
+        b_base[i] = (long)(b_valid[i] ? n : 0) * d.K;
+    }
+
+    uint4 ra[A_ROWS_PER_THREAD], rb[B_ROWS_PER_THREAD];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto load_global = [&](int kt) {
+        const int k0 = kt * BK;
+        const int tap = k0 / d.cin;
+        const int cb = k0 - tap * d.cin + ld_chunk * 8;
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
+            bool ok = ri[i].valid;
+            long off;
+            if (d.a_mode == DS_A_CONV3) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                int iy = ri[i].b * d.stride + ky - 1;
+                int ix = ri[i].c * d.stride + kx - 1;
+                const int hl = d.upsample ? 2 * d.hin : d.hin, wl = d.upsample ? 2 * d.win : d.win;
+                ok = ok && iy >= 0 && iy < hl && ix >= 0 && ix < wl;
+                if (d.upsample) { iy >>= 1; ix >>= 1; }
+                off = (((long)ri[i].a * d.hin + iy) * d.win + ix) * d.lda + cb;
+            } else if (d.a_mode == DS_A_TCONV) {
+                const int tt = ri[i].a + tap - 1;
+                ok = ok && tt >= 0 && tt < d.t_len;
+                off = ri[i].base + (long)(tap - 1) * d.hw * d.lda + cb;
+            } else {
+                off = ri[i].base + cb;
+            }
+            ra[i] = ok ? *reinterpret_cast<const uint4*>(A + off) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
+            rb[i] = b_valid[i] ? *reinterpret_cast<const uint4*>(W + b_base[i] + k0 + ld_chunk * 8) : zero4;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
+            const int row = ld_row + 32 * i;
+            *reinterpret_cast<uint4*>(sA + (buf * BM + row) * BK + swz_chunk(row, ld_chunk) * 8) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
+            const int row = ld_row + 32 * i;
+            *reinterpret_cast<uint4*>(sB + (buf * BN + row) * BK + swz_chunk(row, ld_chunk) * 8) = rb[i];
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[ni][mi][j] = 0.0f;
+
+    const int nk = d.K / BK;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_global(kt + 1);
+        const f16* a_base = sA + (buf * BM + wm * WM) * BK;
+        const f16* b_base_l = sB + (buf * BN + wn * WN) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int row = mi * 32 + fr;
+                af[mi] = *reinterpret_cast<const f16x8*>(a_base + row * BK + swz_chunk(wm * WM + row, 2 * kk + fh) * 8);
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int row = ni * 32 + fr;
+                bf[ni] = *reinterpret_cast<const f16x8*>(b_base_l + row * BK + swz_chunk(wn * WN + row, 2 * kk + fh) * 8);
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32) ----
+    // D[i][j]: j = lane&31 is the output row m, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) the column n.
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int row = wm * WM + mi * 32 + fr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wn * WN + ni * 32 + 8 * g + 4 * fh;
+                f32x4 v = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(sC + row * CS + col) = v;
+            }
+        }
+    __syncthreads();
+
+    const bool geglu = d.epilogue & DS_EPI_GEGLU;
+    const bool silu = d.epilogue & DS_EPI_SILU;
+    const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;
+    const bool fast = !out_f32 && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (!residual || d.ldr % 8 == 0);
+
+    if (fast) {
+        constexpr int OUT_COLS = BN;  // GEGLU uses the first BN/2 chunk columns only
+        const int chunks_per_row = geglu ? BN / 16 : BN / 8;
+        const int total_chunks = BM * chunks_per_row;
+        for (int idx = tid; idx < total_chunks; idx += 256) {
+            const int row = idx / chunks_per_row;
+            const int ch = idx - row * chunks_per_row;
+            const int m = m0 + row;
+            if (m >= d.M) continue;
+            const int nloc = ch * 8;
+            const int n = n0 + nloc;            // column in the N space (x part for GEGLU)
+            if (n >= d.N) continue;
+            const long brow = (long)(m / d.bias_rows) * d.ldbias;
+            float v[8];
+            {
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc);
+                const f32x4 p1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 4);
+                v[0] = p0[0]; v[1] = p0[1]; v[2] = p0[2]; v[3] = p0[3];
+                v[4] = p1[0]; v[5] = p1[1]; v[6] = p1[2]; v[7] = p1[3];
+            }
+            if (bias) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += bias[brow + n + j];
+            }
+            long ocol;
+            if (geglu) {
+                // gate columns live 64 to the right inside the same 128-wide tile
+                float gte[8];
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 64);
+                const f32x4 g1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 68);
+                gte[0] = g0[0]; gte[1] = g0[1]; gte[2] = g0[2]; gte[3] = g0[3];
+                gte[4] = g1[0]; gte[5] = g1[1]; gte[6] = g1[2]; gte[7] = g1[3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float gg = gte[j] + (bias ? bias[brow + n + 64 + j] : 0.0f);
+                    v[j] = v[j] * (0.5f * gg * (1.0f + erff(gg * 0.70710678118654752f)));
+                }
+                ocol = (long)tile_n * (BN / 2) + nloc;
+            } else {
+                ocol = n;
+            }
+            if (residual) {
+                const f16x8 r8 = *reinterpret_cast<const f16x8*>(residual + (long)m * d.ldr + ocol);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
+            }
+            if (silu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.0f + __expf(-v[j]));
+            }
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
+            *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(out) + (long)m * d.ldc + ocol) = o;
+        }
+        (void)OUT_COLS;
+    } else {
+        // generic (rare, tiny layers): scalar stores, any N, fp32 or fp16 out; GEGLU not supported here
+        for (int idx = tid; idx < BM * BN; idx += 256) {
+            const int row = idx / BN, col = idx - row * BN;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= d.M || n >= d.N) continue;
+            float v = sC[row * CS + col];
+            if (bias) v += bias[(long)(m / d.bias_rows) * d.ldbias + n];
+            if (residual) v += (float)residual[(long)m * d.ldr + n];
+            if (silu) v = v / (1.0f + __expf(-v));
+            if (out_f32) reinterpret_cast<float*>(out)[(long)m * d.ldc + n] = v;
+            else reinterpret_cast<f16*>(out)[(long)m * d.ldc + n] = (f16)v;
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch(const void* A, const void* W, const float* bias, const void* residual, void* out,
+           const ds_gemm_desc& d, hipStream_t st) {
+    constexpr size_t stage = (size_t)2 * (BM + BN) * BK * sizeof(f16);
+    constexpr size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t lds = stage > epi ? stage : epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            ds_set_error("ds_gemm_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DS_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const int tiles_m = ds_cdiv(d.M, BM), tiles_n = ds_cdiv(d.N, BN);
+    gemm_f16_kernel<BM, BN><<<tiles_m * tiles_n, 256, lds, st>>>((const f16*)A, (const f16*)W, bias,
+                                                                 (const f16*)residual, out, d, tiles_m, tiles_n);
+    DS_CHECK_LAUNCH("ds_gemm_f16");
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,
+                           const ds_gemm_desc* desc, void* stream) {
+    DS_CHECK_ARG(A && W && out && desc, "ds_gemm_f16: null argument");
+    const ds_gemm_desc& d = *desc;
+    DS_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "ds_gemm_f16: M,N,K must be positive (got %d,%d,%d)", d.M, d.N, d.K);
+    DS_CHECK_ARG(d.K % BK == 0, "ds_gemm_f16: K=%d must be a multiple of %d", d.K, BK);
+    DS_CHECK_ARG(d.cin > 0 && d.cin % BK == 0 && d.K % d.cin == 0, "ds_gemm_f16: cin=%d must be a multiple of %d dividing K=%d", d.cin, BK, d.K);
+    DS_CHECK_ARG(d.lda % 8 == 0 && d.lda >= d.cin, "ds_gemm_f16: lda=%d must be a multiple of 8 and >= cin", d.lda);
+    DS_CHECK_ARG(d.bias_rows > 0, "ds_gemm_f16: bias_rows must be positive");
+    DS_CHECK_ARG(d.ldc > 0, "ds_gemm_f16: ldc must be positive");
+    DS_CHECK_ARG(!bias || d.ldbias >= d.N, "ds_gemm_f16: ldbias=%d must be >= N=%d", d.ldbias, d.N);
+    if (d.a_mode == DS_A_DENSE) {
+        DS_CHECK_ARG(d.cin == d.K, "ds_gemm_f16: dense mode needs cin == K");
+    } else if (d.a_mode == DS_A_CONV3) {
+        DS_CHECK_ARG(d.K == 9 * d.cin, "ds_gemm_f16: conv3 mode needs K == 9*cin");
+        DS_CHECK_ARG(d.stride == 1 || d.stride == 2, "ds_gemm_f16: conv3 stride must be 1 or 2");
+        DS_CHECK_ARG(d.nimg > 0 && d.hin > 0 && d.win > 0 && d.hout > 0 && d.wout > 0, "ds_gemm_f16: conv3 dims");
+        DS_CHECK_ARG((long)d.nimg * d.hout * d.wout == d.M, "ds_gemm_f16: conv3 M != nimg*hout*wout");
+        DS_CHECK_ARG(!(d.upsample && d.stride != 1), "ds_gemm_f16: upsample needs stride 1");
+    } else if (d.a_mode == DS_A_TCONV) {
+        DS_CHECK_ARG(d.K == 3 * d.cin, "ds_gemm_f16: tconv mode needs K == 3*cin");
+        DS_CHECK_ARG(d.t_len > 0 && d.hw > 0 && d.M % (d.t_len * d.hw) == 0, "ds_gemm_f16: tconv M must be nseq*t_len*hw");
+    } else {
+        DS_CHECK_ARG(false, "ds_gemm_f16: unknown a_mode %d", d.a_mode);
+    }
+    if (d.epilogue & DS_EPI_GEGLU) {
+        DS_CHECK_ARG(d.N % 128 == 0, "ds_gemm_f16: GEGLU needs N %% 128 == 0");
+        DS_CHECK_ARG(!(d.epilogue & DS_EPI_OUT_F32) && d.ldc % 8 == 0, "ds_gemm_f16: GEGLU needs fp16 out, ldc %% 8 == 0");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // tile choice: 128x128 unless it wastes too much of N (N=320 -> 3 tiles of 128 = 17% waste) or GEGLU needs it
+    const bool geglu = d.epilogue & DS_EPI_GEGLU;
+    const int waste128 = ds_cdiv(d.N, 128) * 128 - d.N;
+    if (geglu || waste128 * 8 <= d.N) return launch<128, 128>(A, W, bias, residual, out, d, st);
+    return launch<128, 64>(A, W, bias, residual, out, d, st);
+}

@@ -1,0 +1,148 @@
+// Small HBM-bound helpers around the UNet body (layout changes, channel concat, time embedding, SiLU).
+#include "common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+concat_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restrict__ dst, long rows, int c1, int c2) {
+    const int v1 = c1 / 8, v2 = c2 / 8, vt = v1 + v2;
+    const long total = rows * vt;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / vt;
+        const int c = (int)(idx - r * vt);
+        uint4 val;
+        if (c < v1) val = *reinterpret_cast<const uint4*>(a + r * c1 + c * 8);
+        else val = *reinterpret_cast<const uint4*>(b + r * c2 + (c - v1) * 8);
+        *reinterpret_cast<uint4*>(dst + r * (c1 + c2) + c * 8) = val;
+    }
+}
+
+// patches[m][(ky*3+kx)*C + c] = x[b][c][t][y+ky-1][x+kx-1] (zero outside), m = ((b*T+t)*H+y)*W+x; columns >= 9C are 0
+template <typename T>
+__global__ void __launch_bounds__(256)
+im2col_in_kernel(const T* __restrict__ x, f16* __restrict__ patches, int B, int C, int Tn, int H, int W, int kpad) {
+    const long total = (long)B * Tn * H * W * kpad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / kpad;
+        const int col = (int)(idx - m * kpad);
+        float v = 0.0f;
+        if (col < 9 * C) {
+            const int tap = col / C, c = col - tap * C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            long r = m;
+            const int xx = (int)(r % W); r /= W;
+            const int yy = (int)(r % H); r /= H;
+            const int t = (int)(r % Tn);
+            const int b = (int)(r / Tn);
+            const int iy = yy + ky - 1, ix = xx + kx - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = (float)x[((((long)b * C + c) * Tn + t) * H + iy) * W + ix];
+        }
+        patches[idx] = (f16)v;
+    }
+}
+
+template <typename Y, typename O>
+__global__ void __launch_bounds__(256)
+rows_to_ncthw_kernel(const Y* __restrict__ y, int ldy, O* __restrict__ out, int B, int C, int Tn, int H, int W) {
+    const long total = (long)B * C * Tn * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H); r /= H;
+        const int t = (int)(r % Tn); r /= Tn;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const long m = (((long)b * Tn + t) * H + yy) * W + xx;
+        out[idx] = (O)(float)y[m * ldy + c];
+    }
+}
+
+// utils_diffusion.py:8-28: freqs = exp(-ln(10000) * i / half); emb = [cos(t*f) | sin(t*f)]
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, f16* __restrict__ out, int n, int dim) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * dim) return;
+    const int i = idx / dim, j = idx - i * dim;
+    float v = 0.0f;
+    if (j < 2 * half) {
+        const int f = j < half ? j : j - half;
+        const float freq = expf(-9.210340371976184f * (float)f / (float)half);
+        const float arg = (float)t[i] * freq;
+        v = j < half ? cosf(arg) : sinf(arg);
+    }
+    out[idx] = (f16)v;
+}
+
+__global__ void __launch_bounds__(256) silu_kernel(const f16* __restrict__ x, f16* __restrict__ y, size_t n) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const float f = (float)x[idx];
+        y[idx] = (f16)(f / (1.0f + __expf(-f)));
+    }
+}
+
+inline int grid_for(long work) {
+    long b = (work + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+extern "C" int ds_concat_channels(const void* a, const void* b, void* dst, int rows, int c1, int c2, void* stream) {
+    DS_CHECK_ARG(a && b && dst, "ds_concat_channels: null argument");
+    DS_CHECK_ARG(rows > 0 && c1 > 0 && c2 > 0 && c1 % 8 == 0 && c2 % 8 == 0, "ds_concat_channels: rows=%d c1=%d c2=%d (channels must be multiples of 8)", rows, c1, c2);
+    const long work = (long)rows * ((c1 + c2) / 8);
+    concat_kernel<<<grid_for(work), 256, 0, (hipStream_t)stream>>>((const f16*)a, (const f16*)b, (f16*)dst, rows, c1, c2);
+    DS_CHECK_LAUNCH("ds_concat_channels");
+    return DS_OK;
+}
+
+extern "C" int ds_im2col_in(const void* x, int x_dtype, void* patches, int B, int C, int T, int H, int W, int kpad,
+                            void* stream) {
+    DS_CHECK_ARG(x && patches, "ds_im2col_in: null argument");
+    DS_CHECK_ARG(B > 0 && C > 0 && T > 0 && H > 0 && W > 0, "ds_im2col_in: sizes must be positive");
+    DS_CHECK_ARG(kpad >= 9 * C && kpad % 64 == 0, "ds_im2col_in: kpad=%d must be >= 9*C and a multiple of 64", kpad);
+    const long work = (long)B * T * H * W * kpad;
+    if (x_dtype == DS_F16)
+        im2col_in_kernel<f16><<<grid_for(work), 256, 0, (hipStream_t)stream>>>((const f16*)x, (f16*)patches, B, C, T, H, W, kpad);
+    else if (x_dtype == DS_F32)
+        im2col_in_kernel<float><<<grid_for(work), 256, 0, (hipStream_t)stream>>>((const float*)x, (f16*)patches, B, C, T, H, W, kpad);
+    else
+        DS_CHECK_ARG(false, "ds_im2col_in: bad dtype %d", x_dtype);
+    DS_CHECK_LAUNCH("ds_im2col_in");
+    return DS_OK;
+}
+
+extern "C" int ds_rows_to_ncthw(const void* y, int y_dtype, int ldy, void* out, int out_dtype, int B, int C, int T,
+                                int H, int W, void* stream) {
+    DS_CHECK_ARG(y && out, "ds_rows_to_ncthw: null argument");
+    DS_CHECK_ARG(B > 0 && C > 0 && T > 0 && H > 0 && W > 0 && ldy >= C, "ds_rows_to_ncthw: bad sizes");
+    const long work = (long)B * C * T * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    if (y_dtype == DS_F32 && out_dtype == DS_F32)
+        rows_to_ncthw_kernel<float, float><<<grid_for(work), 256, 0, st>>>((const float*)y, ldy, (float*)out, B, C, T, H, W);
+    else if (y_dtype == DS_F32 && out_dtype == DS_F16)
+        rows_to_ncthw_kernel<float, f16><<<grid_for(work), 256, 0, st>>>((const float*)y, ldy, (f16*)out, B, C, T, H, W);
+    else if (y_dtype == DS_F16 && out_dtype == DS_F32)
+        rows_to_ncthw_kernel<f16, float><<<grid_for(work), 256, 0, st>>>((const f16*)y, ldy, (float*)out, B, C, T, H, W);
+    else if (y_dtype == DS_F16 && out_dtype == DS_F16)
+        rows_to_ncthw_kernel<f16, f16><<<grid_for(work), 256, 0, st>>>((const f16*)y, ldy, (f16*)out, B, C, T, H, W);
+    else
+        DS_CHECK_ARG(false, "ds_rows_to_ncthw: bad dtypes %d %d", y_dtype, out_dtype);
+    DS_CHECK_LAUNCH("ds_rows_to_ncthw");
+    return DS_OK;
+}
+
+extern "C" int ds_timestep_embedding(const int64_t* t, void* out, int n, int dim, void* stream) {
+    DS_CHECK_ARG(t && out && n > 0 && dim > 0, "ds_timestep_embedding: bad argument");
+    timestep_embedding_kernel<<<(n * dim + 255) / 256, 256, 0, (hipStream_t)stream>>>(t, (f16*)out, n, dim);
+    DS_CHECK_LAUNCH("ds_timestep_embedding");
+    return DS_OK;
+}
+
+extern "C" int ds_silu_f16(const void* x, void* y, size_t n, void* stream) {
+    DS_CHECK_ARG(x && y && n > 0, "ds_silu_f16: bad argument");
+    silu_kernel<<<grid_for((long)n), 256, 0, (hipStream_t)stream>>>((const f16*)x, (f16*)y, n);
+    DS_CHECK_LAUNCH("ds_silu_f16");
+    return DS_OK;
+}

@@ -1,0 +1,221 @@
+// GroupNorm (32 groups) and LayerNorm for channel-contiguous fp16 activations on gfx950.  HBM-bound:
+// 16-byte vector loads, fp32 statistics, wavefront / LDS reductions, no atomics in global memory
+// (results are bitwise reproducible).
+//
+// GroupNorm is split into
+//   stats   : ds_groupnorm_stats  = partial (sum, sumsq) per (instance, row chunk, group) + finalize in fp64
+//   apply   : ds_groupnorm_apply  = y = x*a[c] + b[c] (+ SiLU), a = rstd*gamma, b = beta - mean*rstd*gamma
+// so the apply can later be folded into the consumer GEMM's A-operand gather.
+// References: GroupNormSpecific lvdm/basics.py:76-86; nn.GroupNorm(32, C, eps=1e-6) attention.py:238,297;
+// nn.GroupNorm(32, C) in TemporalConvBlock openaimodel3d.py:275-292; nn.LayerNorm attention.py:199-201.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_C = 4096;
+constexpr int GN_CHUNK_ROWS = 256;
+
+// partial sums: grid (nchunks, ninst), 256 threads. part[(inst*nchunks + chunk)*groups + g] = (sum, sumsq)
+__global__ void __launch_bounds__(256)
+gn_partial_kernel(const f16* __restrict__ x, float2* __restrict__ part, int rows_per_inst, int C, int groups) {
+    __shared__ float csum[MAX_C];
+    __shared__ float csq[MAX_C];
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, inst = blockIdx.y, nchunks = gridDim.x;
+    const int r0 = chunk * GN_CHUNK_ROWS;
+    const int r1 = min(rows_per_inst, r0 + GN_CHUNK_ROWS);
+    const int nvec = C / 8;
+    const f16* base = x + (long)inst * rows_per_inst * C;
+    const int rl = nvec <= 256 ? 256 / nvec : 1;  // row lanes; rl*C <= 2048 when rl > 1
+    if (nvec <= 256) {
+        if (tid < rl * nvec) {
+            const int col = tid % nvec, rlane = tid / nvec;
+            float s[8], q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
+            for (int r = r0 + rlane; r < r1; r += rl) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(base + (long)r * C + col * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { csum[rlane * C + col * 8 + j] = s[j]; csq[rlane * C + col * 8 + j] = q[j]; }
+        }
+    } else {
+        for (int col = tid; col < nvec; col += 256) {
+            float s[8], q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
+            for (int r = r0; r < r1; ++r) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(base + (long)r * C + col * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { csum[col * 8 + j] = s[j]; csq[col * 8 + j] = q[j]; }
+        }
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    if (tid < groups) {   // fixed summation order -> bitwise reproducible
+        float s = 0.0f, q = 0.0f;
+        for (int l = 0; l < rl; ++l)
+            for (int j = 0; j < cpg; ++j) { s += csum[l * C + tid * cpg + j]; q += csq[l * C + tid * cpg + j]; }
+        part[((long)inst * nchunks + chunk) * groups + tid] = make_float2(s, q);
+    }
+}
+
+__global__ void gn_finalize_kernel(const float2* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
+                                   int ninst, int nchunks, int groups, double count, float eps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ninst * groups) return;
+    const int inst = idx / groups, g = idx - inst * groups;
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+        const float2 p = part[((long)inst * nchunks + c) * groups + g];
+        s += (double)p.x; q += (double)p.y;
+    }
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[idx] = (float)m;
+    rstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// grid (nchunks, ninst)
+__global__ void __launch_bounds__(256)
+gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                const float* __restrict__ gamma, const float* __restrict__ beta, f16* __restrict__ y,
+                int rows_per_inst, int C, int groups, int silu) {
+    __shared__ float sa[MAX_C];
+    __shared__ float sb[MAX_C];
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, inst = blockIdx.y;
+    const int cpg = C / groups;
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float r = rstd[inst * groups + g], m = mean[inst * groups + g];
+        const float a = r * gamma[c];
+        sa[c] = a;
+        sb[c] = beta[c] - m * a;
+    }
+    __syncthreads();
+    const int r0 = chunk * GN_CHUNK_ROWS;
+    const int r1 = min(rows_per_inst, r0 + GN_CHUNK_ROWS);
+    const int nvec = C / 8;
+    const long base = (long)inst * rows_per_inst * C;
+    const int total = (r1 - r0) * nvec;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int r = idx / nvec, col = idx - r * nvec;
+        const long off = base + (long)(r0 + r) * C + col * 8;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(x + off);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j] * sa[col * 8 + j] + sb[col * 8 + j];
+            if (silu) f = f / (1.0f + __expf(-f));
+            o[j] = (f16)f;
+        }
+        *reinterpret_cast<f16x8*>(y + off) = o;
+    }
+}
+
+// one wave per row; C <= 2560 (5 vectors of 8 per lane)
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                 f16* __restrict__ y, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int nvec = C / 8;
+    constexpr int MAXV = 5;
+    float v[MAXV][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int col = lane + 64 * i;
+        if (col < nvec) {
+            const f16x8 t = *reinterpret_cast<const f16x8*>(x + row * C + col * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) s += __shfl_xor(s, sh);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int col = lane + 64 * i;
+        if (col < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) q += __shfl_xor(q, sh);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int col = lane + 64 * i;
+        if (col < nvec) {
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = col * 8 + j;
+                o[j] = (f16)((v[i][j] - mean) * rstd * gamma[c] + beta[c]);
+            }
+            *reinterpret_cast<f16x8*>(y + row * C + col * 8) = o;
+        }
+    }
+}
+
+}  // namespace
+
+// The caller supplies the scratch for the per-chunk partial sums (nothing here allocates).
+extern "C" size_t ds_groupnorm_stats_workspace_floats(int ninst, int rows_per_inst, int groups) {
+    const long nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
+    return (size_t)ninst * groups * nchunks * 2;
+}
+
+extern "C" int ds_groupnorm_stats(const void* x, float* mean, float* rstd, float* workspace, int ninst,
+                                     int rows_per_inst, int C, int groups, float eps, void* stream) {
+    DS_CHECK_ARG(x && mean && rstd && workspace, "ds_groupnorm_stats: null argument");
+    DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0, "ds_groupnorm_stats: ninst/rows_per_inst must be positive");
+    DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_stats: C=%d groups=%d unsupported", C, groups);
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
+    gn_partial_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups);
+    DS_CHECK_LAUNCH("ds_groupnorm_stats(partial)");
+    const int n = ninst * groups;
+    gn_finalize_kernel<<<(n + 255) / 256, 256, 0, st>>>((const float2*)workspace, mean, rstd, ninst, nchunks, groups,
+                                                       (double)rows_per_inst * (C / groups), eps);
+    DS_CHECK_LAUNCH("ds_groupnorm_stats(finalize)");
+    return DS_OK;
+}
+
+extern "C" int ds_groupnorm_apply(const void* x, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, void* y, int ninst, int rows_per_inst, int C, int groups, int silu,
+                                  void* stream) {
+    DS_CHECK_ARG(x && mean && rstd && gamma && beta && y, "ds_groupnorm_apply: null argument");
+    DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0, "ds_groupnorm_apply: ninst/rows_per_inst must be positive");
+    DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && C % groups == 0, "ds_groupnorm_apply: C=%d groups=%d unsupported", C, groups);
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
+    gn_apply_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, mean, rstd, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu);
+    DS_CHECK_LAUNCH("ds_groupnorm_apply");
+    return DS_OK;
+}
+
+extern "C" int ds_layernorm(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
+                            void* stream) {
+    DS_CHECK_ARG(x && gamma && beta && y, "ds_layernorm: null argument");
+    DS_CHECK_ARG(rows > 0 && C % 8 == 0 && C <= 2560, "ds_layernorm: rows=%d C=%d unsupported (C %% 8 == 0, C <= 2560)", rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    layernorm_kernel<<<(rows + 3) / 4, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps);
+    DS_CHECK_LAUNCH("ds_layernorm");
+    return DS_OK;
+}

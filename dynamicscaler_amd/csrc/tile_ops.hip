@@ -1,0 +1,378 @@
+// Ring-panorama tile ops for gfx950: window gather / scatter with wrap-around in F, H, W, the fused
+// re-noise + mask-mix, and the fused CFG + DDIM update.  All are HBM-bound data movement / elementwise
+// work: 16-byte vector accesses along W when the window origin allows it, a scalar path otherwise.
+//
+// Bit-exactness contract: the fp32 arithmetic below repeats the reference's torch op sequence
+// (pipeline/scheduler.py:60-110, utils/tensor_utils.py:19-39) one rounding per op, so FMA contraction
+// is disabled for this translation unit.
+#pragma clang fp contract(off)
+#include "common.h"
+
+namespace {
+
+struct Origins {
+    int n;
+    int f0[DS_MAX_WINDOWS], y0[DS_MAX_WINDOWS], x0[DS_MAX_WINDOWS];
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// gather: tiles[i][c][f][y][x] = pano[c][(f0+f)%F][(y0+y)%H][(x0+x)%W]
+// VEC = elements moved per thread along x (1 = scalar fallback). The vector path requires
+// x0 % VEC == 0, W % VEC == 0, tw % VEC == 0 so a group never straddles the seam and stays aligned.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) ring_gather_kernel(const T* __restrict__ pano, T* __restrict__ tiles,
+                                                          ds_ring_geom g, Origins o) {
+    const int twv = g.tw / VEC;
+    const long per_tile = (long)g.C * g.tf * g.th * twv;
+    const long total = per_tile * o.n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int i = (int)(idx / per_tile);
+        long r = idx - (long)i * per_tile;
+        int xv = (int)(r % twv); r /= twv;
+        int y = (int)(r % g.th); r /= g.th;
+        int f = (int)(r % g.tf);
+        int c = (int)(r / g.tf);
+        int sf = (o.f0[i] + f) % g.F;
+        int sy = (o.y0[i] + y) % g.H;
+        int sx = (o.x0[i] + xv * VEC) % g.W;
+        const T* src = pano + (((long)c * g.F + sf) * g.H + sy) * g.W + sx;
+        T* dst = tiles + idx * VEC;
+        if (VEC == 1) {
+            *dst = *src;
+        } else {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+        }
+    }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) ring_gather_mask_kernel(const uint8_t* __restrict__ pano,
+                                                               uint8_t* __restrict__ tiles, ds_ring_geom g, Origins o) {
+    const int twv = g.tw / VEC;
+    const long per_tile = (long)g.tf * g.th * twv;
+    const long total = per_tile * o.n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int i = (int)(idx / per_tile);
+        long r = idx - (long)i * per_tile;
+        int xv = (int)(r % twv); r /= twv;
+        int y = (int)(r % g.th);
+        int f = (int)(r / g.th);
+        int sf = (o.f0[i] + f) % g.F;
+        int sy = (o.y0[i] + y) % g.H;
+        int sx = (o.x0[i] + xv * VEC) % g.W;
+        const uint8_t* src = pano + ((long)sf * g.H + sy) * g.W + sx;
+        uint8_t* dst = tiles + idx * VEC;
+        if (VEC == 1) {
+            *dst = *src;
+        } else {
+            *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scatter3: pano_lat <- x_prev, pano_x0 <- x0, mask <- 1 (overwrite; windows of a launch are disjoint)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) ring_scatter3_kernel(T* __restrict__ pano_lat, T* __restrict__ pano_x0,
+                                                            uint8_t* __restrict__ mask, const T* __restrict__ xprev,
+                                                            const T* __restrict__ x0t, ds_ring_geom g, Origins o) {
+    const int twv = g.tw / VEC;
+    const long per_tile = (long)g.C * g.tf * g.th * twv;
+    const long total = per_tile * o.n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int i = (int)(idx / per_tile);
+        long r = idx - (long)i * per_tile;
+        int xv = (int)(r % twv); r /= twv;
+        int y = (int)(r % g.th); r /= g.th;
+        int f = (int)(r % g.tf);
+        int c = (int)(r / g.tf);
+        int sf = (o.f0[i] + f) % g.F;
+        int sy = (o.y0[i] + y) % g.H;
+        int sx = (o.x0[i] + xv * VEC) % g.W;
+        long plane = ((long)sf * g.H + sy) * g.W + sx;
+        long dst = (long)c * g.F * g.H * g.W + plane;
+        if (VEC == 1) {
+            if (pano_lat) pano_lat[dst] = xprev[idx];
+            if (pano_x0) pano_x0[dst] = x0t[idx];
+            if (mask && c == 0) mask[plane] = 1;
+        } else {
+            if (pano_lat) *reinterpret_cast<uint4*>(pano_lat + dst) = *reinterpret_cast<const uint4*>(xprev + idx * VEC);
+            if (pano_x0) *reinterpret_cast<uint4*>(pano_x0 + dst) = *reinterpret_cast<const uint4*>(x0t + idx * VEC);
+            if (mask && c == 0) {
+                if (VEC == 8) *reinterpret_cast<uint2*>(mask + plane) = make_uint2(0x01010101u, 0x01010101u);
+                else *reinterpret_cast<uint32_t*>(mask + plane) = 0x01010101u;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller (perf-mode noise; NOT the torch CPU stream)
+// ---------------------------------------------------------------------------------------------
+__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                     uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ inline void normal4(uint64_t seed, uint64_t ctr, float z[4]) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float two_pi = 6.283185307179586f;
+    // (0,1] uniforms
+    float u0 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u1 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+    float u2 = ((float)(r[2] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u3 = (float)(r[3] >> 8) * (1.0f / 16777216.0f);
+    float ra = sqrtf(-2.0f * __logf(u0)), rb = sqrtf(-2.0f * __logf(u2));
+    z[0] = ra * __cosf(two_pi * u1);
+    z[1] = ra * __sinf(two_pi * u1);
+    z[2] = rb * __cosf(two_pi * u3);
+    z[3] = rb * __sinf(two_pi * u3);
+}
+
+template <typename T> __device__ inline float ldf(const T* p, long i) { return (float)p[i]; }
+template <typename T> __device__ inline void stf(T* p, long i, float v) { p[i] = (T)v; }
+
+// ---------------------------------------------------------------------------------------------
+// renoise + mix, 4 elements per thread along x (tw % 4 == 0 required by the host wrapper, else VEC=1)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) renoise_mix_kernel(T* __restrict__ tiles, const uint8_t* __restrict__ mask,
+                                                          const T* __restrict__ noise, float c, float s, float ratio,
+                                                          float one_minus_ratio, int mask_frame0, uint64_t seed,
+                                                          uint64_t offset, ds_ring_geom g, int n) {
+    const int twv = g.tw / VEC;
+    const long plane = (long)g.th * g.tw;
+    const long per_tile_v = (long)g.C * g.tf * g.th * twv;
+    const long total = per_tile_v * n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int i = (int)(idx / per_tile_v);
+        long r = idx - (long)i * per_tile_v;
+        int xv = (int)(r % twv); r /= twv;
+        int y = (int)(r % g.th); r /= g.th;
+        int f = (int)(r % g.tf);
+        long e0 = idx * VEC;
+        long m0 = ((long)i * g.tf + (mask_frame0 ? 0 : f)) * plane + (long)y * g.tw + (long)xv * VEC;
+        float z[4];
+        if (!noise) normal4(seed, offset + (uint64_t)idx, z);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float x = ldf(tiles, e0 + j);
+            float zz = noise ? ldf(noise, e0 + j) : z[j & 3];
+            float m = (float)mask[m0 + j];
+            // scheduler.py:108  x_b = c * x_a + s * eps
+            float t1 = c * x;
+            float t2 = s * zz;
+            float noised = t1 + t2;
+            // tensor_utils.py:30-37
+            float w1 = x * one_minus_ratio;
+            float w2 = noised * ratio;
+            float mixed = w1 + w2;
+            float non_mask = x * (1.0f - m);
+            float mask_area = mixed * m;
+            stf(tiles, e0 + j, non_mask + mask_area);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CFG + DDIM
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename E>
+__global__ void __launch_bounds__(256) cfg_ddim_kernel(const T* __restrict__ x, const E* __restrict__ ec,
+                                                       const E* __restrict__ eu, float guidance, float sq1m,
+                                                       float sqrt_at, float sqrt_aprev, float dir_coef, float sigma,
+                                                       const T* __restrict__ noise, T* __restrict__ xprev,
+                                                       T* __restrict__ x0o, long total) {
+    for (long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; idx < total;
+         idx += (long)gridDim.x * blockDim.x * 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            long k = idx + j;
+            if (k >= total) break;
+            float xv = (float)x[k];
+            float e = (float)ec[k];
+            if (eu) {
+                float u = (float)eu[k];
+                float d = e - u;          // t2v_sphere_panorama_pipeline.py:599
+                float gd = guidance * d;
+                e = u + gd;
+            }
+            float a = sq1m * e;           // scheduler.py:83
+            float num = xv - a;
+            float p0 = num / sqrt_at;
+            float dir = dir_coef * e;     // :85
+            float b = sqrt_aprev * p0;    // :89
+            float xp = b + dir;
+            float nz = noise ? sigma * (float)noise[k] : 0.0f;
+            xp = xp + nz;
+            xprev[k] = (T)xp;
+            x0o[k] = (T)p0;
+        }
+    }
+}
+
+int fill_origins(Origins& o, const ds_ring_geom* g, const int32_t* origins, int n, const char* who) {
+    DS_CHECK_ARG(g && origins, "%s: null geom/origins", who);
+    DS_CHECK_ARG(n >= 1 && n <= DS_MAX_WINDOWS, "%s: n=%d out of [1,%d]", who, n, DS_MAX_WINDOWS);
+    DS_CHECK_ARG(g->C > 0 && g->F > 0 && g->H > 0 && g->W > 0 && g->tf > 0 && g->th > 0 && g->tw > 0,
+                 "%s: non-positive geometry", who);
+    DS_CHECK_ARG(g->dtype == DS_F16 || g->dtype == DS_F32, "%s: dtype must be DS_F16/DS_F32", who);
+    o.n = n;
+    for (int i = 0; i < n; ++i) {
+        int f0 = origins[3 * i], y0 = origins[3 * i + 1], x0 = origins[3 * i + 2];
+        // RingLatent asserts 0 <= lo < hi <= 2*size (shift_window_utils.py:73-75)
+        DS_CHECK_ARG(f0 >= 0 && f0 + g->tf <= 2 * g->F, "%s: Invalid frame_begin %d and frame_end %d", who, f0, f0 + g->tf);
+        DS_CHECK_ARG(y0 >= 0 && y0 + g->th <= 2 * g->H, "%s: Invalid pos_top %d and pos_down %d", who, y0, y0 + g->th);
+        DS_CHECK_ARG(x0 >= 0 && x0 + g->tw <= 2 * g->W, "%s: Invalid pos_left %d and pos_right %d", who, x0, x0 + g->tw);
+        o.f0[i] = f0; o.y0[i] = y0; o.x0[i] = x0;
+    }
+    return DS_OK;
+}
+
+bool vec_ok(const ds_ring_geom* g, const Origins& o, int vec) {
+    if (g->W % vec || g->tw % vec) return false;
+    for (int i = 0; i < o.n; ++i)
+        if (o.x0[i] % vec) return false;
+    return true;
+}
+
+inline int grid_for(long work) {
+    long b = (work + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" int ds_ring_gather(const void* pano, const uint8_t* mask_pano, void* tiles, uint8_t* mask_tiles,
+                              const ds_ring_geom* g, const int32_t* origins, int n, void* stream) {
+    Origins o;
+    int rc = fill_origins(o, g, origins, n, "ds_ring_gather");
+    if (rc) return rc;
+    DS_CHECK_ARG((pano && tiles) || (mask_pano && mask_tiles), "ds_ring_gather: nothing to gather");
+    DS_CHECK_ARG((mask_pano == nullptr) == (mask_tiles == nullptr), "ds_ring_gather: mask_pano/mask_tiles must both be set or both NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (pano) {
+        if (g->dtype == DS_F16) {
+            if (vec_ok(g, o, 8)) {
+                long work = (long)n * g->C * g->tf * g->th * (g->tw / 8);
+                ring_gather_kernel<f16, 8><<<grid_for(work), 256, 0, st>>>((const f16*)pano, (f16*)tiles, *g, o);
+            } else {
+                long work = (long)n * g->C * g->tf * g->th * g->tw;
+                ring_gather_kernel<f16, 1><<<grid_for(work), 256, 0, st>>>((const f16*)pano, (f16*)tiles, *g, o);
+            }
+        } else {
+            if (vec_ok(g, o, 4)) {
+                long work = (long)n * g->C * g->tf * g->th * (g->tw / 4);
+                ring_gather_kernel<float, 4><<<grid_for(work), 256, 0, st>>>((const float*)pano, (float*)tiles, *g, o);
+            } else {
+                long work = (long)n * g->C * g->tf * g->th * g->tw;
+                ring_gather_kernel<float, 1><<<grid_for(work), 256, 0, st>>>((const float*)pano, (float*)tiles, *g, o);
+            }
+        }
+        DS_CHECK_LAUNCH("ds_ring_gather");
+    }
+    if (mask_pano) {
+        if (vec_ok(g, o, 8)) {
+            long work = (long)n * g->tf * g->th * (g->tw / 8);
+            ring_gather_mask_kernel<8><<<grid_for(work), 256, 0, st>>>(mask_pano, mask_tiles, *g, o);
+        } else {
+            long work = (long)n * g->tf * g->th * g->tw;
+            ring_gather_mask_kernel<1><<<grid_for(work), 256, 0, st>>>(mask_pano, mask_tiles, *g, o);
+        }
+        DS_CHECK_LAUNCH("ds_ring_gather(mask)");
+    }
+    return DS_OK;
+}
+
+extern "C" int ds_ring_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const void* x_prev_tiles,
+                                const void* x0_tiles, const ds_ring_geom* g, const int32_t* origins, int n,
+                                void* stream) {
+    Origins o;
+    int rc = fill_origins(o, g, origins, n, "ds_ring_scatter3");
+    if (rc) return rc;
+    // set_window_latent asserts the window does not overlap itself (shift_window_utils.py:145-147)
+    DS_CHECK_ARG(g->tw <= g->W && g->th <= g->H && g->tf <= g->F, "ds_ring_scatter3: warp should not occur");
+    DS_CHECK_ARG(!pano_latent || x_prev_tiles, "ds_ring_scatter3: pano_latent without x_prev_tiles");
+    DS_CHECK_ARG(!pano_x0 || x0_tiles, "ds_ring_scatter3: pano_x0 without x0_tiles");
+    hipStream_t st = (hipStream_t)stream;
+    if (g->dtype == DS_F16) {
+        if (vec_ok(g, o, 8)) {
+            long work = (long)n * g->C * g->tf * g->th * (g->tw / 8);
+            ring_scatter3_kernel<f16, 8><<<grid_for(work), 256, 0, st>>>((f16*)pano_latent, (f16*)pano_x0, mask_pano,
+                                                                        (const f16*)x_prev_tiles, (const f16*)x0_tiles, *g, o);
+        } else {
+            long work = (long)n * g->C * g->tf * g->th * g->tw;
+            ring_scatter3_kernel<f16, 1><<<grid_for(work), 256, 0, st>>>((f16*)pano_latent, (f16*)pano_x0, mask_pano,
+                                                                        (const f16*)x_prev_tiles, (const f16*)x0_tiles, *g, o);
+        }
+    } else {
+        if (vec_ok(g, o, 4)) {
+            long work = (long)n * g->C * g->tf * g->th * (g->tw / 4);
+            ring_scatter3_kernel<float, 4><<<grid_for(work), 256, 0, st>>>((float*)pano_latent, (float*)pano_x0, mask_pano,
+                                                                          (const float*)x_prev_tiles, (const float*)x0_tiles, *g, o);
+        } else {
+            long work = (long)n * g->C * g->tf * g->th * g->tw;
+            ring_scatter3_kernel<float, 1><<<grid_for(work), 256, 0, st>>>((float*)pano_latent, (float*)pano_x0, mask_pano,
+                                                                          (const float*)x_prev_tiles, (const float*)x0_tiles, *g, o);
+        }
+    }
+    DS_CHECK_LAUNCH("ds_ring_scatter3");
+    return DS_OK;
+}
+
+extern "C" int ds_renoise_mix(void* tiles, const uint8_t* mask_tiles, const void* noise, float c, float s,
+                              float ratio, float one_minus_ratio, int mask_frame0, uint64_t seed, uint64_t offset,
+                              const ds_ring_geom* g, int n, void* stream) {
+    DS_CHECK_ARG(tiles && mask_tiles && g, "ds_renoise_mix: null argument");
+    DS_CHECK_ARG(n >= 1, "ds_renoise_mix: n=%d", n);
+    DS_CHECK_ARG(g->dtype == DS_F16 || g->dtype == DS_F32, "ds_renoise_mix: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = (g->tw % 4) == 0;
+    long work = (long)n * g->C * g->tf * g->th * (v4 ? g->tw / 4 : g->tw);
+    if (g->dtype == DS_F16) {
+        if (v4) renoise_mix_kernel<f16, 4><<<grid_for(work), 256, 0, st>>>((f16*)tiles, mask_tiles, (const f16*)noise, c, s, ratio, one_minus_ratio, mask_frame0, seed, offset, *g, n);
+        else renoise_mix_kernel<f16, 1><<<grid_for(work), 256, 0, st>>>((f16*)tiles, mask_tiles, (const f16*)noise, c, s, ratio, one_minus_ratio, mask_frame0, seed, offset, *g, n);
+    } else {
+        if (v4) renoise_mix_kernel<float, 4><<<grid_for(work), 256, 0, st>>>((float*)tiles, mask_tiles, (const float*)noise, c, s, ratio, one_minus_ratio, mask_frame0, seed, offset, *g, n);
+        else renoise_mix_kernel<float, 1><<<grid_for(work), 256, 0, st>>>((float*)tiles, mask_tiles, (const float*)noise, c, s, ratio, one_minus_ratio, mask_frame0, seed, offset, *g, n);
+    }
+    DS_CHECK_LAUNCH("ds_renoise_mix");
+    return DS_OK;
+}
+
+extern "C" int ds_cfg_ddim(const void* x, const void* eps_c, const void* eps_u, int eps_dtype, float guidance,
+                           float sqrt_one_minus_at, float sqrt_at, float sqrt_a_prev, float dir_coef, float sigma,
+                           const void* noise, void* x_prev, void* x0, const ds_ring_geom* g, int n, void* stream) {
+    DS_CHECK_ARG(x && eps_c && x_prev && x0 && g, "ds_cfg_ddim: null argument");
+    DS_CHECK_ARG(n >= 1, "ds_cfg_ddim: n=%d", n);
+    DS_CHECK_ARG(sigma == 0.0f || noise, "ds_cfg_ddim: sigma != 0 needs a noise tensor");
+    DS_CHECK_ARG(eps_dtype == DS_F16 || eps_dtype == DS_F32, "ds_cfg_ddim: bad eps dtype");
+    hipStream_t st = (hipStream_t)stream;
+    long total = (long)n * g->C * g->tf * g->th * g->tw;
+    int grid = grid_for((total + 3) / 4);
+#define DS_LAUNCH_CFG(T, E)                                                                                         \
+    cfg_ddim_kernel<T, E><<<grid, 256, 0, st>>>((const T*)x, (const E*)eps_c, (const E*)eps_u, guidance,            \
+                                                 sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, sigma,           \
+                                                 (const T*)noise, (T*)x_prev, (T*)x0, total)
+    if (g->dtype == DS_F16) {
+        if (eps_dtype == DS_F16) DS_LAUNCH_CFG(f16, f16); else DS_LAUNCH_CFG(f16, float);
+    } else {
+        if (eps_dtype == DS_F16) DS_LAUNCH_CFG(float, f16); else DS_LAUNCH_CFG(float, float);
+    }
+#undef DS_LAUNCH_CFG
+    DS_CHECK_LAUNCH("ds_cfg_ddim");
+    return DS_OK;
+}

@@ -1,0 +1,68 @@
+"""Host-side stand-in for the LatentDiffusion object the pipelines read (`pretrained_t2v`).
+
+Only the members on the hot path exist: `.model` (DiffusionWrapper around the HIP UNetModel), the schedule
+buffers of register_schedule (lvdm/models/ddpm3d.py:113-134), `get_learned_conditioning`, and the plain
+attributes the pipelines / scheduler read.  CLIP and the VAE are out of scope: the
+conditioner is any callable prompt-list -> [1, L, context_dim] tensor (synthetic embeddings in tests / bench).
+"""
+import importlib
+
+import torch
+import torch.nn as nn
+
+from .scheduler import DiffusionTables
+from .unet import UNetModel, DiffusionWrapper
+
+
+def get_obj_from_str(string):
+    module, cls = string.rsplit(".", 1)
+    return getattr(importlib.import_module(module, package=None), cls)
+
+
+def instantiate_from_config(config):
+    """utils/utils.py:56-71."""
+    if "target" not in config:
+        raise KeyError("Expected key `target` to instantiate.")
+    return get_obj_from_str(config["target"])(**config.get("params", dict()))
+
+
+class SyntheticConditioner:
+    """prompt -> seeded N(0,1) embedding [1, L, dim] (fp16-representable), "" -> a different seed."""
+
+    def __init__(self, length=77, dim=1024, cond_seed=1, uncond_seed=2):
+        from .synth import synth_normal
+        self.cond = synth_normal((1, length, dim), cond_seed)
+        self.uncond = synth_normal((1, length, dim), uncond_seed)
+
+    def __call__(self, prompts):
+        return self.uncond if prompts[0] == "" else self.cond
+
+
+class LatentDiffusionHost(nn.Module):
+    def __init__(self, unet_config, timesteps=1000, linear_start=0.00085, linear_end=0.012, uncond_type="empty_seq",
+                 use_scale=False, channels=4, conditioner=None, **_ignored):
+        super().__init__()
+        params = unet_config["params"] if "params" in unet_config else unet_config
+        self.model = DiffusionWrapper(UNetModel(**params), "crossattn")
+        tables = DiffusionTables(timesteps, linear_start, linear_end)
+        self.register_buffer("betas", tables.betas)
+        self.register_buffer("alphas_cumprod", tables.alphas_cumprod)
+        self.register_buffer("alphas_cumprod_prev", tables.alphas_cumprod_prev)
+        self.num_timesteps = tables.num_timesteps
+        self.use_scale = use_scale
+        self.uncond_type = uncond_type
+        self.channels = channels
+        self.temporal_length = params.get("temporal_length", 16)
+        self.first_stage_model = None
+        self.cond_stage_model = None
+        self.conditioner = conditioner
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def get_learned_conditioning(self, prompts):
+        if self.conditioner is None:
+            raise RuntimeError("no conditioner attached: CLIP is outside the hot-path scope (SURVEY.md 8-f N3); "
+                               "attach a callable prompts -> [1, L, context_dim] tensor")
+        return self.conditioner(prompts)

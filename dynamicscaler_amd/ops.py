@@ -1,0 +1,274 @@
+"""Thin torch-tensor front end over the C ABI (include/dynscaler_hip.h).
+
+torch is used for device memory and streams only; every computation below is a HIP kernel of
+libdynscaler_hip.so.  All launches go to torch's current stream (so torch.cuda.Event timing and graph
+capture see them).  There is no CPU path: tensors must live on a HIP device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (DS_F16, DS_F32, DS_A_DENSE, DS_A_CONV3, DS_A_TCONV, DS_EPI_GEGLU, DS_EPI_SILU,
+                   DS_EPI_OUT_F32, DS_MAX_WINDOWS, RingGeom, GemmDesc, check)
+
+_DT = {torch.float16: DS_F16, torch.float32: DS_F32}
+
+# optional per-launch timing hook used by bench.py: called as hook(name, flops, launch_callable)
+_timing_hook = None
+
+
+def set_timing_hook(hook):
+    global _timing_hook
+    _timing_hook = hook
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _dev(t, what):
+    if not t.is_cuda:
+        raise _lib.DsError(f"{what}: tensor is on {t.device}; the DynamicScaler hot path has no CPU fallback")
+    if not t.is_contiguous():
+        raise _lib.DsError(f"{what}: tensor must be contiguous")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ ring tile ops
+def _geom(pano_shape, tile_shape, dtype):
+    _, Cc, F, H, W = pano_shape
+    tf, th, tw = tile_shape
+    return RingGeom(Cc, F, H, W, tf, th, tw, _DT[dtype])
+
+
+def _origins(origins):
+    n = len(origins)
+    if not 1 <= n <= DS_MAX_WINDOWS:
+        raise _lib.DsError(f"need 1..{DS_MAX_WINDOWS} windows per launch, got {n}")
+    arr = (C.c_int32 * (3 * n))()
+    for i, (f0, y0, x0) in enumerate(origins):
+        arr[3 * i], arr[3 * i + 1], arr[3 * i + 2] = int(f0), int(y0), int(x0)
+    return arr, n
+
+
+def ring_gather(pano, origins, tile_fhw, mask_pano=None):
+    """pano [1,C,F,H,W] (fp16/fp32); origins [(f0,y0,x0)]; -> tiles [n,C,tf,th,tw] (+ mask tiles u8 [n,tf,th,tw])."""
+    _dev(pano, "ring_gather")
+    lib = _lib.load()
+    arr, n = _origins(origins)
+    tf, th, tw = tile_fhw
+    g = _geom(pano.shape, tile_fhw, pano.dtype)
+    tiles = torch.empty((n, pano.shape[1], tf, th, tw), dtype=pano.dtype, device=pano.device)
+    mtiles = None
+    if mask_pano is not None:
+        _dev(mask_pano, "ring_gather(mask)")
+        assert mask_pano.dtype == torch.uint8 and tuple(mask_pano.shape) == tuple(pano.shape[2:])
+        mtiles = torch.empty((n, tf, th, tw), dtype=torch.uint8, device=pano.device)
+    check(lib.ds_ring_gather(pano.data_ptr(), _ptr(mask_pano), tiles.data_ptr(), _ptr(mtiles), C.byref(g), arr, n,
+                             _stream()), "ds_ring_gather")
+    return tiles, mtiles
+
+
+def ring_gather_mask(mask_pano, pano_shape, origins, tile_fhw):
+    _dev(mask_pano, "ring_gather_mask")
+    lib = _lib.load()
+    arr, n = _origins(origins)
+    tf, th, tw = tile_fhw
+    g = _geom(pano_shape, tile_fhw, torch.float16)
+    mtiles = torch.empty((n, tf, th, tw), dtype=torch.uint8, device=mask_pano.device)
+    check(lib.ds_ring_gather(0, mask_pano.data_ptr(), 0, mtiles.data_ptr(), C.byref(g), arr, n, _stream()),
+          "ds_ring_gather(mask)")
+    return mtiles
+
+
+def ring_scatter3(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, origins):
+    ref = pano_latent if pano_latent is not None else pano_x0
+    src = x_prev_tiles if x_prev_tiles is not None else x0_tiles
+    _dev(ref, "ring_scatter3")
+    lib = _lib.load()
+    arr, n = _origins(origins)
+    tile_fhw = tuple(src.shape[2:])
+    # RingLatent.set_window_latent shape assert (shift_window_utils.py:190)
+    assert src.shape[0] == n and src.shape[1] == ref.shape[1], \
+        f"Input latent shape {tuple(src.shape)} does not match {n} windows of the panorama {tuple(ref.shape)}"
+    for t in (x_prev_tiles, x0_tiles):
+        if t is not None:
+            _dev(t, "ring_scatter3(tile)")
+            assert t.dtype == ref.dtype and tuple(t.shape) == tuple(src.shape)
+    g = _geom(ref.shape, tile_fhw, ref.dtype)
+    check(lib.ds_ring_scatter3(_ptr(pano_latent), _ptr(pano_x0), _ptr(mask_pano), _ptr(x_prev_tiles), _ptr(x0_tiles),
+                               C.byref(g), arr, n, _stream()), "ds_ring_scatter3")
+
+
+def renoise_mix_(tiles, mask_tiles, pano_shape, c, s, mix_ratio, noise=None, mask_frame0=True, seed=0, offset=0):
+    """In place: tiles <- mix(tiles, c*tiles + s*noise, mask, mix_ratio)."""
+    _dev(tiles, "renoise_mix")
+    _dev(mask_tiles, "renoise_mix(mask)")
+    lib = _lib.load()
+    n = tiles.shape[0]
+    g = _geom(pano_shape, tuple(tiles.shape[2:]), tiles.dtype)
+    if noise is not None:
+        _dev(noise, "renoise_mix(noise)")
+        assert noise.dtype == tiles.dtype and noise.shape == tiles.shape
+    ratio = float(mix_ratio)
+    check(lib.ds_renoise_mix(tiles.data_ptr(), mask_tiles.data_ptr(), _ptr(noise), float(c), float(s), ratio,
+                             float(1 - mix_ratio), int(bool(mask_frame0)), int(seed), int(offset), C.byref(g), n,
+                             _stream()), "ds_renoise_mix")
+    return tiles
+
+
+def cfg_ddim(x, eps_c, eps_u, pano_shape, guidance, coef, noise=None):
+    """Returns (x_prev, x0) tiles. coef: dict from the scheduler (sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, sigma)."""
+    _dev(x, "cfg_ddim")
+    _dev(eps_c, "cfg_ddim(eps_c)")
+    lib = _lib.load()
+    n = x.shape[0]
+    g = _geom(pano_shape, tuple(x.shape[2:]), x.dtype)
+    assert eps_c.shape == x.shape
+    if eps_u is not None:
+        _dev(eps_u, "cfg_ddim(eps_u)")
+        assert eps_u.shape == x.shape and eps_u.dtype == eps_c.dtype
+    x_prev = torch.empty_like(x)
+    x0 = torch.empty_like(x)
+    check(lib.ds_cfg_ddim(x.data_ptr(), eps_c.data_ptr(), _ptr(eps_u), _DT[eps_c.dtype], float(guidance),
+                          float(coef["sqrt_one_minus_at"]), float(coef["sqrt_at"]), float(coef["sqrt_a_prev"]),
+                          float(coef["dir_coef"]), float(coef["sigma"]), _ptr(noise), x_prev.data_ptr(), x0.data_ptr(),
+                          C.byref(g), n, _stream()), "ds_cfg_ddim")
+    return x_prev, x0
+
+
+# ------------------------------------------------------------------------------------------------ UNet ops
+def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE, lda=None, cin=None,
+         conv=None, tconv=None, bias_rows=None, ldbias=None, epilogue=0, stream=None):
+    """out[M, N'] = gatherA[M,K] @ W[N,K]^T with fused epilogue.  conv=(nimg,hin,win,hout,wout,stride,upsample),
+    tconv=(t_len,hw).  N' = N/2 for GEGLU."""
+    lib = _lib.load()
+    n_out = N // 2 if (epilogue & DS_EPI_GEGLU) else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float32 if (epilogue & DS_EPI_OUT_F32) else torch.float16,
+                          device=A.device)
+    d = GemmDesc()
+    d.M, d.N, d.K, d.a_mode = M, N, K, a_mode
+    d.cin = K if cin is None else cin
+    d.lda = d.cin if lda is None else lda
+    if conv is not None:
+        d.nimg, d.hin, d.win, d.hout, d.wout, d.stride, d.upsample = conv
+    if tconv is not None:
+        d.t_len, d.hw = tconv
+    d.ldc = out.stride(0)
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.bias_rows = M if bias_rows is None else bias_rows
+    d.ldbias = N if ldbias is None else ldbias
+    d.epilogue = epilogue
+    st = _stream() if stream is None else stream
+
+    def launch():
+        check(lib.ds_gemm_f16(A.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), C.byref(d), st),
+              "ds_gemm_f16")
+
+    if _timing_hook is not None:
+        _timing_hook("gemm", 2.0 * M * N * K, launch)
+    else:
+        launch()
+    return out
+
+
+def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    stats = torch.empty((2, ninst * groups), dtype=torch.float32, device=x.device)
+    ws = torch.empty((lib.ds_groupnorm_stats_workspace_floats(ninst, rows_per_inst, groups),), dtype=torch.float32,
+                     device=x.device)
+    check(lib.ds_groupnorm_stats(x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(), ninst,
+                                 rows_per_inst, Cch, groups, float(eps), st), "ds_groupnorm_stats")
+    y = torch.empty_like(x)
+    check(lib.ds_groupnorm_apply(x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(),
+                                 beta.data_ptr(), y.data_ptr(), ninst, rows_per_inst, Cch, groups, int(bool(silu)), st),
+          "ds_groupnorm_apply")
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    rows, Cch = x.shape
+    y = torch.empty_like(x)
+    check(lib.ds_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, Cch, float(eps), st),
+          "ds_layernorm")
+    return y
+
+
+def attention(q, k, v, out, *, batch, heads, nq, nk, ldq, ldk, ldv, ldo, kv_batch_div=1, scale, accumulate=False,
+              stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+
+    def launch():
+        check(lib.ds_attention_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), batch, heads, nq, nk, ldq,
+                                   ldk, ldv, ldo, kv_batch_div, float(scale), int(bool(accumulate)), st),
+              "ds_attention_f16")
+
+    if _timing_hook is not None:
+        _timing_hook("attention", 4.0 * batch * heads * nq * nk * 64, launch)
+    else:
+        launch()
+    return out
+
+
+def temporal_attention(q, k, v, out, *, nseq_batches, T, hw, heads, ldq, ldk, ldv, ldo, scale, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    check(lib.ds_temporal_attention_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nseq_batches, T, hw,
+                                        heads, ldq, ldk, ldv, ldo, float(scale), st), "ds_temporal_attention_f16")
+    return out
+
+
+def concat_channels(a, b, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    rows, c1 = a.shape
+    c2 = b.shape[1]
+    dst = torch.empty((rows, c1 + c2), dtype=a.dtype, device=a.device)
+    check(lib.ds_concat_channels(a.data_ptr(), b.data_ptr(), dst.data_ptr(), rows, c1, c2, st), "ds_concat_channels")
+    return dst
+
+
+def im2col_in(x, kpad, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    B, Cc, T, H, W = x.shape
+    patches = torch.empty((B * T * H * W, kpad), dtype=torch.float16, device=x.device)
+    check(lib.ds_im2col_in(x.data_ptr(), _DT[x.dtype], patches.data_ptr(), B, Cc, T, H, W, kpad, st), "ds_im2col_in")
+    return patches
+
+
+def rows_to_ncthw(y, shape, out_dtype, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    B, Cc, T, H, W = shape
+    out = torch.empty(shape, dtype=out_dtype, device=y.device)
+    check(lib.ds_rows_to_ncthw(y.data_ptr(), _DT[y.dtype], y.stride(0), out.data_ptr(), _DT[out_dtype], B, Cc, T, H, W,
+                               st), "ds_rows_to_ncthw")
+    return out
+
+
+def timestep_embedding(t, dim, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    assert t.dtype == torch.int64
+    out = torch.empty((t.shape[0], dim), dtype=torch.float16, device=t.device)
+    check(lib.ds_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, st), "ds_timestep_embedding")
+    return out
+
+
+def silu(x, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    y = torch.empty_like(x)
+    check(lib.ds_silu_f16(x.data_ptr(), y.data_ptr(), x.numel(), st), "ds_silu_f16")
+    return y

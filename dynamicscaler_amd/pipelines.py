@@ -1,0 +1,305 @@
+"""Panorama denoising pipelines (drop-in call surface of pipeline/t2v_normal_pipeline.py and
+pipeline/t2v_sphere_panorama_pipeline.py), MI355X host side.
+
+Same constructor `(pretrained_t2v, scheduler, model_config)`, same method names / keywords / return tuples
+(SURVEY.md 8-b).  What differs is underneath: the panorama, its pred-x0 twin and a 1-byte mask live in HBM for
+the whole loop; a DDIM step is cut into levels of independent windows (parallel.plan_levels) and each level is
+  ds_ring_gather (latent + mask, all windows of the level in one launch) -> ds_renoise_mix ->
+  ONE batched UNet evaluation for [cond | uncond] x windows -> ds_cfg_ddim -> ds_ring_scatter3
+instead of ~300 tiny torch launches per tile.  With torch.distributed initialised, a level's windows are shared
+out over the ranks and all-gathered back (parallel.exchange_level).
+"""
+import numpy as np
+import torch
+
+from . import ops, parallel
+from .ring import RingLatent, VAE_SCALE_FACTOR, ring_axis_steps, t2v_ring_windows
+
+
+def select_prompt_from_multi_prompt_dict_by_factor(prompt_dict, factor):
+    """utils/multi_prompt_utils.py:1-7."""
+    assert 0.0 <= factor <= 1.0, f"select_prompt: input factor {factor} not legal"
+    keys = sorted(prompt_dict.keys())
+    for key in keys:
+        if factor <= key:
+            return prompt_dict[key]
+    return prompt_dict[keys[-1]]
+
+
+class _ProgressBar:
+    def __init__(self, total):
+        self.total, self.n = total, 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def update(self, n=1):
+        self.n += n
+
+
+class VC2_Pipeline_T2V:
+    """pipeline/t2v_normal_pipeline.py:25-210 (diffusers.DiffusionPipeline is not needed: only register_modules,
+    progress_bar, _execution_device and .to are used by the reference)."""
+
+    def __init__(self, pretrained_t2v, scheduler, model_config=None):
+        self.pretrained_t2v = pretrained_t2v
+        self.scheduler = scheduler
+        self.vae = getattr(pretrained_t2v, "first_stage_model", None)
+        self.unet = pretrained_t2v.model.diffusion_model
+        self.text_encoder = getattr(pretrained_t2v, "cond_stage_model", None)
+        self.model_config = model_config
+        self.vae_scale_factor = VAE_SCALE_FACTOR
+        self._device = None
+        self.latent_dtype = torch.float16    # "fp16 latents" (BASELINE.json north_star); torch.float32 for bit-exact tile ops
+        self.max_tile_batch = 8              # windows per batched UNet evaluation (x2 with CFG)
+        self.verbose = False
+
+    # -- the bits of DiffusionPipeline the reference relies on --
+    def to(self, device=None, torch_dtype=None):
+        if device is not None:
+            self._device = torch.device(device)
+        if torch_dtype is not None:
+            self.latent_dtype = torch_dtype
+        return self
+
+    def progress_bar(self, total=None):
+        return _ProgressBar(total)
+
+    @property
+    def _execution_device(self):
+        if self._device is not None:
+            return self._device
+        if torch.cuda.is_available():
+            return torch.device("cuda", torch.cuda.current_device())
+        raise RuntimeError("no HIP device: the DynamicScaler hot path has no CPU fallback")
+
+    def _log(self, *a):
+        if self.verbose:
+            print(*a)
+
+    # -- conditioning --
+    def _encode(self, prompt, prompt_embeds, guidance_scale):
+        if prompt is not None and isinstance(prompt, str):
+            batch_size, prompt = 1, [prompt]
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        assert batch_size == 1, "the reference's latent init is only valid for batch 1 (t2v_sphere_panorama_pipeline.py:418)"
+        text_emb = self.pretrained_t2v.get_learned_conditioning(prompt)
+        uc_emb = None
+        if guidance_scale != 1.0:
+            uncond_type = self.pretrained_t2v.uncond_type
+            if uncond_type == "empty_seq":
+                uc_emb = self.pretrained_t2v.get_learned_conditioning(batch_size * [""])
+            elif uncond_type == "zero_embed":
+                uc_emb = torch.zeros_like(text_emb)
+            else:
+                raise NotImplementedError()
+        return prompt, text_emb, uc_emb
+
+    def _eps(self, x, t, ctx_list, fps, frames, **kwargs):
+        """One batched evaluation of pretrained_t2v.model: x [n,C,T,h,w], ctx_list n context tensors [1,L,D]."""
+        n = x.shape[0]
+        ts = torch.full((n,), int(t), device=x.device, dtype=torch.long)
+        ctx = torch.cat([c.to(x.device) for c in ctx_list], dim=0)
+        return self.pretrained_t2v.model(x, ts, c_crossattn=[ctx], fps=fps, curr_time_steps=ts,
+                                         temporal_length=frames, **kwargs)
+
+    @torch.no_grad()
+    def basic_sample(self, prompt=None, height=320, width=512, frames=16, fps=16, guidance_scale=7.5,
+                     num_videos_per_prompt=1, generator=None, latents=None, num_inference_steps=4, prompt_embeds=None,
+                     output_type="pil", skip_time_step_idx=None, **kwargs):
+        """Single-tile loop (t2v_normal_pipeline.py:69-210).  Returns (videos | denoised, denoised) where
+        `denoised` is the pred_x0 of the LAST step (:205-210)."""
+        unet_config = self.model_config["params"]["unet_config"]
+        frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
+        device = self._execution_device
+        prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
+        self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
+        timesteps = np.flip(self.scheduler.ddim_timesteps)
+        if skip_time_step_idx is not None:
+            timesteps = timesteps[skip_time_step_idx:]
+        total_steps = self.scheduler.ddim_timesteps.shape[0]
+        if latents is None:
+            assert (skip_time_step_idx is None) or (skip_time_step_idx == 0), \
+                "[basic_sample] skip time step should only work with prepared non full noise latents"
+            c = unet_config["params"]["in_channels"]
+            shape = (1, 1, c, frames, height // self.vae_scale_factor, width // self.vae_scale_factor)
+            latents = torch.randn(shape)[0]  # host draw, reference order
+        latents = latents.to(device=device, dtype=self.latent_dtype).contiguous()
+        kwargs.update({"clean_cond": True})
+        denoised = None
+        pano_shape = (1,) + tuple(latents.shape[1:])
+        with self.progress_bar(total=len(timesteps)) as bar:
+            for i, t in enumerate(timesteps):
+                if guidance_scale != 1.0:
+                    eps = self._eps(torch.cat([latents, latents], 0), t, [text_emb, uc_emb], fps, frames, **kwargs)
+                    e_c, e_u = eps[:1].contiguous(), eps[1:].contiguous()
+                else:
+                    e_c, e_u = self._eps(latents, t, [text_emb], fps, frames, **kwargs), None
+                index = total_steps - i - 1
+                coef = self.scheduler.step_coefficients(index)
+                noise = self.scheduler.draw_step_noise(tuple(latents.shape), device, latents.dtype, coef["sigma"])
+                latents, denoised = ops.cfg_ddim(latents, e_c, e_u, pano_shape, guidance_scale, coef, noise)
+                bar.update()
+        if not output_type == "latent":
+            videos = self.pretrained_t2v.decode_first_stage_2DAE(denoised)
+        else:
+            videos = denoised
+        return videos, denoised
+
+
+class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
+    """pipeline/t2v_sphere_panorama_pipeline.py:20 -- the overlapped-ring plane loop (:316-660), which is the path
+    all BASELINE configs take."""
+
+    @torch.no_grad()
+    def basic_sample_shift_multi_windows(self, prompt=None, height=320, width=512, frames=16, fps=16,
+                                         guidance_scale=7.5, num_videos_per_prompt=1, generator=None,
+                                         init_panorama_latent=None, total_w=None, total_h=None, num_windows_w=None,
+                                         num_windows_h=None, num_windows_f=None, loop_step=None, dock_at_h=None,
+                                         latents=None, num_inference_steps=4, prompt_embeds=None, output_type="pil",
+                                         merge_renoised_overlap_latent_ratio=1, window_multi_prompt_dict=None,
+                                         use_skip_time=False, skip_time_step_idx=None, progressive_skip=False,
+                                         step_callback=None, **kwargs):
+        unet_config = self.model_config["params"]["unet_config"]
+        frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
+        device = self._execution_device
+        prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
+        self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
+        timesteps = np.flip(self.scheduler.ddim_timesteps)
+        if use_skip_time and not progressive_skip:
+            timesteps = timesteps[skip_time_step_idx:]
+        total_steps = len(timesteps)
+        vs = self.vae_scale_factor
+        c_lat = unet_config["params"]["in_channels"]
+        lat_h, lat_w = height // vs, width // vs
+        total_shape = (1, c_lat, frames * num_windows_f, total_h // vs, total_w // vs)
+        if init_panorama_latent is None:
+            init_panorama_latent = torch.randn(total_shape)  # host draw (global CPU generator), reference order
+            if use_skip_time:
+                raise NotImplementedError  # same as the reference (:420-422)
+        else:
+            assert tuple(init_panorama_latent.shape) == total_shape, \
+                f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_panorama_latent.shape)} " \
+                f"does not match desired shape {total_shape}"
+        in_device = init_panorama_latent.device
+        pano = init_panorama_latent.to(device=device, dtype=self.latent_dtype).contiguous().clone()
+        pano_x0 = torch.zeros_like(pano)
+        mask = torch.zeros(total_shape[2:], dtype=torch.uint8, device=device)  # 1 byte per (f,y,x)
+
+        ov_w, step_w, off_w = ring_axis_steps(total_w, width, num_windows_w, loop_step)
+        assert 0 <= ov_w < 1, "overlap ratio for W is not legal"
+        assert off_w, "latent_offset_step_size_w <= 0 ! consider increase W windows"
+        ov_h, step_h, off_h = ring_axis_steps(total_h, height, num_windows_h, loop_step)
+        assert 0 <= ov_h < 1, "overlap ratio for H is not legal"
+        assert off_h > 0, "latent_offset_step_size_h <= 0 ! consider increase H windows"
+        step_f = frames // loop_step
+        if num_windows_f == 1:
+            step_f = 0
+        assert step_f > 0 or num_windows_f == 1, \
+            f"[basic_sample_shift_multi_windows] loop_step {loop_step} > frames {frames} while num_windows_f {num_windows_f} > 0"
+
+        rank, world = 0, 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        tile_fhw = (frames, lat_h, lat_w)
+        tile_shape = (1, c_lat) + tile_fhw
+        pano_fhw = tuple(total_shape[2:])
+        sched = self.scheduler
+        kwargs.update({"clean_cond": True})
+        prompt_cache = {}
+        ratio = merge_renoised_overlap_latent_ratio
+
+        with self.progress_bar(total=len(timesteps)) as bar:
+            for i, t in enumerate(timesteps):
+                mask.zero_()  # fresh mask every step (:494)
+                wins = t2v_ring_windows(i, latent_h=lat_h, latent_w=lat_w, frames=frames, total_latent_h=total_h // vs,
+                                        step_w=step_w, step_h=step_h, off_w=off_w, off_h=off_h, step_f=step_f,
+                                        num_windows_w=num_windows_w, num_windows_h=num_windows_h,
+                                        num_windows_f=num_windows_f, loop_step=loop_step, dock_at_h=dock_at_h)
+                renoise = ratio is not None and i < total_steps - 1
+                index = total_steps - i - 1
+                coef = sched.step_coefficients(index)
+                # host noise for the whole step in the reference's tile order (appendix B): randn_like(tile) of
+                # re_noise, then `frames` per-frame draws of ddim_step -- per window
+                noises = []
+                for _ in wins:
+                    nz = sched.draw_renoise_noise(tile_shape, "cpu", torch.float32) if renoise else None
+                    sn = sched.draw_step_noise(tile_shape, "cpu", torch.float32, coef["sigma"])
+                    noises.append((nz, sn))
+                if renoise:
+                    c_rn, s_rn = sched.renoise_coefficients(total_steps - i - 2, total_steps - i - 1)
+                # per-window prompt (R13): embeddings cached per distinct prompt instead of re-running CLIP per tile
+                ctxs = []
+                for (l, r, tp, dn, fb, fe) in wins:
+                    if window_multi_prompt_dict is not None:
+                        cur = select_prompt_from_multi_prompt_dict_by_factor(window_multi_prompt_dict,
+                                                                              dn / (total_h // vs))
+                        if cur not in prompt_cache:
+                            prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur])
+                        ctxs.append(prompt_cache[cur])
+                    else:
+                        ctxs.append(text_emb)
+                self._log(f"i = {i}, t = {t}: {len(wins)} windows")
+                for level in parallel.plan_levels(wins, pano_fhw):
+                    mine = parallel.rank_share(level, rank, world)
+                    xp_parts, x0_parts = [], []
+                    for s in range(0, len(mine), self.max_tile_batch):
+                        ids = mine[s:s + self.max_tile_batch]
+                        origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
+                        tiles, mtiles = ops.ring_gather(pano, origins, tile_fhw, mask)
+                        if renoise:
+                            nz = None
+                            if noises[ids[0]][0] is not None:
+                                nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=pano.dtype)
+                            ops.renoise_mix_(tiles, mtiles, total_shape, c_rn, s_rn, ratio, noise=nz, mask_frame0=True,
+                                             seed=sched.philox_seed,
+                                             offset=(i * len(wins) + ids[0]) * tiles[0].numel())
+                        n = len(ids)
+                        if guidance_scale != 1.0:
+                            eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [uc_emb] * n,
+                                            fps, frames, **kwargs)
+                            e_c, e_u = eps[:n], eps[n:]
+                        else:
+                            e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], fps, frames, **kwargs), None
+                        sn = None
+                        if coef["sigma"] != 0.0:
+                            sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=pano.dtype)
+                        x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, total_shape, guidance_scale, coef, sn)
+                        xp_parts.append(x_prev)
+                        x0_parts.append(x0)
+                    if world > 1:
+                        empty = torch.empty((0,) + tile_shape[1:], dtype=pano.dtype, device=device)
+                        xp_l = torch.cat(xp_parts, 0) if xp_parts else empty
+                        x0_l = torch.cat(x0_parts, 0) if x0_parts else empty
+                        xp_all, x0_all = parallel.exchange_level(xp_l, x0_l, len(level))
+                        order = level
+                    else:
+                        xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
+                    for s in range(0, len(order), ops.DS_MAX_WINDOWS):
+                        ids = order[s:s + ops.DS_MAX_WINDOWS]
+                        origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
+                        ops.ring_scatter3(pano, pano_x0, mask, xp_all[s:s + len(ids)].contiguous(),
+                                          x0_all[s:s + len(ids)].contiguous(), origins)
+                if step_callback is not None:
+                    step_callback(i, int(t), wins, pano, pano_x0)
+                bar.update()
+
+        self.final_latent = pano  # x_t panorama after the last step (not returned by the reference's ring variant)
+        denoised = pano_x0.clone().to(device=in_device) if in_device.type == "cuda" else pano_x0.clone()
+        if not output_type == "latent":
+            # seam-safe decode (:638-655): pad W with wrapped 1/16 chunks, decode per frame, crop
+            chunks = list(torch.chunk(denoised, 16, dim=4))
+            padded = torch.cat([chunks[-1]] + chunks + [chunks[0]], dim=4)
+            frames_out = [self.pretrained_t2v.decode_first_stage_2DAE(padded[:, :, [f]])
+                          for f in range(frames * num_windows_f)]
+            videos = torch.cat(frames_out, dim=2)
+            videos = torch.cat(torch.chunk(videos, 18, dim=4)[1:-1], dim=4)
+        else:
+            videos = denoised
+        return videos, denoised

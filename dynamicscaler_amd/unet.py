@@ -1,0 +1,414 @@
+"""UNetModel -- MI355X host side of the VideoCrafter LVDM 3D-UNet.
+
+Drop-in for `lvdm.modules.networks.openaimodel3d.UNetModel` (openaimodel3d.py:312-708): same constructor
+keywords (the yaml `unet_config.params`), same `forward(x, timesteps, context, features_adapter, fps,
+timestep_cond, **kwargs)`, same state-dict keys.  The arithmetic is NOT torch: the parameters are repacked once
+into the layouts the HIP kernels want (fp16 [N][K] GEMM operands, fused QKV / KV / GEGLU-interleaved / all
+time-embedding projections in one matrix) and the forward is a flat program of C-ABI kernel launches on
+channel-contiguous "NTHWC" fp16 activations.  There is no CPU fallback.
+
+Beyond the reference (which only runs batch 1): a batch of b independent evaluations
+(cond + uncond CFG branches, several tiles) shares one launch sequence; results per item are those of b
+separate b=1 forwards.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import DS_A_CONV3, DS_A_TCONV, DS_EPI_GEGLU, DS_EPI_SILU, DS_EPI_OUT_F32
+from .unet_spec import build_program, param_shapes
+
+HEAD_DIM = 64
+
+
+class _Container(nn.Module):
+    """Name-only node of the parameter tree (keeps the reference's state-dict keys)."""
+
+
+def _interleave_geglu(w):
+    """[2*inner, ...] rows (x half | gate half) -> 64-row groups [x_g | gate_g] (DS_EPI_GEGLU layout)."""
+    inner = w.shape[0] // 2
+    assert inner % 64 == 0, "GEGLU inner dim must be a multiple of 64"
+    x, g = w[:inner], w[inner:]
+    xs = x.reshape(inner // 64, 64, *w.shape[1:])
+    gs = g.reshape(inner // 64, 64, *w.shape[1:])
+    return torch.cat([xs, gs], dim=1).reshape(w.shape)
+
+
+class UNetModel(nn.Module):
+    def __init__(self, **params):
+        super().__init__()
+        self.cfg, self._inputs, self._middle, self._outputs = build_program(params)
+        cfg = self.cfg
+        self.in_channels = cfg["in_channels"]
+        self.model_channels = cfg["model_channels"]
+        self.out_channels = cfg["out_channels"]
+        self.num_res_blocks = cfg["num_res_blocks"]
+        self.attention_resolutions = cfg["attention_resolutions"]
+        self.channel_mult = cfg["channel_mult"]
+        self.temporal_attention = cfg["temporal_attention"]
+        self.addition_attention = cfg["addition_attention"]
+        self.use_image_attention = cfg["use_image_attention"]
+        self.fps_cond = cfg["fps_cond"]
+        self.dtype = torch.float16 if cfg["use_fp16"] else torch.float32  # attribute read by callers
+        if cfg["num_head_channels"] != HEAD_DIM and cfg["num_head_channels"] != -1:
+            raise NotImplementedError("the HIP attention kernels are built for head_dim 64 (the VideoCrafter configs)")
+        if cfg["time_cond_proj_dim"] is not None:
+            raise NotImplementedError("time_cond_proj_dim is not used by DynamicScaler")
+        self._shapes = param_shapes(params)
+        for key, shape in self._shapes.items():
+            node = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, _Container())
+                node = getattr(node, p)
+            node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape), requires_grad=False))
+        self._packed = None
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def invalidate(self):
+        """Call after mutating parameters in place."""
+        self._packed = None
+
+    @torch.no_grad()
+    def prepare(self, device=None):
+        """Repack parameters for the kernels (fp16 GEMM operands, fp32 biases / norm affine)."""
+        sd = dict(self.named_parameters())
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("UNetModel runs on an MI355X only (no CPU path): move the model / inputs to a HIP device")
+        P = {}
+
+        def w16(t):
+            return t.detach().to(dev, torch.float16).contiguous()
+
+        def f32(t):
+            return t.detach().to(dev, torch.float32).contiguous()
+
+        def lin(prefix, bias=True):
+            w = sd[prefix + ".weight"]
+            P[prefix + ".w"] = w16(w.reshape(w.shape[0], -1))
+            if bias:
+                P[prefix + ".b"] = f32(sd[prefix + ".bias"])
+
+        def conv3(prefix):
+            w = sd[prefix + ".weight"]  # [Cout, Cin, 3, 3] -> [Cout, (ky,kx,c)]
+            P[prefix + ".w"] = w16(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
+            P[prefix + ".b"] = f32(sd[prefix + ".bias"])
+
+        def tconv(prefix):
+            w = sd[prefix + ".weight"]  # [Cout, Cin, 3, 1, 1] -> [Cout, (kt, c)]
+            P[prefix + ".w"] = w16(w[:, :, :, 0, 0].permute(0, 2, 1).reshape(w.shape[0], -1))
+            P[prefix + ".b"] = f32(sd[prefix + ".bias"])
+
+        def norm(prefix):
+            P[prefix + ".g"] = f32(sd[prefix + ".weight"])
+            P[prefix + ".be"] = f32(sd[prefix + ".bias"])
+
+        def transformer(prefix, depth, cross, img):
+            norm(prefix + ".norm")
+            lin(prefix + ".proj_in")
+            lin(prefix + ".proj_out")
+            for d in range(depth):
+                p = f"{prefix}.transformer_blocks.{d}"
+                for n in ("norm1", "norm2", "norm3"):
+                    norm(f"{p}.{n}")
+                P[f"{p}.attn1.qkv.w"] = w16(torch.cat([sd[f"{p}.attn1.to_q.weight"], sd[f"{p}.attn1.to_k.weight"],
+                                                       sd[f"{p}.attn1.to_v.weight"]], 0))
+                lin(f"{p}.attn1.to_out.0")
+                if cross:
+                    lin(f"{p}.attn2.to_q", bias=False)
+                    P[f"{p}.attn2.kv.w"] = w16(torch.cat([sd[f"{p}.attn2.to_k.weight"], sd[f"{p}.attn2.to_v.weight"]], 0))
+                    if img:
+                        P[f"{p}.attn2.kv_ip.w"] = w16(torch.cat([sd[f"{p}.attn2.to_k_ip.weight"],
+                                                                 sd[f"{p}.attn2.to_v_ip.weight"]], 0))
+                else:
+                    P[f"{p}.attn2.qkv.w"] = w16(torch.cat([sd[f"{p}.attn2.to_q.weight"], sd[f"{p}.attn2.to_k.weight"],
+                                                           sd[f"{p}.attn2.to_v.weight"]], 0))
+                lin(f"{p}.attn2.to_out.0")
+                P[f"{p}.ff1.w"] = w16(_interleave_geglu(sd[f"{p}.ff.net.0.proj.weight"]))
+                P[f"{p}.ff1.b"] = f32(_interleave_geglu(sd[f"{p}.ff.net.0.proj.bias"]))
+                lin(f"{p}.ff.net.2")
+
+        cfg = self.cfg
+        for name in ("time_embed",) + (("fps_embedding",) if cfg["fps_cond"] else ()):
+            lin(name + ".0")
+            lin(name + ".2")
+        emb_w, emb_b, self._emb_off = [], [], {}
+        off = 0
+
+        def block(b):
+            nonlocal off
+            p = b.prefix
+            if b.kind == "conv_in":
+                w = sd[p + ".weight"]
+                k = 9 * w.shape[1]
+                kpad = ((k + 63) // 64) * 64
+                wp = torch.zeros((w.shape[0], kpad), dtype=torch.float32, device=w.device)
+                wp[:, :k] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+                P[p + ".w"] = w16(wp)
+                P[p + ".b"] = f32(sd[p + ".bias"])
+                self._kpad_in = kpad
+            elif b.kind == "res":
+                norm(p + ".in_layers.0")
+                conv3(p + ".in_layers.2")
+                norm(p + ".out_layers.0")
+                conv3(p + ".out_layers.3")
+                if b.cin != b.cout:
+                    lin(p + ".skip_connection")
+                # time-embedding projection of every ResBlock goes into ONE matrix; the conv-1 bias is folded in
+                emb_w.append(sd[p + ".emb_layers.1.weight"])
+                emb_b.append(sd[p + ".emb_layers.1.bias"] + sd[p + ".in_layers.2.bias"])
+                self._emb_off[p] = off
+                off += b.cout
+                if b.tconv:
+                    for i in (1, 2, 3, 4):
+                        ci = 2 if i == 1 else 3
+                        norm(f"{p}.temopral_conv.conv{i}.0")
+                        tconv(f"{p}.temopral_conv.conv{i}.{ci}")
+            elif b.kind == "st":
+                transformer(p, b.depth, True, cfg["use_image_attention"])
+            elif b.kind == "tt":
+                transformer(p, b.depth, False, False)
+            elif b.kind == "down":
+                conv3(p + ".op")
+            elif b.kind == "up":
+                conv3(p + ".conv")
+
+        for gi, group in enumerate(self._inputs):
+            for b in group:
+                block(b)
+            if gi == 0 and cfg["addition_attention"]:
+                transformer("init_attn.0", cfg["transformer_depth"], False, False)
+        for b in self._middle:
+            block(b)
+        for group in self._outputs:
+            for b in group:
+                block(b)
+        norm("out.0")
+        conv3("out.2")
+        P["emb_all.w"] = w16(torch.cat(emb_w, 0))
+        P["emb_all.b"] = f32(torch.cat(emb_b, 0))
+        self._emb_total = off
+        self._packed = P
+        self._device = dev
+        return self
+
+    # ------------------------------------------------------------------ forward program
+    def _gn(self, h, prefix, ninst, rows, C, eps, silu):
+        P = self._packed
+        return ops.groupnorm(h, P[prefix + ".g"], P[prefix + ".be"], ninst, rows, C, eps, silu)
+
+    def _linear(self, a, prefix, residual=None, epilogue=0, bias=True):
+        P = self._packed
+        w = P[prefix + ".w"]
+        return ops.gemm(a, w, P[prefix + ".b"] if bias else None, residual, M=a.shape[0], N=w.shape[0], K=w.shape[1],
+                        epilogue=epilogue)
+
+    def _conv3(self, a, prefix, dims, cin, stride=1, upsample=0, residual=None, bias=None, bias_rows=None, ldbias=None,
+               epilogue=0):
+        """dims = (nimg, hin, win) physical input; returns (out, (hout, wout))."""
+        P = self._packed
+        w = P[prefix + ".w"]
+        nimg, hin, win = dims
+        hl, wl = (2 * hin, 2 * win) if upsample else (hin, win)
+        hout = (hl - 1) // stride + 1
+        wout = (wl - 1) // stride + 1
+        M = nimg * hout * wout
+        out = ops.gemm(a, w, P[prefix + ".b"] if bias is None else bias, residual, M=M, N=w.shape[0], K=w.shape[1],
+                       a_mode=DS_A_CONV3, cin=cin, lda=a.stride(0), conv=(nimg, hin, win, hout, wout, stride, upsample),
+                       bias_rows=bias_rows, ldbias=ldbias, epilogue=epilogue)
+        return out, (hout, wout)
+
+    def _transformer_block(self, x, p, heads, spatial, geo, ctx):
+        """x [M, inner].  spatial: attention over H*W per frame (+ cross-attention to ctx); else over T per pixel."""
+        P = self._packed
+        B, T, H, W = geo
+        M, inner = x.shape
+        scale = HEAD_DIM ** -0.5
+
+        def self_attn(name, xin):
+            n = ops.layernorm(xin, P[f"{p}.norm{1 if name == 'attn1' else 2}.g"], P[f"{p}.norm{1 if name == 'attn1' else 2}.be"])
+            wq = P[f"{p}.{name}.qkv.w"]
+            qkv = ops.gemm(n, wq, None, None, M=M, N=3 * inner, K=inner)
+            o = torch.empty((M, inner), dtype=torch.float16, device=x.device)
+            ld = 3 * inner
+            if spatial:
+                ops.attention(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, batch=B * T, heads=heads, nq=H * W, nk=H * W,
+                              ldq=ld, ldk=ld, ldv=ld, ldo=inner, scale=scale)
+            else:
+                ops.temporal_attention(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, nseq_batches=B, T=T, hw=H * W,
+                                       heads=heads, ldq=ld, ldk=ld, ldv=ld, ldo=inner, scale=scale)
+            return self._linear(o, f"{p}.{name}.to_out.0", residual=xin)
+
+        x = self_attn("attn1", x)
+        if spatial:
+            n2 = ops.layernorm(x, P[f"{p}.norm2.g"], P[f"{p}.norm2.be"])
+            q = ops.gemm(n2, P[f"{p}.attn2.to_q.w"], None, None, M=M, N=inner, K=inner)
+            ctx_text, ctx_img, ltxt, limg = ctx
+            wkv = P[f"{p}.attn2.kv.w"]
+            kv = ops.gemm(ctx_text, wkv, None, None, M=ctx_text.shape[0], N=2 * inner, K=wkv.shape[1])
+            o = torch.empty((M, inner), dtype=torch.float16, device=x.device)
+            ops.attention(q, kv, kv[:, inner:], o, batch=B * T, heads=heads, nq=H * W, nk=ltxt, ldq=inner, ldk=2 * inner,
+                          ldv=2 * inner, ldo=inner, kv_batch_div=T, scale=scale)
+            if ctx_img is not None and f"{p}.attn2.kv_ip.w" in P:
+                wip = P[f"{p}.attn2.kv_ip.w"]
+                kvi = ops.gemm(ctx_img, wip, None, None, M=ctx_img.shape[0], N=2 * inner, K=wip.shape[1])
+                # out = out + 1.0 * out_ip (attention.py:117-124): second softmax over the image tokens, accumulated
+                ops.attention(q, kvi, kvi[:, inner:], o, batch=B * T, heads=heads, nq=H * W, nk=limg, ldq=inner,
+                              ldk=2 * inner, ldv=2 * inner, ldo=inner, kv_batch_div=T, scale=scale, accumulate=True)
+            x = self._linear(o, f"{p}.attn2.to_out.0", residual=x)
+        else:
+            x = self_attn("attn2", x)
+        n3 = ops.layernorm(x, P[f"{p}.norm3.g"], P[f"{p}.norm3.be"])
+        w1 = P[f"{p}.ff1.w"]
+        g = ops.gemm(n3, w1, P[f"{p}.ff1.b"], None, M=M, N=w1.shape[0], K=w1.shape[1], epilogue=DS_EPI_GEGLU)
+        return self._linear(g, f"{p}.ff.net.2", residual=x)
+
+    def _transformer(self, h, prefix, heads, depth, spatial, geo, ctx):
+        B, T, H, W = geo
+        C = h.shape[1]
+        if spatial:
+            a = self._gn(h, prefix + ".norm", B * T, H * W, C, 1e-6, False)
+        else:
+            a = self._gn(h, prefix + ".norm", B, T * H * W, C, 1e-6, False)
+        x = self._linear(a, prefix + ".proj_in")
+        for d in range(depth):
+            x = self._transformer_block(x, f"{prefix}.transformer_blocks.{d}", heads, spatial, geo, ctx)
+        return self._linear(x, prefix + ".proj_out", residual=h)
+
+    def _resblock(self, h, b, geo, emb_all):
+        P = self._packed
+        B, T, H, W = geo
+        p = b.prefix
+        a = self._gn(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5, True)
+        off = self._emb_off[p]
+        h1, _ = self._conv3(a, p + ".in_layers.2", (B * T, H, W), b.cin, bias=emb_all[:, off:], bias_rows=T * H * W,
+                            ldbias=self._emb_total)
+        a2 = self._gn(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5, True)
+        skip = h if b.cin == b.cout else self._linear(h, p + ".skip_connection")
+        h2, _ = self._conv3(a2, p + ".out_layers.3", (B * T, H, W), b.cout, residual=skip)
+        if b.tconv:
+            x = h2
+            M = x.shape[0]
+            for i in (1, 2, 3, 4):
+                ci = 2 if i == 1 else 3
+                q = f"{p}.temopral_conv.conv{i}"
+                an = self._gn(x, q + ".0", B, T * H * W, b.cout, 1e-5, True)
+                w = P[f"{q}.{ci}.w"]
+                x = ops.gemm(an, w, P[f"{q}.{ci}.b"], h2 if i == 4 else None, M=M, N=w.shape[0], K=w.shape[1],
+                             a_mode=DS_A_TCONV, cin=b.cout, lda=an.stride(0), tconv=(T, H * W))
+            h2 = x
+        return h2
+
+    @torch.no_grad()
+    def forward(self, x, timesteps, context=None, features_adapter=None, fps=16, timestep_cond=None, **kwargs):
+        """x [b,C,t,h,w] (fp16|fp32, HIP device), timesteps int64 [b], context [b,L,context_dim].
+        Returns eps [b,C_out,t,h,w] fp32 (the reference UNet computes and returns fp32)."""
+        if features_adapter is not None or timestep_cond is not None:
+            raise NotImplementedError("features_adapter / timestep_cond are not used by the DynamicScaler pipelines")
+        if not x.is_cuda:
+            raise RuntimeError("UNetModel.forward: input is on the CPU; this build has no CPU path (the HIP kernels are the product)")
+        if self._packed is None or self._device != x.device:
+            self.prepare(x.device)
+        P = self._packed
+        cfg = self.cfg
+        mc = cfg["model_channels"]
+        B, Cin, T, H, W = x.shape
+        dev = x.device
+        x = x.contiguous()
+        timesteps = timesteps.to(dev, torch.int64).reshape(-1)
+        if timesteps.numel() == 1 and B > 1:
+            timesteps = timesteps.expand(B).contiguous()
+        # ---- time (+fps) embedding -> per-ResBlock projections in one GEMM ----
+        t_emb = ops.timestep_embedding(timesteps, mc)
+        e1 = self._linear(t_emb, "time_embed.0", epilogue=DS_EPI_SILU)
+        emb = self._linear(e1, "time_embed.2")
+        if cfg["fps_cond"]:
+            if isinstance(fps, int):
+                fps_t = torch.full_like(timesteps, fps)
+            else:
+                fps_t = fps.to(dev, torch.int64).reshape(-1)
+                if fps_t.numel() == 1 and B > 1:
+                    fps_t = fps_t.expand(B).contiguous()
+            f_emb = ops.timestep_embedding(fps_t, mc)
+            f1 = self._linear(f_emb, "fps_embedding.0", epilogue=DS_EPI_SILU)
+            emb = self._linear(f1, "fps_embedding.2", residual=emb)
+        semb = ops.silu(emb)
+        w_all = P["emb_all.w"]
+        emb_all = ops.gemm(semb, w_all, P["emb_all.b"], None, M=B, N=w_all.shape[0], K=w_all.shape[1],
+                           epilogue=DS_EPI_OUT_F32)
+        # ---- context: text (+ image) tokens as 2-D fp16 matrices, NOT repeated over frames ----
+        context = context.to(dev)
+        L = context.shape[1]
+        if cfg["use_image_attention"] and L > 77:
+            ctx_text = context[:, :77].to(torch.float16).reshape(B * 77, -1).contiguous()
+            ctx_img = context[:, 77:].to(torch.float16).reshape(B * (L - 77), -1).contiguous()
+            ctx = (ctx_text, ctx_img, 77, L - 77)
+        else:
+            ctx = (context.to(torch.float16).reshape(B * L, -1).contiguous(), None, L, 0)
+
+        def run(group, h, geo):
+            for b in group:
+                Bq, Tq, Hq, Wq = geo
+                if b.kind == "conv_in":
+                    patches = ops.im2col_in(x, self._kpad_in)
+                    w = P[b.prefix + ".w"]
+                    h = ops.gemm(patches, w, P[b.prefix + ".b"], None, M=patches.shape[0], N=w.shape[0], K=w.shape[1])
+                elif b.kind == "res":
+                    h = self._resblock(h, b, geo, emb_all)
+                elif b.kind == "st":
+                    h = self._transformer(h, b.prefix, b.heads, b.depth, True, geo, ctx)
+                elif b.kind == "tt":
+                    h = self._transformer(h, b.prefix, b.heads, b.depth, False, geo, ctx)
+                elif b.kind == "down":
+                    h, (ho, wo) = self._conv3(h, b.prefix + ".op", (Bq * Tq, Hq, Wq), b.cin, stride=2)
+                    geo = (Bq, Tq, ho, wo)
+                elif b.kind == "up":
+                    h, (ho, wo) = self._conv3(h, b.prefix + ".conv", (Bq * Tq, Hq, Wq), b.cin, upsample=1)
+                    geo = (Bq, Tq, ho, wo)
+            return h, geo
+
+        geo = (B, T, H, W)
+        h = None
+        hs = []
+        for gi, group in enumerate(self._inputs):
+            h, geo = run(group, h, geo)
+            if gi == 0 and cfg["addition_attention"]:
+                h = self._transformer(h, "init_attn.0", 8, cfg["transformer_depth"], False, geo, ctx)
+            hs.append((h, geo))
+        h, geo = run(self._middle, h, geo)
+        for group in self._outputs:
+            skip, sgeo = hs.pop()
+            assert sgeo == geo, f"skip connection geometry {sgeo} != {geo} (tile h/w must be divisible by 8)"
+            h = ops.concat_channels(h, skip)
+            h, geo = run(group, h, geo)
+        a = self._gn(h, "out.0", B * T, H * W, mc, 1e-5, True)
+        y, _ = self._conv3(a, "out.2", (B * T, H, W), mc, epilogue=DS_EPI_OUT_F32)
+        return ops.rows_to_ncthw(y, (B, cfg["out_channels"], T, H, W), torch.float32)
+
+
+class DiffusionWrapper(nn.Module):
+    """lvdm/models/ddpm3d.py:696-763, conditioning_key='crossattn' branch (:710-712)."""
+
+    def __init__(self, diffusion_model, conditioning_key="crossattn"):
+        super().__init__()
+        self.diffusion_model = diffusion_model
+        self.conditioning_key = conditioning_key
+
+    def forward(self, x, t, c_concat=None, c_crossattn=None, c_adm=None, s=None, mask=None, **kwargs):
+        if self.conditioning_key != "crossattn":
+            raise NotImplementedError("only conditioning_key='crossattn' is on the DynamicScaler hot path")
+        cc = torch.cat(c_crossattn, 1)
+        return self.diffusion_model(x, t, context=cc, **kwargs)

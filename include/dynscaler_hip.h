@@ -1,0 +1,181 @@
+/*
+ * dynscaler_hip.h -- C ABI of libdynscaler_hip.so: the MI355X (gfx950) kernels behind the tiled
+ * panoramic denoising hot path of DynamicScaler.
+ *
+ * The reference (pure Python, /root/reference) has no FFI layer; the entry points below are what a
+ * binding of its hot-path functions binds to.  Each one cites the reference code it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *   - return 0 on success, a negative DS_E* code on error; ds_last_error() returns a thread-local message.
+ *   - no exceptions, no torch types: plain device pointers + sizes.  The CALLER allocates and owns every
+ *     buffer (inputs, outputs, workspaces).  Nothing here allocates, frees or synchronises.
+ *   - every call is asynchronous on the `stream` argument (a hipStream_t passed as void*; NULL = default
+ *     stream) and is legal inside hipGraph stream capture.
+ *   - device = the caller's current HIP device.  Re-entrant across streams.
+ *   - activations are "rows x channels", channel-contiguous fp16 ("NTHWC": row = ((b*T + t)*H + y)*W + x).
+ *     latents / panoramas keep the reference layout [B=1, C, F, H, W] (fp16 or fp32).
+ */
+#ifndef DYNSCALER_HIP_H
+#define DYNSCALER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_OK 0
+#define DS_EINVAL (-1)   /* bad argument (message in ds_last_error) */
+#define DS_ELAUNCH (-2)  /* HIP launch error */
+
+#define DS_F16 0
+#define DS_F32 1
+
+const char* ds_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int ds_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ring (plane) panorama tile ops -- bit-exact restatements of the reference's torch sequences.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Geometry of one batch of equally sized windows on a wrap-around panorama [1,C,F,H,W]. */
+typedef struct ds_ring_geom {
+    int32_t C, F, H, W;   /* panorama */
+    int32_t tf, th, tw;   /* window (tile) size; tf<=F, th<=H, tw<=W for scatter */
+    int32_t dtype;        /* DS_F16 / DS_F32: element type of panorama AND tiles */
+} ds_ring_geom;
+
+#define DS_MAX_WINDOWS 64
+
+/* RingLatent.get_window_latent (utils/shift_window_utils.py:48-114), n windows in one launch:
+ *   tiles[i][c][f][y][x] = pano[c][(f0_i+f)%F][(y0_i+y)%H][(x0_i+x)%W]
+ * and, when mask_pano != NULL, mask_tiles[i][f][y][x] = mask_pano[(f0_i+f)%F][...] (uint8, one byte per
+ * (f,y,x): the reference's 5-D fp32 mask is only ever written uniformly over C --
+ * pipeline/t2v_sphere_panorama_pipeline.py:494,624-632).
+ * origins: HOST pointer to n triples (f0,y0,x0); 0 <= origin < 2*size like the reference asserts (:73-75). */
+int ds_ring_gather(const void* pano, const uint8_t* mask_pano, void* tiles, uint8_t* mask_tiles,
+                   const ds_ring_geom* geom, const int32_t* origins, int n, void* stream);
+
+/* RingLatent.set_window_latent x3 (utils/shift_window_utils.py:116-206; call sites
+ * pipeline/t2v_sphere_panorama_pipeline.py:609-632): overwrite the windows of pano_latent with x_prev,
+ * of pano_x0 with x0, and set mask_pano to 1.  Any of the three destinations may be NULL.
+ * Windows of one launch must be pairwise disjoint (the caller batches only independent columns). */
+int ds_ring_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const void* x_prev_tiles,
+                     const void* x0_tiles, const ds_ring_geom* geom, const int32_t* origins, int n,
+                     void* stream);
+
+/* re_noise + mix_latents_with_mask fused (pipeline/scheduler.py:98-110, utils/tensor_utils.py:19-39;
+ * call site pipeline/t2v_sphere_panorama_pipeline.py:550-559):
+ *   noised = c*x + s*noise ;  out = x*(1-m) + (x*(1-ratio) + noised*ratio)*m     (fp32, same op order)
+ * tiles: [n][C][tf][th][tw] in/out.  mask_tiles uint8 [n][tf][th][tw]; mask_frame0 != 0 uses frame 0 of
+ * the window for every frame (the t2v `[0,0,[0]]` slice, :555).  noise: same shape/dtype as tiles, or NULL.
+ * `ratio` / `one_minus_ratio` are fp32(mix_ratio) and fp32(1 - mix_ratio) with the subtraction done by the
+ * caller in double, exactly as Python evaluates `1 - mix_ratio` before torch narrows it (:30).
+ * NULL noise: draw N(0,1) in-kernel from Philox4x32-10 keyed by (seed, element index + offset) -- the
+ * in-kernel stream is NOT the torch CPU stream (perf mode, not bit-comparable). */
+int ds_renoise_mix(void* tiles, const uint8_t* mask_tiles, const void* noise, float c, float s, float ratio,
+                   float one_minus_ratio, int mask_frame0, uint64_t seed, uint64_t offset,
+                   const ds_ring_geom* geom, int n, void* stream);
+
+/* CFG combine + DDIM step fused (pipeline/t2v_sphere_panorama_pipeline.py:599, pipeline/scheduler.py:60-96):
+ *   e = e_u + g*(e_c - e_u) ; x0 = (x - sqrt_one_minus_at*e)/sqrt_at ; x_prev = sqrt_a_prev*x0 + dir_coef*e + sigma*z
+ * All four coefficient scalars are the fp32 values the reference materialises with torch.full (:78-85).
+ * eps_u may be NULL (guidance 1.0 path: e = e_c).  eps_dtype: DS_F16/DS_F32 element type of eps_c/eps_u;
+ * x / x_prev / x0 use geom->dtype.  noise (sigma*z term) may be NULL when sigma == 0. */
+int ds_cfg_ddim(const void* x, const void* eps_c, const void* eps_u, int eps_dtype, float guidance,
+                float sqrt_one_minus_at, float sqrt_at, float sqrt_a_prev, float dir_coef, float sigma,
+                const void* noise, void* x_prev, void* x0, const ds_ring_geom* geom, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * UNet inner blocks (lvdm/modules/networks/openaimodel3d.py, lvdm/modules/attention.py).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* A-operand addressing of the implicit GEMM. */
+#define DS_A_DENSE 0   /* nn.Linear / 1x1 conv: row m reads A[m*lda + k]                                    */
+#define DS_A_CONV3 1   /* Conv2d 3x3 pad 1 (stride 1|2, optional nearest x2 upsample folded in)            */
+#define DS_A_TCONV 2   /* Conv3d (3,1,1) pad (1,0,0) over T (TemporalConvBlock, openaimodel3d.py:257-309)   */
+
+/* epilogue flags */
+#define DS_EPI_GEGLU 1   /* out[m][j] = (acc[m][x_j]+b) * gelu(acc[m][gate_j]+b)  (attention.py:376-383);
+                            weight rows must be interleaved in 64-row groups [x0..63 | gate0..63] (see
+                            ds_gemm_geglu_row) and N counts x+gate columns; out has N/2 columns            */
+#define DS_EPI_SILU 2    /* out = silu(acc + bias)                                                          */
+#define DS_EPI_OUT_F32 4 /* store fp32 instead of fp16                                                     */
+
+typedef struct ds_gemm_desc {
+    int32_t M, N, K;        /* C[M,N] = A'[M,K] * W[N,K]^T ; K = taps*Cin for conv modes; K % 64 == 0       */
+    int32_t a_mode;         /* DS_A_*                                                                       */
+    int32_t lda;            /* A row stride in elements (>= Cin)                                            */
+    int32_t cin;            /* channels per tap (DENSE: == K)                                               */
+    int32_t nimg, hin, win; /* CONV3: input images (B*T) and PHYSICAL input H,W                             */
+    int32_t hout, wout;     /* CONV3: output H,W (M == nimg*hout*wout)                                      */
+    int32_t stride;         /* CONV3: 1 or 2                                                                */
+    int32_t upsample;       /* CONV3: 1 = input is nearest-x2 upsampled on the fly (F.interpolate + conv,
+                               openaimodel3d.py:98-111); logical input = 2*hin x 2*win                     */
+    int32_t t_len, hw;      /* TCONV: frames per sequence, rows per frame (M == nseq*t_len*hw)              */
+    int32_t ldc;            /* output row stride in elements                                                */
+    int32_t ldr;            /* residual row stride (elements)                                               */
+    int32_t bias_rows;      /* bias index = (m / bias_rows) * ldbias + n ; bias_rows >= M -> one shared vector */
+    int32_t ldbias;         /* row stride of the bias table in floats (>= N)                                */
+    int32_t epilogue;       /* DS_EPI_* flags                                                               */
+} ds_gemm_desc;
+
+/* fp16 x fp16 -> fp32-accumulate MFMA GEMM with fused bias / per-item bias (emb add) / residual / GEGLU /
+ * SiLU epilogues.  Replaces nn.Linear, Conv2d 3x3, Conv2d 1x1, Conv1d 1x1 and Conv3d (3,1,1) call sites:
+ * attention.py:54-57,63-64,242,258,379,399; openaimodel3d.py:155-159,174-184,186-193,65-72,98-111,275-300.
+ * W: [N][K] fp16, K index = tap*Cin + c (conv weights pre-permuted by the host from [Cout,Cin,kh,kw]).
+ * bias: fp32 [ceil(M/bias_rows)][ldbias] or NULL.  residual: fp16 [M][ldr] or NULL.  out: fp16/fp32 [M][ldc]. */
+int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,
+                const ds_gemm_desc* desc, void* stream);
+
+/* GroupNorm statistics: x fp16 [ninst*rows_per_inst][C]; instance i = rows [i*rows_per_inst, (i+1)*...).
+ * Writes mean/rstd fp32 [ninst][groups]; `workspace` = caller scratch of
+ * ds_groupnorm_stats_workspace_floats(...) floats (per-chunk partial sums; no global atomics -> reproducible).  rows_per_inst = H*W (per-frame GroupNorm, basics.py:76-86,
+ * attention.py:238) or T*H*W (5-D GroupNorm over T jointly, openaimodel3d.py:275-292, attention.py:297). */
+size_t ds_groupnorm_stats_workspace_floats(int ninst, int rows_per_inst, int groups);
+int ds_groupnorm_stats(const void* x, float* mean, float* rstd, float* workspace, int ninst, int rows_per_inst,
+                       int C, int groups, float eps, void* stream);
+/* y = (x-mean)*rstd*gamma+beta, optional SiLU; fp16 out. */
+int ds_groupnorm_apply(const void* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, void* y, int ninst, int rows_per_inst, int C, int groups, int silu,
+                       void* stream);
+/* nn.LayerNorm(C) eps 1e-5 over each row (attention.py:199-201). x,y fp16 [rows][C]. */
+int ds_layernorm(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
+                 void* stream);
+
+/* softmax(q k^T * scale) v, head_dim 64 (CrossAttention.forward, attention.py:76-127).
+ * q: fp16, element (b, i, h, d) at q[(b*nq + i)*ldq + h*64 + d]; k/v likewise with nk rows per kv batch;
+ * kv batch of q-batch b is b / kv_batch_div (cross-attention: context shared by the T frames of an eval).
+ * out: fp16 [(b*nq+i)*ldo + h*64 + d].  accumulate != 0 adds into out (image-token branch, attention.py:117-124). */
+int ds_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int heads, int nq, int nk,
+                     int ldq, int ldk, int ldv, int ldo, int kv_batch_div, float scale, int accumulate,
+                     void* stream);
+
+/* Temporal self-attention over T (<=32) tokens per pixel (TemporalTransformer, attention.py:281-373 with
+ * only_self_att, no relative position, no causal mask).  qkv rows are NTHWC rows; token t of sequence
+ * (b, p) is row (b*T + t)*hw + p.  q/k/v element (row, h, d) at ptr[row*ld + h*64 + d]. */
+int ds_temporal_attention_f16(const void* q, const void* k, const void* v, void* out, int nseq_batches, int T,
+                              int hw, int heads, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+
+/* dst[m][0:c1] = a[m][:], dst[m][c1:c1+c2] = b[m][:]  (torch.cat([h, hs.pop()], dim=1), openaimodel3d.py:701). */
+int ds_concat_channels(const void* a, const void* b, void* dst, int rows, int c1, int c2, void* stream);
+
+/* conv-in im2col: x [B][C][T][H][W] (geom dtype) -> patches fp16 [B*T*H*W][kpad], column (ky*3+kx)*C + c,
+ * zero padded borders and columns >= 9*C (openaimodel3d.py:421, 682). */
+int ds_im2col_in(const void* x, int x_dtype, void* patches, int B, int C, int T, int H, int W, int kpad,
+                 void* stream);
+/* y rows fp32/fp16 [B*T*H*W][ldy] (first C columns) -> out [B][C][T][H][W] (out_dtype)  (openaimodel3d.py:707). */
+int ds_rows_to_ncthw(const void* y, int y_dtype, int ldy, void* out, int out_dtype, int B, int C, int T, int H,
+                     int W, void* stream);
+/* timestep_embedding (lvdm/models/utils_diffusion.py:8-28): out fp16 [n][dim] = [cos(t*f) | sin(t*f)]. */
+int ds_timestep_embedding(const int64_t* t, void* out, int n, int dim, void* stream);
+/* y = silu(x), fp16 elementwise (emb_layers SiLU, openaimodel3d.py:172-178). */
+int ds_silu_f16(const void* x, void* y, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNSCALER_HIP_H */

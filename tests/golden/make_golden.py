@@ -50,8 +50,9 @@ from lvdm.modules.networks.openaimodel3d import UNetModel  # noqa: E402  (refere
 from dynamicscaler_amd.unet_spec import param_shapes  # noqa: E402
 from dynamicscaler_amd.synth import synth_state_dict, synth_normal  # noqa: E402
 
-TINY = dict(in_channels=4, out_channels=4, model_channels=32, attention_resolutions=[2, 1], num_res_blocks=1,
-            channel_mult=[1, 2], num_head_channels=16, transformer_depth=1, context_dim=64, use_linear=True,
+# toy UNet with the real head_dim (64) so the HIP attention kernels run it too: 64 -> 128 channels, 2 levels
+TINY = dict(in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[2, 1], num_res_blocks=1,
+            channel_mult=[1, 2], num_head_channels=64, transformer_depth=1, context_dim=64, use_linear=True,
             use_checkpoint=True, temporal_conv=True, temporal_attention=True, temporal_selfatt_only=True,
             use_relative_position=False, use_causal_attention=False, temporal_length=4,
             addition_attention=True, fps_cond=True)

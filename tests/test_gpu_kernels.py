@@ -1,0 +1,344 @@
+"""-m gpu: parity of every HIP kernel (through the C ABI) against the CPU oracle / a plain torch-CPU fp32
+restatement of the same op, on seeded inputs.  Bit-exact for the data-movement and fp32 tile ops; within a stated
+fp16 tolerance for the MFMA paths."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ring as oring
+from oracle import ddim as oddim
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+# ------------------------------------------------------------------------------------------------ ring tile ops
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("geom", [
+    # (pano F,H,W), (tile f,h,w), origins [(f0,y0,x0)]
+    ((6, 8, 16), (4, 4, 8), [(0, 0, 0), (4, 6, 8), (5, 7, 16)]),             # vector path (x0 % 8 == 0), wraps F,H,W
+    ((6, 8, 16), (3, 5, 7), [(1, 2, 3), (5, 6, 13), (11, 15, 31)]),          # scalar path, max origins (< 2*size)
+    ((16, 64, 512), (16, 40, 64), [(0, 3, 8 + 64 * k) for k in range(8)]),   # config-3 step-1 row 0
+    ((16, 64, 512), (16, 40, 64), [(0, 27, 456)]),                           # crosses the W seam and the H seam
+])
+def test_ring_gather_scatter_bit_exact(dtype, geom):
+    from dynamicscaler_amd import ops
+    d = dev()
+    (Fp, Hp, Wp), (tf, th, tw), origins = geom
+    pano = rnd((1, 4, Fp, Hp, Wp), 1).to(dtype)
+    maskp = (rnd((Fp, Hp, Wp), 2) > 0).to(torch.uint8)
+    tiles, mt = ops.ring_gather(pano.to(d), origins, (tf, th, tw), maskp.to(d))
+    for i, (f0, y0, x0) in enumerate(origins):
+        ref = oring.ring_gather(pano, x0, x0 + tw, y0, y0 + th, f0, f0 + tf)
+        assert torch.equal(tiles[i:i + 1].cpu(), ref)
+        refm = oring.ring_gather(maskp[None, None], x0, x0 + tw, y0, y0 + th, f0, f0 + tf)[0, 0]
+        assert torch.equal(mt[i].cpu(), refm)
+    # scatter: disjoint windows only (the pipelines guarantee that per launch)
+    from dynamicscaler_amd.parallel import windows_overlap
+    wins = [(x0, x0 + tw, y0, y0 + th, f0, f0 + tf) for (f0, y0, x0) in origins]
+    keep = []
+    for j, w in enumerate(wins):
+        if all(not windows_overlap(wins[k], w, (Fp, Hp, Wp)) for k in keep):
+            keep.append(j)
+    xp = rnd((len(keep), 4, tf, th, tw), 3).to(dtype)
+    x0t = rnd((len(keep), 4, tf, th, tw), 4).to(dtype)
+    p1, p2, pm = pano.clone().to(d), torch.zeros_like(pano).to(d), torch.zeros((Fp, Hp, Wp), dtype=torch.uint8, device=d)
+    ops.ring_scatter3(p1, p2, pm, xp.to(d), x0t.to(d), [origins[j] for j in keep])
+    r1, r2, rm = pano.clone(), torch.zeros_like(pano), torch.zeros((1, 1, Fp, Hp, Wp))
+    for n, j in enumerate(keep):
+        f0, y0, x0 = origins[j]
+        oring.ring_scatter(r1, xp[n:n + 1], x0, x0 + tw, y0, y0 + th, f0, f0 + tf)
+        oring.ring_scatter(r2, x0t[n:n + 1], x0, x0 + tw, y0, y0 + th, f0, f0 + tf)
+        oring.ring_scatter(rm, torch.ones(1, 1, tf, th, tw), x0, x0 + tw, y0, y0 + th, f0, f0 + tf)
+    assert torch.equal(p1.cpu(), r1) and torch.equal(p2.cpu(), r2)
+    assert torch.equal(pm.cpu().float(), rm[0, 0])
+
+
+def test_ring_errors_match_reference_asserts():
+    from dynamicscaler_amd import ops, _lib
+    from dynamicscaler_amd.ring import RingLatent
+    d = dev()
+    pano = torch.zeros(1, 4, 6, 8, 16, device=d)
+    with pytest.raises(_lib.DsError, match="Invalid pos_left"):
+        ops.ring_gather(pano, [(0, 0, 10)], (6, 8, 32))          # right edge > 2*W
+    with pytest.raises(_lib.DsError, match="warp should not occur"):
+        ops.ring_scatter3(pano, None, None, torch.zeros(1, 4, 6, 8, 17, device=d), None, [(0, 0, 0)])
+    r = RingLatent(pano)
+    with pytest.raises(AssertionError):
+        r.set_window_latent(torch.zeros(1, 4, 6, 8, 3, device=d), 0, 4, 0, 8, 0, 6)   # shape mismatch (:190)
+    with pytest.raises(AssertionError):
+        r.get_window_latent(10, 42, 0, 8, 0, 6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("ratio", [1, 0.3])
+def test_renoise_mix_bit_exact(dtype, ratio):
+    from dynamicscaler_amd import ops
+    d = dev()
+    sched = oddim.DDIMSchedule(oddim.DiffusionTables(), 50)
+    n, shape = 3, (3, 4, 4, 8, 16)
+    x = rnd(shape, 11).to(dtype)
+    nz = rnd(shape, 12).to(dtype)
+    m = (rnd((n, 4, 8, 16), 13) > 0).to(torch.uint8)
+    c, s = sched.renoise_coefficients(20, 21)
+    out = ops.renoise_mix_(x.clone().to(d), m.to(d), (1, 4, 4, 8, 16), c, s, ratio, noise=nz.to(d), mask_frame0=True)
+    for i in range(n):
+        xi = x[i:i + 1].float()
+        noised = oddim.re_noise(sched, xi, 20, 21, noise=nz[i:i + 1].float())
+        ref = oddim.mix_latents_with_mask(xi, noised, m[i, 0][None].float(), ratio).to(dtype)
+        assert torch.equal(out[i:i + 1].cpu(), ref)
+    # 5-D (per-frame) mask form
+    out5 = ops.renoise_mix_(x.clone().to(d), m.to(d), (1, 4, 4, 8, 16), c, s, ratio, noise=nz.to(d), mask_frame0=False)
+    for i in range(n):
+        xi = x[i:i + 1].float()
+        noised = oddim.re_noise(sched, xi, 20, 21, noise=nz[i:i + 1].float())
+        m5 = m[i][None, None].float().expand(1, 4, -1, -1, -1)
+        assert torch.equal(out5[i:i + 1].cpu(), oddim.mix_latents_with_mask(xi, noised, m5, ratio).to(dtype))
+
+
+def test_renoise_philox_statistics():
+    from dynamicscaler_amd import ops
+    d = dev()
+    x = torch.zeros((8, 4, 16, 40, 64), device=d)
+    m = torch.ones((8, 16, 40, 64), dtype=torch.uint8, device=d)
+    out = ops.renoise_mix_(x, m, (1, 4, 16, 64, 512), 0.0, 1.0, 1.0, noise=None, mask_frame0=False, seed=7, offset=0)
+    z = out.float().cpu()
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.05      # kurtosis of a normal
+    out2 = ops.renoise_mix_(torch.zeros_like(x), m, (1, 4, 16, 64, 512), 0.0, 1.0, 1.0, noise=None, mask_frame0=False,
+                            seed=7, offset=0)
+    assert torch.equal(out, out2)                          # counter-based: reproducible
+
+
+@pytest.mark.parametrize("dtype,edt", [(torch.float32, torch.float32), (torch.float16, torch.float32),
+                                       (torch.float16, torch.float16)])
+@pytest.mark.parametrize("eta", [0.0, 1.0])
+def test_cfg_ddim_bit_exact(dtype, edt, eta):
+    from dynamicscaler_amd import ops
+    d = dev()
+    sched = oddim.DDIMSchedule(oddim.DiffusionTables(), 50, eta=eta)
+    shape = (2, 4, 4, 8, 16)
+    x, ec, eu = rnd(shape, 21).to(dtype), rnd(shape, 22).to(edt), rnd(shape, 23).to(edt)
+    z = rnd(shape, 24).to(dtype)
+    for index in (0, 25, 49):
+        coef = sched.step_coefficients(index)
+        xp, x0 = ops.cfg_ddim(x.to(d), ec.to(d), eu.to(d), (1, 4, 4, 8, 16), 7.5, coef, z.to(d) if eta else None)
+        e = oddim.cfg_combine(ec.float(), eu.float(), 7.5)
+        rxp, rx0 = oddim.ddim_step(sched, x.float(), e, [index] * 4, noise=z.float())
+        assert torch.equal(xp.cpu(), rxp.to(dtype)) and torch.equal(x0.cpu(), rx0.to(dtype))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM family
+def _h(t):
+    return t.half().float()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (257, 256, 128), (128, 1280, 1024), (640, 64, 64), (5, 192, 64)])
+def test_gemm_dense_bias_residual(M, N, K):
+    from dynamicscaler_amd import ops
+    d = dev()
+    A, W = _h(rnd((M, K), 1)), _h(rnd((N, K), 2, 0.1))
+    b = rnd((N,), 3)
+    R = _h(rnd((M, N), 4))
+    out = ops.gemm(A.half().to(d), W.half().to(d), b.to(d), R.half().to(d), M=M, N=N, K=K)
+    ref = A @ W.t() + b + R
+    assert relerr(out, ref) < 1e-3
+    assert float((out.float().cpu() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    # no bias / no residual, and an exact small-integer A=I style check with an asymmetric W
+    Ai = torch.zeros((M, K)); Ai[torch.arange(min(M, K)), torch.arange(min(M, K))] = 1.0
+    Wi = (torch.arange(N * K).reshape(N, K) % 17 - 8).float()
+    out = ops.gemm(Ai.half().to(d), Wi.half().to(d), None, None, M=M, N=N, K=K)
+    assert torch.equal(out.float().cpu(), Ai @ Wi.t())
+
+
+def test_gemm_epilogues():
+    from dynamicscaler_amd import ops, _lib
+    from dynamicscaler_amd.unet import _interleave_geglu
+    d = dev()
+    M, K = 200, 128
+    A = _h(rnd((M, K), 1))
+    # per-item bias (time-embedding add): 4 items of 50 rows, bias table wider than N (ldbias)
+    N = 192
+    W = _h(rnd((N, K), 2, 0.1))
+    table = rnd((4, 400), 3)
+    out = ops.gemm(A.half().to(d), W.half().to(d), table.to(d)[:, 100:], None, M=M, N=N, K=K, bias_rows=50, ldbias=400)
+    ref = A @ W.t() + table[:, 100:100 + N].repeat_interleave(50, 0)
+    assert relerr(out, ref) < 1e-3
+    # SiLU
+    b = rnd((N,), 4)
+    out = ops.gemm(A.half().to(d), W.half().to(d), b.to(d), None, M=M, N=N, K=K, epilogue=_lib.DS_EPI_SILU)
+    assert relerr(out, F.silu(A @ W.t() + b)) < 1e-3
+    # fp32 output with N=4 (conv-out shape) and N not a multiple of 8
+    W4 = _h(rnd((4, K), 5, 0.1))
+    out = ops.gemm(A.half().to(d), W4.half().to(d), b[:4].contiguous().to(d), None, M=M, N=4, K=K, epilogue=_lib.DS_EPI_OUT_F32)
+    assert out.dtype == torch.float32 and relerr(out, A @ W4.t() + b[:4]) < 1e-5
+    # GEGLU (attention.py:376-383): proj -> chunk(2) -> x * gelu(gate)
+    inner = 256
+    Wg, bg = _h(rnd((2 * inner, K), 6, 0.1)), rnd((2 * inner,), 7)
+    out = ops.gemm(A.half().to(d), _interleave_geglu(Wg).half().to(d), _interleave_geglu(bg).to(d), None, M=M,
+                   N=2 * inner, K=K, epilogue=_lib.DS_EPI_GEGLU)
+    xg = A @ Wg.t() + bg
+    ref = xg[:, :inner] * F.gelu(xg[:, inner:])
+    assert out.shape == (M, inner) and relerr(out, ref) < 1e-3
+
+
+@pytest.mark.parametrize("stride,upsample,hin,win", [(1, 0, 10, 12), (2, 0, 10, 12), (2, 0, 5, 8), (1, 1, 5, 6)])
+def test_gemm_conv3x3(stride, upsample, hin, win):
+    from dynamicscaler_amd import ops, _lib
+    d = dev()
+    nimg, cin, cout = 3, 64, 128
+    x = _h(rnd((nimg, cin, hin, win), 1))
+    w = _h(rnd((cout, cin, 3, 3), 2, 0.05))
+    b = rnd((cout,), 3)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if upsample else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=1)
+    hout, wout = ref.shape[-2:]
+    a = x.permute(0, 2, 3, 1).reshape(-1, cin).half().to(d)
+    wp = w.permute(0, 2, 3, 1).reshape(cout, -1).half().to(d)
+    out = ops.gemm(a, wp, b.to(d), None, M=nimg * hout * wout, N=cout, K=9 * cin, a_mode=_lib.DS_A_CONV3, cin=cin, lda=cin,
+                   conv=(nimg, hin, win, hout, wout, stride, upsample))
+    got = out.float().cpu().reshape(nimg, hout, wout, cout).permute(0, 3, 1, 2)
+    assert relerr(got, ref) < 1e-3
+
+
+def test_gemm_temporal_conv():
+    from dynamicscaler_amd import ops, _lib
+    d = dev()
+    B, T, H, W, Cc = 2, 4, 5, 6, 64
+    x = _h(rnd((B, Cc, T, H, W), 1))
+    w = _h(rnd((Cc, Cc, 3, 1, 1), 2, 0.05))
+    b = rnd((Cc,), 3)
+    ref = F.conv3d(x, w, b, padding=(1, 0, 0))
+    a = x.permute(0, 2, 3, 4, 1).reshape(-1, Cc).half().to(d)
+    wp = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(Cc, -1).half().to(d)
+    out = ops.gemm(a, wp, b.to(d), None, M=B * T * H * W, N=Cc, K=3 * Cc, a_mode=_lib.DS_A_TCONV, cin=Cc, lda=Cc,
+                   tconv=(T, H * W))
+    got = out.float().cpu().reshape(B, T, H, W, Cc).permute(0, 4, 1, 2, 3)
+    assert relerr(got, ref) < 1e-3
+
+
+def test_gemm_rejects_bad_shapes():
+    from dynamicscaler_amd import ops, _lib
+    d = dev()
+    a = torch.zeros((8, 48), dtype=torch.float16, device=d)
+    with pytest.raises(_lib.DsError, match="multiple of 64"):
+        ops.gemm(a, a, None, None, M=8, N=8, K=48)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, scale):
+    s = torch.einsum("bhid,bhjd->bhij", q, k) * scale
+    return torch.einsum("bhij,bhjd->bhid", s.softmax(-1), v)
+
+
+@pytest.mark.parametrize("nq,nk,batch,heads,kvdiv", [(160, 160, 3, 2, 1), (700, 700, 2, 1, 1), (40, 40, 4, 3, 1),
+                                                      (200, 77, 4, 2, 2), (64, 16, 6, 1, 3), (2560, 2560, 1, 1, 1)])
+def test_attention_matches_softmax_reference(nq, nk, batch, heads, kvdiv):
+    from dynamicscaler_amd import ops
+    d = dev()
+    C = heads * 64
+    kvb = batch // kvdiv
+    q = _h(rnd((batch, nq, C), 1))
+    kv = _h(rnd((kvb, nk, 2 * C), 2))
+    # spike one key against one query so the running max jumps mid-sequence (online-softmax rescale branch)
+    kv[0, nk // 2, :64] = 6.0 * q[0, 0, :64]
+    kk, vv = kv[..., :C], kv[..., C:]
+    qh = q.reshape(batch, nq, heads, 64).permute(0, 2, 1, 3)
+    kh = kk.reshape(kvb, nk, heads, 64).permute(0, 2, 1, 3).repeat_interleave(kvdiv, 0)
+    vh = vv.reshape(kvb, nk, heads, 64).permute(0, 2, 1, 3).repeat_interleave(kvdiv, 0)
+    ref = _attn_ref(qh, kh, vh, 0.125).permute(0, 2, 1, 3).reshape(batch, nq, C)
+    qd, kvd = q.half().to(d).reshape(batch * nq, C), kv.half().to(d).reshape(kvb * nk, 2 * C)
+    out = torch.empty((batch * nq, C), dtype=torch.float16, device=d)
+    ops.attention(qd, kvd, kvd[:, C:], out, batch=batch, heads=heads, nq=nq, nk=nk, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C,
+                  kv_batch_div=kvdiv, scale=0.125)
+    got = out.float().cpu().reshape(batch, nq, C)
+    assert relerr(got, ref) < 2e-3
+    assert float((got - ref).abs().max()) < 1e-2 * max(1.0, float(ref.abs().max()))
+    # accumulate form (image-token branch): out += attention
+    ops.attention(qd, kvd, kvd[:, C:], out, batch=batch, heads=heads, nq=nq, nk=nk, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C,
+                  kv_batch_div=kvdiv, scale=0.125, accumulate=True)
+    assert relerr(out.float().cpu().reshape(batch, nq, C), 2 * ref) < 3e-3
+
+
+@pytest.mark.parametrize("T", [16, 4, 24])
+def test_temporal_attention(T):
+    from dynamicscaler_amd import ops
+    d = dev()
+    B, hw, heads = 2, 37, 2
+    C = heads * 64
+    qkv = _h(rnd((B * T * hw, 3 * C), 5))
+    x = qkv.reshape(B, T, hw, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)   # [3, B, hw, heads, T, 64]
+    ref = _attn_ref(x[0].reshape(-1, heads, T, 64), x[1].reshape(-1, heads, T, 64), x[2].reshape(-1, heads, T, 64), 0.125)
+    ref = ref.reshape(B, hw, heads, T, 64).permute(0, 3, 1, 2, 4).reshape(B * T * hw, C)
+    qd = qkv.half().to(d)
+    out = torch.empty((B * T * hw, C), dtype=torch.float16, device=d)
+    ops.temporal_attention(qd, qd[:, C:], qd[:, 2 * C:], out, nseq_batches=B, T=T, hw=hw, heads=heads, ldq=3 * C,
+                           ldk=3 * C, ldv=3 * C, ldo=C, scale=0.125)
+    assert relerr(out, ref) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ norms / misc
+@pytest.mark.parametrize("ninst,rows,C", [(6, 80, 320), (2, 4 * 80, 64), (3, 40, 2560), (2, 700, 1920), (5, 33, 128)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm(ninst, rows, C, silu):
+    from dynamicscaler_amd import ops
+    d = dev()
+    x = _h(rnd((ninst * rows, C), 1) * 2 + 0.5)
+    g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    y = ops.groupnorm(x.half().to(d), g.to(d), b.to(d), ninst, rows, C, 1e-5, silu)
+    xr = x.reshape(ninst, rows, C).permute(0, 2, 1)
+    ref = F.group_norm(xr, 32, g, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(ninst * rows, C)
+    assert relerr(y, ref) < 1e-3
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (77, 1280), (5, 64), (333, 512)])
+def test_layernorm(rows, C):
+    from dynamicscaler_amd import ops
+    d = dev()
+    x = _h(rnd((rows, C), 1) * 3 + 1)
+    g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    y = ops.layernorm(x.half().to(d), g.to(d), b.to(d))
+    assert relerr(y, F.layer_norm(x, (C,), g, b, 1e-5)) < 1e-3
+
+
+def test_misc_ops():
+    from dynamicscaler_amd import ops
+    d = dev()
+    a, b = _h(rnd((100, 64), 1)), _h(rnd((100, 128), 2))
+    assert torch.equal(ops.concat_channels(a.half().to(d), b.half().to(d)).cpu(), torch.cat([a, b], 1).half())
+    x = _h(rnd((2, 4, 3, 6, 8), 3))
+    for dt in (torch.float32, torch.float16):
+        p = ops.im2col_in(x.to(dt).to(d), 64).float().cpu()
+        ref = F.unfold(x.permute(0, 2, 1, 3, 4).reshape(6, 4, 6, 8), 3, padding=1)          # [6, C*9, L] (c-major)
+        ref = ref.reshape(6, 4, 9, 48).permute(0, 3, 2, 1).reshape(6 * 48, 36)                # -> (tap, c)
+        assert torch.equal(p[:, :36], ref) and float(p[:, 36:].abs().max()) == 0.0
+    y = rnd((2 * 3 * 6 * 8, 4), 4)
+    out = ops.rows_to_ncthw(y.to(d), (2, 4, 3, 6, 8), torch.float32).cpu()
+    assert torch.equal(out, y.reshape(2, 3, 6, 8, 4).permute(0, 4, 1, 2, 3))
+    t = torch.tensor([0, 20, 499, 999], dtype=torch.int64)
+    from oracle.unet import timestep_embedding
+    e = ops.timestep_embedding(t.to(d), 320).float().cpu()
+    assert float((e - timestep_embedding(t, 320)).abs().max()) < 2e-3
+    s = _h(rnd((1000,), 5) * 4)
+    assert relerr(ops.silu(s.half().to(d)), F.silu(s)) < 1e-3

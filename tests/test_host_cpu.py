@@ -1,0 +1,189 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports what include/*.h declares,
+host tables / window arithmetic equal the reference's golden vectors, the product never imports the oracle,
+and the product path fails loudly without a GPU."""
+import ast
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(REPO, "tests", "golden")
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from dynamicscaler_amd import build, _lib
+    build.build(verbose=False)
+    header = open(os.path.join(REPO, "include", "dynscaler_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert lib.ds_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from dynamicscaler_amd import _lib
+    header = open(os.path.join(REPO, "include", "dynscaler_hip.h")).read()
+    for struct, cls in (("ds_ring_geom", _lib.RingGeom), ("ds_gemm_desc", _lib.GemmDesc)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in re.findall(r"int32_t\s+([^;]+);", body):
+            names += [n.strip() for n in decl.split(",")]
+        assert names == [f[0] for f in cls._fields_], (struct, names)
+        assert C.sizeof(cls) == 4 * len(names)
+
+
+def test_product_never_imports_oracle_or_reference():
+    pkg = os.path.join(REPO, "dynamicscaler_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(root, f)).read())
+            for node in ast.walk(tree):
+                mods = []
+                if isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom) and node.module:
+                    mods = [node.module] if node.level == 0 else []
+                for m in mods:
+                    assert not m.split(".")[0] in ("oracle",), f"{f} imports {m}"
+            src = open(os.path.join(root, f)).read()
+            assert "/root/reference" not in src, f"{f} reads the reference tree"
+
+
+def test_product_fails_loudly_on_cpu():
+    from dynamicscaler_amd import ops, _lib
+    from dynamicscaler_amd.ring import RingLatent
+    from dynamicscaler_amd.unet import UNetModel
+    with pytest.raises(_lib.DsError, match="no CPU fallback"):
+        ops.ring_gather(torch.zeros(1, 4, 4, 8, 16), [(0, 0, 0)], (4, 8, 16))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        RingLatent(torch.zeros(1, 4, 4, 8, 16))
+    params = json.loads(bytes(np.load(os.path.join(G, "unet_tiny_t2v.npz"))["params_json"]).decode())
+    m = UNetModel(**params)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 4, 4, 8, 16), torch.tensor([1]), context=torch.zeros(1, 77, 64))
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    from dynamicscaler_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.HipLibraryMissing):
+        _lib.load()
+
+
+def test_scheduler_tables_equal_reference_golden():
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler, DiffusionTables
+    z = np.load(os.path.join(G, "scheduler.npz"))
+    tables = DiffusionTables()
+    assert np.array_equal(tables.alphas_cumprod.numpy(), z["alphas_cumprod"])
+    assert np.array_equal(tables.betas.numpy(), z["betas"])
+    for n in (4, 48, 50):
+        s = lvdm_DDIM_Scheduler(tables)
+        s.make_schedule(n, verbose=False)
+        assert np.array_equal(s.ddim_timesteps, z[f"ts_{n}"])
+        assert np.array_equal(s.ddim_alphas.numpy(), z[f"alphas_{n}"])
+        assert np.array_equal(np.asarray(s.ddim_alphas_prev, dtype=np.float64), z[f"alphas_prev_{n}"])
+        assert np.array_equal(np.asarray(s.ddim_sigmas, dtype=np.float64), z[f"sigmas_{n}"])
+        assert np.array_equal(s.ddim_sqrt_one_minus_alphas.numpy(), z[f"sqrt1m_{n}"])
+    # coefficient scalars are the oracle's
+    from oracle.ddim import DDIMSchedule, DiffusionTables as OT
+    o = DDIMSchedule(OT(), 50)
+    s = lvdm_DDIM_Scheduler(tables)
+    s.make_schedule(50, verbose=False)
+    for idx in (0, 10, 49):
+        assert s.step_coefficients(idx) == o.step_coefficients(idx)
+    assert s.renoise_coefficients(20, 21) == o.renoise_coefficients(20, 21)
+
+
+def test_host_rng_order_matches_reference_stream():
+    """draw_renoise_noise + draw_step_noise consume the global CPU generator exactly like re_noise + ddim_step."""
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler, DiffusionTables
+    s = lvdm_DDIM_Scheduler(DiffusionTables())
+    s.make_schedule(10, verbose=False)
+    shape = (1, 4, 4, 8, 16)
+    torch.manual_seed(5)
+    a = s.draw_renoise_noise(shape, "cpu", torch.float32)
+    s.draw_step_noise(shape, "cpu", torch.float32, 0.0)
+    b = s.draw_renoise_noise(shape, "cpu", torch.float32)
+    torch.manual_seed(5)
+    ra = torch.randn(shape)
+    for _ in range(4):
+        torch.randn((1, 4, 1, 8, 16))
+    rb = torch.randn(shape)
+    assert torch.equal(a, ra) and torch.equal(b, rb)
+
+
+def test_ring_windows_equal_reference_traces():
+    from dynamicscaler_amd.ring import ring_axis_steps, t2v_ring_windows, get_dimension_slices_and_sizes
+    for case in json.load(open(os.path.join(G, "ring_segments.json"))):
+        slices, sizes = get_dimension_slices_and_sizes(case["begin"], case["end"], case["size"])
+        assert [[s.start, s.stop] for s in slices] == case["slices"] and sizes == case["sizes"]
+
+    def windows(geom, i):
+        _, sw, ow = ring_axis_steps(geom["total_w"], geom["width"], geom["num_windows_w"], geom["loop_step"])
+        _, sh, oh = ring_axis_steps(geom["total_h"], geom["height"], geom["num_windows_h"], geom["loop_step"])
+        sf = 0 if geom["num_windows_f"] == 1 else geom["frames"] // geom["loop_step"]
+        return t2v_ring_windows(i, latent_h=geom["height"] // 8, latent_w=geom["width"] // 8, frames=geom["frames"],
+                                total_latent_h=geom["total_h"] // 8, step_w=sw, step_h=sh, off_w=ow, off_h=oh, step_f=sf,
+                                num_windows_w=geom["num_windows_w"], num_windows_h=geom["num_windows_h"],
+                                num_windows_f=geom["num_windows_f"], loop_step=geom["loop_step"],
+                                dock_at_h=geom.get("dock_at_h"))
+
+    for name, rec in json.load(open(os.path.join(G, "loop_traces.json"))).items():
+        for step in rec["trace"]:
+            assert [list(w) for w in windows(rec["geom"], step["i"])] == step["windows"], (name, step["i"])
+    small = json.load(open(os.path.join(G, "loops_small_traces.json")))
+    for name, trace in small["traces"].items():
+        for step in trace:
+            assert [list(w) for w in windows(small["geoms"][name], step["i"])] == step["windows"], (name, step["i"])
+
+
+def test_plan_levels_respects_reference_order():
+    from dynamicscaler_amd.parallel import plan_levels, windows_overlap
+    rec = json.load(open(os.path.join(G, "loop_traces.json")))
+    for name, expect_levels in (("cfg3_4096x512", 2), ("cfg2_2048x512", 2), ("cfg5_8192x1024x24", 4)):
+        geom = rec[name]["geom"]
+        fhw = (geom["frames"], geom["total_h"] // 8, geom["total_w"] // 8)
+        for step in rec[name]["trace"][:9]:
+            wins = [tuple(w) for w in step["windows"]]
+            levels = plan_levels(wins, fhw)
+            assert len(levels) == expect_levels
+            assert sorted(j for lv in levels for j in lv) == list(range(len(wins)))
+            lvl_of = {j: n for n, lv in enumerate(levels) for j in lv}
+            for a in range(len(wins)):
+                for b in range(a + 1, len(wins)):
+                    if windows_overlap(wins[a], wins[b], fhw):
+                        assert lvl_of[a] < lvl_of[b]          # reference order kept for every dependent pair
+                    # same level => disjoint
+                    assert lvl_of[a] != lvl_of[b] or not windows_overlap(wins[a], wins[b], fhw)
+    # the W-overlapped variant is one sequential chain per ... at least deeper than the column case
+    geom = rec["cfg3_overlap_nw10"]["geom"]
+    wins = [tuple(w) for w in rec["cfg3_overlap_nw10"]["trace"][1]["windows"]]
+    assert len(plan_levels(wins, (16, 64, 512))) >= 4
+
+
+def test_unet_state_dict_keys_and_geglu_interleave():
+    from dynamicscaler_amd.unet import UNetModel, _interleave_geglu
+    from dynamicscaler_amd.unet_spec import param_shapes
+    params = json.loads(bytes(np.load(os.path.join(G, "unet_tiny_t2v.npz"))["params_json"]).decode())
+    m = UNetModel(**params)
+    sd = m.state_dict()
+    shapes = param_shapes(params)
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+    assert "input_blocks.1.0.temopral_conv.conv1.0.weight" in sd and "init_attn.0.proj_in.weight" in sd
+    w = torch.arange(256).float()
+    iw = _interleave_geglu(w)
+    assert iw[:64].tolist() == list(range(0, 64)) and iw[64:128].tolist() == list(range(128, 192))
+    assert iw[128:192].tolist() == list(range(64, 128)) and iw[192:].tolist() == list(range(192, 256))
