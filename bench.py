@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- denoising-steps/sec of the tiled panoramic denoising loop on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric: 4096x512x16f): t2v overlapped-ring panorama, P = [1,4,16,64,512], 8x2 windows of
+512x320x16f (16 tiles / DDIM step, shifted every step), CFG 7.5 (2 UNet evaluations per tile), 50-step DDIM schedule,
+VideoCrafter2 t2v UNet (1.41 B parameters, synthetic fp16-representable weights), fp16 latents and activations
+with fp32 accumulation.  A "step" = one DDIM step over ALL tiles: ring gather -> re-noise/mix -> 32 UNet evaluations
+-> CFG+DDIM -> scatter (+ the per-level tile all-gather when N > 1).  Inputs are resident in HBM before the timed
+region; nothing is skipped.  N > 1 shards the tiles of the SAME panorama over the ranks (strong scaling).
+
+One JSON line on rank 0 with the driver's fields plus
+  "roofline":     the dominant kernel family (implicit-GEMM MFMA kernel): algorithmic FLOPs of every launch of one
+                  step / sum of their HIP-event durations, against the dense fp16 MFMA peak (2.5 PFLOP/s)
+  "cpu_baseline": the CPU oracle (oracle/, torch fp32) timed on this host on a bounded sample (one UNet evaluation
+                  of one tile = 1/32 of a step + the tile ops), extrapolated to steps/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+F_UNET_T2V = 12580.6e9       # FLOPs (2*MAC) per UNet evaluation at tile [1,4,16,40,64]
+MFMA_PEAK_F16 = 2500e12      # dense fp16 MFMA peak, MI355X_MICROARCH.md
+GEOM = dict(height=320, width=512, frames=16, total_w=4096, total_h=512, num_windows_w=8, num_windows_h=2,
+            num_windows_f=1, loop_step=8, num_inference_steps=50)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tile-batch", type=int, default=int(os.environ.get("DS_TILE_BATCH", "8")))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dynamicscaler_amd import ops
+    from dynamicscaler_amd.host_model import LatentDiffusionHost, SyntheticConditioner
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict, synth_normal
+
+    params = yaml.safe_load(open(os.path.join(REPO, "dynamicscaler_amd", "configs", "t2v_512_v2_unet.yaml")))
+    t0 = time.time()
+    sd = synth_state_dict(param_shapes(params), seed=0)
+    ld = LatentDiffusionHost({"params": params}, conditioner=SyntheticConditioner(77, params["context_dim"]))
+    unet = ld.model.diffusion_model
+    unet.load_state_dict(sd, strict=True)
+    unet.prepare(dev)                      # fp16 repack straight to HBM
+    if rank != 0 or args.no_cpu_baseline or world > 1:
+        del sd
+    setup_s = time.time() - t0
+
+    sched = lvdm_DDIM_Scheduler(ld, rng_mode="device")   # Philox noise in-kernel: no host RNG in the timed loop
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, sched, {"params": {"unet_config": {"params": params}}})
+    pipe.to(dev, torch.float16)
+    pipe.max_tile_batch = args.tile_batch
+    init = synth_normal((1, 4, 16, 64, 512), 2333333).to(dev)
+    st = pipe.ring_begin(prompt="a synthetic prompt", fps=8, guidance_scale=7.5, init_panorama_latent=init, **GEOM)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    step_idx = 0
+    for _ in range(args.warmup):
+        pipe.ring_step(st, step_idx)
+        step_idx += 1
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.ring_step(st, step_idx)
+        step_idx += 1
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert bool(torch.isfinite(st.pano.float()).all()), "non-finite latent after the timed steps"
+    ms_per_step = 1e3 * elapsed / args.steps
+    steps_per_s = args.steps / elapsed
+    tiles_per_step = GEOM["num_windows_w"] * GEOM["num_windows_h"]
+    flops_per_step = tiles_per_step * 2 * F_UNET_T2V
+
+    # ---- roofline of the dominant kernel: per-launch HIP events on one extra (untimed) step, this rank's share ----
+    roofline = None
+    if not args.no_roofline:
+        events = []
+
+        def hook(name, flops, launch):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch()
+            e1.record()
+            events.append((name, flops, e0, e1))
+
+        ops.set_timing_hook(hook)
+        pipe.ring_step(st, step_idx)
+        torch.cuda.synchronize()
+        ops.set_timing_hook(None)
+        agg = {}
+        for name, flops, e0, e1 in events:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        g = agg["gemm"]
+        achieved = g[1] / g[2] / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": "gemm_f16_kernel (implicit GEMM: linear / conv3x3 / temporal conv)",
+            "achieved": round(achieved, 2), "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
+            "frac": round(achieved * 1e12 / MFMA_PEAK_F16, 4), "traffic": None,
+            "launches_per_step": g[0], "algorithmic_tflop_per_step": round(g[1] / 1e12, 2),
+            "avg_launch_us": round(1e6 * g[2] / g[0], 2), "gemm_time_share_of_step": round(g[2] / (elapsed / args.steps), 3),
+            "attention_tflops": round(agg["attention"][1] / agg["attention"][2] / 1e12, 2) if "attention" in agg else None,
+            "whole_step_tflops": round(flops_per_step / (elapsed / args.steps) / 1e12, 2),
+            "whole_step_frac": round(flops_per_step / (elapsed / args.steps) / MFMA_PEAK_F16, 4),
+        }
+
+    # ---- CPU baseline: the oracle on this host, bounded sample ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.unet import unet_forward
+        from oracle import ring as oring, ddim as oddim
+        ncpu = os.cpu_count()
+        torch.set_num_threads(ncpu)
+        x = synth_normal((1, 4, 16, 40, 64), 7)
+        ctx = synth_normal((1, 77, 1024), 1)
+        tc = time.perf_counter()
+        e = unet_forward(sd, params, x, torch.tensor([499]), ctx, fps=8)
+        t_fwd = time.perf_counter() - tc
+        pano_c = synth_normal((1, 4, 16, 64, 512), 3)
+        osched = oddim.DDIMSchedule(oddim.DiffusionTables(), 50)
+        tc = time.perf_counter()
+        for _ in range(3):
+            w = oring.ring_gather(pano_c, 8, 72, 3, 43, 0, 16)
+            m = oring.ring_gather(torch.zeros_like(pano_c), 8, 72, 3, 43, 0, 16)
+            w = oddim.mix_latents_with_mask(w, oddim.re_noise(osched, w, 24, 25), m[0, 0, [0]], 1)
+            xp, x0 = oddim.ddim_step(osched, w, oddim.cfg_combine(e, e, 7.5), [25] * 16)
+            for dst in (pano_c, pano_c, pano_c):
+                oring.ring_scatter(dst, xp, 8, 72, 3, 43, 0, 16)
+        t_ops = (time.perf_counter() - tc) / 3
+        t_step = tiles_per_step * (2 * t_fwd + t_ops)
+        cpu_baseline = {
+            "value": 1.0 / t_step, "unit": "denoising-steps/sec", "cores": ncpu, "kind": "port",
+            "sample": f"1 fp32 UNet evaluation of one 512x320x16f tile ({t_fwd:.1f} s) = 1/32 of a step + the tile ops of "
+                      f"one tile ({t_ops * 1e3:.1f} ms); step time extrapolated as 16 tiles x (2 x UNet + tile ops)",
+            "sec_per_step": round(t_step, 1),
+        }
+
+    if rank == 0:
+        line = {
+            "metric": "denoising-steps/sec (whole node), 4096x512x16f panorama", "value": steps_per_s,
+            "unit": "denoising-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "t2v_sphere_panorama 4096x512x16f, 8x2 shifted ring windows (16 tiles/step), CFG 7.5, "
+                                   "VideoCrafter2 t2v UNet 1.41B, DDIM 50-step schedule",
+                       "tiles_per_step": tiles_per_step, "unet_evals_per_step": 2 * tiles_per_step,
+                       "tile_batch": args.tile_batch, "parallelism": f"tiles sharded over {world} GPU(s)",
+                       "rng": "philox in-kernel (perf mode)"},
+            "sec_per_50_step_panorama": 50 * elapsed / args.steps,
+            "speedup_vs_cpu_baseline": (steps_per_s / cpu_baseline["value"]) if cpu_baseline else None,
+            "setup_s": round(setup_s, 1),
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,6 +166,29 @@ class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
                                          merge_renoised_overlap_latent_ratio=1, window_multi_prompt_dict=None,
                                          use_skip_time=False, skip_time_step_idx=None, progressive_skip=False,
                                          step_callback=None, **kwargs):
+        st = self.ring_begin(prompt=prompt, height=height, width=width, frames=frames, fps=fps,
+                             guidance_scale=guidance_scale, init_panorama_latent=init_panorama_latent, total_w=total_w,
+                             total_h=total_h, num_windows_w=num_windows_w, num_windows_h=num_windows_h,
+                             num_windows_f=num_windows_f, loop_step=loop_step, dock_at_h=dock_at_h,
+                             num_inference_steps=num_inference_steps, prompt_embeds=prompt_embeds,
+                             merge_renoised_overlap_latent_ratio=merge_renoised_overlap_latent_ratio,
+                             window_multi_prompt_dict=window_multi_prompt_dict, use_skip_time=use_skip_time,
+                             skip_time_step_idx=skip_time_step_idx, progressive_skip=progressive_skip, **kwargs)
+        with self.progress_bar(total=len(st.timesteps)) as bar:
+            for i in range(len(st.timesteps)):
+                wins = self.ring_step(st, i)
+                if step_callback is not None:
+                    step_callback(i, int(st.timesteps[i]), wins, st.pano, st.pano_x0)
+                bar.update()
+        return self.ring_finish(st, output_type)
+
+    # ---- the loop in three pieces so a caller (bench.py) can time individual DDIM steps ----
+    @torch.no_grad()
+    def ring_begin(self, prompt=None, height=320, width=512, frames=16, fps=16, guidance_scale=7.5,
+                   init_panorama_latent=None, total_w=None, total_h=None, num_windows_w=None, num_windows_h=None,
+                   num_windows_f=None, loop_step=None, dock_at_h=None, num_inference_steps=4, prompt_embeds=None,
+                   merge_renoised_overlap_latent_ratio=1, window_multi_prompt_dict=None, use_skip_time=False,
+                   skip_time_step_idx=None, progressive_skip=False, **kwargs):
         unet_config = self.model_config["params"]["unet_config"]
         frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
         device = self._execution_device
@@ -174,10 +197,8 @@ class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
         timesteps = np.flip(self.scheduler.ddim_timesteps)
         if use_skip_time and not progressive_skip:
             timesteps = timesteps[skip_time_step_idx:]
-        total_steps = len(timesteps)
         vs = self.vae_scale_factor
         c_lat = unet_config["params"]["in_channels"]
-        lat_h, lat_w = height // vs, width // vs
         total_shape = (1, c_lat, frames * num_windows_f, total_h // vs, total_w // vs)
         if init_panorama_latent is None:
             init_panorama_latent = torch.randn(total_shape)  # host draw (global CPU generator), reference order
@@ -187,119 +208,129 @@ class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
             assert tuple(init_panorama_latent.shape) == total_shape, \
                 f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_panorama_latent.shape)} " \
                 f"does not match desired shape {total_shape}"
-        in_device = init_panorama_latent.device
-        pano = init_panorama_latent.to(device=device, dtype=self.latent_dtype).contiguous().clone()
-        pano_x0 = torch.zeros_like(pano)
-        mask = torch.zeros(total_shape[2:], dtype=torch.uint8, device=device)  # 1 byte per (f,y,x)
-
-        ov_w, step_w, off_w = ring_axis_steps(total_w, width, num_windows_w, loop_step)
+        st = _RingState()
+        st.in_device = init_panorama_latent.device
+        st.pano = init_panorama_latent.to(device=device, dtype=self.latent_dtype).contiguous().clone()
+        st.pano_x0 = torch.zeros_like(st.pano)
+        st.mask = torch.zeros(total_shape[2:], dtype=torch.uint8, device=device)  # 1 byte per (f,y,x)
+        ov_w, st.step_w, st.off_w = ring_axis_steps(total_w, width, num_windows_w, loop_step)
         assert 0 <= ov_w < 1, "overlap ratio for W is not legal"
-        assert off_w, "latent_offset_step_size_w <= 0 ! consider increase W windows"
-        ov_h, step_h, off_h = ring_axis_steps(total_h, height, num_windows_h, loop_step)
+        assert st.off_w, "latent_offset_step_size_w <= 0 ! consider increase W windows"
+        ov_h, st.step_h, st.off_h = ring_axis_steps(total_h, height, num_windows_h, loop_step)
         assert 0 <= ov_h < 1, "overlap ratio for H is not legal"
-        assert off_h > 0, "latent_offset_step_size_h <= 0 ! consider increase H windows"
-        step_f = frames // loop_step
+        assert st.off_h > 0, "latent_offset_step_size_h <= 0 ! consider increase H windows"
+        st.step_f = frames // loop_step
         if num_windows_f == 1:
-            step_f = 0
-        assert step_f > 0 or num_windows_f == 1, \
+            st.step_f = 0
+        assert st.step_f > 0 or num_windows_f == 1, \
             f"[basic_sample_shift_multi_windows] loop_step {loop_step} > frames {frames} while num_windows_f {num_windows_f} > 0"
-
-        rank, world = 0, 1
+        st.rank, st.world = 0, 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
-            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
-        tile_fhw = (frames, lat_h, lat_w)
-        tile_shape = (1, c_lat) + tile_fhw
-        pano_fhw = tuple(total_shape[2:])
-        sched = self.scheduler
+            st.rank, st.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        st.timesteps, st.total_steps = timesteps, len(timesteps)
+        st.total_shape, st.device, st.frames, st.fps = total_shape, device, frames, fps
+        st.lat_h, st.lat_w, st.total_lat_h = height // vs, width // vs, total_h // vs
+        st.tile_fhw = (frames, st.lat_h, st.lat_w)
+        st.tile_shape = (1, c_lat) + st.tile_fhw
+        st.pano_fhw = tuple(total_shape[2:])
+        st.nw, st.nh, st.nf, st.loop_step, st.dock_at_h = num_windows_w, num_windows_h, num_windows_f, loop_step, dock_at_h
+        st.guidance_scale, st.ratio = guidance_scale, merge_renoised_overlap_latent_ratio
+        st.text_emb = text_emb.to(device)
+        st.uc_emb = uc_emb.to(device) if uc_emb is not None else None
+        st.window_multi_prompt_dict, st.prompt_cache = window_multi_prompt_dict, {}
         kwargs.update({"clean_cond": True})
-        prompt_cache = {}
-        ratio = merge_renoised_overlap_latent_ratio
+        st.kwargs = kwargs
+        return st
 
-        with self.progress_bar(total=len(timesteps)) as bar:
-            for i, t in enumerate(timesteps):
-                mask.zero_()  # fresh mask every step (:494)
-                wins = t2v_ring_windows(i, latent_h=lat_h, latent_w=lat_w, frames=frames, total_latent_h=total_h // vs,
-                                        step_w=step_w, step_h=step_h, off_w=off_w, off_h=off_h, step_f=step_f,
-                                        num_windows_w=num_windows_w, num_windows_h=num_windows_h,
-                                        num_windows_f=num_windows_f, loop_step=loop_step, dock_at_h=dock_at_h)
-                renoise = ratio is not None and i < total_steps - 1
-                index = total_steps - i - 1
-                coef = sched.step_coefficients(index)
-                # host noise for the whole step in the reference's tile order (appendix B): randn_like(tile) of
-                # re_noise, then `frames` per-frame draws of ddim_step -- per window
-                noises = []
-                for _ in wins:
-                    nz = sched.draw_renoise_noise(tile_shape, "cpu", torch.float32) if renoise else None
-                    sn = sched.draw_step_noise(tile_shape, "cpu", torch.float32, coef["sigma"])
-                    noises.append((nz, sn))
+    @torch.no_grad()
+    def ring_step(self, st, i):
+        """One DDIM step over all windows of the panorama (t2v_sphere_panorama_pipeline.py:481-634)."""
+        t = st.timesteps[i]
+        sched, device, pano = self.scheduler, st.device, st.pano
+        st.mask.zero_()  # fresh mask every step (:494)
+        wins = t2v_ring_windows(i, latent_h=st.lat_h, latent_w=st.lat_w, frames=st.frames,
+                                total_latent_h=st.total_lat_h, step_w=st.step_w, step_h=st.step_h, off_w=st.off_w,
+                                off_h=st.off_h, step_f=st.step_f, num_windows_w=st.nw, num_windows_h=st.nh,
+                                num_windows_f=st.nf, loop_step=st.loop_step, dock_at_h=st.dock_at_h)
+        renoise = st.ratio is not None and i < st.total_steps - 1
+        coef = sched.step_coefficients(st.total_steps - i - 1)
+        # host noise for the whole step in the reference's tile order (appendix B): randn_like(tile) of re_noise,
+        # then `frames` per-frame draws of ddim_step -- per window.  (No host draws at all in rng_mode "device".)
+        noises = []
+        for _ in wins:
+            nz = sched.draw_renoise_noise(st.tile_shape, "cpu", torch.float32) if renoise else None
+            sn = sched.draw_step_noise(st.tile_shape, "cpu", torch.float32, coef["sigma"])
+            noises.append((nz, sn))
+        if renoise:
+            c_rn, s_rn = sched.renoise_coefficients(st.total_steps - i - 2, st.total_steps - i - 1)
+        # per-window prompt (R13): embeddings cached per distinct prompt instead of re-running CLIP per tile
+        ctxs = []
+        for (l, r, tp, dn, fb, fe) in wins:
+            if st.window_multi_prompt_dict is not None:
+                cur = select_prompt_from_multi_prompt_dict_by_factor(st.window_multi_prompt_dict, dn / st.total_lat_h)
+                if cur not in st.prompt_cache:
+                    st.prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(device)
+                ctxs.append(st.prompt_cache[cur])
+            else:
+                ctxs.append(st.text_emb)
+        self._log(f"i = {i}, t = {t}: {len(wins)} windows")
+        for level in parallel.plan_levels(wins, st.pano_fhw):
+            mine = parallel.rank_share(level, st.rank, st.world)
+            xp_parts, x0_parts = [], []
+            for s in range(0, len(mine), self.max_tile_batch):
+                ids = mine[s:s + self.max_tile_batch]
+                origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
+                tiles, mtiles = ops.ring_gather(pano, origins, st.tile_fhw, st.mask)
                 if renoise:
-                    c_rn, s_rn = sched.renoise_coefficients(total_steps - i - 2, total_steps - i - 1)
-                # per-window prompt (R13): embeddings cached per distinct prompt instead of re-running CLIP per tile
-                ctxs = []
-                for (l, r, tp, dn, fb, fe) in wins:
-                    if window_multi_prompt_dict is not None:
-                        cur = select_prompt_from_multi_prompt_dict_by_factor(window_multi_prompt_dict,
-                                                                              dn / (total_h // vs))
-                        if cur not in prompt_cache:
-                            prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur])
-                        ctxs.append(prompt_cache[cur])
-                    else:
-                        ctxs.append(text_emb)
-                self._log(f"i = {i}, t = {t}: {len(wins)} windows")
-                for level in parallel.plan_levels(wins, pano_fhw):
-                    mine = parallel.rank_share(level, rank, world)
-                    xp_parts, x0_parts = [], []
-                    for s in range(0, len(mine), self.max_tile_batch):
-                        ids = mine[s:s + self.max_tile_batch]
-                        origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
-                        tiles, mtiles = ops.ring_gather(pano, origins, tile_fhw, mask)
-                        if renoise:
-                            nz = None
-                            if noises[ids[0]][0] is not None:
-                                nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=pano.dtype)
-                            ops.renoise_mix_(tiles, mtiles, total_shape, c_rn, s_rn, ratio, noise=nz, mask_frame0=True,
-                                             seed=sched.philox_seed,
-                                             offset=(i * len(wins) + ids[0]) * tiles[0].numel())
-                        n = len(ids)
-                        if guidance_scale != 1.0:
-                            eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [uc_emb] * n,
-                                            fps, frames, **kwargs)
-                            e_c, e_u = eps[:n], eps[n:]
-                        else:
-                            e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], fps, frames, **kwargs), None
-                        sn = None
-                        if coef["sigma"] != 0.0:
-                            sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=pano.dtype)
-                        x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, total_shape, guidance_scale, coef, sn)
-                        xp_parts.append(x_prev)
-                        x0_parts.append(x0)
-                    if world > 1:
-                        empty = torch.empty((0,) + tile_shape[1:], dtype=pano.dtype, device=device)
-                        xp_l = torch.cat(xp_parts, 0) if xp_parts else empty
-                        x0_l = torch.cat(x0_parts, 0) if x0_parts else empty
-                        xp_all, x0_all = parallel.exchange_level(xp_l, x0_l, len(level))
-                        order = level
-                    else:
-                        xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
-                    for s in range(0, len(order), ops.DS_MAX_WINDOWS):
-                        ids = order[s:s + ops.DS_MAX_WINDOWS]
-                        origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
-                        ops.ring_scatter3(pano, pano_x0, mask, xp_all[s:s + len(ids)].contiguous(),
-                                          x0_all[s:s + len(ids)].contiguous(), origins)
-                if step_callback is not None:
-                    step_callback(i, int(t), wins, pano, pano_x0)
-                bar.update()
+                    nz = None
+                    if noises[ids[0]][0] is not None:
+                        nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=pano.dtype)
+                    ops.renoise_mix_(tiles, mtiles, st.total_shape, c_rn, s_rn, st.ratio, noise=nz, mask_frame0=True,
+                                     seed=sched.philox_seed, offset=(i * len(wins) + ids[0]) * tiles[0].numel())
+                n = len(ids)
+                if st.guidance_scale != 1.0:
+                    eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n,
+                                    st.fps, st.frames, **st.kwargs)
+                    e_c, e_u = eps[:n], eps[n:]
+                else:
+                    e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], st.fps, st.frames, **st.kwargs), None
+                sn = None
+                if coef["sigma"] != 0.0:
+                    sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=pano.dtype)
+                x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, st.total_shape, st.guidance_scale, coef, sn)
+                xp_parts.append(x_prev)
+                x0_parts.append(x0)
+            if st.world > 1:
+                empty = torch.empty((0,) + st.tile_shape[1:], dtype=pano.dtype, device=device)
+                xp_l = torch.cat(xp_parts, 0) if xp_parts else empty
+                x0_l = torch.cat(x0_parts, 0) if x0_parts else empty
+                xp_all, x0_all = parallel.exchange_level(xp_l, x0_l, len(level))
+                order = level
+            else:
+                xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
+            for s in range(0, len(order), ops.DS_MAX_WINDOWS):
+                ids = order[s:s + ops.DS_MAX_WINDOWS]
+                origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
+                ops.ring_scatter3(pano, st.pano_x0, st.mask, xp_all[s:s + len(ids)].contiguous(),
+                                  x0_all[s:s + len(ids)].contiguous(), origins)
+        return wins
 
-        self.final_latent = pano  # x_t panorama after the last step (not returned by the reference's ring variant)
-        denoised = pano_x0.clone().to(device=in_device) if in_device.type == "cuda" else pano_x0.clone()
+    @torch.no_grad()
+    def ring_finish(self, st, output_type="latent"):
+        self.final_latent = st.pano  # x_t panorama after the last step (not returned by the reference's ring variant)
+        denoised = st.pano_x0.clone()
         if not output_type == "latent":
             # seam-safe decode (:638-655): pad W with wrapped 1/16 chunks, decode per frame, crop
             chunks = list(torch.chunk(denoised, 16, dim=4))
             padded = torch.cat([chunks[-1]] + chunks + [chunks[0]], dim=4)
             frames_out = [self.pretrained_t2v.decode_first_stage_2DAE(padded[:, :, [f]])
-                          for f in range(frames * num_windows_f)]
+                          for f in range(st.total_shape[2])]
             videos = torch.cat(frames_out, dim=2)
             videos = torch.cat(torch.chunk(videos, 18, dim=4)[1:-1], dim=4)
         else:
             videos = denoised
         return videos, denoised
+
+
+class _RingState:
+    """Mutable state of one overlapped-ring sampling run (panoramas resident in HBM)."""

@@ -35,7 +35,7 @@ def relerr(a, b):
 @pytest.mark.parametrize("geom", [
     # (pano F,H,W), (tile f,h,w), origins [(f0,y0,x0)]
     ((6, 8, 16), (4, 4, 8), [(0, 0, 0), (4, 6, 8), (5, 7, 16)]),             # vector path (x0 % 8 == 0), wraps F,H,W
-    ((6, 8, 16), (3, 5, 7), [(1, 2, 3), (5, 6, 13), (11, 15, 31)]),          # scalar path, max origins (< 2*size)
+    ((6, 8, 16), (3, 5, 7), [(1, 2, 3), (5, 6, 13), (9, 11, 25)]),          # scalar path, max origins (< 2*size)
     ((16, 64, 512), (16, 40, 64), [(0, 3, 8 + 64 * k) for k in range(8)]),   # config-3 step-1 row 0
     ((16, 64, 512), (16, 40, 64), [(0, 27, 456)]),                           # crosses the W seam and the H seam
 ])

@@ -163,7 +163,8 @@ def test_ring_pipeline_fake_eps_bit_exact_fp32():
         def forward(self, x, t, c_crossattn=None, fps=None, **kw):
             ctx = torch.cat(c_crossattn, 1)
             # per-item mean of the context, computed on the host in fp32 like the reference does on CPU
-            m = torch.stack([0.01 * c.float().cpu().mean() for c in ctx]).to(x.device)
+            # (same [1,L,D] shape as the reference's tensor: torch's CPU reduction order depends on it)
+            m = torch.stack([0.01 * c[None].float().cpu().mean() for c in ctx]).to(x.device)
             return 0.1 * x.float() + m.reshape(-1, 1, 1, 1, 1)
 
     class Host:
