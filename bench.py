@@ -35,6 +35,19 @@ GEOM = dict(height=320, width=512, frames=16, total_w=4096, total_h=512, num_win
             num_windows_f=1, loop_step=8, num_inference_steps=50)
 
 
+def usable_cpus():
+    """Threads this process may really use: affinity mask, capped by the cgroup CPU quota (a 256-thread pool on a
+    throttled container is far slower than a right-sized one)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,7 +161,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.unet import unet_forward
         from oracle import ring as oring, ddim as oddim
-        ncpu = os.cpu_count()
+        ncpu = usable_cpus()
         torch.set_num_threads(ncpu)
         x = synth_normal((1, 4, 16, 40, 64), 7)
         ctx = synth_normal((1, 77, 1024), 1)

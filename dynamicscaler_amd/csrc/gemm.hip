@@ -27,16 +27,19 @@ constexpr int BK = 64;  // halfs per K-step (128-byte LDS rows, 8 chunks of 16 b
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 struct RowInfo {   // per staged A row, computed once
-    long base;     // element offset of the row's "centre" source (DENSE/TCONV: m*lda)
+    unsigned base; // BYTE offset of the row's source (DENSE/TCONV: m*lda*2; CONV3: image origin)
     int a, b, c;   // CONV3: img, oy, ox ; TCONV: t ; validity
     bool valid;
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int AMODE>
 __global__ void __launch_bounds__(256, 2)
 gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const float* __restrict__ bias,
-                const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n) {
+                const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n,
+                unsigned a_bytes, unsigned w_bytes) {
     constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
     constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
     constexpr int A_ROWS_PER_THREAD = BM / 32, B_ROWS_PER_THREAD = BN / 32;
@@ -64,78 +67,83 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const int ld_row = tid >> 3;   // 0..31
     const int ld_chunk = tid & 7;  // 16-byte chunk within the 64-half K-step
 
-    // ---- per-row source bookkeeping for the A gather ----
+    // ---- per-row source bookkeeping for the A gather.  All global reads are raw BUFFER loads: a padding tap or a
+    //      tail row gets byte offset OOB (> num_records), for which the hardware returns zeros -- no branch, no
+    //      select, so the loads of the next K-step stay in flight behind the MFMAs of the current one. ----
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(A), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W), 0, (int)w_bytes, 0x00020000);
     RowInfo ri[A_ROWS_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
         const int m = m0 + ld_row + 32 * i;
         ri[i].valid = m < d.M;
         const int mm = ri[i].valid ? m : 0;
-        if (d.a_mode == DS_A_CONV3) {
+        if constexpr (AMODE == DS_A_CONV3) {
             const int hw = d.hout * d.wout;
             const int img = mm / hw, rem = mm - img * hw;
-            ri[i].a = img; ri[i].b = rem / d.wout; ri[i].c = rem - ri[i].b * d.wout;
-            ri[i].base = 0;
-        } else if (d.a_mode == DS_A_TCONV) {
+            const int oy = rem / d.wout;
+            ri[i].a = img; ri[i].b = oy * d.stride - 1; ri[i].c = (rem - oy * d.wout) * d.stride - 1;
+            ri[i].base = (unsigned)(img * d.hin * d.win) * (unsigned)d.lda * 2u;
+        } else if constexpr (AMODE == DS_A_TCONV) {
             ri[i].a = (mm / d.hw) % d.t_len; ri[i].b = 0; ri[i].c = 0;
-            ri[i].base = (long)mm * d.lda;
+            ri[i].base = (unsigned)mm * (unsigned)d.lda * 2u;
         } else {
             ri[i].a = ri[i].b = ri[i].c = 0;
-            ri[i].base = (long)mm * d.lda;
+            ri[i].base = (unsigned)mm * (unsigned)d.lda * 2u;
         }
     }
-    bool b_valid[B_ROWS_PER_THREAD];
-    long b_base[B_ROWS_PER_THREAD];
+    unsigned b_off[B_ROWS_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
         const int n = n0 + ld_row + 32 * i;
-        b_valid[i] = n < d.N;
-        b_base[i] = (long)(b_valid[i] ? n : 0) * d.K;
+        b_off[i] = n < d.N ? ((unsigned)n * (unsigned)d.K + ld_chunk * 8) * 2u : OOB;
     }
 
-    uint4 ra[A_ROWS_PER_THREAD], rb[B_ROWS_PER_THREAD];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    u32x4 ra[A_ROWS_PER_THREAD], rb[B_ROWS_PER_THREAD];
+    const int hl = d.upsample ? 2 * d.hin : d.hin, wl = d.upsample ? 2 * d.win : d.win;
+    const int ups = d.upsample ? 1 : 0;
+    int tap = 0, cb = 0;   // position of the next K-step inside (tap, channel)
+    unsigned kbytes = 0;   // byte offset of the next K-step inside a W row
 
-    auto load_global = [&](int kt) {
-        const int k0 = kt * BK;
-        const int tap = k0 / d.cin;
-        const int cb = k0 - tap * d.cin + ld_chunk * 8;
+    // issue the global loads of the NEXT K-step (no waits, no branches)
+    auto load_global = [&]() {
+        const unsigned cbl = (unsigned)(cb + ld_chunk * 8) * 2u;
 #pragma unroll
         for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
             bool ok = ri[i].valid;
-            long off;
-            if (d.a_mode == DS_A_CONV3) {
+            unsigned off;
+            if constexpr (AMODE == DS_A_CONV3) {
                 const int ky = tap / 3, kx = tap - ky * 3;
-                int iy = ri[i].b * d.stride + ky - 1;
-                int ix = ri[i].c * d.stride + kx - 1;
-                const int hl = d.upsample ? 2 * d.hin : d.hin, wl = d.upsample ? 2 * d.win : d.win;
+                const int iy = ri[i].b + ky, ix = ri[i].c + kx;
                 ok = ok && iy >= 0 && iy < hl && ix >= 0 && ix < wl;
-                if (d.upsample) { iy >>= 1; ix >>= 1; }
-                off = (((long)ri[i].a * d.hin + iy) * d.win + ix) * d.lda + cb;
-            } else if (d.a_mode == DS_A_TCONV) {
+                off = ri[i].base + (unsigned)((iy >> ups) * d.win + (ix >> ups)) * (unsigned)d.lda * 2u + cbl;
+            } else if constexpr (AMODE == DS_A_TCONV) {
                 const int tt = ri[i].a + tap - 1;
                 ok = ok && tt >= 0 && tt < d.t_len;
-                off = ri[i].base + (long)(tap - 1) * d.hw * d.lda + cb;
+                off = ri[i].base + (unsigned)((tap - 1) * d.hw * d.lda * 2) + cbl;
             } else {
-                off = ri[i].base + cb;
+                off = ri[i].base + cbl;
             }
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(A + off) : zero4;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : OOB, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
-            rb[i] = b_valid[i] ? *reinterpret_cast<const uint4*>(W + b_base[i] + k0 + ld_chunk * 8) : zero4;
-        }
+        for (int i = 0; i < B_ROWS_PER_THREAD; ++i)
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_off[i] == OOB ? OOB : b_off[i] + kbytes, 0, 0);
+        kbytes += BK * 2;
+        cb += BK;
+        if (cb == d.cin) { cb = 0; ++tap; }
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
             const int row = ld_row + 32 * i;
-            *reinterpret_cast<uint4*>(sA + (buf * BM + row) * BK + swz_chunk(row, ld_chunk) * 8) = ra[i];
+            *reinterpret_cast<u32x4*>(sA + (buf * BM + row) * BK + swz_chunk(row, ld_chunk) * 8) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
             const int row = ld_row + 32 * i;
-            *reinterpret_cast<uint4*>(sB + (buf * BN + row) * BK + swz_chunk(row, ld_chunk) * 8) = rb[i];
+            *reinterpret_cast<u32x4*>(sB + (buf * BN + row) * BK + swz_chunk(row, ld_chunk) * 8) = rb[i];
         }
     };
 
@@ -150,13 +158,13 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const int nk = d.K / BK;
     const int fr = lane & 31, fh = lane >> 5;
 
-    load_global(0);
+    load_global();
     store_lds(0);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_global(kt + 1);
+        if (kt + 1 < nk) load_global();
         const f16* a_base = sA + (buf * BM + wm * WM) * BK;
         const f16* b_base_l = sB + (buf * BN + wn * WN) * BK;
 #pragma unroll
@@ -201,7 +209,8 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const bool geglu = d.epilogue & DS_EPI_GEGLU;
     const bool silu = d.epilogue & DS_EPI_SILU;
     const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;
-    const bool fast = !out_f32 && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (!residual || d.ldr % 8 == 0);
+    const bool fast = !out_f32 && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (!residual || d.ldr % 8 == 0) &&
+                      (!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0));
 
     if (fast) {
         constexpr int OUT_COLS = BN;  // GEGLU uses the first BN/2 chunk columns only
@@ -224,8 +233,10 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 v[4] = p1[0]; v[5] = p1[1]; v[6] = p1[2]; v[7] = p1[3];
             }
             if (bias) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += bias[brow + n + j];
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + brow + n);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + brow + n + 4);
+                v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3];
+                v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
             }
             long ocol;
             if (geglu) {
@@ -235,9 +246,15 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 const f32x4 g1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 68);
                 gte[0] = g0[0]; gte[1] = g0[1]; gte[2] = g0[2]; gte[3] = g0[3];
                 gte[4] = g1[0]; gte[5] = g1[1]; gte[6] = g1[2]; gte[7] = g1[3];
+                if (bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + brow + n + 64);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + brow + n + 68);
+                    gte[0] += b0[0]; gte[1] += b0[1]; gte[2] += b0[2]; gte[3] += b0[3];
+                    gte[4] += b1[0]; gte[5] += b1[1]; gte[6] += b1[2]; gte[7] += b1[3];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float gg = gte[j] + (bias ? bias[brow + n + 64 + j] : 0.0f);
+                    const float gg = gte[j];
                     v[j] = v[j] * (0.5f * gg * (1.0f + erff(gg * 0.70710678118654752f)));
                 }
                 ocol = (long)tile_n * (BN / 2) + nloc;
@@ -275,7 +292,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int AMODE>
 int launch(const void* A, const void* W, const float* bias, const void* residual, void* out,
            const ds_gemm_desc& d, hipStream_t st) {
     constexpr size_t stage = (size_t)2 * (BM + BN) * BK * sizeof(f16);
@@ -283,7 +300,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
     constexpr size_t lds = stage > epi ? stage : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, AMODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("ds_gemm_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -292,8 +309,17 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
         attr_set = true;
     }
     const int tiles_m = ds_cdiv(d.M, BM), tiles_n = ds_cdiv(d.N, BN);
-    gemm_f16_kernel<BM, BN><<<tiles_m * tiles_n, 256, lds, st>>>((const f16*)A, (const f16*)W, bias,
-                                                                 (const f16*)residual, out, d, tiles_m, tiles_n);
+    // buffer-load addressing is 32-bit: the A operand and W must each stay below 4 GiB
+    const long a_rows = AMODE == DS_A_CONV3 ? (long)d.nimg * d.hin * d.win : (long)d.M;
+    const long a_bytes = ((a_rows - 1) * d.lda + d.cin) * 2;
+    const long w_bytes = (long)d.N * d.K * 2;
+    if (a_bytes >= 0xFFFFFF00L || w_bytes >= 0xFFFFFF00L) {
+        ds_set_error("ds_gemm_f16: operand of %ld / %ld bytes exceeds the 4 GiB buffer-addressing range; lower the tile batch", a_bytes, w_bytes);
+        return DS_EINVAL;
+    }
+    gemm_f16_kernel<BM, BN, AMODE><<<tiles_m * tiles_n, 256, lds, st>>>((const f16*)A, (const f16*)W, bias,
+                                                                 (const f16*)residual, out, d, tiles_m, tiles_n,
+                                                                 (unsigned)a_bytes, (unsigned)w_bytes);
     DS_CHECK_LAUNCH("ds_gemm_f16");
     return DS_OK;
 }
@@ -333,6 +359,12 @@ extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, cons
     // tile choice: 128x128 unless it wastes too much of N (N=320 -> 3 tiles of 128 = 17% waste) or GEGLU needs it
     const bool geglu = d.epilogue & DS_EPI_GEGLU;
     const int waste128 = ds_cdiv(d.N, 128) * 128 - d.N;
-    if (geglu || waste128 * 8 <= d.N) return launch<128, 128>(A, W, bias, residual, out, d, st);
-    return launch<128, 64>(A, W, bias, residual, out, d, st);
+    const bool big = geglu || waste128 * 8 <= d.N;
+#define DS_DISPATCH(MODE)                                                                  \
+    return big ? launch<128, 128, MODE>(A, W, bias, residual, out, d, st)                  \
+               : launch<128, 64, MODE>(A, W, bias, residual, out, d, st)
+    if (d.a_mode == DS_A_CONV3) { DS_DISPATCH(DS_A_CONV3); }
+    if (d.a_mode == DS_A_TCONV) { DS_DISPATCH(DS_A_TCONV); }
+    DS_DISPATCH(DS_A_DENSE);
+#undef DS_DISPATCH
 }
