@@ -67,8 +67,10 @@ def exchange_level(x_prev_local, x0_local, n_items, group=None):
     if n_local:
         send[0, :n_local] = x_prev_local
         send[1, :n_local] = x0_local
-    recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+    # output = concatenation along dim 0 (the form both RCCL and gloo accept), viewed back as [world, 2, cmax, ...]
+    recv = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
     dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view((world,) + tuple(send.shape))
     x_prev_all = torch.empty((n_items,) + tile_shape, dtype=send.dtype, device=send.device)
     x0_all = torch.empty_like(x_prev_all)
     for r in range(world):
