@@ -14,6 +14,7 @@
 //      * O^T keeps the query on the lane as well, so the online-softmax rescale is a per-lane scalar.
 // 2) ds_temporal_attention_f16 -- self-attention over T (<= 32) frames per pixel (TemporalTransformer,
 //    attention.py:281-373): 0.1% of the FLOPs, pure HBM traffic; one wave per (pixel, head), VALU math.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -67,7 +68,9 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
             for (int j = 0; j < 16; ++j) o[qb][db][j] = 0.0f;
     }
 
-    // staging: thread -> (key row = tid/8 (+32), 16-byte chunk = tid%8)
+    // staging: K rows go in as 16-byte chunks (thread -> key row tid/8 (+32), chunk tid%8); V is TRANSPOSED on the
+    // way in: a thread takes the same 8-column chunk of keys 2p and 2p+1 and writes 8 dwords {V[2p][d], V[2p+1][d]}
+    // into V^T[d][2p] (32-bit LDS stores, no sub-dword writes).
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
     uint4 rk[2], rv[2];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
@@ -75,12 +78,9 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int key = t * KT + ld_row + 32 * i;
-            if (key < nk) {
-                rk[i] = *reinterpret_cast<const uint4*>(kp + (long)key * ldk + ld_chunk * 8);
-                rv[i] = *reinterpret_cast<const uint4*>(vp + (long)key * ldv + ld_chunk * 8);
-            } else {
-                rk[i] = zero4; rv[i] = zero4;
-            }
+            rk[i] = key < nk ? *reinterpret_cast<const uint4*>(kp + (long)key * ldk + ld_chunk * 8) : zero4;
+            const int vkey = t * KT + 2 * ld_row + i;
+            rv[i] = vkey < nk ? *reinterpret_cast<const uint4*>(vp + (long)vkey * ldv + ld_chunk * 8) : zero4;
         }
     };
     auto store_l = [&]() {
@@ -88,10 +88,13 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
         for (int i = 0; i < 2; ++i) {
             const int row = ld_row + 32 * i;
             *reinterpret_cast<uint4*>(sK + row * HD + swz_chunk(row, ld_chunk) * 8) = rk[i];
-            const f16* vv = reinterpret_cast<const f16*>(&rv[i]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sVT[(ld_chunk * 8 + j) * VT_STRIDE + row] = vv[j];
         }
+        const unsigned short* v0 = reinterpret_cast<const unsigned short*>(&rv[0]);
+        const unsigned short* v1 = reinterpret_cast<const unsigned short*>(&rv[1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            *reinterpret_cast<unsigned*>(sVT + (ld_chunk * 8 + j) * VT_STRIDE + 2 * ld_row) =
+                (unsigned)v0[j] | ((unsigned)v1[j] << 16);
     };
 
     const int ntiles = (nk + KT - 1) / KT;
@@ -123,36 +126,45 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
                 for (int ks = 0; ks < 4; ++ks)
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[qb][ks], s[kb], 0, 0, 0);
             }
-            // scale, mask the keys past nk, running max
+            // running max on the raw scores (scale > 0), keys past nk masked (last tile only)
+            if (t == ntiles - 1 && (nk % KT) != 0) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int key = t * KT + kb * 32 + (j & 3) + 8 * (j >> 2) + 4 * fh;
+                        s[kb][j] = key < nk ? s[kb][j] : -1e30f;
+                    }
+            }
             float mt = -1e30f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int key = t * KT + kb * 32 + (j & 3) + 8 * (j >> 2) + 4 * fh;
-                    float sv = s[kb][j] * scale_log2;
-                    sv = key < nk ? sv : -1e30f;
-                    s[kb][j] = sv;
-                    mt = fmaxf(mt, sv);
-                }
+                for (int j = 0; j < 16; ++j) mt = fmaxf(mt, s[kb][j]);
             mt = fmaxf(mt, __shfl_xor(mt, 32));
-            const float mnew = fmaxf(mrun[qb], mt);
-            const float alpha = exp2f(mrun[qb] - mnew);
+            const float mold = mrun[qb];
+            const float mnew = fmaxf(mold, mt);
             mrun[qb] = mnew;
+            const float mneg = -mnew * scale_log2;
             float lsum = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const float p = exp2f(s[kb][j] - mnew);
+                    const float p = exp2f(fmaf(s[kb][j], scale_log2, mneg));
                     s[kb][j] = p;
                     lsum += p;
                 }
-            lrun[qb] = lrun[qb] * alpha + lsum;
+            if (__all(mnew == mold)) {
+                lrun[qb] += lsum;          // no query of this wave moved its max: alpha == 1 everywhere
+            } else {
+                const float alpha = exp2f((mold - mnew) * scale_log2);
+                lrun[qb] = lrun[qb] * alpha + lsum;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+                for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) o[qb][db][j] *= alpha;
+                    for (int j = 0; j < 16; ++j) o[qb][db][j] *= alpha;
+            }
 
             // O^T[d][q] += V^T[d][key] * P^T[key][q]
 #pragma unroll
@@ -323,7 +335,9 @@ extern "C" int ds_attention_f16(const void* q, const void* k, const void* v, voi
     DS_CHECK_ARG(ldq >= heads * HD && ldk >= heads * HD && ldv >= heads * HD && ldo >= heads * HD, "ds_attention_f16: row stride < heads*64");
     hipStream_t st = (hipStream_t)stream;
     const float scale_log2 = scale * 1.4426950408889634f;
-    if (nq >= 512) {
+    static const int force_qb = getenv("DS_ATTN_QB") ? atoi(getenv("DS_ATTN_QB")) : 0;
+    // QB=1 (128 queries / workgroup, 2 waves per SIMD) measured faster than QB=2 at every UNet shape (round 1)
+    if (force_qb == 2) {
         const int q_tiles = ds_cdiv(nq, 256);
         attention_kernel<2><<<(long)batch * heads * q_tiles, 256, 0, st>>>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out,
                                                                          heads, nq, nk, ldq, ldk, ldv, ldo, kv_batch_div, scale_log2, accumulate, q_tiles);

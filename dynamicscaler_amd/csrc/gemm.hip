@@ -19,6 +19,7 @@
 //     coalesced stores.
 //   * blockIdx is remapped so that the blocks that share an XCD (bid % 8) walk neighbouring N tiles of the same
 //     A row panel (L2 reuse; performance only).
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -213,69 +214,97 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                       (!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0));
 
     if (fast) {
-        constexpr int OUT_COLS = BN;  // GEGLU uses the first BN/2 chunk columns only
-        const int chunks_per_row = geglu ? BN / 16 : BN / 8;
-        const int total_chunks = BM * chunks_per_row;
-        for (int idx = tid; idx < total_chunks; idx += 256) {
-            const int row = idx / chunks_per_row;
-            const int ch = idx - row * chunks_per_row;
-            const int m = m0 + row;
-            if (m >= d.M) continue;
+        // Each thread owns one 8-column chunk (fixed for the whole tile) and walks rows; the global loads of an
+        // unrolled group of rows (residual, per-item bias) are issued together before any of them is consumed, so the
+        // epilogue pays one memory latency per group instead of one per row.
+        auto run = [&](auto ge_tag) {
+            constexpr bool GE = decltype(ge_tag)::value;
+            constexpr int CPR = GE ? BN / 16 : BN / 8;   // chunks per row
+            constexpr int RPI = 256 / CPR;               // rows per sweep of the 256 threads
+            constexpr int NIT = BM / RPI;
+            constexpr int U = NIT < 4 ? NIT : 4;
+            const int ch = tid % CPR, r0 = tid / CPR;
             const int nloc = ch * 8;
-            const int n = n0 + nloc;            // column in the N space (x part for GEGLU)
-            if (n >= d.N) continue;
-            const long brow = (long)(m / d.bias_rows) * d.ldbias;
-            float v[8];
-            {
-                const f32x4 p0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc);
-                const f32x4 p1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 4);
-                v[0] = p0[0]; v[1] = p0[1]; v[2] = p0[2]; v[3] = p0[3];
-                v[4] = p1[0]; v[5] = p1[1]; v[6] = p1[2]; v[7] = p1[3];
+            const int n = n0 + nloc;                     // column in the N space (x part for GEGLU)
+            if (n >= d.N) return;
+            const long ocol = GE ? (long)tile_n * (BN / 2) + nloc : (long)n;
+            const bool shared_bias = bias && d.bias_rows >= d.M;
+            float bx[8], bg[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { bx[j] = 0.0f; bg[j] = 0.0f; }
+            if (shared_bias) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
+                bx[0] = b0[0]; bx[1] = b0[1]; bx[2] = b0[2]; bx[3] = b0[3];
+                bx[4] = b1[0]; bx[5] = b1[1]; bx[6] = b1[2]; bx[7] = b1[3];
+                if (GE) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(bias + n + 64);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(bias + n + 68);
+                    bg[0] = c0[0]; bg[1] = c0[1]; bg[2] = c0[2]; bg[3] = c0[3];
+                    bg[4] = c1[0]; bg[5] = c1[1]; bg[6] = c1[2]; bg[7] = c1[3];
+                }
             }
-            if (bias) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + brow + n);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + brow + n + 4);
-                v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3];
-                v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
-            }
-            long ocol;
-            if (geglu) {
-                // gate columns live 64 to the right inside the same 128-wide tile
-                float gte[8];
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 64);
-                const f32x4 g1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 68);
-                gte[0] = g0[0]; gte[1] = g0[1]; gte[2] = g0[2]; gte[3] = g0[3];
-                gte[4] = g1[0]; gte[5] = g1[1]; gte[6] = g1[2]; gte[7] = g1[3];
-                if (bias) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + brow + n + 64);
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + brow + n + 68);
-                    gte[0] += b0[0]; gte[1] += b0[1]; gte[2] += b0[2]; gte[3] += b0[3];
-                    gte[4] += b1[0]; gte[5] += b1[1]; gte[6] += b1[2]; gte[7] += b1[3];
+#pragma unroll 1
+            for (int it0 = 0; it0 < NIT; it0 += U) {
+                f16x8 res[U];
+                f32x4 pb0[U], pb1[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int m = m0 + r0 + (it0 + u) * RPI;
+                    ok[u] = m < d.M;
+                    const long mm = ok[u] ? m : 0;
+                    if (residual) res[u] = *reinterpret_cast<const f16x8*>(residual + mm * d.ldr + ocol);
+                    if (bias && !shared_bias) {
+                        const long brow = (mm / d.bias_rows) * d.ldbias;
+                        pb0[u] = *reinterpret_cast<const f32x4*>(bias + brow + n);
+                        pb1[u] = *reinterpret_cast<const f32x4*>(bias + brow + n + 4);
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float gg = gte[j];
-                    v[j] = v[j] * (0.5f * gg * (1.0f + erff(gg * 0.70710678118654752f)));
+                for (int u = 0; u < U; ++u) {
+                    if (!ok[u]) continue;
+                    const int row = r0 + (it0 + u) * RPI;
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc);
+                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 4);
+                    float v[8] = {p0[0] + bx[0], p0[1] + bx[1], p0[2] + bx[2], p0[3] + bx[3],
+                                  p1[0] + bx[4], p1[1] + bx[5], p1[2] + bx[6], p1[3] + bx[7]};
+                    if (bias && !shared_bias) {
+                        v[0] += pb0[u][0]; v[1] += pb0[u][1]; v[2] += pb0[u][2]; v[3] += pb0[u][3];
+                        v[4] += pb1[u][0]; v[5] += pb1[u][1]; v[6] += pb1[u][2]; v[7] += pb1[u][3];
+                    }
+                    if (GE) {
+                        // gate columns live 64 to the right inside the same 128-wide tile (shared bias only: the
+                        // GEGLU projection never takes a per-item bias)
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 64);
+                        const f32x4 g1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 68);
+                        const float gte[8] = {g0[0] + bg[0], g0[1] + bg[1], g0[2] + bg[2], g0[3] + bg[3],
+                                              g1[0] + bg[4], g1[1] + bg[5], g1[2] + bg[6], g1[3] + bg[7]};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            v[j] = v[j] * (0.5f * gte[j] * (1.0f + erff(gte[j] * 0.70710678118654752f)));
+                    }
+                    if (residual) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)res[u][j];
+                    }
+                    if (silu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.0f + __expf(-v[j]));
+                    }
+                    f16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
+                    const long m = m0 + row;
+                    *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(out) + m * d.ldc + ocol) = o;
                 }
-                ocol = (long)tile_n * (BN / 2) + nloc;
-            } else {
-                ocol = n;
             }
-            if (residual) {
-                const f16x8 r8 = *reinterpret_cast<const f16x8*>(residual + (long)m * d.ldr + ocol);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
-            }
-            if (silu) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.0f + __expf(-v[j]));
-            }
-            f16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
-            *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(out) + (long)m * d.ldc + ocol) = o;
+        };
+        if (geglu) {
+            if constexpr (BN == 128) run(std::true_type{});
+        } else {
+            run(std::false_type{});
         }
-        (void)OUT_COLS;
     } else {
         // generic (rare, tiny layers): scalar stores, any N, fp32 or fp16 out; GEGLU not supported here
         for (int idx = tid; idx < BM * BN; idx += 256) {

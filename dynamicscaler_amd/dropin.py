@@ -23,13 +23,15 @@ def _mod(name, **attrs):
 
 
 def install():
-    from . import unet, scheduler, pipelines, ring, tensor_utils, host_model
+    from . import unet, scheduler, pipelines, pipelines_i2v, ring, tensor_utils, host_model
     _mod("lvdm.modules.networks.openaimodel3d", UNetModel=unet.UNetModel)
     _mod("lvdm.models.ddpm3d", DiffusionWrapper=unet.DiffusionWrapper, LatentDiffusion=host_model.LatentDiffusionHost)
     _mod("pipeline.scheduler", lvdm_DDIM_Scheduler=scheduler.lvdm_DDIM_Scheduler)
     _mod("pipeline.t2v_normal_pipeline", VC2_Pipeline_T2V=pipelines.VC2_Pipeline_T2V)
     _mod("pipeline.t2v_sphere_panorama_pipeline", VC2_Pipeline_T2V_SpherePano=pipelines.VC2_Pipeline_T2V_SpherePano)
-    _mod("utils.shift_window_utils", RingLatent=ring.RingLatent,
+    _mod("pipeline.i2v_normal_pipeline", VC2_Pipeline_I2V=pipelines_i2v.VC2_Pipeline_I2V)
+    _mod("pipeline.i2v_sphere_panorama_pipeline", VC2_Pipeline_I2V_SpherePano=pipelines_i2v.VC2_Pipeline_I2V_SpherePano)
+    _mod("utils.shift_window_utils", RingLatent=ring.RingLatent, RingImageTensor=pipelines_i2v.RingImageTensor,
          get_dimension_slices_and_sizes=ring.get_dimension_slices_and_sizes)
     _mod("utils.tensor_utils", mix_latents_with_mask=tensor_utils.mix_latents_with_mask)
     _mod("utils.multi_prompt_utils",

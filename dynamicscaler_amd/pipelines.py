@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import ops, parallel
-from .ring import RingLatent, VAE_SCALE_FACTOR, ring_axis_steps, t2v_ring_windows
+from .ring import RingLatent, VAE_SCALE_FACTOR, ring_axis_steps, t2v_ring_windows, t2v_grid_windows
 
 
 def select_prompt_from_multi_prompt_dict_by_factor(prompt_dict, factor):
@@ -153,6 +153,168 @@ class VC2_Pipeline_T2V:
         return videos, denoised
 
 
+    # ------------------------------------------------------------------ the tile engine shared by all ring loops
+    @torch.no_grad()
+    def _denoise_windows(self, st, i, wins, ctxs, renoise, mask_frame0, merge_prev_ratio=None, use_mask=True):
+        """Process the windows of DDIM step i (reference order `wins`) with the reference's sequential semantics:
+        levels of pairwise-disjoint windows (parallel.plan_levels), each level = one batched gather -> re-noise/mix
+        -> UNet [cond | uncond] -> CFG + DDIM (-> merge-prev) -> scatter.  st: _RingState."""
+        t = st.timesteps[i]
+        sched, device, pano = self.scheduler, st.device, st.pano
+        coef = sched.step_coefficients(st.total_steps - i - 1)
+        # host noise for the whole step in the reference's tile order (appendix B): randn_like(tile) of re_noise,
+        # then `frames` per-frame draws of ddim_step -- per window.  (No host draws at all in rng_mode "device".)
+        noises = []
+        for _ in wins:
+            nz = sched.draw_renoise_noise(st.tile_shape, "cpu", torch.float32) if renoise else None
+            sn = sched.draw_step_noise(st.tile_shape, "cpu", torch.float32, coef["sigma"])
+            noises.append((nz, sn))
+        if renoise:
+            c_rn, s_rn = sched.renoise_coefficients(st.total_steps - i - 2, st.total_steps - i - 1)
+        self._log(f"i = {i}, t = {t}: {len(wins)} windows")
+        mask = st.mask if use_mask else None
+        for level in parallel.plan_levels(wins, st.pano_fhw):
+            mine = parallel.rank_share(level, st.rank, st.world)
+            xp_parts, x0_parts = [], []
+            for s in range(0, len(mine), self.max_tile_batch):
+                ids = mine[s:s + self.max_tile_batch]
+                origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
+                tiles, mtiles = ops.ring_gather(pano, origins, st.tile_fhw, mask)
+                prev = tiles.clone() if merge_prev_ratio is not None else None
+                if renoise:
+                    nz = None
+                    if noises[ids[0]][0] is not None:
+                        nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=pano.dtype)
+                    ops.renoise_mix_(tiles, mtiles, st.total_shape, c_rn, s_rn, st.ratio, noise=nz,
+                                     mask_frame0=mask_frame0, seed=sched.philox_seed,
+                                     offset=(i * len(wins) + ids[0]) * tiles[0].numel())
+                n = len(ids)
+                if st.guidance_scale != 1.0:
+                    eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n,
+                                    st.fps, st.frames, **st.kwargs)
+                    e_c, e_u = eps[:n], eps[n:]
+                else:
+                    e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], st.fps, st.frames, **st.kwargs), None
+                sn = None
+                if coef["sigma"] != 0.0:
+                    sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=pano.dtype)
+                x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, st.total_shape, st.guidance_scale, coef, sn)
+                if merge_prev_ratio is not None:
+                    # merge-prev (i2v_sphere_panorama_pipeline.py:938-943): mix(x_prev, window_before_renoise, mask, r_i)
+                    ops.renoise_mix_(x_prev, mtiles, st.total_shape, 0.0, 1.0, merge_prev_ratio, noise=prev,
+                                     mask_frame0=mask_frame0)
+                xp_parts.append(x_prev)
+                x0_parts.append(x0)
+            if st.world > 1:
+                empty = torch.empty((0,) + st.tile_shape[1:], dtype=pano.dtype, device=device)
+                xp_l = torch.cat(xp_parts, 0) if xp_parts else empty
+                x0_l = torch.cat(x0_parts, 0) if x0_parts else empty
+                xp_all, x0_all = parallel.exchange_level(xp_l, x0_l, len(level))
+                order = level
+            else:
+                xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
+            for s in range(0, len(order), ops.DS_MAX_WINDOWS):
+                ids = order[s:s + ops.DS_MAX_WINDOWS]
+                origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
+                ops.ring_scatter3(pano, st.pano_x0, mask, xp_all[s:s + len(ids)].contiguous(),
+                                  x0_all[s:s + len(ids)].contiguous(), origins)
+
+    def _new_state(self, init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
+                   text_emb, uc_emb, ratio, kwargs):
+        device = self._execution_device
+        st = _RingState()
+        st.in_device = init_panorama_latent.device
+        st.pano = init_panorama_latent.to(device=device, dtype=self.latent_dtype).contiguous().clone()
+        st.pano_x0 = torch.zeros_like(st.pano)
+        st.mask = torch.zeros(total_shape[2:], dtype=torch.uint8, device=device)  # 1 byte per (f,y,x)
+        st.rank, st.world = 0, 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            st.rank, st.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        st.timesteps, st.total_steps = timesteps, len(timesteps)
+        st.total_shape, st.device, st.frames, st.fps = total_shape, device, frames, fps
+        st.lat_h, st.lat_w = lat_h, lat_w
+        st.tile_fhw = (frames, lat_h, lat_w)
+        st.tile_shape = (1, total_shape[1]) + st.tile_fhw
+        st.pano_fhw = tuple(total_shape[2:])
+        st.guidance_scale, st.ratio = guidance_scale, ratio
+        st.text_emb = text_emb.to(device)
+        st.uc_emb = uc_emb.to(device) if uc_emb is not None else None
+        kwargs = dict(kwargs)
+        kwargs.update({"clean_cond": True})
+        st.kwargs = kwargs
+        return st
+
+    def _finish(self, st, output_type, total_frames, seam_safe):
+        self.final_latent = st.pano  # x_t panorama after the last step (not returned by the reference's ring variants)
+        denoised = st.pano_x0.clone()
+        if output_type == "latent":
+            return denoised, denoised
+        if not seam_safe:
+            return self.pretrained_t2v.decode_first_stage_2DAE(denoised), denoised
+        # seam-safe decode (t2v_sphere_panorama_pipeline.py:638-655): pad W with wrapped 1/16 chunks, decode per
+        # frame, crop.  The VAE itself is the caller's (SURVEY.md 8-f N2).
+        chunks = list(torch.chunk(denoised, 16, dim=4))
+        padded = torch.cat([chunks[-1]] + chunks + [chunks[0]], dim=4)
+        frames_out = [self.pretrained_t2v.decode_first_stage_2DAE(padded[:, :, [f]]) for f in range(total_frames)]
+        videos = torch.cat(frames_out, dim=2)
+        videos = torch.cat(torch.chunk(videos, 18, dim=4)[1:-1], dim=4)
+        return videos, denoised
+
+    @torch.no_grad()
+    def basic_sample_shift_multi_windows(self, prompt=None, height=320, width=512, frames=16, fps=16, guidance_scale=7.5,
+                                         num_videos_per_prompt=1, generator=None, init_panorama_latent=None,
+                                         clear_pre_denoised_latent=None, clear_pre_denoised_video_tensor=None,
+                                         num_windows_w=None, num_windows_h=None, num_windows_f=None, loop_step=None,
+                                         latents=None, num_inference_steps=50, prompt_embeds=None, output_type="pil",
+                                         use_pre_denoise=False, pre_denoise_steps=None, skip_steps_after_pre_denoise=0,
+                                         shift_jump_odd_w=False, shift_jump_odd_h=False, shift_jump_odd_f=False,
+                                         docking_w=False, docking_h=False, docking_f=False, docking_step_range=None,
+                                         merge_predenoise_ratio_list=None, random_shuffle_init_frame_stride=0,
+                                         sparse_add_residual=True, use_skip_time=False, skip_time_step_idx=None,
+                                         progressive_skip=False, step_callback=None, **kwargs):
+        """Non-overlapping shifted grid (pipeline/t2v_normal_pipeline.py:213-568): the panorama is exactly
+        num_windows_h x num_windows_w tiles; every step the grid is shifted by (i % loop_step) * tile/loop_step in
+        W, H and F (wrap-around), optionally jumped by half the panorama on odd steps and docked to the borders.
+        No mask / re-noise in this variant.  The pre-denoise branch (VAE encode of a resized clip, :345-412) is outside
+        the hot-path scope."""
+        if use_pre_denoise or use_skip_time or random_shuffle_init_frame_stride:
+            raise NotImplementedError("pre-denoise / skip-time / frame shuffle need the VAE stage hand-off (SURVEY.md 8-f N1/N2)")
+        unet_config = self.model_config["params"]["unet_config"]
+        frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
+        prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
+        self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
+        timesteps = np.flip(self.scheduler.ddim_timesteps)
+        vs = self.vae_scale_factor
+        lat_h, lat_w = height // vs, width // vs
+        total_shape = (1, unet_config["params"]["in_channels"], frames * num_windows_f, lat_h * num_windows_h,
+                       lat_w * num_windows_w)
+        if init_panorama_latent is None:
+            init_panorama_latent = torch.randn(total_shape)  # host draw, reference order
+        else:
+            assert tuple(init_panorama_latent.shape) == total_shape, \
+                f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_panorama_latent.shape)} " \
+                f"does not match desired shape {total_shape}"
+        step_f = 0 if num_windows_f == 1 else frames // loop_step
+        assert step_f > 0 or num_windows_f == 1, \
+            f"[basic_sample_shift_multi_windows] loop_step {loop_step} > frames {frames} while num_windows_f {num_windows_f} > 0"
+        st = self._new_state(init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
+                             text_emb, uc_emb, None, kwargs)
+        for i in range(len(timesteps)):
+            wins = t2v_grid_windows(i, latent_h=lat_h, latent_w=lat_w, frames=frames, num_windows_w=num_windows_w,
+                                    num_windows_h=num_windows_h, num_windows_f=num_windows_f, loop_step=loop_step,
+                                    shift_jump_odd_w=shift_jump_odd_w, shift_jump_odd_h=shift_jump_odd_h,
+                                    shift_jump_odd_f=shift_jump_odd_f, docking_w=docking_w, docking_h=docking_h,
+                                    docking_f=docking_f, docking_step_range=docking_step_range)
+            self._denoise_windows(st, i, wins, [st.text_emb] * len(wins), renoise=False, mask_frame0=True, use_mask=False)
+            if step_callback is not None:
+                step_callback(i, int(timesteps[i]), wins, st.pano, st.pano_x0)
+        return self._finish(st, output_type, total_shape[2], seam_safe=False)
+
+
+class _RingState:
+    """Mutable state of one ring sampling run (panoramas resident in HBM)."""
+
+
 class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
     """pipeline/t2v_sphere_panorama_pipeline.py:20 -- the overlapped-ring plane loop (:316-660), which is the path
     all BASELINE configs take."""
@@ -191,7 +353,6 @@ class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
                    skip_time_step_idx=None, progressive_skip=False, **kwargs):
         unet_config = self.model_config["params"]["unet_config"]
         frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
-        device = self._execution_device
         prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
         self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
         timesteps = np.flip(self.scheduler.ddim_timesteps)
@@ -208,11 +369,8 @@ class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
             assert tuple(init_panorama_latent.shape) == total_shape, \
                 f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_panorama_latent.shape)} " \
                 f"does not match desired shape {total_shape}"
-        st = _RingState()
-        st.in_device = init_panorama_latent.device
-        st.pano = init_panorama_latent.to(device=device, dtype=self.latent_dtype).contiguous().clone()
-        st.pano_x0 = torch.zeros_like(st.pano)
-        st.mask = torch.zeros(total_shape[2:], dtype=torch.uint8, device=device)  # 1 byte per (f,y,x)
+        st = self._new_state(init_panorama_latent, total_shape, timesteps, frames, fps, height // vs, width // vs,
+                             guidance_scale, text_emb, uc_emb, merge_renoised_overlap_latent_ratio, kwargs)
         ov_w, st.step_w, st.off_w = ring_axis_steps(total_w, width, num_windows_w, loop_step)
         assert 0 <= ov_w < 1, "overlap ratio for W is not legal"
         assert st.off_w, "latent_offset_step_size_w <= 0 ! consider increase W windows"
@@ -224,113 +382,33 @@ class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
             st.step_f = 0
         assert st.step_f > 0 or num_windows_f == 1, \
             f"[basic_sample_shift_multi_windows] loop_step {loop_step} > frames {frames} while num_windows_f {num_windows_f} > 0"
-        st.rank, st.world = 0, 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            st.rank, st.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
-        st.timesteps, st.total_steps = timesteps, len(timesteps)
-        st.total_shape, st.device, st.frames, st.fps = total_shape, device, frames, fps
-        st.lat_h, st.lat_w, st.total_lat_h = height // vs, width // vs, total_h // vs
-        st.tile_fhw = (frames, st.lat_h, st.lat_w)
-        st.tile_shape = (1, c_lat) + st.tile_fhw
-        st.pano_fhw = tuple(total_shape[2:])
+        st.total_lat_h = total_h // vs
         st.nw, st.nh, st.nf, st.loop_step, st.dock_at_h = num_windows_w, num_windows_h, num_windows_f, loop_step, dock_at_h
-        st.guidance_scale, st.ratio = guidance_scale, merge_renoised_overlap_latent_ratio
-        st.text_emb = text_emb.to(device)
-        st.uc_emb = uc_emb.to(device) if uc_emb is not None else None
         st.window_multi_prompt_dict, st.prompt_cache = window_multi_prompt_dict, {}
-        kwargs.update({"clean_cond": True})
-        st.kwargs = kwargs
         return st
 
     @torch.no_grad()
     def ring_step(self, st, i):
         """One DDIM step over all windows of the panorama (t2v_sphere_panorama_pipeline.py:481-634)."""
-        t = st.timesteps[i]
-        sched, device, pano = self.scheduler, st.device, st.pano
         st.mask.zero_()  # fresh mask every step (:494)
         wins = t2v_ring_windows(i, latent_h=st.lat_h, latent_w=st.lat_w, frames=st.frames,
                                 total_latent_h=st.total_lat_h, step_w=st.step_w, step_h=st.step_h, off_w=st.off_w,
                                 off_h=st.off_h, step_f=st.step_f, num_windows_w=st.nw, num_windows_h=st.nh,
                                 num_windows_f=st.nf, loop_step=st.loop_step, dock_at_h=st.dock_at_h)
         renoise = st.ratio is not None and i < st.total_steps - 1
-        coef = sched.step_coefficients(st.total_steps - i - 1)
-        # host noise for the whole step in the reference's tile order (appendix B): randn_like(tile) of re_noise,
-        # then `frames` per-frame draws of ddim_step -- per window.  (No host draws at all in rng_mode "device".)
-        noises = []
-        for _ in wins:
-            nz = sched.draw_renoise_noise(st.tile_shape, "cpu", torch.float32) if renoise else None
-            sn = sched.draw_step_noise(st.tile_shape, "cpu", torch.float32, coef["sigma"])
-            noises.append((nz, sn))
-        if renoise:
-            c_rn, s_rn = sched.renoise_coefficients(st.total_steps - i - 2, st.total_steps - i - 1)
         # per-window prompt (R13): embeddings cached per distinct prompt instead of re-running CLIP per tile
         ctxs = []
         for (l, r, tp, dn, fb, fe) in wins:
             if st.window_multi_prompt_dict is not None:
                 cur = select_prompt_from_multi_prompt_dict_by_factor(st.window_multi_prompt_dict, dn / st.total_lat_h)
                 if cur not in st.prompt_cache:
-                    st.prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(device)
+                    st.prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(st.device)
                 ctxs.append(st.prompt_cache[cur])
             else:
                 ctxs.append(st.text_emb)
-        self._log(f"i = {i}, t = {t}: {len(wins)} windows")
-        for level in parallel.plan_levels(wins, st.pano_fhw):
-            mine = parallel.rank_share(level, st.rank, st.world)
-            xp_parts, x0_parts = [], []
-            for s in range(0, len(mine), self.max_tile_batch):
-                ids = mine[s:s + self.max_tile_batch]
-                origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
-                tiles, mtiles = ops.ring_gather(pano, origins, st.tile_fhw, st.mask)
-                if renoise:
-                    nz = None
-                    if noises[ids[0]][0] is not None:
-                        nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=pano.dtype)
-                    ops.renoise_mix_(tiles, mtiles, st.total_shape, c_rn, s_rn, st.ratio, noise=nz, mask_frame0=True,
-                                     seed=sched.philox_seed, offset=(i * len(wins) + ids[0]) * tiles[0].numel())
-                n = len(ids)
-                if st.guidance_scale != 1.0:
-                    eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n,
-                                    st.fps, st.frames, **st.kwargs)
-                    e_c, e_u = eps[:n], eps[n:]
-                else:
-                    e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], st.fps, st.frames, **st.kwargs), None
-                sn = None
-                if coef["sigma"] != 0.0:
-                    sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=pano.dtype)
-                x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, st.total_shape, st.guidance_scale, coef, sn)
-                xp_parts.append(x_prev)
-                x0_parts.append(x0)
-            if st.world > 1:
-                empty = torch.empty((0,) + st.tile_shape[1:], dtype=pano.dtype, device=device)
-                xp_l = torch.cat(xp_parts, 0) if xp_parts else empty
-                x0_l = torch.cat(x0_parts, 0) if x0_parts else empty
-                xp_all, x0_all = parallel.exchange_level(xp_l, x0_l, len(level))
-                order = level
-            else:
-                xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
-            for s in range(0, len(order), ops.DS_MAX_WINDOWS):
-                ids = order[s:s + ops.DS_MAX_WINDOWS]
-                origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
-                ops.ring_scatter3(pano, st.pano_x0, st.mask, xp_all[s:s + len(ids)].contiguous(),
-                                  x0_all[s:s + len(ids)].contiguous(), origins)
+        self._denoise_windows(st, i, wins, ctxs, renoise=renoise, mask_frame0=True)
         return wins
 
     @torch.no_grad()
     def ring_finish(self, st, output_type="latent"):
-        self.final_latent = st.pano  # x_t panorama after the last step (not returned by the reference's ring variant)
-        denoised = st.pano_x0.clone()
-        if not output_type == "latent":
-            # seam-safe decode (:638-655): pad W with wrapped 1/16 chunks, decode per frame, crop
-            chunks = list(torch.chunk(denoised, 16, dim=4))
-            padded = torch.cat([chunks[-1]] + chunks + [chunks[0]], dim=4)
-            frames_out = [self.pretrained_t2v.decode_first_stage_2DAE(padded[:, :, [f]])
-                          for f in range(st.total_shape[2])]
-            videos = torch.cat(frames_out, dim=2)
-            videos = torch.cat(torch.chunk(videos, 18, dim=4)[1:-1], dim=4)
-        else:
-            videos = denoised
-        return videos, denoised
-
-
-class _RingState:
-    """Mutable state of one overlapped-ring sampling run (panoramas resident in HBM)."""
+        return self._finish(st, output_type, st.total_shape[2], seam_safe=True)

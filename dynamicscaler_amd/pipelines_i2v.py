@@ -1,0 +1,150 @@
+"""Image-to-video overlapped-ring pipeline (drop-in call surface of
+pipeline/i2v_sphere_panorama_pipeline.py:VC2_Pipeline_I2V_SpherePano.basic_sample_shift_multi_windows, :564-996)
+and the pixel-space ring crop `RingImageTensor` (utils/shift_window_utils.py:209-276).
+
+Differences from the t2v ring that are kept exactly: window placement is round(idx * float_step) (:818-820),
+frame windows wrap modulo total_f and can be docked to both ends (:786-854), the denoised mask is used per frame
+(5-D, :877), every window gets its own image tokens from the crop of the panorama image under it (:889-893),
+and after the DDIM update x_prev is mixed with the window's pre-re-noise content under the mask (merge-prev,
+:938-943).  The tile engine is the one of pipelines.py (batched levels of independent windows).
+
+Out of scope here: the CLIP image encoder / Resampler (`pretrained_t2v.get_image_embeds` is
+called as a black box, once per distinct crop position -- the reference calls it per tile per step) and the tiled
+VAE encode behind `use_skip_time`.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .pipelines import VC2_Pipeline_T2V, select_prompt_from_multi_prompt_dict_by_factor
+from .ring import i2v_ring_windows
+
+def load_image_tensor_from_path(image_path, height, width, norm_to_1=True):
+    """utils/tensor_utils.py:7-16 with PIL's bilinear resize in place of cv2.INTER_LINEAR (cv2 is not in this
+    image; the two filters are not bit-identical -- image preprocessing parity is unpinned)."""
+    from PIL import Image
+    img = Image.open(image_path).convert("RGB").resize((width, height), Image.BILINEAR)
+    t = torch.from_numpy(np.array(img, np.float32)).permute(2, 0, 1)
+    if norm_to_1:
+        t = (t / 255.0 - 0.5) * 2
+    return t
+
+
+class RingImageTensor:
+    def __init__(self, image_path=None, image_tensor=None, height=320, width=512):
+        self.image_tensor = load_image_tensor_from_path(image_path, height, width) if image_tensor is None else image_tensor
+        assert list(self.image_tensor.shape) == [3, height, width], \
+            f"[RingImageTensor] image shape {self.image_tensor.shape} does not match {[3, height, width]}"
+
+    def get_shape(self):
+        return self.image_tensor.shape
+
+    def get_window_tensor(self, pos_left, pos_right, pos_top=None, pos_down=None):
+        height, width = self.get_shape()[-2], self.get_shape()[-1]
+        pos_top = 0 if pos_top is None else pos_top
+        pos_down = height if pos_down is None else pos_down
+        assert 0 <= pos_left < pos_right <= width * 2, f"[RingImageTensor.get_window_tensor] pos_left {pos_left}, pos_right {pos_right} not legal"
+        assert 0 <= pos_top < pos_down <= height * 2, f"[RingImageTensor.get_window_tensor] pos_top {pos_top}, pos_down {pos_down} not legal"
+        dev = self.image_tensor.device
+        yi = torch.arange(pos_top, pos_down, device=dev) % height
+        xi = torch.arange(pos_left, pos_right, device=dev) % width
+        return self.image_tensor[:, yi][:, :, xi]
+
+    def get_encoded_image_cond(self, pretrained_t2v, pos_left, pos_right, pos_top=None, pos_down=None):
+        crop = self.get_window_tensor(pos_left, pos_right, pos_top, pos_down)
+        return pretrained_t2v.get_image_embeds(crop.to(pretrained_t2v.device).unsqueeze(0))
+
+
+class VC2_Pipeline_I2V(VC2_Pipeline_T2V):
+    """Base of the i2v pipelines (pipeline/i2v_normal_pipeline.py:27): same members as the t2v base."""
+
+    def _load_imgs_from_paths(self, img_path_list, height=320, width=512):
+        return torch.stack([load_image_tensor_from_path(p, height, width) for p in img_path_list], dim=0)
+
+
+class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
+    @torch.no_grad()
+    def basic_sample_shift_multi_windows(self, prompt=None, img_cond_path=None, height=320, width=512, frames=16, fps=16,
+                                         guidance_scale=7.5, num_videos_per_prompt=1, generator=None,
+                                         init_panorama_latent=None, total_w=None, total_h=None, total_f=None,
+                                         num_windows_w=None, num_windows_h=None, num_windows_f=None, loop_step=None,
+                                         begin_index_offset=0, dock_at_f=None, overlap_ratio_list_f=None,
+                                         loop_step_frame=None, pano_image_path=None, latents=None,
+                                         num_inference_steps=4, prompt_embeds=None, output_type="pil",
+                                         merge_renoised_overlap_latent_ratio=1, merge_prev_denoised_ratio_list=None,
+                                         window_multi_prompt_dict=None, use_skip_time=False, skip_time_step_idx=None,
+                                         progressive_skip=False, pano_image_tensor=None, step_callback=None, **kwargs):
+        """`pano_image_tensor` ([3,total_h,total_w], optional) is an extension: the panorama image as a tensor
+        instead of a path (RingImageTensor accepts both, shift_window_utils.py:211-220)."""
+        if use_skip_time:
+            raise NotImplementedError("use_skip_time needs the tiled VAE encode (SURVEY.md 8-f N2)")
+        unet_config = self.model_config["params"]["unet_config"]
+        frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
+        vs = self.vae_scale_factor
+        prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
+        # uncond image tokens (:652-658): a zero image of the LATENT size through get_image_embeds
+        if guidance_scale != 1.0 and hasattr(self.pretrained_t2v, "embedder"):
+            uc_img = torch.zeros(1, 3, height // vs, width // vs).to(self.pretrained_t2v.device)
+            uc_emb = torch.cat([uc_emb.to(uc_img.device), self.pretrained_t2v.get_image_embeds(uc_img)], dim=1)
+        self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
+        timesteps = np.flip(self.scheduler.ddim_timesteps)
+        if total_f is None:
+            total_f = frames * num_windows_f
+        lat_h, lat_w = height // vs, width // vs
+        total_shape = (1, unet_config["params"]["in_channels"], total_f, total_h // vs, total_w // vs)
+        if init_panorama_latent is None:
+            init_panorama_latent = torch.randn(total_shape)  # host draw, reference order
+        else:
+            assert tuple(init_panorama_latent.shape) == total_shape, \
+                f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_panorama_latent.shape)} " \
+                f"does not match desired shape {total_shape}"
+        ov_w = 1 - (total_w / width - 1) / (num_windows_w - 1)
+        step_w = width / vs * (1 - ov_w)                     # float, rounded per window (:818)
+        off_w = int((1 - ov_w) * width / loop_step) // vs
+        assert 0 <= ov_w < 1, "overlap ratio for W is not legal"
+        assert off_w >= 1, "latent_offset_step_size_w should > 1"
+        ov_h = 1 - (total_h / height - 1) / (num_windows_h - 1)
+        step_h = height / vs * (1 - ov_h)
+        off_h = int((1 - ov_h) * height / loop_step) // vs
+        assert 0 <= ov_h < 1, "overlap ratio for H is not legal"
+        assert off_h >= 1, "latent_offset_step_size_h should > 1"
+        step_f = 0 if total_f == frames else frames // loop_step
+        assert step_f > 0 or total_f == frames, \
+            f"[basic_sample_shift_multi_windows] loop_step {loop_step} > frames {frames} while total_f {total_f} > frame"
+        ring_image = RingImageTensor(image_path=pano_image_path, image_tensor=pano_image_tensor, height=total_h, width=total_w)
+        st = self._new_state(init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
+                             text_emb, uc_emb, merge_renoised_overlap_latent_ratio, kwargs)
+        img_cache, prompt_cache = {}, {}
+        total_steps = len(timesteps)
+        with self.progress_bar(total=total_steps) as bar:
+            for i in range(total_steps):
+                st.mask.zero_()  # reset denoised mask record (:810)
+                wins = i2v_ring_windows(i, latent_h=lat_h, latent_w=lat_w, frames=frames, total_f=total_f, step_w=step_w,
+                                        step_h=step_h, off_w=off_w, off_h=off_h, num_windows_w=num_windows_w,
+                                        num_windows_h=num_windows_h, loop_step=loop_step,
+                                        overlap_ratio_f=overlap_ratio_list_f[i], loop_step_frame=loop_step_frame,
+                                        dock_at_f=dock_at_f, begin_index_offset=begin_index_offset)
+                ctxs = []
+                for (left, _r, top, _d, _fb, _fe) in wins:
+                    cur_text = st.text_emb
+                    if window_multi_prompt_dict is not None:
+                        cur = select_prompt_from_multi_prompt_dict_by_factor(window_multi_prompt_dict,
+                                                                              (top * vs + height) / total_h)
+                        if cur not in prompt_cache:
+                            prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(st.device)
+                        cur_text = prompt_cache[cur]
+                    key = (left, top)
+                    if key not in img_cache:   # same crop position recurs every loop_step steps
+                        img_cache[key] = ring_image.get_encoded_image_cond(
+                            self.pretrained_t2v, left * vs, left * vs + width, top * vs, top * vs + height).to(st.device)
+                    ctxs.append(torch.cat([cur_text, img_cache[key].to(cur_text.dtype)], dim=1))
+                renoise = st.ratio is not None and i < total_steps - 1
+                merge_prev = None
+                if merge_prev_denoised_ratio_list is not None and i < total_steps - 1:
+                    merge_prev = merge_prev_denoised_ratio_list[i]
+                self._denoise_windows(st, i, wins, ctxs, renoise=renoise, mask_frame0=False, merge_prev_ratio=merge_prev)
+                if step_callback is not None:
+                    step_callback(i, int(timesteps[i]), wins, st.pano, st.pano_x0)
+                bar.update()
+        return self._finish(st, output_type, total_f, seam_safe=True)

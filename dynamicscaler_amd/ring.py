@@ -108,3 +108,98 @@ def t2v_ring_windows(i, *, latent_h, latent_w, frames, total_latent_h, step_w, s
                         continue  # regular window crossing the bottom edge is skipped when docking (:530-532)
                 wins.append((left, left + latent_w, top, top + latent_h, fb, fb + frames))
     return wins
+
+
+def t2v_grid_windows(i, *, latent_h, latent_w, frames, num_windows_w, num_windows_h, num_windows_f, loop_step,
+                     shift_jump_odd_w=False, shift_jump_odd_h=False, shift_jump_odd_f=False, docking_w=False,
+                     docking_h=False, docking_f=False, docking_step_range=None):
+    """Windows of step i of the NON-overlapping shifted grid, reference order f -> w -> h
+    (pipeline/t2v_normal_pipeline.py:419-432, 441-443, 471-522).  NB the reference crosses the two jump flags:
+    shift_jump_odd_h moves the LEFT start, shift_jump_odd_w the TOP (:471-474) -- kept."""
+    vs = VAE_SCALE_FACTOR
+    step_w = 0 if num_windows_w == 1 else (latent_w * vs // loop_step) // vs
+    step_h = 0 if num_windows_h == 1 else (latent_h * vs // loop_step) // vs
+    step_f = 0 if num_windows_f == 1 else frames // loop_step
+    k = i % loop_step
+    left0, top0, fr0 = k * step_w, k * step_h, k * step_f
+    if i % 2 == 1 and shift_jump_odd_h and num_windows_h > 1:
+        left0 += latent_w * num_windows_w // 2
+    if i % 2 == 1 and shift_jump_odd_w and num_windows_w > 1:
+        top0 += latent_h * num_windows_h // 2
+    if i % 2 == 1 and shift_jump_odd_f and num_windows_f > 1:
+        fr0 += frames * num_windows_f // 2
+    in_dock = docking_step_range is not None and i in docking_step_range
+    wins = []
+    for fi in (range(-1, num_windows_f) if docking_f else range(num_windows_f)):
+        for wi in (range(-1, num_windows_w) if docking_w else range(num_windows_w)):
+            for hi in (range(-1, num_windows_h) if docking_h else range(num_windows_h)):
+                left, top, fb = left0 + wi * latent_w, top0 + hi * latent_h, fr0 + fi * frames
+                if docking_w and in_dock:
+                    if wi == -1:
+                        left = 0
+                    if wi == num_windows_w - 1:
+                        left = latent_w * (num_windows_w - 1)
+                elif wi == -1:
+                    continue
+                if docking_h and in_dock:
+                    if hi == -1:
+                        top = 0
+                    if hi == num_windows_h - 1:
+                        top = latent_h * (num_windows_h - 1)
+                elif hi == -1:
+                    continue
+                if docking_f and in_dock:
+                    if fi == -1:
+                        fb = 0
+                    if fi == num_windows_f - 1:
+                        fb = frames * (num_windows_f - 1)
+                elif fi == -1:
+                    continue
+                wins.append((left, left + latent_w, top, top + latent_h, fb, fb + frames))
+    return wins
+
+
+I2V_DOCK_START_INDEX = -101
+I2V_DOCK_END_INDEX = -111
+
+
+def i2v_ring_windows(i, *, latent_h, latent_w, frames, total_f, step_w, step_h, off_w, off_h, num_windows_w,
+                     num_windows_h, loop_step, overlap_ratio_f, loop_step_frame=None, dock_at_f=None,
+                     begin_index_offset=0):
+    """Windows of step i of the i2v overlapped ring, reference order f -> w -> h
+    (pipeline/i2v_sphere_panorama_pipeline.py:779-854).  step_w / step_h are FLOAT latent strides rounded per window
+    (:818-820); frame windows wrap modulo total_f (:828-830) and are docked / skipped when dock_at_f (:832-854)."""
+    import math
+    k = (i + begin_index_offset) % loop_step
+    left0, top0 = k * off_w, k * off_h
+    n_f = math.ceil((total_f // frames - 1) / (1 - overlap_ratio_f)) + 1
+    if total_f > frames:
+        fr0 = (i % loop_step_frame) * max(int(overlap_ratio_f * frames / loop_step_frame), 1)
+        f_ids = list(range(n_f))
+        if dock_at_f:
+            f_ids = [I2V_DOCK_START_INDEX] + f_ids + [I2V_DOCK_END_INDEX]
+    elif total_f == frames:
+        fr0, f_ids = 0, [0]
+    else:
+        raise ValueError(f"total_f {total_f} should >= frames {frames} !")
+    wins = []
+    for fi in f_ids:
+        for wi in range(num_windows_w):
+            for hi in range(num_windows_h):
+                left = left0 + round(wi * step_w)
+                top = top0 + round(hi * step_h)
+                fb = (fr0 + fi * int(frames * (1 - overlap_ratio_f))) % total_f
+                fe = fb + frames
+                if dock_at_f:
+                    if fi == I2V_DOCK_START_INDEX:
+                        if fr0 == 0:
+                            continue
+                        fb, fe = 0, frames
+                    if fi == I2V_DOCK_END_INDEX:
+                        if fr0 == 0:
+                            continue
+                        fb, fe = total_f - frames, total_f
+                    if fe > total_f:
+                        continue
+                wins.append((left, left + latent_w, top, top + latent_h, fb, fe))
+    return wins

@@ -151,3 +151,197 @@ def t2v_ring_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, *,
                 on_tile(i, (l, r, tp, dn, fb, fe), pano, pano_x0)
     denoised = pano_x0.clone()
     return denoised, denoised, pano
+
+
+# ================================================================================================
+# P4: non-overlapping shifted grid -- VC2_Pipeline_T2V.basic_sample_shift_multi_windows
+#     (pipeline/t2v_normal_pipeline.py:213-568), the path without pre-denoise
+# ================================================================================================
+def t2v_grid_windows(i, *, latent_h, latent_w, frames, num_windows_w, num_windows_h, num_windows_f, loop_step,
+                     shift_jump_odd_w=False, shift_jump_odd_h=False, shift_jump_odd_f=False, docking_w=False,
+                     docking_h=False, docking_f=False, docking_step_range=None):
+    """Window list of step i in reference order f -> w -> h (t2v_normal_pipeline.py:419-432, 441-443, 471-522).
+    NB the reference's jump-odd flags are crossed: shift_jump_odd_h moves the LEFT start, shift_jump_odd_w the TOP
+    (:471-474) -- kept as is."""
+    step_w = 0 if num_windows_w == 1 else (latent_w * VAE_SCALE // loop_step) // VAE_SCALE
+    step_h = 0 if num_windows_h == 1 else (latent_h * VAE_SCALE // loop_step) // VAE_SCALE
+    step_f = 0 if num_windows_f == 1 else frames // loop_step
+    left0 = (i % loop_step) * step_w
+    top0 = (i % loop_step) * step_h
+    fr0 = (i % loop_step) * step_f
+    if i % 2 == 1 and shift_jump_odd_h and num_windows_h > 1:
+        left0 = left0 + (latent_w * num_windows_w // 2)
+    if i % 2 == 1 and shift_jump_odd_w and num_windows_w > 1:
+        top0 = top0 + (latent_h * num_windows_h // 2)
+    if i % 2 == 1 and shift_jump_odd_f and num_windows_f > 1:
+        fr0 = fr0 + (frames * num_windows_f // 2)
+    in_dock = docking_step_range is not None and i in docking_step_range
+    wins = []
+    for fi in (range(-1, num_windows_f) if docking_f else range(num_windows_f)):
+        for wi in (range(-1, num_windows_w) if docking_w else range(num_windows_w)):
+            for hi in (range(-1, num_windows_h) if docking_h else range(num_windows_h)):
+                left = left0 + wi * latent_w
+                right = left + latent_w
+                top = top0 + hi * latent_h
+                down = top + latent_h
+                fb = fr0 + fi * frames
+                fe = fb + frames
+                if docking_w and in_dock:
+                    if wi == -1:
+                        left, right = 0, latent_w
+                    if wi == num_windows_w - 1:
+                        left, right = latent_w * (num_windows_w - 1), latent_w * num_windows_w
+                elif wi == -1:
+                    continue
+                if docking_h and in_dock:
+                    if hi == -1:
+                        top, down = 0, latent_h
+                    if hi == num_windows_h - 1:
+                        top, down = latent_h * (num_windows_h - 1), latent_h * num_windows_h
+                elif hi == -1:
+                    continue
+                if docking_f and in_dock:
+                    if fi == -1:
+                        fb, fe = 0, frames
+                    if fi == num_windows_f - 1:
+                        fb, fe = frames * (num_windows_f - 1), frames * num_windows_f
+                elif fi == -1:
+                    continue
+                wins.append((left, right, top, down, fb, fe))
+    return wins
+
+
+@torch.no_grad()
+def t2v_grid_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, *, height=320, width=512, frames=16,
+                    guidance_scale=7.5, num_windows_w, num_windows_h, num_windows_f=1, loop_step=8,
+                    num_inference_steps=50, init_panorama_latent=None, in_channels=4, trace=None, **grid_kw):
+    """Returns (denoised, denoised) for output_type='latent' (t2v_normal_pipeline.py:561-568)."""
+    sched = DDIMSchedule(tables, num_inference_steps)
+    timesteps = np.flip(sched.ddim_timesteps)
+    total_steps = len(timesteps)
+    lh, lw = height // VAE_SCALE, width // VAE_SCALE
+    total_shape = (1, in_channels, frames * num_windows_f, lh * num_windows_h, lw * num_windows_w)
+    pano = torch.randn(total_shape) if init_panorama_latent is None else init_panorama_latent.clone()
+    pano_x0 = torch.zeros_like(pano)
+    for i, t in enumerate(timesteps):
+        wins = t2v_grid_windows(i, latent_h=lh, latent_w=lw, frames=frames, num_windows_w=num_windows_w,
+                                num_windows_h=num_windows_h, num_windows_f=num_windows_f, loop_step=loop_step, **grid_kw)
+        if trace is not None:
+            trace.append((i, int(t), wins))
+        for (l, r, tp, dn, fb, fe) in wins:
+            win = ring_gather(pano, l, r, tp, dn, fb, fe)
+            ts = torch.full((1,), int(t), dtype=torch.long)
+            e_c = eps_model(win, ts, cond_ctx)
+            e = cfg_combine(e_c, eps_model(win, ts, uncond_ctx), guidance_scale) if guidance_scale != 1.0 else e_c
+            x_prev, x0 = ddim_step(sched, win, e, [total_steps - i - 1] * win.shape[2])
+            ring_scatter(pano, x_prev, l, r, tp, dn, fb, fe)
+            ring_scatter(pano_x0, x0, l, r, tp, dn, fb, fe)
+    return pano_x0.clone(), pano_x0.clone()
+
+
+# ================================================================================================
+# P3: i2v overlapped ring with temporal windows / docking / merge-prev --
+#     VC2_Pipeline_I2V_SpherePano.basic_sample_shift_multi_windows (pipeline/i2v_sphere_panorama_pipeline.py:564-996)
+# ================================================================================================
+_DOCK_START_INDEX = -101
+_DOCK_END_INDEX = -111
+
+
+def i2v_ring_windows(i, *, height, width, frames, total_h, total_w, total_f, num_windows_h, num_windows_w, loop_step,
+                     overlap_ratio_f, loop_step_frame=None, dock_at_f=None, begin_index_offset=0):
+    """Windows of step i in reference order f -> w -> h (i2v_sphere_panorama_pipeline.py:732-766, 779-854).
+    Unlike the t2v ring, window placement is round(idx * float_step) (:818-820) and frame windows wrap modulo
+    total_f (:828-830)."""
+    import math
+    lh, lw = height // VAE_SCALE, width // VAE_SCALE
+    ov_w = 1 - (total_w / width - 1) / (num_windows_w - 1)
+    step_w = width / VAE_SCALE * (1 - ov_w)
+    off_w = int((1 - ov_w) * width / loop_step) // VAE_SCALE
+    ov_h = 1 - (total_h / height - 1) / (num_windows_h - 1)
+    step_h = height / VAE_SCALE * (1 - ov_h)
+    off_h = int((1 - ov_h) * height / loop_step) // VAE_SCALE
+    assert 0 <= ov_w < 1 and off_w >= 1 and 0 <= ov_h < 1 and off_h >= 1
+    k = (i + begin_index_offset) % loop_step
+    left0, top0 = k * off_w, k * off_h
+    n_f = math.ceil((total_f // frames - 1) / (1 - overlap_ratio_f)) + 1
+    if total_f > frames:
+        off_f = max(int(overlap_ratio_f * frames / loop_step_frame), 1)
+        fr0 = (i % loop_step_frame) * off_f
+        f_ids = list(range(n_f))
+        if dock_at_f:
+            f_ids = [_DOCK_START_INDEX] + f_ids + [_DOCK_END_INDEX]
+    elif total_f == frames:
+        fr0, f_ids = 0, [0]
+    else:
+        raise ValueError(f"total_f {total_f} should >= frames {frames} !")
+    wins = []
+    for fi in f_ids:
+        for wi in range(num_windows_w):
+            for hi in range(num_windows_h):
+                left = left0 + round(wi * step_w)
+                top = top0 + round(hi * step_h)
+                fb = (fr0 + fi * int(frames * (1 - overlap_ratio_f))) % total_f
+                fe = fb + frames
+                if dock_at_f:
+                    if fi == _DOCK_START_INDEX:
+                        if fr0 == 0:
+                            continue
+                        fb, fe = 0, frames
+                    if fi == _DOCK_END_INDEX:
+                        if fr0 == 0:
+                            continue
+                        fb, fe = total_f - frames, total_f
+                    if fe > total_f:
+                        continue
+                wins.append((left, left + lw, top, top + lh, fb, fe))
+    return wins
+
+
+@torch.no_grad()
+def i2v_ring_sample(eps_model, image_embedder, tables: DiffusionTables, text_ctx, uncond_ctx, pano_image, *, height=320,
+                    width=512, frames=16, guidance_scale=7.5, total_w, total_h, total_f=None, num_windows_w,
+                    num_windows_h, num_windows_f=1, loop_step=8, begin_index_offset=0, dock_at_f=None,
+                    overlap_ratio_list_f=None, loop_step_frame=None, num_inference_steps=4, init_panorama_latent=None,
+                    merge_renoised_overlap_latent_ratio=1, merge_prev_denoised_ratio_list=None, in_channels=4,
+                    trace=None):
+    """output_type='latent'.  `image_embedder(crop [1,3,h,w]) -> [1,L_img,D]` stands for get_image_embeds;
+    `pano_image` [3,total_h,total_w] for the RingImageTensor content (utils/shift_window_utils.py:209-276).
+    uncond_ctx must already contain the image-token part (i2v_sphere…py:652-658)."""
+    sched = DDIMSchedule(tables, num_inference_steps)
+    timesteps = np.flip(sched.ddim_timesteps)
+    total_steps = len(timesteps)
+    if total_f is None:
+        total_f = frames * num_windows_f
+    total_shape = (1, in_channels, total_f, total_h // VAE_SCALE, total_w // VAE_SCALE)
+    pano = torch.randn(total_shape) if init_panorama_latent is None else init_panorama_latent.clone()
+    pano_x0 = torch.zeros_like(pano)
+    img5 = pano_image[None, :, None]  # [1,3,1,H,W] so ring_gather can crop with wrap
+    for i, t in enumerate(timesteps):
+        wins = i2v_ring_windows(i, height=height, width=width, frames=frames, total_h=total_h, total_w=total_w,
+                                total_f=total_f, num_windows_h=num_windows_h, num_windows_w=num_windows_w,
+                                loop_step=loop_step, overlap_ratio_f=overlap_ratio_list_f[i],
+                                loop_step_frame=loop_step_frame, dock_at_f=dock_at_f,
+                                begin_index_offset=begin_index_offset)
+        if trace is not None:
+            trace.append((i, int(t), wins))
+        mask = torch.zeros_like(pano)
+        for (l, r, tp, dn, fb, fe) in wins:
+            win = ring_gather(pano, l, r, tp, dn, fb, fe)
+            prev = win.clone()
+            wmask = ring_gather(mask, l, r, tp, dn, fb, fe)
+            if merge_renoised_overlap_latent_ratio is not None and i < total_steps - 1:
+                noised = re_noise(sched, win.clone(), total_steps - i - 2, total_steps - i - 1)
+                win = mix_latents_with_mask(win, noised, wmask, merge_renoised_overlap_latent_ratio)  # 5-D mask (:877)
+            crop = ring_gather(img5, l * VAE_SCALE, l * VAE_SCALE + width, tp * VAE_SCALE, tp * VAE_SCALE + height, 0, 1)
+            img_emb = image_embedder(crop[:, :, 0])
+            ctx = torch.cat([text_ctx, img_emb], dim=1)
+            ts = torch.full((1,), int(t), dtype=torch.long)
+            e_c = eps_model(win, ts, ctx)
+            e = cfg_combine(e_c, eps_model(win, ts, uncond_ctx), guidance_scale) if guidance_scale != 1.0 else e_c
+            x_prev, x0 = ddim_step(sched, win, e, [total_steps - i - 1] * win.shape[2])
+            if merge_prev_denoised_ratio_list is not None and i < total_steps - 1:
+                x_prev = mix_latents_with_mask(x_prev, prev, wmask, merge_prev_denoised_ratio_list[i])
+            ring_scatter(pano, x_prev, l, r, tp, dn, fb, fe)
+            ring_scatter(pano_x0, x0, l, r, tp, dn, fb, fe)
+            ring_scatter(mask, torch.ones_like(x_prev), l, r, tp, dn, fb, fe)
+    return pano_x0.clone(), pano_x0.clone(), pano

@@ -13,6 +13,8 @@ so parity is pinned by what this script captures from the imported reference cod
   G8 unet_tiny_{t2v,i2v}.npz UNetModel forward, toy config           lvdm/modules/networks/openaimodel3d.py:657-708
   G9 loops_small.npz         t2v basic_sample + ring loops, toy geometry, tiny UNet and fake eps
      loop_traces.json        window coordinates + final-panorama SHA-256 for BASELINE configs 2/3/5 (fake eps)
+  G11 loops_grid_i2v.npz     non-overlapping grid loop (P4) and i2v ring loop (P3: round() placement, temporal
+                             windows + docking, 5-D mask, merge-prev, per-window image tokens), fake eps + tiny UNet
   G10 unet_full_t2v.npz      (--full) full-size t2v UNet eps at tile [1,4,16,40,64] (2 forwards, ~2 min)
 
 Only data is written (inputs, expected outputs, seeds); no reference source text.
@@ -126,7 +128,7 @@ class WrappedUNet(nn.Module):
 
 
 WIN_RE = re.compile(r"window_latent: f\[(\d+) - (\d+)\] h\[(-?\d+) - (-?\d+)\] w\[(\d+) - (\d+)\]")
-STEP_RE = re.compile(r"^i = (\d+), t = (\d+)")
+STEP_RE = re.compile(r"^i = (\d+)(?: => \+offset \d+ )?, t = (\d+)")
 
 
 def parse_trace(text):
@@ -337,13 +339,101 @@ def g10_unet_full():
     save_npz("unet_full_t2v.npz", **arrays)
 
 
+GRID_GEOMS = {
+    "plain": dict(num_windows_w=4, num_windows_h=2, num_windows_f=1, loop_step=4, num_inference_steps=5),
+    "jump": dict(num_windows_w=4, num_windows_h=2, num_windows_f=2, loop_step=4, num_inference_steps=5,
+                 shift_jump_odd_w=True, shift_jump_odd_h=True, shift_jump_odd_f=True),
+    "dock": dict(num_windows_w=3, num_windows_h=2, num_windows_f=2, loop_step=4, num_inference_steps=6,
+                 docking_w=True, docking_h=True, docking_f=True, docking_step_range=[1, 2, 4]),
+}
+I2V_GEOMS = {
+    "ring": dict(height=64, width=128, frames=4, total_w=512, total_h=96, total_f=4, num_windows_w=4, num_windows_h=2,
+                 num_windows_f=1, loop_step=4, num_inference_steps=5, overlap_ratio_list_f=[0.0] * 5,
+                 merge_prev_denoised_ratio_list=[0.5, 0.4, 0.3, 0.2, 0.1]),
+    "round_frames": dict(height=64, width=128, frames=4, total_w=512, total_h=96, total_f=8, num_windows_w=5,
+                         num_windows_h=2, num_windows_f=2, loop_step=4, num_inference_steps=5, begin_index_offset=1,
+                         overlap_ratio_list_f=[0.5, 0.5, 0.25, 0.5, 0.5], loop_step_frame=2, dock_at_f=True,
+                         merge_prev_denoised_ratio_list=[0.5, 0.4, 0.3, 0.2, 0.1]),
+}
+
+
+def synth_image_embedder(dim, tokens=16, seed=77):
+    """Deterministic stand-in for get_image_embeds (CLIP image encoder + Resampler are out of scope): a 4x4 average
+    pool of the crop projected 3 -> dim by a fixed seeded matrix.  Same function in tests/helpers.py."""
+    proj = synth_normal((3, dim), seed)
+
+    def embed(img):
+        pooled = torch.nn.functional.adaptive_avg_pool2d(img.float(), (4, 4))     # [b,3,4,4]
+        return pooled.flatten(2).transpose(1, 2) @ proj                            # [b,16,dim]
+    return embed
+
+
+def g11_grid_and_i2v():
+    import utils.shift_window_utils as swu
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    cond = synth_normal((1, 77, 64), 61)
+    uncond = synth_normal((1, 77, 64), 62)
+    arrays = {"cond": cond, "uncond": uncond}
+    traces = {}
+    # ---- P4: non-overlapping grid (t2v_normal_pipeline.py:213-568) ----
+    unet = build_reference_unet(dict(TINY), seed=5)
+    for eps_name, eps_mod in (("fake", FakeEps()), ("tiny", WrappedUNet(unet))):
+        ld = FakeLatentDiffusion(eps_mod, cond, uncond, temporal_length=4)
+        for gname, geom in GRID_GEOMS.items():
+            if eps_name == "tiny" and gname != "plain":
+                continue
+            pipe = VC2_Pipeline_T2V(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": dict(TINY)}}})
+            buf = io.StringIO()
+            torch.manual_seed(2333333)
+            with contextlib.redirect_stdout(buf):
+                _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=64, width=128, frames=4, fps=8,
+                                                               guidance_scale=7.5, output_type="latent",
+                                                               skip_time_step_idx=0,  # printed unconditionally (:306)
+                                                               **geom)
+            arrays[f"grid_{gname}_{eps_name}"] = den
+            traces[f"grid_{gname}"] = parse_trace(buf.getvalue())
+    # ---- P3: i2v overlapped ring (i2v_sphere_panorama_pipeline.py:564-996) ----
+    p_i2v = dict(TINY)
+    p_i2v["use_image_attention"] = True
+    unet_i2v = build_reference_unet(p_i2v, seed=5)
+    embed = synth_image_embedder(64)
+    pano_img = synth_normal((3, 96, 512), 88).clamp(-1, 1)
+    orig_loader = swu.load_image_tensor_from_path
+    swu.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: pano_img   # I/O stub (cv2 absent)
+    try:
+        for eps_name, eps_mod in (("fake", FakeEps()), ("tiny", WrappedUNet(unet_i2v))):
+            ld = FakeLatentDiffusion(eps_mod, cond, uncond, temporal_length=4)
+            ld.get_image_embeds = embed
+            ld.embedder = object()          # hasattr(pretrained_t2v, 'embedder') -> uncond gets image tokens (:652-658)
+            for gname, geom in I2V_GEOMS.items():
+                if eps_name == "tiny" and gname != "ring":
+                    continue
+                pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": p_i2v}}})
+                pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+                buf = io.StringIO()
+                torch.manual_seed(2333333)
+                with contextlib.redirect_stdout(buf):
+                    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", img_cond_path="unused.png", fps=8,
+                                                                   guidance_scale=7.5, pano_image_path="unused.png",
+                                                                   output_type="latent", **geom)
+                arrays[f"i2v_{gname}_{eps_name}"] = den
+                traces[f"i2v_{gname}"] = parse_trace(buf.getvalue())
+    finally:
+        swu.load_image_tensor_from_path = orig_loader
+    arrays["pano_img"] = pano_img
+    save_npz("loops_grid_i2v.npz", **arrays)
+    with open(os.path.join(HERE, "loops_grid_i2v_traces.json"), "w") as f:
+        json.dump({"grid_geoms": GRID_GEOMS, "i2v_geoms": I2V_GEOMS, "traces": traces}, f)
+    print("wrote loops_grid_i2v_traces.json")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size UNet fixture (minutes)")
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v}
     if args.full:
         steps["g10"] = g10_unet_full
     for k, fn in steps.items():

@@ -1,0 +1,16 @@
+"""Shared test helpers (data only / deterministic stand-ins for out-of-scope producers)."""
+import torch
+
+from dynamicscaler_amd.synth import synth_normal
+
+
+def synth_image_embedder(dim, tokens=16, seed=77):
+    """Deterministic stand-in for get_image_embeds (CLIP image encoder + Resampler are out of scope):
+    4x4 average pool of the crop projected 3 -> dim by a fixed seeded matrix.  Identical to the function
+    tests/golden/make_golden.py used when it ran the reference."""
+    proj = synth_normal((3, dim), seed)
+
+    def embed(img):
+        pooled = torch.nn.functional.adaptive_avg_pool2d(img.float().cpu(), (4, 4))
+        return (pooled.flatten(2).transpose(1, 2) @ proj).to(img.device)
+    return embed

@@ -146,42 +146,144 @@ def test_pipelines_small_vs_reference_golden():
                 assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"]
 
 
+def _oracle_fake(x, ts, ctx):
+    return 0.1 * x + 0.01 * ctx.mean()
+
+
 def test_ring_pipeline_fake_eps_bit_exact_fp32():
     """The whole loop with the survey's fake eps-model (0.1*x + 0.01*mean(ctx)) in fp32 latents: every HIP tile op on
-    the path is then bit-exact, so the final panorama must EQUAL the reference's (all four toy geometries,
-    incl. dock_at_h and num_windows_f=2)."""
-    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler, DiffusionTables
+    the path is then bit-exact, so the final panorama must EQUAL the CPU oracle's for all four toy geometries (incl.
+    dock_at_h and num_windows_f=2).  The oracle itself is pinned bit-exactly to the reference's panoramas in the build
+    container (tests/test_oracle_golden.py); it is re-run HERE because torch's CPU normal stream is not bit-identical
+    across CPU vendors (Intel build container vs the GPU box's EPYC), so seeded golden panoramas only match to ~1e-5
+    on another host."""
+    from oracle import loops as oloops, ddim as oddim
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
     from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
     d = dev()
     z = np.load(os.path.join(G, "loops_small.npz"))
     meta = json.load(open(os.path.join(G, "loops_small_traces.json")))
     cond, uncond = T(z["cond"]), T(z["uncond"])
-
-    class FakeModel(torch.nn.Module):
-        diffusion_model = None
-
-        def forward(self, x, t, c_crossattn=None, fps=None, **kw):
-            ctx = torch.cat(c_crossattn, 1)
-            # per-item mean of the context, computed on the host in fp32 like the reference does on CPU
-            # (same [1,L,D] shape as the reference's tensor: torch's CPU reduction order depends on it)
-            m = torch.stack([0.01 * c[None].float().cpu().mean() for c in ctx]).to(x.device)
-            return 0.1 * x.float() + m.reshape(-1, 1, 1, 1, 1)
-
-    class Host:
-        pass
-
-    tables = DiffusionTables()
-    ld = Host()
-    ld.model = FakeModel()
-    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "num_timesteps", "use_scale"):
-        setattr(ld, k, getattr(tables, k))
-    ld.uncond_type, ld.temporal_length, ld.device = "empty_seq", 4, d
-    ld.get_learned_conditioning = lambda p: uncond if p[0] == "" else cond
+    ld = _fake_host(cond, uncond, d)
     for gname, geom in meta["geoms"].items():
         pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": {"in_channels": 4}}}})
         pipe.to(d, torch.float32)
         torch.manual_seed(2333333)
         _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5,
                                                        output_type="latent", **geom)
-        ref = T(z[f"ring_{gname}_fake"])
+        torch.manual_seed(2333333)
+        ref, _, _ = oloops.t2v_ring_sample(_oracle_fake, oddim.DiffusionTables(), cond, uncond, guidance_scale=7.5, **geom)
         assert torch.equal(den.cpu(), ref), (gname, float((den.cpu() - ref).abs().max()))
+        assert relerr(den, T(z[f"ring_{gname}_fake"])) < 1e-4          # and the reference's own panorama (other host's RNG)
+
+
+# ------------------------------------------------------------------------------------------------ P4 / P3
+class _FakeModel(torch.nn.Module):
+    """The survey's fake eps-model 0.1*x + 0.01*mean(ctx); the mean is taken on the host over the same [1,L,D] shape
+    as the reference's tensor (torch's CPU reduction order depends on it)."""
+    diffusion_model = None
+
+    def forward(self, x, t, c_crossattn=None, fps=None, **kw):
+        ctx = torch.cat(c_crossattn, 1)
+        m = torch.stack([0.01 * c[None].float().cpu().mean() for c in ctx]).to(x.device)
+        return 0.1 * x.float() + m.reshape(-1, 1, 1, 1, 1)
+
+
+def _fake_host(cond, uncond, d, embed=None):
+    from dynamicscaler_amd.scheduler import DiffusionTables
+
+    class Host:
+        pass
+    tables = DiffusionTables()
+    ld = Host()
+    ld.model = _FakeModel()
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "num_timesteps", "use_scale"):
+        setattr(ld, k, getattr(tables, k))
+    ld.uncond_type, ld.temporal_length, ld.device = "empty_seq", 4, d
+    ld.get_learned_conditioning = lambda p: uncond if p[0] == "" else cond
+    if embed is not None:
+        ld.get_image_embeds = embed
+        ld.embedder = object()
+    return ld
+
+
+def test_grid_pipeline_vs_reference_golden():
+    """P4 (t2v_normal_pipeline.py:213-568): plain shift, crossed jump-odd flags, docking in W/H/F -- fake eps bit-exact
+    in fp32, tiny UNet within tolerance, window traces identical."""
+    from oracle import loops as oloops, ddim as oddim
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V
+    d = dev()
+    z = np.load(os.path.join(G, "loops_grid_i2v.npz"))
+    meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    ld = _fake_host(cond, uncond, d)
+    cfgd = {"params": {"unet_config": {"params": {"in_channels": 4}}}}
+    for gname, geom in meta["grid_geoms"].items():
+        pipe = VC2_Pipeline_T2V(ld, lvdm_DDIM_Scheduler(ld), cfgd).to(d, torch.float32)
+        trace = []
+        torch.manual_seed(2333333)
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=64, width=128, frames=4, fps=8,
+                                                       guidance_scale=7.5, output_type="latent",
+                                                       step_callback=lambda i, t, w, p, p0: trace.append((i, t, w)), **geom)
+        torch.manual_seed(2333333)
+        oref, _ = oloops.t2v_grid_sample(_oracle_fake, oddim.DiffusionTables(), cond, uncond, height=64, width=128, frames=4,
+                                         guidance_scale=7.5, **geom)
+        assert torch.equal(den.cpu(), oref), (gname, float((den.cpu() - oref).abs().max()))
+        assert relerr(den, T(z[f"grid_{gname}_fake"])) < 1e-4
+        for (i, t, wins), ref in zip(trace, meta["traces"][f"grid_{gname}"]):
+            assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"], (gname, i)
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    ldu = _host(params, 5, cond, uncond, d)
+    pipe = VC2_Pipeline_T2V(ldu, lvdm_DDIM_Scheduler(ldu), {"params": {"unet_config": {"params": params}}}).to(d, torch.float16)
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=64, width=128, frames=4, fps=8,
+                                                   guidance_scale=7.5, output_type="latent", **meta["grid_geoms"]["plain"])
+    e = relerr(den, T(z["grid_plain_tiny"]))
+    print(f"grid plain tiny fp16: rel err {e:.3e}")
+    assert e < 3e-2
+
+
+def test_i2v_ring_pipeline_vs_reference_golden():
+    """P3 (i2v_sphere_panorama_pipeline.py:564-996): round() placement, temporal windows + docking, 5-D mask,
+    merge-prev, per-window image tokens, begin_index_offset."""
+    from helpers import synth_image_embedder
+    from oracle import loops as oloops, ddim as oddim
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano
+    d = dev()
+    z = np.load(os.path.join(G, "loops_grid_i2v.npz"))
+    meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    embed = synth_image_embedder(64)
+    pano_img = T(z["pano_img"])
+    ld = _fake_host(cond, uncond, d, embed)
+    cfgd = {"params": {"unet_config": {"params": {"in_channels": 4}}}}
+    for gname, geom in meta["i2v_geoms"].items():
+        pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), cfgd).to(d, torch.float32)
+        trace = []
+        torch.manual_seed(2333333)
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                       pano_image_tensor=pano_img,
+                                                       step_callback=lambda i, t, w, p, p0: trace.append((i, t, w)), **geom)
+        torch.manual_seed(2333333)
+        uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
+        oref, _, _ = oloops.i2v_ring_sample(_oracle_fake, embed, oddim.DiffusionTables(), cond, uc, pano_img,
+                                            guidance_scale=7.5, **geom)
+        assert torch.equal(den.cpu(), oref), (gname, float((den.cpu() - oref).abs().max()))
+        assert relerr(den, T(z[f"i2v_{gname}_fake"])) < 1e-4
+        for (i, t, wins), ref in zip(trace, meta["traces"][f"i2v_{gname}"]):
+            assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"], (gname, i)
+    zt = np.load(os.path.join(G, "unet_tiny_i2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    ldu = _host(params, 5, cond, uncond, d)
+    ldu.get_image_embeds = embed
+    ldu.embedder = object()
+    pipe = VC2_Pipeline_I2V_SpherePano(ldu, lvdm_DDIM_Scheduler(ldu), {"params": {"unet_config": {"params": params}}}).to(d, torch.float16)
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                   pano_image_tensor=pano_img, **meta["i2v_geoms"]["ring"])
+    e = relerr(den, T(z["i2v_ring_tiny"]))
+    print(f"i2v ring tiny fp16: rel err {e:.3e}")
+    assert e < 3e-2

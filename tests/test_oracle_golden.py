@@ -200,3 +200,60 @@ def test_g9_baseline_geometry_final_panorama_sha(name):
                                        **rec["geom"])
     assert list(den.shape) == rec["shape"]
     assert hashlib.sha256(den.numpy().tobytes()).hexdigest() == rec["denoised_sha256"]
+
+
+# ------------------------------------------------------------------------------------------------ P4 / P3
+def test_g11_grid_loop_fake_eps_bit_exact_and_traces():
+    z = npz("loops_grid_i2v.npz")
+    meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    for gname, geom in meta["grid_geoms"].items():
+        trace = []
+        torch.manual_seed(2333333)
+        den, _ = oloops.t2v_grid_sample(_fake_eps, oddim.DiffusionTables(), cond, uncond, height=64, width=128, frames=4,
+                                        guidance_scale=7.5, trace=trace, **geom)
+        assert torch.equal(den, T(z[f"grid_{gname}_fake"])), gname
+        for (i, t, wins), ref in zip(trace, meta["traces"][f"grid_{gname}"]):
+            assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"], (gname, i)
+
+
+def test_g11_i2v_ring_loop_fake_eps_bit_exact_and_traces():
+    from helpers import synth_image_embedder
+    z = npz("loops_grid_i2v.npz")
+    meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    embed = synth_image_embedder(64)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
+    for gname, geom in meta["i2v_geoms"].items():
+        trace = []
+        torch.manual_seed(2333333)
+        den, _, _ = oloops.i2v_ring_sample(_fake_eps, embed, oddim.DiffusionTables(), cond, uc, T(z["pano_img"]),
+                                           guidance_scale=7.5, trace=trace, **geom)
+        assert torch.equal(den, T(z[f"i2v_{gname}_fake"])), gname
+        for (i, t, wins), ref in zip(trace, meta["traces"][f"i2v_{gname}"]):
+            assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"], (gname, i)
+
+
+def test_g11_grid_and_i2v_tiny_unet():
+    from helpers import synth_image_embedder
+    z = npz("loops_grid_i2v.npz")
+    meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    params, sd = _tiny_setup()
+    torch.manual_seed(2333333)
+    den, _ = oloops.t2v_grid_sample(lambda x, ts, ctx: unet_forward(sd, params, x, ts, ctx, fps=8),
+                                    oddim.DiffusionTables(), cond, uncond, height=64, width=128, frames=4,
+                                    guidance_scale=7.5, **meta["grid_geoms"]["plain"])
+    ref = T(z["grid_plain_tiny"])
+    assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4
+    p2 = dict(params)
+    p2["use_image_attention"] = True
+    sd2 = synth_state_dict(param_shapes(p2), seed=5)
+    embed = synth_image_embedder(64)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
+    torch.manual_seed(2333333)
+    den, _, _ = oloops.i2v_ring_sample(lambda x, ts, ctx: unet_forward(sd2, p2, x, ts, ctx, fps=8), embed,
+                                       oddim.DiffusionTables(), cond, uc, T(z["pano_img"]), guidance_scale=7.5,
+                                       **meta["i2v_geoms"]["ring"])
+    ref = T(z["i2v_ring_tiny"])
+    assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4
