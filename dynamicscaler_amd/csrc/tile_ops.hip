@@ -224,6 +224,44 @@ __global__ void __launch_bounds__(256) cfg_ddim_kernel(const T* __restrict__ x, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Sphere path: perspective view <-> equirect panorama through a host-computed int32 index map
+// (utils/panorama_tensor_utils.py:154-202).  idx[i][p] < 0 = skip (invalid sample / duplicate-target loser).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) map_gather_kernel(const T* __restrict__ pano, T* __restrict__ tiles,
+                                                         const int* __restrict__ idx, int CF, int HW, int P, int n) {
+    const long total = (long)n * CF * P;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(t % P);
+        const long r = t / P;
+        const int cf = (int)(r % CF);
+        const int i = (int)(r / CF);
+        const int src = idx[(long)i * P + p];
+        tiles[t] = src >= 0 ? pano[(long)cf * HW + src] : (T)0;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) map_scatter3_kernel(T* __restrict__ pano_lat, T* __restrict__ pano_x0,
+                                                           uint8_t* __restrict__ mask, const T* __restrict__ xprev,
+                                                           const T* __restrict__ x0t, const int* __restrict__ idx, int CF,
+                                                           int HW, int P, int n) {
+    const long total = (long)n * CF * P;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(t % P);
+        const long r = t / P;
+        const int cf = (int)(r % CF);
+        const int i = (int)(r / CF);
+        const int dst = idx[(long)i * P + p];
+        if (dst < 0) continue;
+        if (pano_lat) pano_lat[(long)cf * HW + dst] = xprev[t];
+        if (pano_x0) pano_x0[(long)cf * HW + dst] = x0t[t];
+        if (mask && cf == 0) mask[dst] = 1;
+    }
+}
+
 int fill_origins(Origins& o, const ds_ring_geom* g, const int32_t* origins, int n, const char* who) {
     DS_CHECK_ARG(g && origins, "%s: null geom/origins", who);
     DS_CHECK_ARG(n >= 1 && n <= DS_MAX_WINDOWS, "%s: n=%d out of [1,%d]", who, n, DS_MAX_WINDOWS);
@@ -374,5 +412,37 @@ extern "C" int ds_cfg_ddim(const void* x, const void* eps_c, const void* eps_u, 
     }
 #undef DS_LAUNCH_CFG
     DS_CHECK_LAUNCH("ds_cfg_ddim");
+    return DS_OK;
+}
+
+extern "C" int ds_map_gather(const void* pano, void* tiles, const int32_t* idx, int CF, int HW, int P, int n, int dtype,
+                             void* stream) {
+    DS_CHECK_ARG(pano && tiles && idx, "ds_map_gather: null argument");
+    DS_CHECK_ARG(CF > 0 && HW > 0 && P > 0 && n > 0, "ds_map_gather: sizes must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    const long work = (long)n * CF * P;
+    if (dtype == DS_F16) map_gather_kernel<f16><<<grid_for(work), 256, 0, st>>>((const f16*)pano, (f16*)tiles, idx, CF, HW, P, n);
+    else if (dtype == DS_F32) map_gather_kernel<float><<<grid_for(work), 256, 0, st>>>((const float*)pano, (float*)tiles, idx, CF, HW, P, n);
+    else if (dtype == 2) map_gather_kernel<uint8_t><<<grid_for(work), 256, 0, st>>>((const uint8_t*)pano, (uint8_t*)tiles, idx, CF, HW, P, n);
+    else DS_CHECK_ARG(false, "ds_map_gather: bad dtype %d", dtype);
+    DS_CHECK_LAUNCH("ds_map_gather");
+    return DS_OK;
+}
+
+extern "C" int ds_map_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const void* x_prev_tiles,
+                               const void* x0_tiles, const int32_t* idx, int CF, int HW, int P, int n, int dtype,
+                               void* stream) {
+    DS_CHECK_ARG(idx, "ds_map_scatter3: null index map");
+    DS_CHECK_ARG(CF > 0 && HW > 0 && P > 0 && n > 0, "ds_map_scatter3: sizes must be positive");
+    DS_CHECK_ARG(!pano_latent || x_prev_tiles, "ds_map_scatter3: pano_latent without x_prev_tiles");
+    DS_CHECK_ARG(!pano_x0 || x0_tiles, "ds_map_scatter3: pano_x0 without x0_tiles");
+    hipStream_t st = (hipStream_t)stream;
+    const long work = (long)n * CF * P;
+    if (dtype == DS_F16)
+        map_scatter3_kernel<f16><<<grid_for(work), 256, 0, st>>>((f16*)pano_latent, (f16*)pano_x0, mask_pano, (const f16*)x_prev_tiles, (const f16*)x0_tiles, idx, CF, HW, P, n);
+    else if (dtype == DS_F32)
+        map_scatter3_kernel<float><<<grid_for(work), 256, 0, st>>>((float*)pano_latent, (float*)pano_x0, mask_pano, (const float*)x_prev_tiles, (const float*)x0_tiles, idx, CF, HW, P, n);
+    else DS_CHECK_ARG(false, "ds_map_scatter3: bad dtype %d", dtype);
+    DS_CHECK_LAUNCH("ds_map_scatter3");
     return DS_OK;
 }

@@ -142,6 +142,37 @@ def cfg_ddim(x, eps_c, eps_u, pano_shape, guidance, coef, noise=None):
     return x_prev, x0
 
 
+def map_gather(pano, idx):
+    """pano [1,C,F,H,W] (fp16/fp32) or uint8 [H,W]; idx int32 device [n,P] -> tiles [n,C,F,P] (or [n,P] for uint8)."""
+    _dev(pano, "map_gather")
+    lib = _lib.load()
+    n, P = idx.shape
+    assert idx.dtype == torch.int32 and idx.is_cuda and idx.is_contiguous()
+    if pano.dtype == torch.uint8:
+        CF, HW, dt = 1, pano.numel(), 2
+        out = torch.empty((n, P), dtype=torch.uint8, device=pano.device)
+    else:
+        _, Cc, F, H, W = pano.shape
+        CF, HW, dt = Cc * F, H * W, _DT[pano.dtype]
+        out = torch.empty((n, Cc, F, P), dtype=pano.dtype, device=pano.device)
+    check(lib.ds_map_gather(pano.data_ptr(), out.data_ptr(), idx.data_ptr(), CF, HW, P, n, dt, _stream()), "ds_map_gather")
+    return out
+
+
+def map_scatter3(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, idx):
+    ref = pano_latent if pano_latent is not None else pano_x0
+    _dev(ref, "map_scatter3")
+    lib = _lib.load()
+    n, P = idx.shape
+    _, Cc, F, H, W = ref.shape
+    for t in (x_prev_tiles, x0_tiles):
+        if t is not None:
+            _dev(t, "map_scatter3(tile)")
+            assert t.dtype == ref.dtype and t.numel() == n * Cc * F * P
+    check(lib.ds_map_scatter3(_ptr(pano_latent), _ptr(pano_x0), _ptr(mask_pano), _ptr(x_prev_tiles), _ptr(x0_tiles),
+                              idx.data_ptr(), Cc * F, H * W, P, n, _DT[ref.dtype], _stream()), "ds_map_scatter3")
+
+
 # ------------------------------------------------------------------------------------------------ UNet ops
 def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE, lda=None, cin=None,
          conv=None, tconv=None, bias_rows=None, ldbias=None, epilogue=0, stream=None):

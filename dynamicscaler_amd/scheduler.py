@@ -102,10 +102,20 @@ class lvdm_DDIM_Scheduler(object):
             return None
         return torch.cat(frames, dim=2).to(device=device, dtype=dtype)
 
-    def draw_renoise_noise(self, shape, device, dtype):
-        """torch.randn_like(x_a) of re_noise (scheduler.py:106) drawn on the host, or None in 'device' mode."""
+    def draw_renoise_noise(self, shape, device, dtype, sphere_view=None):
+        """torch.randn_like(x_a) of re_noise (scheduler.py:106) drawn on the host, or None in 'device' mode.
+
+        sphere_view: None for the ring loops (their windows are contiguous clones).  In the t2v SPHERE loop the
+        tensor handed to re_noise is a view of PanoramaLatentProxy's storage and its STRIDES decide which of torch's CPU
+        normal paths runs: the first view of a run is contiguous (plain randn); after the first
+        set_view_tensor_no_interpolation the storage becomes [B,N,C,H,W]-contiguous (panorama_tensor_utils.py:183), every
+        later view is a non-contiguous permute, randn_like keeps the strides and the scalar normal path produces a
+        different stream.  "later" reproduces that by calling randn_like on an identically strided tensor."""
         if self.rng_mode != "reference":
             return None
+        if sphere_view == "later":
+            b, c, n, h, w = shape
+            return torch.randn_like(torch.empty((b, n, c, h, w)).permute(0, 2, 1, 3, 4)).contiguous().to(device=device, dtype=dtype)
         return torch.randn(shape).to(device=device, dtype=dtype)
 
     def next_philox_offset(self, count):

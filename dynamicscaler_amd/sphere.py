@@ -1,0 +1,255 @@
+"""Sphere path host side: perspective-view <-> equirect index maps, GPU-backed PanoramaLatentProxy, and the t2v sphere
+loop `basic_sample_shift_shpere_panorama` (pipeline/t2v_sphere_panorama_pipeline.py:23-312).
+
+Index maps (S1): `_get_uv` (utils/panorama_tensor_utils.py:204-245) is evaluated ON THE HOST with the same fp32 torch
+CPU ops the reference uses -- floor() turns any ulp difference of a device libm into a different pixel -- and cached
+per (fov, theta, phi, w, h, W, H) as int32 device tensors (<= 44 views x 10 theta offsets for gen_pano_360.py).
+Gather / scatter (S2/S3) are ds_map_gather / ds_map_scatter3; duplicate scatter targets are resolved on the host
+(last source in row-major view order wins, like torch's CPU index_put), so the kernel is race-free.
+"""
+import numpy as np
+import torch
+
+from . import ops, parallel
+from .pipelines import VC2_Pipeline_T2V_SpherePano as _RingPipe, _RingState
+
+
+def view_uv(fov, theta, phi, width, height, W, H, dtype=torch.float32):
+    """(u, v) float maps [height, width] of a pinhole view (fov, yaw theta, pitch phi, degrees) on a W x H equirect.
+    Same op sequence and dtype as panorama_tensor_utils.py:204-245 (fp32 on the CPU)."""
+    rad = [torch.deg2rad(torch.tensor(a, dtype=dtype)) for a in (fov, theta, phi)]
+    fov_r, th, ph = rad
+    focal = 0.5 * width / torch.tan(fov_r / 2)
+    xs = torch.linspace(-width / 2, width / 2 - 1, steps=width, dtype=dtype)
+    ys = torch.linspace(-height / 2, height / 2 - 1, steps=height, dtype=dtype)
+    yv, xv = torch.meshgrid(ys, xs, indexing="ij")
+    rays = torch.stack([xv, yv, torch.full_like(xv, focal)], dim=-1)
+    rays = rays / torch.norm(rays, dim=-1, keepdim=True)
+    r_phi = torch.tensor([[1, 0, 0], [0, torch.cos(ph), -torch.sin(ph)], [0, torch.sin(ph), torch.cos(ph)]], dtype=dtype)
+    r_theta = torch.tensor([[torch.cos(th), 0, torch.sin(th)], [0, 1, 0], [-torch.sin(th), 0, torch.cos(th)]], dtype=dtype)
+    rot = torch.matmul(r_theta, r_phi)
+    d = torch.matmul(rays.view(-1, 3), rot.t()).view(height, width, 3)
+    lon = (torch.atan2(d[..., 0], d[..., 2]) + 2 * torch.pi) % (2 * torch.pi)
+    lat = torch.asin(d[..., 1])
+    return lon / (2 * torch.pi) * (W - 1), (lat + torch.pi / 2) / torch.pi * (H - 1)
+
+
+class ViewMaps:
+    """gather / scatter index maps of one view, host (numpy) and device (int32)."""
+
+    def __init__(self, fov, theta, phi, width, height, W, H, device):
+        u, v = view_uv(fov, theta, phi, width, height, W, H)
+        fu, fv = torch.floor(u).long(), torch.floor(v).long()
+        g = (torch.clamp(fv, 0, H - 1) * W + fu % W)
+        gvalid = (u >= 0) & (u < W) & (v >= 0) & (v < H)                       # :197-200
+        g = torch.where(gvalid, g, torch.full_like(g, -1)).view(-1)
+        s = fv * W + fu
+        svalid = ((fu >= 0) & (fu < W) & (fv >= 0) & (fv < H)).view(-1)        # :166
+        s = s.view(-1).numpy()
+        sv = svalid.numpy()
+        # duplicate targets: the LAST valid source in row-major order wins
+        last = np.full(H * W, -1, dtype=np.int64)
+        src = np.nonzero(sv)[0]
+        last[s[src]] = src                      # numpy fancy assignment keeps the last write for repeated indices
+        winner = np.zeros(len(s), dtype=bool)
+        winner[last[last >= 0]] = True
+        s_final = np.where(winner, s, -1).astype(np.int32)
+        self.gather_np = g.numpy().astype(np.int32)
+        self.scatter_np = s_final
+        self.gather = torch.from_numpy(self.gather_np).to(device)
+        self.scatter = torch.from_numpy(s_final).to(device)
+        # footprints for the dependency analysis
+        self.read_set = np.zeros(H * W, dtype=bool)
+        self.read_set[self.gather_np[self.gather_np >= 0]] = True
+        self.write_set = np.zeros(H * W, dtype=bool)
+        self.write_set[s_final[s_final >= 0]] = True
+        self.gather_valid_mask = gvalid.to(torch.float32)
+
+
+class ViewMapCache:
+    def __init__(self, device):
+        self.device = device
+        self._maps = {}
+
+    def get(self, fov, theta, phi, width, height, W, H):
+        key = (fov, theta, phi, width, height, W, H)
+        m = self._maps.get(key)
+        if m is None:
+            m = self._maps[key] = ViewMaps(fov, theta, phi, width, height, W, H, self.device)
+        return m
+
+
+class PanoramaLatentProxy:
+    """GPU-backed drop-in for utils/panorama_tensor_utils.py:249-290 (no [B,C,N,H,W] <-> [B,N,C,H,W] permute copies:
+    the kernels index the latent layout directly)."""
+
+    def __init__(self, equirect_tensor):
+        assert equirect_tensor.dim() == 5, "expects [B, C, N, H, W]"
+        if not equirect_tensor.is_cuda:
+            raise RuntimeError("PanoramaLatentProxy lives on the GPU in this build (no CPU path)")
+        H, W = equirect_tensor.shape[-2:]
+        assert W == 2 * H                                            # panorama_tensor_utils.py:9
+        self.equirect = equirect_tensor.clone().contiguous()
+        self._cache = ViewMapCache(equirect_tensor.device)
+
+    def get_equirect_tensor(self):
+        return self.equirect
+
+    def get_view_tensor_no_interpolate(self, fov, theta, phi, width, height):
+        B, C, N, H, W = self.equirect.shape
+        m = self._cache.get(fov, theta, phi, width, height, W, H)
+        view = ops.map_gather(self.equirect, m.gather[None]).reshape(1, C, N, height, width)
+        return view, m.gather_valid_mask.to(self.equirect.device)
+
+    def set_view_tensor_no_interpolation(self, view_tensor, fov, theta, phi):
+        B, C, N, H, W = self.equirect.shape
+        height, width = view_tensor.shape[-2:]
+        m = self._cache.get(fov, theta, phi, width, height, W, H)
+        src = view_tensor.to(self.equirect.dtype).contiguous()
+        ops.map_scatter3(self.equirect, None, None, src, None, m.scatter[None])
+
+
+def plan_levels_sets(reads, writes):
+    """Dependency levels for items with arbitrary footprints (boolean arrays over the panorama): item j must come after
+    an earlier item k when k writes something j reads or writes, or j writes something k reads.  Same guarantees as
+    parallel.plan_levels."""
+    level = []
+    for j in range(len(reads)):
+        lv = 0
+        touch_j = reads[j] | writes[j]
+        for k in range(j):
+            if level[k] >= lv and ((writes[k] & touch_j).any() or (reads[k] & writes[j]).any()):
+                lv = level[k] + 1
+        level.append(lv)
+    out = [[] for _ in range(max(level) + 1)] if level else []
+    for j, lv in enumerate(level):
+        out[lv].append(j)
+    return out
+
+
+class VC2_Pipeline_T2V_SpherePano(_RingPipe):
+    """Adds the sphere loop to the ring pipeline class (one class in the reference, t2v_sphere_panorama_pipeline.py:20)."""
+
+    @torch.no_grad()
+    def basic_sample_shift_shpere_panorama(self, prompt=None, height=320, width=512, frames=16, fps=16, guidance_scale=7.5,
+                                           num_videos_per_prompt=1, generator=None, init_sphere_latent=None,
+                                           equirect_width=None, equirect_height=None, phi_theta_dict=None,
+                                           phi_prompt_dict=None, view_fov=None, view_get_scale_factor=1,
+                                           view_set_scale_factor=1, loop_step_theta=None,
+                                           merge_renoised_overlap_latent_ratio=None, phi_fov_dict=None,
+                                           denoise_to_step=None, latents=None, num_inference_steps=4, prompt_embeds=None,
+                                           output_type="pil", downsample_factor_before_vae_decode=None, use_skip_time=False,
+                                           skip_time_step_idx=None, progressive_skip=False, step_callback=None, **kwargs):
+        """[sic] name kept from the reference.  Views are perspective crops of the 2:1 equirect latent; they are
+        processed with the reference's sequential semantics (levels of views with disjoint footprints are batched).
+        Returns (final_latents, denoised) for output_type='latent' (:307-312)."""
+        if view_get_scale_factor != 1 or view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
+            raise NotImplementedError("view / decode scale factors other than 1 (gen_pano_360.py uses 1) need the "
+                                      "resize_video_latent hand-off (SURVEY.md 8-f N1)")
+        if use_skip_time:
+            raise NotImplementedError  # like the reference (:146-148)
+        unet_config = self.model_config["params"]["unet_config"]
+        frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
+        prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
+        self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
+        timesteps = np.flip(self.scheduler.ddim_timesteps)
+        if denoise_to_step is not None:
+            timesteps = timesteps[:denoise_to_step]
+        total_steps = self.scheduler.ddim_timesteps.shape[0]     # NB: the full schedule length here (:125), unlike the ring loops
+        vs = self.vae_scale_factor
+        lat_h, lat_w = height // vs, width // vs
+        H, W = equirect_height // vs, equirect_width // vs
+        shape = (1, unet_config["params"]["in_channels"], frames, H, W)
+        if init_sphere_latent is None:
+            init_sphere_latent = torch.randn(shape)               # host draw, reference order
+        else:
+            assert tuple(init_sphere_latent.shape) == shape, \
+                f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_sphere_latent.shape)} does not match desired shape {shape}"
+        assert W == 2 * H                                         # PanoramaTensor (:9)
+        st = self._new_state(init_sphere_latent, shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale, text_emb,
+                             uc_emb, merge_renoised_overlap_latent_ratio, kwargs)
+        st.total_steps = total_steps
+        device = st.device
+        mask = torch.zeros((H * W,), dtype=torch.uint8, device=device)
+        cache = ViewMapCache(device)
+        prompt_cache = {}
+        sched = self.scheduler
+        scattered = 0
+        P = lat_h * lat_w
+        for i in range(len(timesteps)):
+            t = timesteps[i]
+            theta_offset = (i % loop_step_theta) * (view_fov // loop_step_theta)
+            mask.zero_()                                          # reset mask record (:181)
+            views, ctxs = [], []
+            for phi_angle in list(phi_theta_dict.keys()):
+                for theta_angle in phi_theta_dict[phi_angle]:
+                    cphi, cth = phi_angle, theta_angle + theta_offset
+                    cfov = phi_fov_dict.get(cphi, view_fov) if phi_fov_dict is not None else view_fov
+                    views.append((cphi, cth, cfov))
+                    if phi_prompt_dict is not None:
+                        cur = phi_prompt_dict[phi_angle]
+                        if cur not in prompt_cache:
+                            prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(device)
+                        ctxs.append(prompt_cache[cur])
+                    else:
+                        ctxs.append(st.text_emb)
+            lat_maps = [cache.get(view_fov, th, ph, lat_w, lat_h, W, H) for (ph, th, fv) in views]   # latent gather: view_fov (:196)
+            set_maps = [cache.get(fv, th, ph, lat_w, lat_h, W, H) for (ph, th, fv) in views]          # mask gather + scatters: curr_fov
+            renoise = st.ratio is not None and i < total_steps - 1
+            coef = sched.step_coefficients(total_steps - i - 1)
+            # host noise in reference order; see scheduler.draw_renoise_noise(sphere_view=...) for the layout quirk
+            noises = []
+            for j in range(len(views)):
+                nz = sched.draw_renoise_noise(st.tile_shape, "cpu", torch.float32,
+                                              sphere_view="first" if scattered + j == 0 else "later") if renoise else None
+                sn = sched.draw_step_noise(st.tile_shape, "cpu", torch.float32, coef["sigma"])
+                noises.append((nz, sn))
+            if renoise:
+                c_rn, s_rn = sched.renoise_coefficients(total_steps - i - 2, total_steps - i - 1)
+            reads = [lat_maps[j].read_set | set_maps[j].read_set for j in range(len(views))]
+            writes = [set_maps[j].write_set for j in range(len(views))]
+            for level in plan_levels_sets(reads, writes):
+                mine = parallel.rank_share(level, st.rank, st.world)
+                xp_parts, x0_parts = [], []
+                for s0 in range(0, len(mine), self.max_tile_batch):
+                    ids = mine[s0:s0 + self.max_tile_batch]
+                    n = len(ids)
+                    g_idx = torch.stack([lat_maps[j].gather for j in ids])
+                    m_idx = torch.stack([set_maps[j].gather for j in ids])
+                    tiles = ops.map_gather(st.pano, g_idx).reshape((n,) + st.tile_shape[1:])
+                    if renoise:
+                        mt = ops.map_gather(mask, m_idx).reshape(n, 1, lat_h, lat_w).expand(n, frames, lat_h, lat_w).contiguous()
+                        nz = None
+                        if noises[ids[0]][0] is not None:
+                            nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=st.pano.dtype)
+                        ops.renoise_mix_(tiles, mt, shape, c_rn, s_rn, st.ratio, noise=nz, mask_frame0=True,
+                                         seed=sched.philox_seed, offset=(i * len(views) + ids[0]) * tiles[0].numel())
+                    if st.guidance_scale != 1.0:
+                        eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n, fps,
+                                        frames, **st.kwargs)
+                        e_c, e_u = eps[:n], eps[n:]
+                    else:
+                        e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], fps, frames, **st.kwargs), None
+                    sn = None
+                    if coef["sigma"] != 0.0:
+                        sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=st.pano.dtype)
+                    x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, shape, st.guidance_scale, coef, sn)
+                    xp_parts.append(x_prev)
+                    x0_parts.append(x0)
+                if st.world > 1:
+                    empty = torch.empty((0,) + st.tile_shape[1:], dtype=st.pano.dtype, device=device)
+                    xp_all, x0_all = parallel.exchange_level(torch.cat(xp_parts, 0) if xp_parts else empty,
+                                                             torch.cat(x0_parts, 0) if x0_parts else empty, len(level))
+                    order = level
+                else:
+                    xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
+                s_idx = torch.stack([set_maps[j].scatter for j in order])
+                ops.map_scatter3(st.pano, st.pano_x0, mask, xp_all.contiguous(), x0_all.contiguous(), s_idx)
+            scattered += len(views)
+            if step_callback is not None:
+                step_callback(i, int(t), views, st.pano, st.pano_x0)
+        denoised = st.pano_x0.clone()
+        final_latents = st.pano.clone()
+        if output_type == "latent":
+            return final_latents, denoised
+        return self.pretrained_t2v.decode_first_stage_2DAE(denoised), denoised

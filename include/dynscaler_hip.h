@@ -89,6 +89,21 @@ int ds_cfg_ddim(const void* x, const void* eps_c, const void* eps_u, int eps_dty
                 float sqrt_one_minus_at, float sqrt_at, float sqrt_a_prev, float dir_coef, float sigma,
                 const void* noise, void* x_prev, void* x0, const ds_ring_geom* geom, int n, void* stream);
 
+/* Sphere path (utils/panorama_tensor_utils.py, utils/ring_panorama_tensor_utils.py): perspective view <-> equirect
+ * panorama by a host-computed nearest-neighbour index map (the map comes from the reference's fp32 torch op sequence of
+ * _get_uv, :204-245, evaluated on the host so floor() sees identical values; cached per (fov,theta,phi,w,h,W,H)).
+ *   ds_map_gather   : get_view_tensor_no_interpolate / _sample_equirect_tensor_nearest (:53-70,:185-202)
+ *                     tiles[i][cf][p] = idx[i][p] >= 0 ? pano[cf][idx[i][p]] : 0     (cf = fused channel*frame index)
+ *                     dtype DS_F16 / DS_F32 / 2 (uint8, the denoised-mask panorama)
+ *   ds_map_scatter3 : set_view_tensor_no_interpolation x3 (:154-183); idx[i][p] < 0 skips the source.  The caller
+ *                     resolves duplicate targets on the host (torch's CPU index_put keeps the LAST source in row-major
+ *                     view order; losers get -1), so the kernel is race-free; views of one launch must be disjoint.
+ * idx is a DEVICE pointer [n][P] (P = view h*w), HW = panorama H*W. */
+int ds_map_gather(const void* pano, void* tiles, const int32_t* idx, int CF, int HW, int P, int n, int dtype,
+                  void* stream);
+int ds_map_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const void* x_prev_tiles,
+                    const void* x0_tiles, const int32_t* idx, int CF, int HW, int P, int n, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * UNet inner blocks (lvdm/modules/networks/openaimodel3d.py, lvdm/modules/attention.py).
  * ---------------------------------------------------------------------------------------------- */

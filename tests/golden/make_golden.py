@@ -15,6 +15,8 @@ so parity is pinned by what this script captures from the imported reference cod
      loop_traces.json        window coordinates + final-panorama SHA-256 for BASELINE configs 2/3/5 (fake eps)
   G11 loops_grid_i2v.npz     non-overlapping grid loop (P4) and i2v ring loop (P3: round() placement, temporal
                              windows + docking, 5-D mask, merge-prev, per-window image tokens), fake eps + tiny UNet
+  G12 sphere.npz             _get_uv index maps (gen_pano_360 view set, one view at all 10 theta offsets), sphere
+                             gather/scatter round trips (duplicate winners), t2v sphere loop (P5), fake eps + tiny UNet
   G10 unet_full_t2v.npz      (--full) full-size t2v UNet eps at tile [1,4,16,40,64] (2 forwards, ~2 min)
 
 Only data is written (inputs, expected outputs, seeds); no reference source text.
@@ -427,13 +429,97 @@ def g11_grid_and_i2v():
     print("wrote loops_grid_i2v_traces.json")
 
 
+SPHERE_GEOMS = {
+    "base": dict(height=64, width=128, frames=4, equirect_width=512, equirect_height=256, view_fov=120, loop_step_theta=4,
+                 phi_theta_dict={"90": [0], "-90": [0], "45": [0, 120, 240], "-45": [0, 120, 240], "0": [0, 90, 180, 270]},
+                 merge_renoised_overlap_latent_ratio=1, num_inference_steps=5, denoise_to_step=4),
+    "fovdict": dict(height=64, width=128, frames=4, equirect_width=512, equirect_height=256, view_fov=120, loop_step_theta=3,
+                    phi_theta_dict={"90": [0], "0": [0, 120, 240], "-60": [0, 180]}, phi_fov_dict={"90": 100, "-60": 110},
+                    merge_renoised_overlap_latent_ratio=0.7, num_inference_steps=4),
+}
+GEN_PANO_VIEWS = {90: [0], -90: [0], 75: [0, 60, 120, 180, 240, 300], -75: [0, 60, 120, 180, 240, 300],
+                  60: [0, 60, 120, 180, 240, 300], -60: [0, 60, 120, 180, 240, 300], 45: [0, 60, 120, 180, 240, 300],
+                  -45: [0, 60, 120, 180, 240, 300], 0: [0, 60, 120, 180, 240, 300]}   # gen_pano_360.py:444-455 shape (phi_num=6)
+
+VIEW_RE = re.compile(r"window: phi = (-?\d+), theta = (-?\d+), .* fov = (-?\d+)")
+
+
+def g12_sphere():
+    from utils.panorama_tensor_utils import PanoramaTensor, PanoramaLatentProxy
+    arrays = {}
+    # ---- G5: index maps of the gen_pano_360 view set on a 128x64 latent panorama, view 16x8... and the real 64x40 view on 256x128
+    for tag, (W, H, w, h) in {"small": (128, 64, 16, 8), "real": (256, 128, 64, 40)}.items():
+        pt = PanoramaTensor(torch.zeros(1, H, W))
+        gi, si = [], []
+        views = []
+        for phi, thetas in GEN_PANO_VIEWS.items():
+            for th in thetas:
+                for off in ((0, 12, 24, 36, 48, 60, 72, 84, 96, 108) if (phi == 45 and th == 60) else (0,)):
+                    u, v = pt._get_uv(fov=120, theta=th + off, phi=phi, width=w, height=h)
+                    u0 = torch.floor(u).long() % W
+                    v0 = torch.clamp(torch.floor(v).long(), 0, H - 1)
+                    gi.append((v0 * W + u0).to(torch.int32))
+                    si.append((torch.floor(v).long() * W + torch.floor(u).long()).to(torch.int32))
+                    views.append((phi, th + off))
+        arrays[f"maps_{tag}_gather"] = torch.stack(gi)
+        arrays[f"maps_{tag}_scatter"] = torch.stack(si)
+        arrays[f"maps_{tag}_views"] = np.array(views, dtype=np.int32)
+    # ---- G6: gather / scatter round trip with duplicate winners and untouched pixels
+    pano = synth_normal((1, 4, 3, 32, 64), 91)
+    arrays["rt_pano"] = pano
+    for n, (fov, th, ph) in enumerate([(120, 0, 0), (120, 60, 45), (120, 300, -75), (120, 0, 90), (90, 12, -90), (120, 348, 60)]):
+        p = PanoramaLatentProxy(pano)
+        v, m = p.get_view_tensor_no_interpolate(fov, th, ph, 16, 8)
+        tile = synth_normal((1, 4, 3, 8, 16), 200 + n)
+        p.set_view_tensor_no_interpolation(tile, fov, th, ph)
+        arrays[f"rt_view_{n}"] = v
+        arrays[f"rt_after_{n}"] = p.get_equirect_tensor()
+        arrays[f"rt_args_{n}"] = np.array([fov, th, ph], dtype=np.int32)
+    # ---- P5 (t2v): whole sphere loop, fake eps and tiny UNet
+    cond = synth_normal((1, 77, 64), 61)
+    uncond = synth_normal((1, 77, 64), 62)
+    arrays["cond"], arrays["uncond"] = cond, uncond
+    traces = {}
+    unet = build_reference_unet(dict(TINY), seed=5)
+    for eps_name, eps_mod in (("fake", FakeEps()), ("tiny", WrappedUNet(unet))):
+        ld = FakeLatentDiffusion(eps_mod, cond, uncond, temporal_length=4)
+        for gname, geom in SPHERE_GEOMS.items():
+            if eps_name == "tiny" and gname != "base":
+                continue
+            g = dict(geom)
+            g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+            if "phi_fov_dict" in g:
+                g["phi_fov_dict"] = {int(k): v for k, v in g["phi_fov_dict"].items()}
+            pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": dict(TINY)}}})
+            buf = io.StringIO()
+            torch.manual_seed(2333333)
+            with contextlib.redirect_stdout(buf):
+                final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", fps=8, guidance_scale=7.5,
+                                                                     output_type="latent", **g)
+            arrays[f"sphere_{gname}_{eps_name}_final"] = final
+            arrays[f"sphere_{gname}_{eps_name}_denoised"] = den
+            steps = []
+            for line in buf.getvalue().splitlines():
+                m = STEP_RE.match(line.strip())
+                if m:
+                    steps.append({"i": int(m.group(1)), "t": int(m.group(2)), "views": []})
+                m = VIEW_RE.search(line)
+                if m:
+                    steps[-1]["views"].append([int(m.group(1)), int(m.group(2)), int(m.group(3))])
+            traces[gname] = steps
+    save_npz("sphere.npz", **arrays)
+    with open(os.path.join(HERE, "sphere_traces.json"), "w") as f:
+        json.dump({"geoms": SPHERE_GEOMS, "traces": traces}, f)
+    print("wrote sphere_traces.json")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size UNet fixture (minutes)")
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere}
     if args.full:
         steps["g10"] = g10_unet_full
     for k, fn in steps.items():

@@ -187,3 +187,33 @@ def test_unet_state_dict_keys_and_geglu_interleave():
     iw = _interleave_geglu(w)
     assert iw[:64].tolist() == list(range(0, 64)) and iw[64:128].tolist() == list(range(128, 192))
     assert iw[128:192].tolist() == list(range(64, 128)) and iw[192:].tolist() == list(range(192, 256))
+
+
+def test_sphere_index_maps_equal_reference_golden_and_winner_rule():
+    from dynamicscaler_amd.sphere import ViewMaps, plan_levels_sets
+    z = np.load(os.path.join(G, "sphere.npz"))
+    for tag, (W, H, w, h) in {"small": (128, 64, 16, 8), "real": (256, 128, 64, 40)}.items():
+        views = z[f"maps_{tag}_views"].tolist()
+        maps = []
+        for n, (phi, th) in enumerate(views):
+            m = ViewMaps(120, th, phi, w, h, W, H, "cpu")
+            maps.append(m)
+            assert np.array_equal(m.gather_np.reshape(h, w), z[f"maps_{tag}_gather"][n]), (tag, phi, th)
+            s = z[f"maps_{tag}_scatter"][n].reshape(-1)
+            keep = m.scatter_np >= 0
+            assert np.array_equal(m.scatter_np[keep], s[keep])
+            # exactly one kept source per distinct target, and it is the LAST source of that target (row-major)
+            assert len(np.unique(s)) == int(keep.sum())
+            last = {int(t): p for p, t in enumerate(s)}
+            assert sorted(last.values()) == np.nonzero(keep)[0].tolist()
+        if tag == "small":
+            reads = [m.read_set for m in maps[:14]]
+            writes = [m.write_set for m in maps[:14]]
+            levels = plan_levels_sets(reads, writes)
+            lvl = {j: n for n, lv in enumerate(levels) for j in lv}
+            for a in range(14):
+                for b in range(a + 1, 14):
+                    dep = (writes[a] & (reads[b] | writes[b])).any() or (reads[a] & writes[b]).any()
+                    assert (lvl[a] < lvl[b]) if dep else True
+                    assert lvl[a] != lvl[b] or not dep
+            assert lvl[0] == lvl[1] == 0          # the two polar caps (phi = +90 / -90) are disjoint -> batched together

@@ -257,3 +257,73 @@ def test_g11_grid_and_i2v_tiny_unet():
                                        **meta["i2v_geoms"]["ring"])
     ref = T(z["i2v_ring_tiny"])
     assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ sphere path
+def test_g12_sphere_index_maps_bit_exact():
+    from oracle import sphere as S
+    z = npz("sphere.npz")
+    for tag, (W, H, w, h) in {"small": (128, 64, 16, 8), "real": (256, 128, 64, 40)}.items():
+        views = z[f"maps_{tag}_views"]
+        for n, (phi, th) in enumerate(views.tolist()):
+            u, v = S.view_uv(120, th, phi, w, h, W, H)
+            gi, gv = S.gather_index_map(u, v, W, H)
+            si, sv = S.scatter_index_map(u, v, W, H)
+            assert bool(gv.all()) and bool(sv.all())
+            assert np.array_equal(gi.numpy().astype(np.int32), z[f"maps_{tag}_gather"][n]), (tag, phi, th)
+            assert np.array_equal(si.numpy().astype(np.int32), z[f"maps_{tag}_scatter"][n]), (tag, phi, th)
+
+
+def test_g12_sphere_gather_scatter_roundtrip_bit_exact():
+    from oracle import sphere as S
+    from dynamicscaler_amd.synth import synth_normal
+    z = npz("sphere.npz")
+    pano = T(z["rt_pano"])
+    n = 0
+    while f"rt_args_{n}" in z:
+        fov, th, ph = z[f"rt_args_{n}"].tolist()
+        view, _ = S.sphere_gather(pano, fov, th, ph, 16, 8)
+        assert torch.equal(view, T(z[f"rt_view_{n}"]))
+        tile = synth_normal((1, 4, 3, 8, 16), 200 + n)
+        assert torch.equal(S.sphere_scatter(pano.clone(), tile, fov, th, ph), T(z[f"rt_after_{n}"]))
+        assert torch.equal(S.sphere_scatter_fast(pano.clone(), tile, fov, th, ph), T(z[f"rt_after_{n}"]))
+        n += 1
+    assert n == 6
+
+
+def _sphere_geom(geom):
+    g = dict(geom)
+    g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+    if "phi_fov_dict" in g:
+        g["phi_fov_dict"] = {int(k): v for k, v in g["phi_fov_dict"].items()}
+    return g
+
+
+def test_g12_sphere_loop_fake_eps_bit_exact():
+    from oracle import sphere as S
+    z = npz("sphere.npz")
+    meta = json.load(open(os.path.join(G, "sphere_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    for gname, geom in meta["geoms"].items():
+        trace = []
+        torch.manual_seed(2333333)
+        final, den = S.t2v_sphere_sample(_fake_eps, oddim.DiffusionTables(), cond, uncond, guidance_scale=7.5, trace=trace,
+                                         **_sphere_geom(geom))
+        assert torch.equal(final, T(z[f"sphere_{gname}_fake_final"])), gname
+        assert torch.equal(den, T(z[f"sphere_{gname}_fake_denoised"])), gname
+        for (i, t, views), ref in zip(trace, meta["traces"][gname]):
+            assert i == ref["i"] and t == ref["t"] and [list(v) for v in views] == ref["views"], (gname, i)
+
+
+def test_g12_sphere_loop_tiny_unet():
+    from oracle import sphere as S
+    z = npz("sphere.npz")
+    meta = json.load(open(os.path.join(G, "sphere_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    params, sd = _tiny_setup()
+    torch.manual_seed(2333333)
+    final, den = S.t2v_sphere_sample(lambda x, ts, ctx: unet_forward(sd, params, x, ts, ctx, fps=8), oddim.DiffusionTables(),
+                                     cond, uncond, guidance_scale=7.5, **_sphere_geom(meta["geoms"]["base"]))
+    for got, key in ((final, "final"), (den, "denoised")):
+        ref = T(z[f"sphere_base_tiny_{key}"])
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-4, key
