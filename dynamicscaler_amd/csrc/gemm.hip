@@ -20,6 +20,7 @@
 //   * blockIdx is remapped so that the blocks that share an XCD (bid % 8) walk neighbouring N tiles of the same
 //     A row panel (L2 reuse; performance only).
 #include <type_traits>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -27,6 +28,21 @@ namespace {
 constexpr int BK = 64;  // halfs per K-step (128-byte LDS rows, 8 chunks of 16 bytes)
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// Epilogue activations.  The kernel is vector-issue bound, so these avoid the IEEE-division sequence (10 VALU ops) and
+// the libm erff polynomial (~40 ops): v_rcp_f32 is accurate to 1 ulp, and erf comes from Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute) -- both far below the fp16 rounding of the stored result.
+__device__ __forceinline__ float fast_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float fast_gelu_erf(float g) {
+    const float x = fabsf(g) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-x * x);       // erf(|g|/sqrt2)
+    return 0.5f * g * (1.0f + copysignf(e, g));
+}
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -71,7 +87,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     // ---- per-row source bookkeeping for the A gather.  All global reads are raw BUFFER loads: a padding tap or a
     //      tail row gets byte offset OOB (> num_records), for which the hardware returns zeros -- no branch, no
     //      select, so the loads of the next K-step stay in flight behind the MFMAs of the current one. ----
-    constexpr unsigned OOB = 0xFFFFFFF0u;
+    constexpr unsigned OOB = 0x80000000u;   // >= num_records (operands are < 2 GiB); + soffset (< 64 KiB) cannot wrap
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(A), 0, (int)a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W), 0, (int)w_bytes, 0x00020000);
     RowInfo ri[A_ROWS_PER_THREAD];
@@ -107,9 +123,12 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     int tap = 0, cb = 0;   // position of the next K-step inside (tap, channel)
     unsigned kbytes = 0;   // byte offset of the next K-step inside a W row
 
-    // issue the global loads of the NEXT K-step (no waits, no branches)
-    auto load_global = [&]() {
-        const unsigned cbl = (unsigned)(cb + ld_chunk * 8) * 2u;
+    // Per-lane VGPR offsets are computed once per TAP (conv / temporal) or once per tile (dense); inside the K loop
+    // the K position travels in the scalar `soffset` operand of the buffer load, so a K-step costs no vector ALU for
+    // addressing -- the kernel is vector-issue bound (MI355X: every VALU op takes 4 issue cycles of the SIMD that also
+    // has to issue the MFMAs; profiles/r1_notes.md), so instructions removed here are MFMA slots won.
+    unsigned voff_a[A_ROWS_PER_THREAD];
+    auto tap_offsets = [&]() {
 #pragma unroll
         for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
             bool ok = ri[i].valid;
@@ -118,22 +137,35 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 const int ky = tap / 3, kx = tap - ky * 3;
                 const int iy = ri[i].b + ky, ix = ri[i].c + kx;
                 ok = ok && iy >= 0 && iy < hl && ix >= 0 && ix < wl;
-                off = ri[i].base + (unsigned)((iy >> ups) * d.win + (ix >> ups)) * (unsigned)d.lda * 2u + cbl;
+                off = ri[i].base + (unsigned)((iy >> ups) * d.win + (ix >> ups)) * (unsigned)d.lda * 2u;
             } else if constexpr (AMODE == DS_A_TCONV) {
                 const int tt = ri[i].a + tap - 1;
                 ok = ok && tt >= 0 && tt < d.t_len;
-                off = ri[i].base + (unsigned)((tap - 1) * d.hw * d.lda * 2) + cbl;
+                off = ri[i].base + (unsigned)((tap - 1) * d.hw * d.lda * 2);
             } else {
-                off = ri[i].base + cbl;
+                off = ri[i].base;
             }
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : OOB, 0, 0);
+            voff_a[i] = ok ? off + (unsigned)ld_chunk * 16u : OOB;
         }
+    };
+    tap_offsets();
+
+    // issue the global loads of the NEXT K-step (no waits, no branches, no vector address math)
+    auto load_global = [&]() {
+        const unsigned soff_a = (unsigned)cb * 2u;
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PER_THREAD; ++i)
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff_a[i], soff_a, 0);
 #pragma unroll
         for (int i = 0; i < B_ROWS_PER_THREAD; ++i)
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_off[i] == OOB ? OOB : b_off[i] + kbytes, 0, 0);
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_off[i], kbytes, 0);
         kbytes += BK * 2;
         cb += BK;
-        if (cb == d.cin) { cb = 0; ++tap; }
+        if (cb == d.cin) {
+            cb = 0;
+            ++tap;
+            if constexpr (AMODE != DS_A_DENSE) tap_offsets();
+        }
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
@@ -168,25 +200,30 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         if (kt + 1 < nk) load_global();
         const f16* a_base = sA + (buf * BM + wm * WM) * BK;
         const f16* b_base_l = sB + (buf * BN + wn * WN) * BK;
+        // all fragment reads of the K-step are issued up front (16 x ds_read_b128 in flight); the MFMAs of k-slice kk
+        // then wait only for their own operands (counted lgkmcnt), so LDS latency hides behind the MFMAs of kk-1
+        f16x8 af[4][TM], bf[4][TN];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            f16x8 af[TM], bf[TN];
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
                 const int row = mi * 32 + fr;
-                af[mi] = *reinterpret_cast<const f16x8*>(a_base + row * BK + swz_chunk(wm * WM + row, 2 * kk + fh) * 8);
+                af[kk][mi] = *reinterpret_cast<const f16x8*>(a_base + row * BK + swz_chunk(wm * WM + row, 2 * kk + fh) * 8);
             }
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
                 const int row = ni * 32 + fr;
-                bf[ni] = *reinterpret_cast<const f16x8*>(b_base_l + row * BK + swz_chunk(wn * WN + row, 2 * kk + fh) * 8);
+                bf[kk][ni] = *reinterpret_cast<const f16x8*>(b_base_l + row * BK + swz_chunk(wn * WN + row, 2 * kk + fh) * 8);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMA block (the scheduler would sink them)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        }
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][ni], af[kk][mi], acc[ni][mi], 0, 0, 0);
         if (kt + 1 < nk) store_lds(buf ^ 1);
         __syncthreads();
     }
@@ -282,7 +319,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                                               g1[0] + bg[4], g1[1] + bg[5], g1[2] + bg[6], g1[3] + bg[7]};
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            v[j] = v[j] * (0.5f * gte[j] * (1.0f + erff(gte[j] * 0.70710678118654752f)));
+                            v[j] = v[j] * fast_gelu_erf(gte[j]);
                     }
                     if (residual) {
 #pragma unroll
@@ -290,7 +327,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                     }
                     if (silu) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.0f + __expf(-v[j]));
+                        for (int j = 0; j < 8; ++j) v[j] = fast_silu(v[j]);
                     }
                     f16x8 o;
 #pragma unroll
@@ -314,7 +351,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             float v = sC[row * CS + col];
             if (bias) v += bias[(long)(m / d.bias_rows) * d.ldbias + n];
             if (residual) v += (float)residual[(long)m * d.ldr + n];
-            if (silu) v = v / (1.0f + __expf(-v));
+            if (silu) v = fast_silu(v);
             if (out_f32) reinterpret_cast<float*>(out)[(long)m * d.ldc + n] = v;
             else reinterpret_cast<f16*>(out)[(long)m * d.ldc + n] = (f16)v;
         }
@@ -338,12 +375,12 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
         attr_set = true;
     }
     const int tiles_m = ds_cdiv(d.M, BM), tiles_n = ds_cdiv(d.N, BN);
-    // buffer-load addressing is 32-bit: the A operand and W must each stay below 4 GiB
+    // buffer-load addressing is 32-bit and offset 2^31 marks 'out of range': the A operand and W must each stay below 2 GiB
     const long a_rows = AMODE == DS_A_CONV3 ? (long)d.nimg * d.hin * d.win : (long)d.M;
     const long a_bytes = ((a_rows - 1) * d.lda + d.cin) * 2;
     const long w_bytes = (long)d.N * d.K * 2;
-    if (a_bytes >= 0xFFFFFF00L || w_bytes >= 0xFFFFFF00L) {
-        ds_set_error("ds_gemm_f16: operand of %ld / %ld bytes exceeds the 4 GiB buffer-addressing range; lower the tile batch", a_bytes, w_bytes);
+    if (a_bytes >= 0x7FFF0000L || w_bytes >= 0x7FFF0000L) {
+        ds_set_error("ds_gemm_f16: operand of %ld / %ld bytes exceeds the 2 GiB buffer-addressing range; lower the tile batch", a_bytes, w_bytes);
         return DS_EINVAL;
     }
     gemm_f16_kernel<BM, BN, AMODE><<<tiles_m * tiles_n, 256, lds, st>>>((const f16*)A, (const f16*)W, bias,
@@ -354,6 +391,10 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
 }
 
 }  // namespace
+
+// LDS-DMA ring variant (gemm_ring.hip)
+int dsi_gemm_ring(const void* A, const void* W, const float* bias, const void* residual, void* out,
+                  const ds_gemm_desc* d, hipStream_t st);
 
 extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,
                            const ds_gemm_desc* desc, void* stream) {
@@ -385,10 +426,32 @@ extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, cons
         DS_CHECK_ARG(!(d.epilogue & DS_EPI_OUT_F32) && d.ldc % 8 == 0, "ds_gemm_f16: GEGLU needs fp16 out, ldc %% 8 == 0");
     }
     hipStream_t st = (hipStream_t)stream;
+    static const int use_ring = getenv("DS_GEMM_RING") ? atoi(getenv("DS_GEMM_RING")) : 0;
+    if (use_ring) return dsi_gemm_ring(A, W, bias, residual, out, desc, st);
     // tile choice: 128x128 unless it wastes too much of N (N=320 -> 3 tiles of 128 = 17% waste) or GEGLU needs it
     const bool geglu = d.epilogue & DS_EPI_GEGLU;
     const int waste128 = ds_cdiv(d.N, 128) * 128 - d.N;
     const bool big = geglu || waste128 * 8 <= d.N;
+    // 32-bit buffer addressing with offset 2^31 as the 'out of range' marker: an A operand of 2 GiB or more (dense
+    // only: e.g. the 2048-wide FF hidden of init_attn at 655k rows) is processed in row chunks.
+    if (d.a_mode == DS_A_DENSE && ((long)d.M - 1) * d.lda * 2 + (long)d.cin * 2 >= 0x7FFF0000L) {
+        DS_CHECK_ARG(!bias || d.bias_rows >= d.M, "ds_gemm_f16: a >= 2 GiB dense operand with a per-item bias is not supported");
+        const long rows_max = ((0x7FFF0000L / ((long)d.lda * 2)) / 128) * 128;
+        DS_CHECK_ARG(rows_max >= 128, "ds_gemm_f16: lda=%d too large", d.lda);
+        const long out_elt = (d.epilogue & DS_EPI_OUT_F32) ? 4 : 2;
+        for (long r0 = 0; r0 < d.M; r0 += rows_max) {
+            ds_gemm_desc c = d;
+            c.M = (int)((d.M - r0) < rows_max ? (d.M - r0) : rows_max);
+            c.bias_rows = d.bias_rows;   // shared bias: any value >= c.M
+            const char* a_p = (const char*)A + r0 * d.lda * 2;
+            const char* r_p = residual ? (const char*)residual + r0 * d.ldr * 2 : nullptr;
+            char* o_p = (char*)out + r0 * d.ldc * out_elt;
+            int rc = big ? launch<128, 128, DS_A_DENSE>(a_p, W, bias, r_p, o_p, c, st)
+                         : launch<128, 64, DS_A_DENSE>(a_p, W, bias, r_p, o_p, c, st);
+            if (rc) return rc;
+        }
+        return DS_OK;
+    }
 #define DS_DISPATCH(MODE)                                                                  \
     return big ? launch<128, 128, MODE>(A, W, bias, residual, out, d, st)                  \
                : launch<128, 64, MODE>(A, W, bias, residual, out, d, st)

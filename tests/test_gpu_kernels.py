@@ -342,3 +342,19 @@ def test_misc_ops():
     assert float((e - timestep_embedding(t, 320)).abs().max()) < 2e-3
     s = _h(rnd((1000,), 5) * 4)
     assert relerr(ops.silu(s.half().to(d)), F.silu(s)) < 1e-3
+
+
+def test_gemm_dense_operand_over_2gib_is_chunked():
+    """A dense A operand of >= 2 GiB (the buffer-offset range the kernel addresses) is split into row chunks by the C
+    entry point; the result equals the un-split math."""
+    from dynamicscaler_amd import ops
+    d = dev()
+    M, K, N = 540000, 2048, 64          # A = 2.2 GB fp16
+    torch.manual_seed(0)
+    A = (torch.randn(M, K, device=d) * 0.25).half()
+    W = (torch.randn(N, K, device=d) * 0.05).half()
+    b = torch.randn(N, device=d)
+    out = ops.gemm(A, W, b, None, M=M, N=N, K=K)
+    for r0 in (0, 262144 - 64, 524288 - 64, M - 128):   # around the chunk seams (rows_max = 524160) and the tail
+        ref = A[r0:r0 + 128].float().cpu() @ W.float().cpu().t() + b.cpu()
+        assert relerr(out[r0:r0 + 128], ref) < 1e-3, r0
