@@ -81,6 +81,52 @@ __global__ void __launch_bounds__(256) silu_kernel(const f16* __restrict__ x, f1
     }
 }
 
+
+// resize_video_latent (utils/diffusion_utils.py:21-33): F.interpolate over the last two dims of [B,C,F,H,W], per frame.
+//   mode 0 = 'nearest'  : src = min(floor(dst * (in/out as float)), in-1)                     (exact copy semantics)
+//   mode 1 = 'bicubic'  : align_corners=False, A = -0.75, border-clamped taps (ATen upsample_bicubic2d)
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; }
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+resize_kernel(const T* __restrict__ in, T* __restrict__ out, long planes, int hin, int win, int hout, int wout, int mode,
+              float scale_h, float scale_w) {
+    const long total = planes * hout * wout;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % wout);
+        const long r = idx / wout;
+        const int y = (int)(r % hout);
+        const long pl = r / hout;
+        const T* src = in + pl * hin * win;
+        if (mode == 0) {
+            const int sy = min((int)floorf((float)y * scale_h), hin - 1);
+            const int sx = min((int)floorf((float)x * scale_w), win - 1);
+            out[idx] = src[(long)sy * win + sx];
+        } else {
+            const float A = -0.75f;
+            const float fy = scale_h * ((float)y + 0.5f) - 0.5f, fx = scale_w * ((float)x + 0.5f) - 0.5f;
+            const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+            const float ty = fy - (float)iy, tx = fx - (float)ix;
+            const float wy[4] = {cubic2(ty + 1.0f, A), cubic1(ty, A), cubic1(1.0f - ty, A), cubic2(2.0f - ty, A)};
+            const float wx[4] = {cubic2(tx + 1.0f, A), cubic1(tx, A), cubic1(1.0f - tx, A), cubic2(2.0f - tx, A)};
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yy = min(max(iy - 1 + j, 0), hin - 1);
+                float row = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int xx = min(max(ix - 1 + i, 0), win - 1);
+                    row += (float)src[(long)yy * win + xx] * wx[i];
+                }
+                acc += row * wy[j];
+            }
+            out[idx] = (T)acc;
+        }
+    }
+}
+
 inline int grid_for(long work) {
     long b = (work + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -144,5 +190,20 @@ extern "C" int ds_silu_f16(const void* x, void* y, size_t n, void* stream) {
     DS_CHECK_ARG(x && y && n > 0, "ds_silu_f16: bad argument");
     silu_kernel<<<grid_for((long)n), 256, 0, (hipStream_t)stream>>>((const f16*)x, (f16*)y, n);
     DS_CHECK_LAUNCH("ds_silu_f16");
+    return DS_OK;
+}
+
+extern "C" int ds_resize_latent(const void* in, void* out, int dtype, long planes, int hin, int win, int hout, int wout,
+                                int mode, void* stream) {
+    DS_CHECK_ARG(in && out, "ds_resize_latent: null argument");
+    DS_CHECK_ARG(planes > 0 && hin > 0 && win > 0 && hout > 0 && wout > 0, "ds_resize_latent: sizes must be positive");
+    DS_CHECK_ARG(mode == 0 || mode == 1, "ds_resize_latent: mode must be 0 (nearest) or 1 (bicubic)");
+    const float sh = (float)hin / (float)hout, sw = (float)win / (float)wout;
+    const long work = planes * hout * wout;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DS_F16) resize_kernel<f16><<<grid_for(work), 256, 0, st>>>((const f16*)in, (f16*)out, planes, hin, win, hout, wout, mode, sh, sw);
+    else if (dtype == DS_F32) resize_kernel<float><<<grid_for(work), 256, 0, st>>>((const float*)in, (float*)out, planes, hin, win, hout, wout, mode, sh, sw);
+    else DS_CHECK_ARG(false, "ds_resize_latent: bad dtype %d", dtype);
+    DS_CHECK_LAUNCH("ds_resize_latent");
     return DS_OK;
 }

@@ -262,6 +262,30 @@ __global__ void __launch_bounds__(256) map_scatter3_kernel(T* __restrict__ pano_
     }
 }
 
+// Bilinear splat with normaliser (set_view_tensor_bilinear, utils/panorama_tensor_utils.py:98-152): every view pixel
+// contributes to 4 panorama pixels with weights (1-du)(1-dv) ...; a panorama pixel becomes sum(v*w) / sum(w).
+// The reference accumulates with index_add_; here the host inverts the map once per view into a CSR list per TARGET
+// pixel whose entries keep the reference's summation order (tap 00 sources ascending, then 01, 10, 11), so the sum is
+// a plain per-thread loop: no atomics, bit-reproducible, and bit-identical to the CPU index_add_ result.
+template <typename T>
+__global__ void __launch_bounds__(256)
+map_splat_kernel(T* __restrict__ pano, const T* __restrict__ view, const int* __restrict__ tgt, const int* __restrict__ row_ptr,
+                 const int* __restrict__ src, const float* __restrict__ wgt, int CF, int HW, int P, int ntgt) {
+    const long total = (long)CF * ntgt;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(t % ntgt);
+        const int cf = (int)(t / ntgt);
+        const int b = row_ptr[k], e = row_ptr[k + 1];
+        float acc = 0.0f, ws = 0.0f;
+        for (int j = b; j < e; ++j) {
+            const float w = wgt[j];
+            acc = acc + (float)view[(long)cf * P + src[j]] * w;
+            ws = ws + w;
+        }
+        if (ws > 0.0f) pano[(long)cf * HW + tgt[k]] = (T)(acc / ws);
+    }
+}
+
 int fill_origins(Origins& o, const ds_ring_geom* g, const int32_t* origins, int n, const char* who) {
     DS_CHECK_ARG(g && origins, "%s: null geom/origins", who);
     DS_CHECK_ARG(n >= 1 && n <= DS_MAX_WINDOWS, "%s: n=%d out of [1,%d]", who, n, DS_MAX_WINDOWS);
@@ -444,5 +468,18 @@ extern "C" int ds_map_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_p
         map_scatter3_kernel<float><<<grid_for(work), 256, 0, st>>>((float*)pano_latent, (float*)pano_x0, mask_pano, (const float*)x_prev_tiles, (const float*)x0_tiles, idx, CF, HW, P, n);
     else DS_CHECK_ARG(false, "ds_map_scatter3: bad dtype %d", dtype);
     DS_CHECK_LAUNCH("ds_map_scatter3");
+    return DS_OK;
+}
+
+extern "C" int ds_map_splat(void* pano, const void* view, const int32_t* tgt, const int32_t* row_ptr, const int32_t* src,
+                            const float* wgt, int CF, int HW, int P, int ntgt, int dtype, void* stream) {
+    DS_CHECK_ARG(pano && view && tgt && row_ptr && src && wgt, "ds_map_splat: null argument");
+    DS_CHECK_ARG(CF > 0 && HW > 0 && P > 0 && ntgt > 0, "ds_map_splat: sizes must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    const long work = (long)CF * ntgt;
+    if (dtype == DS_F16) map_splat_kernel<f16><<<grid_for(work), 256, 0, st>>>((f16*)pano, (const f16*)view, tgt, row_ptr, src, wgt, CF, HW, P, ntgt);
+    else if (dtype == DS_F32) map_splat_kernel<float><<<grid_for(work), 256, 0, st>>>((float*)pano, (const float*)view, tgt, row_ptr, src, wgt, CF, HW, P, ntgt);
+    else DS_CHECK_ARG(false, "ds_map_splat: bad dtype %d", dtype);
+    DS_CHECK_LAUNCH("ds_map_splat");
     return DS_OK;
 }

@@ -35,6 +35,7 @@ def install():
     _mod("utils.shift_window_utils", RingLatent=ring.RingLatent, RingImageTensor=pipelines_i2v.RingImageTensor,
          get_dimension_slices_and_sizes=ring.get_dimension_slices_and_sizes)
     _mod("utils.tensor_utils", mix_latents_with_mask=tensor_utils.mix_latents_with_mask)
+    _mod("utils.diffusion_utils", resize_video_latent=tensor_utils.resize_video_latent)
     _mod("utils.multi_prompt_utils",
          select_prompt_from_multi_prompt_dict_by_factor=pipelines.select_prompt_from_multi_prompt_dict_by_factor)
     _mod("utils.utils", instantiate_from_config=host_model.instantiate_from_config)

@@ -173,6 +173,33 @@ def map_scatter3(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, idx):
                               idx.data_ptr(), Cc * F, H * W, P, n, _DT[ref.dtype], _stream()), "ds_map_scatter3")
 
 
+def map_splat_(pano, view, tgt, row_ptr, src, wgt):
+    """In place bilinear splat of one view [1,C,F,h,w] into pano [1,C,F,H,W] (CSR per target on the device)."""
+    _dev(pano, "map_splat")
+    _dev(view, "map_splat(view)")
+    lib = _lib.load()
+    _, Cc, F, H, W = pano.shape
+    P = view.shape[-2] * view.shape[-1]
+    assert view.dtype == pano.dtype
+    check(lib.ds_map_splat(pano.data_ptr(), view.data_ptr(), tgt.data_ptr(), row_ptr.data_ptr(), src.data_ptr(),
+                           wgt.data_ptr(), Cc * F, H * W, P, tgt.numel(), _DT[pano.dtype], _stream()), "ds_map_splat")
+    return pano
+
+
+def resize_latent(x, target_height, target_width, mode="nearest"):
+    """[B,C,F,H,W] -> [B,C,F,target_height,target_width] per frame (resize_video_latent)."""
+    _dev(x, "resize_latent")
+    lib = _lib.load()
+    B, Cc, F, H, W = x.shape
+    out = torch.empty((B, Cc, F, target_height, target_width), dtype=x.dtype, device=x.device)
+    m = {"nearest": 0, "bicubic": 1}.get(mode)
+    if m is None:
+        raise NotImplementedError(f"resize mode {mode!r}: only 'nearest' and 'bicubic' are used by gen_pano_360.py")
+    check(lib.ds_resize_latent(x.data_ptr(), out.data_ptr(), _DT[x.dtype], B * Cc * F, H, W, target_height, target_width,
+                               m, _stream()), "ds_resize_latent")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ UNet ops
 def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE, lda=None, cin=None,
          conv=None, tconv=None, bias_rows=None, ldbias=None, epilogue=0, stream=None):

@@ -66,6 +66,34 @@ class ViewMaps:
         self.gather_valid_mask = gvalid.to(torch.float32)
 
 
+class SplatMaps:
+    """Inverse (per-target CSR) form of the 4-tap bilinear splat of one view (panorama_tensor_utils.py:98-152).
+    Entry order inside a target = the reference's index_add_ order: tap 00 sources ascending, then 01, 10, 11."""
+
+    def __init__(self, fov, theta, phi, width, height, W, H, device):
+        u, v = view_uv(fov, theta, phi, width, height, W, H)
+        u0, v0 = torch.floor(u).long(), torch.floor(v).long()
+        u1 = (u0 + 1) % W
+        v1 = torch.clamp(v0 + 1, 0, H - 1)
+        du, dv = u - u0.float(), v - v0.float()
+        ws = [((1 - du) * (1 - dv)), ((1 - du) * dv), (du * (1 - dv)), (du * dv)]
+        ids = [v0 * W + u0, v1 * W + u0, v0 * W + u1, v1 * W + u1]
+        P = width * height
+        tgt_all = np.concatenate([i.view(-1).numpy() for i in ids])
+        w_all = np.concatenate([w.view(-1).numpy() for w in ws]).astype(np.float32)
+        tap_all = np.repeat(np.arange(4), P)
+        src_all = np.tile(np.arange(P), 4)
+        order = np.lexsort((src_all, tap_all, tgt_all))        # by target, then tap, then source
+        tgt_sorted = tgt_all[order]
+        uniq, first = np.unique(tgt_sorted, return_index=True)
+        row_ptr = np.append(first, len(tgt_sorted)).astype(np.int32)
+        dev = device
+        self.tgt = torch.from_numpy(uniq.astype(np.int32)).to(dev)
+        self.row_ptr = torch.from_numpy(row_ptr).to(dev)
+        self.src = torch.from_numpy(src_all[order].astype(np.int32)).to(dev)
+        self.wgt = torch.from_numpy(w_all[order]).to(dev)
+
+
 class ViewMapCache:
     def __init__(self, device):
         self.device = device
@@ -100,6 +128,16 @@ class PanoramaLatentProxy:
         m = self._cache.get(fov, theta, phi, width, height, W, H)
         view = ops.map_gather(self.equirect, m.gather[None]).reshape(1, C, N, height, width)
         return view, m.gather_valid_mask.to(self.equirect.device)
+
+    def set_view_tensor_bilinear(self, view_tensor, fov, theta, phi):
+        """4-tap splat with normaliser (panorama_tensor_utils.py:98-152); unused by the pipelines, kept for parity."""
+        B, C, N, H, W = self.equirect.shape
+        height, width = view_tensor.shape[-2:]
+        key = ("splat", fov, theta, phi, width, height, W, H)
+        m = self._cache._maps.get(key)
+        if m is None:
+            m = self._cache._maps[key] = SplatMaps(fov, theta, phi, width, height, W, H, self.equirect.device)
+        ops.map_splat_(self.equirect, view_tensor.to(self.equirect.dtype).contiguous(), m.tgt, m.row_ptr, m.src, m.wgt)
 
     def set_view_tensor_no_interpolation(self, view_tensor, fov, theta, phi):
         B, C, N, H, W = self.equirect.shape

@@ -23,3 +23,9 @@ def mix_latents_with_mask(latent_1, latent_to_add, mask, mix_ratio):
     ops.renoise_mix_(out, m, pano_shape, 0.0, 1.0, mix_ratio, noise=latent_to_add.to(out.dtype).contiguous(),
                      mask_frame0=frame0)
     return out
+
+
+def resize_video_latent(input_latent, target_height, target_width, mode="bilinear", align_corners=False):
+    """utils/diffusion_utils.py:21-33 on the GPU (stage hand-off of gen_pano_360.py:287-289 'nearest', :345-347
+    'bicubic').  Only the two modes the driver uses are implemented."""
+    return ops.resize_latent(input_latent.contiguous(), target_height, target_width, mode)

@@ -103,6 +103,16 @@ int ds_map_gather(const void* pano, void* tiles, const int32_t* idx, int CF, int
                   void* stream);
 int ds_map_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const void* x_prev_tiles,
                     const void* x0_tiles, const int32_t* idx, int CF, int HW, int P, int n, int dtype, void* stream);
+/* set_view_tensor_bilinear (utils/panorama_tensor_utils.py:98-152): 4-tap splat with weight normaliser,
+ * pano[t] = sum_j view[src_j] * w_j / sum_j w_j for every panorama pixel t that receives weight.  The host inverts the
+ * view's map into a CSR list per target (tgt[ntgt], row_ptr[ntgt+1], src/wgt[nnz], all DEVICE pointers) whose entry
+ * order is the reference's index_add_ order, so the kernel needs no atomics and reproduces the CPU sums bit for bit. */
+int ds_map_splat(void* pano, const void* view, const int32_t* tgt, const int32_t* row_ptr, const int32_t* src,
+                 const float* wgt, int CF, int HW, int P, int ntgt, int dtype, void* stream);
+/* resize_video_latent (utils/diffusion_utils.py:21-33; stage hand-off gen_pano_360.py:287-289,345-347): F.interpolate
+ * over H,W of `planes` = B*C*F images.  mode 0 'nearest', mode 1 'bicubic' (align_corners=False, A=-0.75). */
+int ds_resize_latent(const void* in, void* out, int dtype, long planes, int hin, int win, int hout, int wout, int mode,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * UNet inner blocks (lvdm/modules/networks/openaimodel3d.py, lvdm/modules/attention.py).

@@ -179,3 +179,32 @@ def t2v_sphere_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, 
         if trace is not None:
             trace.append((i, int(t), views))
     return pano.clone(), pano_x0.clone()
+
+
+def sphere_splat_bilinear(pano, view, fov, theta, phi):
+    """PanoramaLatentProxy.set_view_tensor_bilinear (utils/panorama_tensor_utils.py:98-152, :281-283): 4-tap splat of a
+    view [B,C,N,h,w] into pano [B,C,N,H,W] with weight normaliser; in place.  Same op order as the reference
+    (index_add_ per tap), hence the same fp32 sums."""
+    B, C, N, H, W = pano.shape
+    height, width = view.shape[-2], view.shape[-1]
+    u, v = view_uv(fov, theta, phi, width, height, W, H, pano.dtype)
+    u0 = torch.floor(u).long()
+    v0 = torch.floor(v).long()
+    u1 = (u0 + 1) % W
+    v1 = torch.clamp(v0 + 1, 0, H - 1)
+    du = (u - u0.float())
+    dv = (v - v0.float())
+    ws = [((1 - du) * (1 - dv)).view(-1), ((1 - du) * dv).view(-1), (du * (1 - dv)).view(-1), (du * dv).view(-1)]
+    ids = [(v0 * W + u0).view(-1), (v1 * W + u0).view(-1), (v0 * W + u1).view(-1), (v1 * W + u1).view(-1)]
+    flat = pano.reshape(B * C * N, H * W)
+    src = view.reshape(B * C * N, height * width)
+    for r in range(B * C * N):
+        acc = torch.zeros(H * W, dtype=pano.dtype)
+        wsum = torch.zeros(H * W, dtype=pano.dtype)
+        for idx, w in zip(ids, ws):
+            acc.index_add_(0, idx, src[r] * w)
+            wsum.index_add_(0, idx, w)
+        m = wsum > 0
+        flat[r][m] = acc[m] / wsum[m]
+    pano.copy_(flat.reshape(pano.shape))
+    return pano

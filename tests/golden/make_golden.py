@@ -475,6 +475,22 @@ def g12_sphere():
         arrays[f"rt_view_{n}"] = v
         arrays[f"rt_after_{n}"] = p.get_equirect_tensor()
         arrays[f"rt_args_{n}"] = np.array([fov, th, ph], dtype=np.int32)
+    # ---- S5: bilinear splat with normaliser (unused by the pipelines; the only accumulate+normalise code in the tree)
+    for n, (fov, th, ph) in enumerate([(120, 0, 0), (120, 60, 45), (120, 0, 90), (100, 200, -60)]):
+        p = PanoramaLatentProxy(pano)
+        tile = synth_normal((1, 4, 3, 8, 16), 300 + n)
+        p.set_view_tensor_bilinear(tile, fov, th, ph)
+        arrays[f"splat_after_{n}"] = p.get_equirect_tensor()
+        arrays[f"splat_args_{n}"] = np.array([fov, th, ph], dtype=np.int32)
+    # ---- N1: resize_video_latent, the two modes gen_pano_360.py uses
+    from utils.diffusion_utils import resize_video_latent
+    lat = synth_normal((1, 4, 3, 16, 32), 400)
+    arrays["resize_in"] = lat
+    arrays["resize_nearest_x2"] = resize_video_latent(lat, 32, 64, mode="nearest")
+    arrays["resize_nearest_half"] = resize_video_latent(lat, 8, 16, mode="nearest")
+    arrays["resize_nearest_odd"] = resize_video_latent(lat, 20, 48, mode="nearest")
+    arrays["resize_bicubic_x2"] = resize_video_latent(lat, 32, 64, mode="bicubic")
+    arrays["resize_bicubic_odd"] = resize_video_latent(lat, 24, 40, mode="bicubic")
     # ---- P5 (t2v): whole sphere loop, fake eps and tiny UNet
     cond = synth_normal((1, 77, 64), 61)
     uncond = synth_normal((1, 77, 64), 62)

@@ -358,3 +358,35 @@ def test_gemm_dense_operand_over_2gib_is_chunked():
     for r0 in (0, 262144 - 64, 524288 - 64, M - 128):   # around the chunk seams (rows_max = 524160) and the tail
         ref = A[r0:r0 + 128].float().cpu() @ W.float().cpu().t() + b.cpu()
         assert relerr(out[r0:r0 + 128], ref) < 1e-3, r0
+
+
+def test_bilinear_splat_and_resize_vs_reference_golden():
+    """S5 (set_view_tensor_bilinear: 4-tap splat + normaliser, CSR-per-target kernel, no atomics) bit-exact vs the oracle;
+    N1 resize_video_latent: nearest bit-exact, bicubic within fp32 round-off of ATen's kernel."""
+    import os
+    from oracle import sphere as S
+    from dynamicscaler_amd.sphere import PanoramaLatentProxy
+    from dynamicscaler_amd.tensor_utils import resize_video_latent
+    from dynamicscaler_amd.synth import synth_normal
+    d = dev()
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sphere.npz"))
+    pano = torch.from_numpy(z["rt_pano"])
+    n = 0
+    while f"splat_args_{n}" in z:
+        fov, th, ph = z[f"splat_args_{n}"].tolist()
+        tile = synth_normal((1, 4, 3, 8, 16), 300 + n)
+        proxy = PanoramaLatentProxy(pano.to(d))
+        proxy.set_view_tensor_bilinear(tile.to(d), fov, th, ph)
+        ref = S.sphere_splat_bilinear(pano.clone(), tile, fov, th, ph)
+        assert torch.equal(proxy.get_equirect_tensor().cpu(), ref), n
+        assert relerr(proxy.get_equirect_tensor(), torch.from_numpy(z[f"splat_after_{n}"])) < 1e-5
+        n += 1
+    assert n == 4
+    lat = torch.from_numpy(z["resize_in"])
+    for key, (h, w, mode) in {"nearest_x2": (32, 64, "nearest"), "nearest_half": (8, 16, "nearest"),
+                              "nearest_odd": (20, 48, "nearest")}.items():
+        assert torch.equal(resize_video_latent(lat.to(d), h, w, mode=mode).cpu(), torch.from_numpy(z[f"resize_{key}"])), key
+        assert torch.equal(resize_video_latent(lat.half().to(d), h, w, mode=mode).cpu(), torch.from_numpy(z[f"resize_{key}"]).half())
+    for key, (h, w) in {"bicubic_x2": (32, 64), "bicubic_odd": (24, 40)}.items():
+        got = resize_video_latent(lat.to(d), h, w, mode="bicubic").cpu()
+        assert float((got - torch.from_numpy(z[f"resize_{key}"])).abs().max()) < 2e-6, key

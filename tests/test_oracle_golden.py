@@ -327,3 +327,17 @@ def test_g12_sphere_loop_tiny_unet():
     for got, key in ((final, "final"), (den, "denoised")):
         ref = T(z[f"sphere_base_tiny_{key}"])
         assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-4, key
+
+
+def test_g12_bilinear_splat_bit_exact():
+    from oracle import sphere as S
+    from dynamicscaler_amd.synth import synth_normal
+    z = npz("sphere.npz")
+    pano = T(z["rt_pano"])
+    n = 0
+    while f"splat_args_{n}" in z:
+        fov, th, ph = z[f"splat_args_{n}"].tolist()
+        tile = synth_normal((1, 4, 3, 8, 16), 300 + n)
+        assert torch.equal(S.sphere_splat_bilinear(pano.clone(), tile, fov, th, ph), T(z[f"splat_after_{n}"])), n
+        n += 1
+    assert n == 4
