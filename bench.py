@@ -126,23 +126,30 @@ def main():
     if not args.no_roofline:
         events = []
 
-        def hook(name, flops, launch):
+        def hook(name, flops, launch, info=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             launch()
             e1.record()
-            events.append((name, flops, e0, e1))
+            events.append((name, flops, e0, e1, info))
 
         ops.set_timing_hook(hook)
         pipe.ring_step(st, step_idx)
         torch.cuda.synchronize()
         ops.set_timing_hook(None)
         agg = {}
-        for name, flops, e0, e1 in events:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += flops
-            a[2] += e0.elapsed_time(e1) * 1e-3
+        shapes = {}
+        for name, flops, e0, e1, info in events:
+            dt = e0.elapsed_time(e1) * 1e-3
+            for a in (agg.setdefault(name, [0, 0.0, 0.0]), shapes.setdefault((name,) + tuple(info or ()), [0, 0.0, 0.0])):
+                a[0] += 1
+                a[1] += flops
+                a[2] += dt
+        if os.environ.get("DS_BENCH_BREAKDOWN") and rank == 0:   # per-shape table (diagnostics, profiles/)
+            with open(os.environ["DS_BENCH_BREAKDOWN"], "w") as f:
+                f.write("kernel,shape,launches,ms_per_step,tflops\n")
+                for k, a in sorted(shapes.items(), key=lambda kv: -kv[1][2]):
+                    f.write(f"{k[0]},{'x'.join(map(str, k[1:]))},{a[0]},{a[2] * 1e3:.3f},{a[1] / a[2] / 1e12:.1f}\n")
         g = agg["gemm"]
         achieved = g[1] / g[2] / 1e12
         roofline = {

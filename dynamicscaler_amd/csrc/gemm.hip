@@ -45,6 +45,29 @@ __device__ __forceinline__ float fast_gelu_erf(float g) {
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+// LDS-DMA: 16 bytes per lane, lane l lands at dst + 16*l (dst wave-uniform).  Kept in a __device__ helper: with the
+// builtin written directly inside the templated kernel, clang's host pass silently drops the kernel's launch stub.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, f16* dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, voff, soff, 0, 0);
+}
+
+// Diagnostic build only (tools/gemm_stamps.py compiles this file with -DDS_GEMM_STAMPS into its own library):
+// s_memtime stamps of the kernel phases, written to a debug buffer nothing else reads.  The product build has no stamps.
+#ifdef DS_GEMM_STAMPS
+__device__ unsigned long long* ds_dbg_stamps = nullptr;
+#define DS_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (ds_dbg_stamps && threadIdx.x == 0) ds_dbg_stamps[(size_t)blockIdx.x * 8 + (i)] = t_;      \
+    } while (0)
+#else
+#define DS_STAMP(i) do {} while (0)
+#endif
 
 struct RowInfo {   // per staged A row, computed once
     unsigned base; // BYTE offset of the row's source (DENSE/TCONV: m*lda*2; CONV3: image origin)
@@ -52,20 +75,53 @@ struct RowInfo {   // per staged A row, computed once
     bool valid;
 };
 
-template <int BM, int BN, int AMODE>
-__global__ void __launch_bounds__(256, 2)
+// Compile-time shape of one kernel variant: block tile BM x BN, WGM x WGN waves.
+template <int BM, int BN, int WGM, int WGN>
+struct TileCfg {
+    static constexpr int NT = 64 * WGM * WGN;                 // threads
+    static constexpr int WM = BM / WGM, WN = BN / WGN;        // wave tile
+    static constexpr int TM = WM / 32, TN = WN / 32;          // 32x32 MFMA tiles per wave
+    static constexpr int LROWS = NT / 8;                      // rows staged per sweep (8 lanes x 16 B per 128-B row)
+    static constexpr int AR = BM / LROWS, BR = BN / LROWS;    // staged rows per thread
+    static constexpr int CS = BN + 4;                         // fp32 epilogue tile stride
+    static constexpr size_t STAGE = (size_t)2 * (BM + BN) * BK * sizeof(f16);
+    // epilogue pass: as many wave-row groups as fit the LDS budget (80 KiB when two workgroups share a CU)
+    static constexpr size_t BUDGET = STAGE <= 81920 ? 81920 : 163840;
+    static constexpr int pass_rows() {
+        int p = BM;
+        while ((size_t)p * CS * sizeof(float) > BUDGET && p / 2 >= WM) p /= 2;
+        return p;
+    }
+    static constexpr int PROWS = pass_rows();
+    static constexpr int NPASS = BM / PROWS;
+    static constexpr size_t EPI = (size_t)PROWS * CS * sizeof(float);
+    static constexpr size_t LDS = STAGE > EPI ? STAGE : EPI;
+    static constexpr int WG_PER_CU = LDS <= 81920 && NT <= 256 ? 2 : 1;
+    // fragment scheduling: all four k-slices of a K-step up front when that is <= 16 fragments, else one k-slice
+    // ahead (double-buffered fragment registers)
+    static constexpr bool HOIST_ALL = 4 * (TM + TN) <= 16;
+    // one workgroup per CU: operands go global -> LDS by LDS-DMA (no VGPR staging, no ds_write phase in which all
+    // eight waves would leave the matrix pipe idle together); two per CU: register staging (the partner workgroup's
+    // MFMAs cover the store phase)
+    static constexpr bool DMA = WG_PER_CU == 1;
+    static_assert(BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0 && BM % LROWS == 0 && BN % LROWS == 0, "tile shape");
+    static_assert(EPI <= BUDGET && LDS <= 163840, "LDS budget");
+};
+
+template <int BM, int BN, int WGM, int WGN, int AMODE>
+__global__ void __launch_bounds__((TileCfg<BM, BN, WGM, WGN>::NT), (TileCfg<BM, BN, WGM, WGN>::WG_PER_CU))
 gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const float* __restrict__ bias,
                 const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n,
                 unsigned a_bytes, unsigned w_bytes) {
-    constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
-    constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
-    constexpr int A_ROWS_PER_THREAD = BM / 32, B_ROWS_PER_THREAD = BN / 32;
-    constexpr int CS = BN + 4;                // fp32 epilogue tile stride
+    using Cfg = TileCfg<BM, BN, WGM, WGN>;
+    constexpr int NT = Cfg::NT, WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
+    constexpr int LROWS = Cfg::LROWS, A_ROWS_PER_THREAD = Cfg::AR, B_ROWS_PER_THREAD = Cfg::BR, CS = Cfg::CS;
+    constexpr int PROWS = Cfg::PROWS, NPASS = Cfg::NPASS;
 
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     f16* sA = reinterpret_cast<f16*>(smem);                 // [2][BM][64]
     f16* sB = sA + 2 * BM * BK;                             // [2][BN][64]
-    float* sC = reinterpret_cast<float*>(smem);             // [BM][CS] (reuses the staging space)
+    float* sC = reinterpret_cast<float*>(smem);             // [PROWS][CS] (reuses the staging space)
 
     // ---- XCD-aware block remap (bijective for any grid size) ----
     const int nwg = tiles_m * tiles_n;
@@ -79,10 +135,14 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ld_row = tid >> 3;   // 0..31
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int ld_row = tid >> 3;   // 0..LROWS-1
     const int ld_chunk = tid & 7;  // 16-byte chunk within the 64-half K-step
+    // LDS-DMA writes lane l of a wave-instruction at LDS offset 16*l (8 rows x 128 B per instruction), so the physical
+    // chunk is fixed (= ld_chunk) and the XOR swizzle moves to the SOURCE: the lane fetches logical chunk
+    // ld_chunk ^ ((row>>1)&7).  LROWS is a multiple of 16, so the swizzle term is the same for every staged row.
+    const unsigned src_chunk_bytes = Cfg::DMA ? (unsigned)(ld_chunk ^ ((ld_row >> 1) & 7)) * 16u : (unsigned)ld_chunk * 16u;
 
     // ---- per-row source bookkeeping for the A gather.  All global reads are raw BUFFER loads: a padding tap or a
     //      tail row gets byte offset OOB (> num_records), for which the hardware returns zeros -- no branch, no
@@ -93,7 +153,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     RowInfo ri[A_ROWS_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
-        const int m = m0 + ld_row + 32 * i;
+        const int m = m0 + ld_row + LROWS * i;
         ri[i].valid = m < d.M;
         const int mm = ri[i].valid ? m : 0;
         if constexpr (AMODE == DS_A_CONV3) {
@@ -113,8 +173,8 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     unsigned b_off[B_ROWS_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
-        const int n = n0 + ld_row + 32 * i;
-        b_off[i] = n < d.N ? ((unsigned)n * (unsigned)d.K + ld_chunk * 8) * 2u : OOB;
+        const int n = n0 + ld_row + LROWS * i;
+        b_off[i] = n < d.N ? (unsigned)n * (unsigned)d.K * 2u + src_chunk_bytes : OOB;
     }
 
     u32x4 ra[A_ROWS_PER_THREAD], rb[B_ROWS_PER_THREAD];
@@ -145,20 +205,29 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             } else {
                 off = ri[i].base;
             }
-            voff_a[i] = ok ? off + (unsigned)ld_chunk * 16u : OOB;
+            voff_a[i] = ok ? off + src_chunk_bytes : OOB;
         }
     };
     tap_offsets();
 
-    // issue the global loads of the NEXT K-step (no waits, no branches, no vector address math)
-    auto load_global = [&]() {
+    // issue the global loads of the NEXT K-step (no waits, no branches, no vector address math); DMA: straight into
+    // LDS buffer `buf` (an out-of-range lane zero-fills its 16 bytes)
+    auto load_global = [&](int buf) {
         const unsigned soff_a = (unsigned)cb * 2u;
 #pragma unroll
-        for (int i = 0; i < A_ROWS_PER_THREAD; ++i)
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff_a[i], soff_a, 0);
+        for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
+            if constexpr (Cfg::DMA)
+                dma16(rsA, sA + (buf * BM + LROWS * i + 8 * wave) * BK, voff_a[i], soff_a);
+            else
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff_a[i], soff_a, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < B_ROWS_PER_THREAD; ++i)
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_off[i], kbytes, 0);
+        for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
+            if constexpr (Cfg::DMA)
+                dma16(rsW, sB + (buf * BN + LROWS * i + 8 * wave) * BK, b_off[i], kbytes);
+            else
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_off[i], kbytes, 0);
+        }
         kbytes += BK * 2;
         cb += BK;
         if (cb == d.cin) {
@@ -170,12 +239,12 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     auto store_lds = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
-            const int row = ld_row + 32 * i;
+            const int row = ld_row + LROWS * i;
             *reinterpret_cast<u32x4*>(sA + (buf * BM + row) * BK + swz_chunk(row, ld_chunk) * 8) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
-            const int row = ld_row + 32 * i;
+            const int row = ld_row + LROWS * i;
             *reinterpret_cast<u32x4*>(sB + (buf * BN + row) * BK + swz_chunk(row, ld_chunk) * 8) = rb[i];
         }
     };
@@ -191,182 +260,234 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const int nk = d.K / BK;
     const int fr = lane & 31, fh = lane >> 5;
 
-    load_global();
-    store_lds(0);
-    __syncthreads();
+    // K-step synchronisation.  Register staging: store the staged operands, one barrier.  DMA: wait for this wave's
+    // LDS-DMA of the next K-step, one barrier (then every wave's part has landed and the current buffer is free).
+    auto stage_sync = [&](int nbuf, bool more) {
+        if constexpr (Cfg::DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            if (more) store_lds(nbuf);
+            __syncthreads();
+        }
+    };
+
+    DS_STAMP(0);
+    load_global(0);
+    stage_sync(0, true);
+    DS_STAMP(1);
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_global();
+        if (kt + 1 < nk) load_global(buf ^ 1);
         const f16* a_base = sA + (buf * BM + wm * WM) * BK;
         const f16* b_base_l = sB + (buf * BN + wn * WN) * BK;
-        // all fragment reads of the K-step are issued up front (16 x ds_read_b128 in flight); the MFMAs of k-slice kk
-        // then wait only for their own operands (counted lgkmcnt), so LDS latency hides behind the MFMAs of kk-1
-        f16x8 af[4][TM], bf[4][TN];
+        auto read_a = [&](int kk, int mi) {
+            const int row = mi * 32 + fr;
+            return *reinterpret_cast<const f16x8*>(a_base + row * BK + swz_chunk(wm * WM + row, 2 * kk + fh) * 8);
+        };
+        auto read_b = [&](int kk, int ni) {
+            const int row = ni * 32 + fr;
+            return *reinterpret_cast<const f16x8*>(b_base_l + row * BK + swz_chunk(wn * WN + row, 2 * kk + fh) * 8);
+        };
+        if constexpr (Cfg::HOIST_ALL) {
+            // all fragment reads of the K-step are issued up front (<= 16 ds_read_b128 in flight); the MFMAs of k-slice
+            // kk then wait only for their own operands (counted lgkmcnt), so LDS latency hides behind the MFMAs of kk-1
+            f16x8 af[4][TM], bf[4][TN];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const int row = mi * 32 + fr;
-                af[kk][mi] = *reinterpret_cast<const f16x8*>(a_base + row * BK + swz_chunk(wm * WM + row, 2 * kk + fh) * 8);
+                for (int mi = 0; mi < TM; ++mi) af[kk][mi] = read_a(kk, mi);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) bf[kk][ni] = read_b(kk, ni);
             }
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMA block (the scheduler would sink them)
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int row = ni * 32 + fr;
-                bf[kk][ni] = *reinterpret_cast<const f16x8*>(b_base_l + row * BK + swz_chunk(wn * WN + row, 2 * kk + fh) * 8);
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][ni], af[kk][mi], acc[ni][mi], 0, 0, 0);
+        } else {
+            // big wave tiles: the fragments of k-slice kk+1 are read while the MFMAs of kk run (two register sets)
+            f16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) af[0][mi] = read_a(0, mi);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) bf[0][ni] = read_b(0, ni);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk + 1 < 4) {
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) af[(kk + 1) & 1][mi] = read_a(kk + 1, mi);
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) bf[(kk + 1) & 1][ni] = read_b(kk + 1, ni);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk & 1][ni], af[kk & 1][mi], acc[ni][mi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMA block (the scheduler would sink them)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][ni], af[kk][mi], acc[ni][mi], 0, 0, 0);
-        if (kt + 1 < nk) store_lds(buf ^ 1);
-        __syncthreads();
+        stage_sync(buf ^ 1, kt + 1 < nk);
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32) ----
-    // D[i][j]: j = lane&31 is the output row m, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) the column n.
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const int row = wm * WM + mi * 32 + fr;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = wn * WN + ni * 32 + 8 * g + 4 * fh;
-                f32x4 v = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(sC + row * CS + col) = v;
-            }
-        }
-    __syncthreads();
-
+    DS_STAMP(2);
     const bool geglu = d.epilogue & DS_EPI_GEGLU;
     const bool silu = d.epilogue & DS_EPI_SILU;
     const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;
     const bool fast = !out_f32 && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (!residual || d.ldr % 8 == 0) &&
                       (!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0));
 
-    if (fast) {
-        // Each thread owns one 8-column chunk (fixed for the whole tile) and walks rows; the global loads of an
-        // unrolled group of rows (residual, per-item bias) are issued together before any of them is consumed, so the
-        // epilogue pays one memory latency per group instead of one per row.
-        auto run = [&](auto ge_tag) {
-            constexpr bool GE = decltype(ge_tag)::value;
-            constexpr int CPR = GE ? BN / 16 : BN / 8;   // chunks per row
-            constexpr int RPI = 256 / CPR;               // rows per sweep of the 256 threads
-            constexpr int NIT = BM / RPI;
-            constexpr int U = NIT < 4 ? NIT : 4;
-            const int ch = tid % CPR, r0 = tid / CPR;
-            const int nloc = ch * 8;
-            const int n = n0 + nloc;                     // column in the N space (x part for GEGLU)
-            if (n >= d.N) return;
-            const long ocol = GE ? (long)tile_n * (BN / 2) + nloc : (long)n;
-            const bool shared_bias = bias && d.bias_rows >= d.M;
-            float bx[8], bg[8];
+    // ---- epilogue, NPASS passes of PROWS rows: accumulators -> LDS (fp32) -> bias / activation / residual -> fp16 ----
+    // D[i][j]: j = lane&31 is the output row m, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) the column n.
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { bx[j] = 0.0f; bg[j] = 0.0f; }
-            if (shared_bias) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
-                bx[0] = b0[0]; bx[1] = b0[1]; bx[2] = b0[2]; bx[3] = b0[3];
-                bx[4] = b1[0]; bx[5] = b1[1]; bx[6] = b1[2]; bx[7] = b1[3];
-                if (GE) {
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(bias + n + 64);
-                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(bias + n + 68);
-                    bg[0] = c0[0]; bg[1] = c0[1]; bg[2] = c0[2]; bg[3] = c0[3];
-                    bg[4] = c1[0]; bg[5] = c1[1]; bg[6] = c1[2]; bg[7] = c1[3];
-                }
-            }
-#pragma unroll 1
-            for (int it0 = 0; it0 < NIT; it0 += U) {
-                f16x8 res[U];
-                f32x4 pb0[U], pb1[U];
-                bool ok[U];
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int prow0 = pass * PROWS;
+        if (wm * WM >= prow0 && wm * WM < prow0 + PROWS) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int m = m0 + r0 + (it0 + u) * RPI;
-                    ok[u] = m < d.M;
-                    const long mm = ok[u] ? m : 0;
-                    if (residual) res[u] = *reinterpret_cast<const f16x8*>(residual + mm * d.ldr + ocol);
-                    if (bias && !shared_bias) {
-                        const long brow = (mm / d.bias_rows) * d.ldbias;
-                        pb0[u] = *reinterpret_cast<const f32x4*>(bias + brow + n);
-                        pb1[u] = *reinterpret_cast<const f32x4*>(bias + brow + n + 4);
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int row = wm * WM - prow0 + mi * 32 + fr;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = wn * WN + ni * 32 + 8 * g + 4 * fh;
+                        f32x4 v = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(sC + row * CS + col) = v;
                     }
                 }
+        }
+        __syncthreads();
+        if (pass == 0) DS_STAMP(3);
+
+        if (fast) {
+            // Each thread owns one 8-column chunk (fixed for the whole tile) and walks rows; the global loads of an
+            // unrolled group of rows (residual, per-item bias) are issued together before any of them is consumed, so
+            // the epilogue pays one memory latency per group instead of one per row.
+            auto run = [&](auto ge_tag) {
+                constexpr bool GE = decltype(ge_tag)::value;
+                constexpr int CPR = GE ? BN / 16 : BN / 8;   // chunks per row
+                constexpr int RPI = NT / CPR;                // rows per sweep of the workgroup
+                constexpr int NIT = (PROWS + RPI - 1) / RPI;
+                constexpr int U = NIT < 4 ? NIT : 4;
+                if (tid >= RPI * CPR) return;
+                const int ch = tid % CPR, r0 = tid / CPR;
+                // GEGLU: the projection is stored in 128-column groups [x(64) | gate(64)]
+                const int nloc = GE ? (ch >> 3) * 128 + (ch & 7) * 8 : ch * 8;
+                const int n = n0 + nloc;                     // column in the N space (x part for GEGLU)
+                if (n >= d.N) return;
+                const long ocol = GE ? (long)tile_n * (BN / 2) + (ch >> 3) * 64 + (ch & 7) * 8 : (long)n;
+                const bool shared_bias = bias && d.bias_rows >= d.M;
+                float bx[8], bg[8];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (!ok[u]) continue;
-                    const int row = r0 + (it0 + u) * RPI;
-                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc);
-                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 4);
-                    float v[8] = {p0[0] + bx[0], p0[1] + bx[1], p0[2] + bx[2], p0[3] + bx[3],
-                                  p1[0] + bx[4], p1[1] + bx[5], p1[2] + bx[6], p1[3] + bx[7]};
-                    if (bias && !shared_bias) {
-                        v[0] += pb0[u][0]; v[1] += pb0[u][1]; v[2] += pb0[u][2]; v[3] += pb0[u][3];
-                        v[4] += pb1[u][0]; v[5] += pb1[u][1]; v[6] += pb1[u][2]; v[7] += pb1[u][3];
-                    }
+                for (int j = 0; j < 8; ++j) { bx[j] = 0.0f; bg[j] = 0.0f; }
+                if (shared_bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
+                    bx[0] = b0[0]; bx[1] = b0[1]; bx[2] = b0[2]; bx[3] = b0[3];
+                    bx[4] = b1[0]; bx[5] = b1[1]; bx[6] = b1[2]; bx[7] = b1[3];
                     if (GE) {
-                        // gate columns live 64 to the right inside the same 128-wide tile (shared bias only: the
-                        // GEGLU projection never takes a per-item bias)
-                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 64);
-                        const f32x4 g1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 68);
-                        const float gte[8] = {g0[0] + bg[0], g0[1] + bg[1], g0[2] + bg[2], g0[3] + bg[3],
-                                              g1[0] + bg[4], g1[1] + bg[5], g1[2] + bg[6], g1[3] + bg[7]};
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            v[j] = v[j] * fast_gelu_erf(gte[j]);
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(bias + n + 64);
+                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(bias + n + 68);
+                        bg[0] = c0[0]; bg[1] = c0[1]; bg[2] = c0[2]; bg[3] = c0[3];
+                        bg[4] = c1[0]; bg[5] = c1[1]; bg[6] = c1[2]; bg[7] = c1[3];
                     }
-                    if (residual) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)res[u][j];
-                    }
-                    if (silu) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = fast_silu(v[j]);
-                    }
-                    f16x8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
-                    const long m = m0 + row;
-                    *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(out) + m * d.ldc + ocol) = o;
                 }
+#pragma unroll 1
+                for (int it0 = 0; it0 < NIT; it0 += U) {
+                    f16x8 res[U];
+                    f32x4 pb0[U], pb1[U];
+                    bool ok[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int prow = r0 + (it0 + u) * RPI;
+                        const int m = m0 + prow0 + prow;
+                        ok[u] = prow < PROWS && m < d.M;
+                        const long mm = ok[u] ? m : 0;
+                        if (residual) res[u] = *reinterpret_cast<const f16x8*>(residual + mm * d.ldr + ocol);
+                        if (bias && !shared_bias) {
+                            const long brow = (long)((int)mm / d.bias_rows) * d.ldbias;
+                            pb0[u] = *reinterpret_cast<const f32x4*>(bias + brow + n);
+                            pb1[u] = *reinterpret_cast<const f32x4*>(bias + brow + n + 4);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (!ok[u]) continue;
+                        const int row = r0 + (it0 + u) * RPI;
+                        const f32x4 p0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc);
+                        const f32x4 p1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 4);
+                        float v[8] = {p0[0] + bx[0], p0[1] + bx[1], p0[2] + bx[2], p0[3] + bx[3],
+                                      p1[0] + bx[4], p1[1] + bx[5], p1[2] + bx[6], p1[3] + bx[7]};
+                        if (bias && !shared_bias) {
+                            v[0] += pb0[u][0]; v[1] += pb0[u][1]; v[2] += pb0[u][2]; v[3] += pb0[u][3];
+                            v[4] += pb1[u][0]; v[5] += pb1[u][1]; v[6] += pb1[u][2]; v[7] += pb1[u][3];
+                        }
+                        if (GE) {
+                            // gate columns live 64 to the right inside the same 128-wide group (shared bias only: the
+                            // GEGLU projection never takes a per-item bias)
+                            const f32x4 g0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 64);
+                            const f32x4 g1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 68);
+                            const float gte[8] = {g0[0] + bg[0], g0[1] + bg[1], g0[2] + bg[2], g0[3] + bg[3],
+                                                  g1[0] + bg[4], g1[1] + bg[5], g1[2] + bg[6], g1[3] + bg[7]};
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                v[j] = v[j] * fast_gelu_erf(gte[j]);
+                        }
+                        if (residual) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += (float)res[u][j];
+                        }
+                        if (silu) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = fast_silu(v[j]);
+                        }
+                        f16x8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
+                        const long m = m0 + prow0 + row;
+                        *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(out) + m * d.ldc + ocol) = o;
+                    }
+                }
+            };
+            if (geglu) {
+                if constexpr (BN % 128 == 0) run(std::true_type{});
+            } else {
+                run(std::false_type{});
             }
-        };
-        if (geglu) {
-            if constexpr (BN == 128) run(std::true_type{});
         } else {
-            run(std::false_type{});
+            // generic (rare, tiny layers): scalar stores, any N, fp32 or fp16 out; GEGLU not supported here
+            for (int idx = tid; idx < PROWS * BN; idx += NT) {
+                const int row = idx / BN, col = idx - row * BN;
+                const int m = m0 + prow0 + row, n = n0 + col;
+                if (m >= d.M || n >= d.N) continue;
+                float v = sC[row * CS + col];
+                if (bias) v += bias[(long)(m / d.bias_rows) * d.ldbias + n];
+                if (residual) v += (float)residual[(long)m * d.ldr + n];
+                if (silu) v = fast_silu(v);
+                if (out_f32) reinterpret_cast<float*>(out)[(long)m * d.ldc + n] = v;
+                else reinterpret_cast<f16*>(out)[(long)m * d.ldc + n] = (f16)v;
+            }
         }
-    } else {
-        // generic (rare, tiny layers): scalar stores, any N, fp32 or fp16 out; GEGLU not supported here
-        for (int idx = tid; idx < BM * BN; idx += 256) {
-            const int row = idx / BN, col = idx - row * BN;
-            const int m = m0 + row, n = n0 + col;
-            if (m >= d.M || n >= d.N) continue;
-            float v = sC[row * CS + col];
-            if (bias) v += bias[(long)(m / d.bias_rows) * d.ldbias + n];
-            if (residual) v += (float)residual[(long)m * d.ldr + n];
-            if (silu) v = fast_silu(v);
-            if (out_f32) reinterpret_cast<float*>(out)[(long)m * d.ldc + n] = v;
-            else reinterpret_cast<f16*>(out)[(long)m * d.ldc + n] = (f16)v;
-        }
+        if (pass + 1 < NPASS) __syncthreads();
     }
+    DS_STAMP(4);
 }
 
-template <int BM, int BN, int AMODE>
+template <int BM, int BN, int WGM, int WGN, int AMODE>
 int launch(const void* A, const void* W, const float* bias, const void* residual, void* out,
            const ds_gemm_desc& d, hipStream_t st) {
-    constexpr size_t stage = (size_t)2 * (BM + BN) * BK * sizeof(f16);
-    constexpr size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
-    constexpr size_t lds = stage > epi ? stage : epi;
+    using Cfg = TileCfg<BM, BN, WGM, WGN>;
+    constexpr size_t lds = Cfg::LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, AMODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WGM, WGN, AMODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("ds_gemm_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -383,14 +504,53 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
         ds_set_error("ds_gemm_f16: operand of %ld / %ld bytes exceeds the 2 GiB buffer-addressing range; lower the tile batch", a_bytes, w_bytes);
         return DS_EINVAL;
     }
-    gemm_f16_kernel<BM, BN, AMODE><<<tiles_m * tiles_n, 256, lds, st>>>((const f16*)A, (const f16*)W, bias,
-                                                                 (const f16*)residual, out, d, tiles_m, tiles_n,
-                                                                 (unsigned)a_bytes, (unsigned)w_bytes);
+    gemm_f16_kernel<BM, BN, WGM, WGN, AMODE><<<tiles_m * tiles_n, Cfg::NT, lds, st>>>(
+        (const f16*)A, (const f16*)W, bias, (const f16*)residual, out, d, tiles_m, tiles_n, (unsigned)a_bytes, (unsigned)w_bytes);
     DS_CHECK_LAUNCH("ds_gemm_f16");
     return DS_OK;
 }
 
+// Tile choice.  256-row tiles halve the operand bytes a CU pulls through its vector-memory path and LDS per MFMA
+// (profiles/r1_notes.md: on 128x128 tiles each of the three -- loads, LDS, MFMA -- is near its limit), but need one
+// workgroup per CU to have work: they are used when the grid still fills the chip.
+enum { TILE_128x64 = 0, TILE_128x128 = 1, TILE_256x256 = 2, TILE_256x320 = 3 };
+
+int choose_tile(const ds_gemm_desc& d) {
+    static const int forced = getenv("DS_GEMM_TILE") ? atoi(getenv("DS_GEMM_TILE")) : -1;
+    const bool geglu = d.epilogue & DS_EPI_GEGLU;
+    const int waste128 = ds_cdiv(d.N, 128) * 128 - d.N;
+    const int small = (geglu || waste128 * 8 <= d.N) ? TILE_128x128 : TILE_128x64;
+    if (forced == TILE_128x64 || forced == TILE_128x128) return geglu ? TILE_128x128 : forced;
+    const long tiles_m256 = ds_cdiv(d.M, 256);
+    int big = -1;
+    if (d.N % 256 == 0) big = TILE_256x256;
+    else if (d.N % 320 == 0 && !geglu) big = TILE_256x320;
+    if (big < 0) return small;
+    if (forced == TILE_256x256 || forced == TILE_256x320) return big;
+    const long nblk = tiles_m256 * (d.N / (big == TILE_256x256 ? 256 : 320));
+    static const long big_min = getenv("DS_GEMM_BIG_MIN") ? atol(getenv("DS_GEMM_BIG_MIN")) : 160;
+    return nblk >= big_min ? big : small;
+}
+
+template <int AMODE>
+int dispatch(int tile, const void* A, const void* W, const float* bias, const void* residual, void* out,
+             const ds_gemm_desc& d, hipStream_t st) {
+    switch (tile) {
+        case TILE_256x256: return launch<256, 256, 2, 4, AMODE>(A, W, bias, residual, out, d, st);
+        case TILE_256x320: return launch<256, 320, 4, 2, AMODE>(A, W, bias, residual, out, d, st);
+        case TILE_128x128: return launch<128, 128, 2, 2, AMODE>(A, W, bias, residual, out, d, st);
+        default:           return launch<128, 64, 2, 2, AMODE>(A, W, bias, residual, out, d, st);
+    }
+}
+
 }  // namespace
+
+#ifdef DS_GEMM_STAMPS
+extern "C" int ds_dbg_set_stamps(void* p) {
+    unsigned long long* q = (unsigned long long*)p;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(ds_dbg_stamps), &q, sizeof(q));
+}
+#endif
 
 // LDS-DMA ring variant (gemm_ring.hip)
 int dsi_gemm_ring(const void* A, const void* W, const float* bias, const void* residual, void* out,
@@ -428,16 +588,13 @@ extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, cons
     hipStream_t st = (hipStream_t)stream;
     static const int use_ring = getenv("DS_GEMM_RING") ? atoi(getenv("DS_GEMM_RING")) : 0;
     if (use_ring) return dsi_gemm_ring(A, W, bias, residual, out, desc, st);
-    // tile choice: 128x128 unless it wastes too much of N (N=320 -> 3 tiles of 128 = 17% waste) or GEGLU needs it
-    const bool geglu = d.epilogue & DS_EPI_GEGLU;
-    const int waste128 = ds_cdiv(d.N, 128) * 128 - d.N;
-    const bool big = geglu || waste128 * 8 <= d.N;
+    const int tile = choose_tile(d);
     // 32-bit buffer addressing with offset 2^31 as the 'out of range' marker: an A operand of 2 GiB or more (dense
     // only: e.g. the 2048-wide FF hidden of init_attn at 655k rows) is processed in row chunks.
     if (d.a_mode == DS_A_DENSE && ((long)d.M - 1) * d.lda * 2 + (long)d.cin * 2 >= 0x7FFF0000L) {
         DS_CHECK_ARG(!bias || d.bias_rows >= d.M, "ds_gemm_f16: a >= 2 GiB dense operand with a per-item bias is not supported");
-        const long rows_max = ((0x7FFF0000L / ((long)d.lda * 2)) / 128) * 128;
-        DS_CHECK_ARG(rows_max >= 128, "ds_gemm_f16: lda=%d too large", d.lda);
+        const long rows_max = ((0x7FFF0000L / ((long)d.lda * 2)) / 256) * 256;
+        DS_CHECK_ARG(rows_max >= 256, "ds_gemm_f16: lda=%d too large", d.lda);
         const long out_elt = (d.epilogue & DS_EPI_OUT_F32) ? 4 : 2;
         for (long r0 = 0; r0 < d.M; r0 += rows_max) {
             ds_gemm_desc c = d;
@@ -446,17 +603,12 @@ extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, cons
             const char* a_p = (const char*)A + r0 * d.lda * 2;
             const char* r_p = residual ? (const char*)residual + r0 * d.ldr * 2 : nullptr;
             char* o_p = (char*)out + r0 * d.ldc * out_elt;
-            int rc = big ? launch<128, 128, DS_A_DENSE>(a_p, W, bias, r_p, o_p, c, st)
-                         : launch<128, 64, DS_A_DENSE>(a_p, W, bias, r_p, o_p, c, st);
+            int rc = dispatch<DS_A_DENSE>(tile, a_p, W, bias, r_p, o_p, c, st);
             if (rc) return rc;
         }
         return DS_OK;
     }
-#define DS_DISPATCH(MODE)                                                                  \
-    return big ? launch<128, 128, MODE>(A, W, bias, residual, out, d, st)                  \
-               : launch<128, 64, MODE>(A, W, bias, residual, out, d, st)
-    if (d.a_mode == DS_A_CONV3) { DS_DISPATCH(DS_A_CONV3); }
-    if (d.a_mode == DS_A_TCONV) { DS_DISPATCH(DS_A_TCONV); }
-    DS_DISPATCH(DS_A_DENSE);
-#undef DS_DISPATCH
+    if (d.a_mode == DS_A_CONV3) return dispatch<DS_A_CONV3>(tile, A, W, bias, residual, out, d, st);
+    if (d.a_mode == DS_A_TCONV) return dispatch<DS_A_TCONV>(tile, A, W, bias, residual, out, d, st);
+    return dispatch<DS_A_DENSE>(tile, A, W, bias, residual, out, d, st);
 }

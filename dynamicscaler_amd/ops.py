@@ -230,7 +230,7 @@ def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE
               "ds_gemm_f16")
 
     if _timing_hook is not None:
-        _timing_hook("gemm", 2.0 * M * N * K, launch)
+        _timing_hook("gemm", 2.0 * M * N * K, launch, (a_mode, M, N, K, epilogue))
     else:
         launch()
     return out
@@ -272,7 +272,7 @@ def attention(q, k, v, out, *, batch, heads, nq, nk, ldq, ldk, ldv, ldo, kv_batc
               "ds_attention_f16")
 
     if _timing_hook is not None:
-        _timing_hook("attention", 4.0 * batch * heads * nq * nk * 64, launch)
+        _timing_hook("attention", 4.0 * batch * heads * nq * nk * 64, launch, (batch, heads, nq, nk))
     else:
         launch()
     return out
