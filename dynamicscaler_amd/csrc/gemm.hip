@@ -83,18 +83,12 @@ struct TileCfg {
     static constexpr int TM = WM / 32, TN = WN / 32;          // 32x32 MFMA tiles per wave
     static constexpr int LROWS = NT / 8;                      // rows staged per sweep (8 lanes x 16 B per 128-B row)
     static constexpr int AR = BM / LROWS, BR = BN / LROWS;    // staged rows per thread
-    static constexpr int CS = BN + 4;                         // fp32 epilogue tile stride
     static constexpr size_t STAGE = (size_t)2 * (BM + BN) * BK * sizeof(f16);
-    // epilogue pass: as many wave-row groups as fit the LDS budget (80 KiB when two workgroups share a CU)
-    static constexpr size_t BUDGET = STAGE <= 81920 ? 81920 : 163840;
-    static constexpr int pass_rows() {
-        int p = BM;
-        while ((size_t)p * CS * sizeof(float) > BUDGET && p / 2 >= WM) p /= 2;
-        return p;
-    }
-    static constexpr int PROWS = pass_rows();
-    static constexpr int NPASS = BM / PROWS;
-    static constexpr size_t EPI = (size_t)PROWS * CS * sizeof(float);
+    // epilogue: every wave transposes its own accumulators through a private LDS strip of 32 rows x NG MFMA tiles
+    // (fp32, +4 floats of padding per row) -- no workgroup barrier after the main loop
+    static constexpr int NG = TN <= 4 ? TN : (TN + (TN + 3) / 4 - 1) / ((TN + 3) / 4);   // tiles per column group
+    static constexpr int STR = 32 * NG + 4;                    // floats per strip row
+    static constexpr size_t EPI = (size_t)(NT / 64) * 32 * STR * sizeof(float);
     static constexpr size_t LDS = STAGE > EPI ? STAGE : EPI;
     static constexpr int WG_PER_CU = LDS <= 81920 && NT <= 256 ? 2 : 1;
     // fragment scheduling: all four k-slices of a K-step up front when that is <= 16 fragments, else one k-slice
@@ -105,7 +99,7 @@ struct TileCfg {
     // MFMAs cover the store phase)
     static constexpr bool DMA = WG_PER_CU == 1;
     static_assert(BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0 && BM % LROWS == 0 && BN % LROWS == 0, "tile shape");
-    static_assert(EPI <= BUDGET && LDS <= 163840, "LDS budget");
+    static_assert(LDS <= 163840, "LDS budget");
 };
 
 template <int BM, int BN, int WGM, int WGN, int AMODE>
@@ -115,13 +109,12 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 unsigned a_bytes, unsigned w_bytes) {
     using Cfg = TileCfg<BM, BN, WGM, WGN>;
     constexpr int NT = Cfg::NT, WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
-    constexpr int LROWS = Cfg::LROWS, A_ROWS_PER_THREAD = Cfg::AR, B_ROWS_PER_THREAD = Cfg::BR, CS = Cfg::CS;
-    constexpr int PROWS = Cfg::PROWS, NPASS = Cfg::NPASS;
+    constexpr int LROWS = Cfg::LROWS, A_ROWS_PER_THREAD = Cfg::AR, B_ROWS_PER_THREAD = Cfg::BR;
 
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     f16* sA = reinterpret_cast<f16*>(smem);                 // [2][BM][64]
     f16* sB = sA + 2 * BM * BK;                             // [2][BN][64]
-    float* sC = reinterpret_cast<float*>(smem);             // [PROWS][CS] (reuses the staging space)
+    float* sW = reinterpret_cast<float*>(smem) + (size_t)(threadIdx.x >> 6) * 32 * Cfg::STR;   // this wave's epilogue strip
 
     // ---- XCD-aware block remap (bijective for any grid size) ----
     const int nwg = tiles_m * tiles_n;
@@ -278,9 +271,28 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     stage_sync(0, true);
     DS_STAMP(1);
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // one LDS-DMA piece (8 rows x 128 B of this wave's share) of the next K-step, and the cursor advance after all pieces
+    constexpr int NPIECE = A_ROWS_PER_THREAD + B_ROWS_PER_THREAD;
+    auto dma_piece = [&](int j, int buf) {
+        if (j < A_ROWS_PER_THREAD) dma16(rsA, sA + (buf * BM + LROWS * j + 8 * wave) * BK, voff_a[j], (unsigned)cb * 2u);
+        else dma16(rsW, sB + (buf * BN + LROWS * (j - A_ROWS_PER_THREAD) + 8 * wave) * BK, b_off[j - A_ROWS_PER_THREAD], kbytes);
+    };
+    auto advance_k = [&]() {
+        kbytes += BK * 2;
+        cb += BK;
+        if (cb == d.cin) {
+            cb = 0;
+            ++tap;
+            if constexpr (AMODE != DS_A_DENSE) tap_offsets();
+        }
+    };
+
+    auto kstep = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;   // a next K-step exists: stage it while computing this one
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_global(buf ^ 1);
+        if constexpr (!Cfg::DMA) {
+            if (MORE) load_global(buf ^ 1);
+        }
         const f16* a_base = sA + (buf * BM + wm * WM) * BK;
         const f16* b_base_l = sB + (buf * BN + wn * WN) * BK;
         auto read_a = [&](int kk, int mi) {
@@ -311,7 +323,12 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                     for (int mi = 0; mi < TM; ++mi)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][ni], af[kk][mi], acc[ni][mi], 0, 0, 0);
         } else {
-            // big wave tiles: the fragments of k-slice kk+1 are read while the MFMAs of kk run (two register sets)
+            // big wave tiles: the fragments of k-slice kk+1 are read while the MFMAs of kk run (two register sets), and
+            // the LDS-DMA pieces of the next K-step are issued one at a time BETWEEN the MFMAs of the first two k-slices:
+            // issuing a piece costs the wave ~60-100 cycles, which fit in the shadow of the matrix pipe instead of
+            // delaying the first MFMA after the barrier (in-kernel stamps: 3.07k -> cycles per K-step, profiles/r1_notes.md)
+            constexpr int NMF = TM * TN;
+            constexpr int P0 = (NPIECE + 1) / 2, P1 = NPIECE - P0;
             f16x8 af[2][TM], bf[2][TN];
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) af[0][mi] = read_a(0, mi);
@@ -326,16 +343,28 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                     for (int ni = 0; ni < TN; ++ni) bf[(kk + 1) & 1][ni] = read_b(kk + 1, ni);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                const int np = kk == 0 ? P0 : (kk == 1 ? P1 : 0);     // pieces issued inside this k-slice
+                const int stride = np > 0 ? NMF / np : NMF + 1;
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk & 1][ni], af[kk & 1][mi], acc[ni][mi], 0, 0, 0);
+                for (int idx = 0; idx < NMF; ++idx) {
+                    const int ni = idx / TM, mi = idx % TM;
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk & 1][ni], af[kk & 1][mi], acc[ni][mi], 0, 0, 0);
+                    if (Cfg::DMA && MORE && np > 0 && idx % stride == stride - 1 && idx / stride < np) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma_piece((kk == 0 ? 0 : P0) + idx / stride, buf ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (Cfg::DMA) {
+                if (MORE) advance_k();
+            }
         }
-        stage_sync(buf ^ 1, kt + 1 < nk);
-    }
+        stage_sync(buf ^ 1, MORE);
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
+    kstep(nk - 1, std::false_type{});
 
     DS_STAMP(2);
     const bool geglu = d.epilogue & DS_EPI_GEGLU;
@@ -343,139 +372,156 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;
     const bool fast = !out_f32 && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (!residual || d.ldr % 8 == 0) &&
                       (!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0));
+    const bool shared_bias = bias && d.bias_rows >= d.M;
 
-    // ---- epilogue, NPASS passes of PROWS rows: accumulators -> LDS (fp32) -> bias / activation / residual -> fp16 ----
-    // D[i][j]: j = lane&31 is the output row m, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) the column n.
+    // ---- epilogue.  D[i][j] of an MFMA tile: j = lane&31 is the output row m, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    //      the column n.  Each wave moves its own tiles through its private LDS strip (32 rows x up to NG tiles, fp32),
+    //      reads them back as 8-column chunks of one row, applies bias / per-item bias / residual / SiLU in fp32,
+    //      rounds once to fp16 and stores 16 bytes per lane (row segments of 64..256 bytes).  LDS operations of one wave
+    //      execute in order, so the strip needs no barrier -- the eight waves run their epilogues independently. ----
+    auto wave_sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto epilogue = [&](auto ge_tag) {
+        constexpr bool GE = decltype(ge_tag)::value;
+        constexpr int TNE = GE ? TN / 2 : TN;          // output tiles per wave row (GEGLU halves the columns)
+        constexpr int NG = Cfg::NG, STR = Cfg::STR;
+        if constexpr (GE) {
+            // GEGLU in registers: weight rows are interleaved in 32-row groups [x | gate], so tile 2p holds x and tile
+            // 2p+1 the gate of the same 32 outputs; acc[p] <- (x + b) * gelu(gate + b)
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int prow0 = pass * PROWS;
-        if (wm * WM >= prow0 && wm * WM < prow0 + PROWS) {
+            for (int p2 = 0; p2 < TNE; ++p2) {
+                const int nx = n0 + wn * WN + 2 * p2 * 32 + 4 * fh;   // + 8g : x column of quad g
+                f32x4 bxq[4], bgq[4];
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    const int row = wm * WM - prow0 + mi * 32 + fr;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = wn * WN + ni * 32 + 8 * g + 4 * fh;
-                        f32x4 v = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
-                        *reinterpret_cast<f32x4*>(sC + row * CS + col) = v;
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    const bool okn = nx + 8 * g + 32 < d.N && bias;
+                    bxq[g] = okn ? *reinterpret_cast<const f32x4*>(bias + nx + 8 * g) : f32x4{0, 0, 0, 0};
+                    bgq[g] = okn ? *reinterpret_cast<const f32x4*>(bias + nx + 8 * g + 32) : f32x4{0, 0, 0, 0};
                 }
-        }
-        __syncthreads();
-        if (pass == 0) DS_STAMP(3);
-
-        if (fast) {
-            // Each thread owns one 8-column chunk (fixed for the whole tile) and walks rows; the global loads of an
-            // unrolled group of rows (residual, per-item bias) are issued together before any of them is consumed, so
-            // the epilogue pays one memory latency per group instead of one per row.
-            auto run = [&](auto ge_tag) {
-                constexpr bool GE = decltype(ge_tag)::value;
-                constexpr int CPR = GE ? BN / 16 : BN / 8;   // chunks per row
-                constexpr int RPI = NT / CPR;                // rows per sweep of the workgroup
-                constexpr int NIT = (PROWS + RPI - 1) / RPI;
-                constexpr int U = NIT < 4 ? NIT : 4;
-                if (tid >= RPI * CPR) return;
-                const int ch = tid % CPR, r0 = tid / CPR;
-                // GEGLU: the projection is stored in 128-column groups [x(64) | gate(64)]
-                const int nloc = GE ? (ch >> 3) * 128 + (ch & 7) * 8 : ch * 8;
-                const int n = n0 + nloc;                     // column in the N space (x part for GEGLU)
-                if (n >= d.N) return;
-                const long ocol = GE ? (long)tile_n * (BN / 2) + (ch >> 3) * 64 + (ch & 7) * 8 : (long)n;
-                const bool shared_bias = bias && d.bias_rows >= d.M;
-                float bx[8], bg[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { bx[j] = 0.0f; bg[j] = 0.0f; }
-                if (shared_bias) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n);
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
-                    bx[0] = b0[0]; bx[1] = b0[1]; bx[2] = b0[2]; bx[3] = b0[3];
-                    bx[4] = b1[0]; bx[5] = b1[1]; bx[6] = b1[2]; bx[7] = b1[3];
-                    if (GE) {
-                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(bias + n + 64);
-                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(bias + n + 68);
-                        bg[0] = c0[0]; bg[1] = c0[1]; bg[2] = c0[2]; bg[3] = c0[3];
-                        bg[4] = c1[0]; bg[5] = c1[1]; bg[6] = c1[2]; bg[7] = c1[3];
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float xv = acc[2 * p2][mi][j] + bxq[j >> 2][j & 3];
+                        const float gv = acc[2 * p2 + 1][mi][j] + bgq[j >> 2][j & 3];
+                        acc[p2][mi][j] = xv * fast_gelu_erf(gv);
                     }
-                }
-#pragma unroll 1
-                for (int it0 = 0; it0 < NIT; it0 += U) {
-                    f16x8 res[U];
-                    f32x4 pb0[U], pb1[U];
-                    bool ok[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int prow = r0 + (it0 + u) * RPI;
-                        const int m = m0 + prow0 + prow;
-                        ok[u] = prow < PROWS && m < d.M;
-                        const long mm = ok[u] ? m : 0;
-                        if (residual) res[u] = *reinterpret_cast<const f16x8*>(residual + mm * d.ldr + ocol);
-                        if (bias && !shared_bias) {
-                            const long brow = (long)((int)mm / d.bias_rows) * d.ldbias;
-                            pb0[u] = *reinterpret_cast<const f32x4*>(bias + brow + n);
-                            pb1[u] = *reinterpret_cast<const f32x4*>(bias + brow + n + 4);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (!ok[u]) continue;
-                        const int row = r0 + (it0 + u) * RPI;
-                        const f32x4 p0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc);
-                        const f32x4 p1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 4);
-                        float v[8] = {p0[0] + bx[0], p0[1] + bx[1], p0[2] + bx[2], p0[3] + bx[3],
-                                      p1[0] + bx[4], p1[1] + bx[5], p1[2] + bx[6], p1[3] + bx[7]};
-                        if (bias && !shared_bias) {
-                            v[0] += pb0[u][0]; v[1] += pb0[u][1]; v[2] += pb0[u][2]; v[3] += pb0[u][3];
-                            v[4] += pb1[u][0]; v[5] += pb1[u][1]; v[6] += pb1[u][2]; v[7] += pb1[u][3];
-                        }
-                        if (GE) {
-                            // gate columns live 64 to the right inside the same 128-wide group (shared bias only: the
-                            // GEGLU projection never takes a per-item bias)
-                            const f32x4 g0 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 64);
-                            const f32x4 g1 = *reinterpret_cast<const f32x4*>(sC + row * CS + nloc + 68);
-                            const float gte[8] = {g0[0] + bg[0], g0[1] + bg[1], g0[2] + bg[2], g0[3] + bg[3],
-                                                  g1[0] + bg[4], g1[1] + bg[5], g1[2] + bg[6], g1[3] + bg[7]};
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                v[j] = v[j] * fast_gelu_erf(gte[j]);
-                        }
-                        if (residual) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] += (float)res[u][j];
-                        }
-                        if (silu) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] = fast_silu(v[j]);
-                        }
-                        f16x8 o;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
-                        const long m = m0 + prow0 + row;
-                        *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(out) + m * d.ldc + ocol) = o;
-                    }
-                }
-            };
-            if (geglu) {
-                if constexpr (BN % 128 == 0) run(std::true_type{});
-            } else {
-                run(std::false_type{});
-            }
-        } else {
-            // generic (rare, tiny layers): scalar stores, any N, fp32 or fp16 out; GEGLU not supported here
-            for (int idx = tid; idx < PROWS * BN; idx += NT) {
-                const int row = idx / BN, col = idx - row * BN;
-                const int m = m0 + prow0 + row, n = n0 + col;
-                if (m >= d.M || n >= d.N) continue;
-                float v = sC[row * CS + col];
-                if (bias) v += bias[(long)(m / d.bias_rows) * d.ldbias + n];
-                if (residual) v += (float)residual[(long)m * d.ldr + n];
-                if (silu) v = fast_silu(v);
-                if (out_f32) reinterpret_cast<float*>(out)[(long)m * d.ldc + n] = v;
-                else reinterpret_cast<f16*>(out)[(long)m * d.ldc + n] = (f16)v;
             }
         }
-        if (pass + 1 < NPASS) __syncthreads();
+        DS_STAMP(3);
+#pragma unroll
+        for (int c0 = 0; c0 < TNE; c0 += NG) {
+            const int gw = (TNE - c0) < NG ? (TNE - c0) : NG;   // tiles in this column group (compile-time after unroll)
+            const int cpr = gw * 4;                             // 8-column chunks per strip row
+            const int rps = 64 / cpr;                           // rows per sweep of the wave
+            const int ch = lane % cpr, r0 = lane / cpr;
+            const bool lane_on = lane < rps * cpr;
+            // column of this lane's chunk: in the N space (bias, bounds) and in the output
+            const int ncol = GE ? n0 + wn * WN + 2 * (c0 * 32 + ch * 8 - (ch * 8) % 32) + (ch * 8) % 32
+                                : n0 + wn * WN + c0 * 32 + ch * 8;
+            const long ocol = GE ? (long)tile_n * (BN / 2) + wn * (WN / 2) + c0 * 32 + ch * 8 : (long)ncol;
+            const bool col_on = lane_on && (GE ? ncol + 32 < d.N : ncol < d.N);
+            float bx[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bx[j] = 0.0f;
+            if (!GE && shared_bias && fast && col_on) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + ncol);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + ncol + 4);
+                bx[0] = b0[0]; bx[1] = b0[1]; bx[2] = b0[2]; bx[3] = b0[3];
+                bx[4] = b1[0]; bx[5] = b1[1]; bx[6] = b1[2]; bx[7] = b1[3];
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int mrow0 = m0 + wm * WM + mi * 32;
+                // accumulators -> strip
+#pragma unroll
+                for (int t = 0; t < NG; ++t) {
+                    if (t < gw) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x16& a = acc[c0 + t][mi];
+                            f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+                            *reinterpret_cast<f32x4*>(sW + fr * STR + t * 32 + 8 * g + 4 * fh) = v;
+                        }
+                    }
+                }
+                wave_sync();
+                if (fast) {
+                    // the global loads of a batch of sweeps (residual, per-item bias) are issued before any is consumed
+                    constexpr int SB = 4;
+                    const int nsw = (32 + rps - 1) / rps;
+#pragma unroll
+                    for (int sb = 0; sb < 8; sb += SB) {
+                        if (sb < nsw) {
+                            f16x8 res[SB];
+                            f32x4 pb0[SB], pb1[SB];
+#pragma unroll
+                            for (int u = 0; u < SB; ++u) {
+                                const int row = (sb + u) * rps + r0;
+                                const int m = mrow0 + row;
+                                const bool ok = col_on && row < 32 && m < d.M;
+                                const long mm = ok ? m : 0;
+                                const long oc = ok ? ocol : 0;
+                                if (residual) res[u] = *reinterpret_cast<const f16x8*>(residual + mm * d.ldr + oc);
+                                if (bias && !shared_bias) {
+                                    const long brow = (long)((int)mm / d.bias_rows) * d.ldbias + (ok ? ncol : 0);
+                                    pb0[u] = *reinterpret_cast<const f32x4*>(bias + brow);
+                                    pb1[u] = *reinterpret_cast<const f32x4*>(bias + brow + 4);
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < SB; ++u) {
+                                const int row = (sb + u) * rps + r0;
+                                const int m = mrow0 + row;
+                                if (col_on && row < 32 && m < d.M) {
+                                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * 8);
+                                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * 8 + 4);
+                                    float v[8] = {p0[0] + bx[0], p0[1] + bx[1], p0[2] + bx[2], p0[3] + bx[3],
+                                                  p1[0] + bx[4], p1[1] + bx[5], p1[2] + bx[6], p1[3] + bx[7]};
+                                    if (!GE && bias && !shared_bias) {
+                                        v[0] += pb0[u][0]; v[1] += pb0[u][1]; v[2] += pb0[u][2]; v[3] += pb0[u][3];
+                                        v[4] += pb1[u][0]; v[5] += pb1[u][1]; v[6] += pb1[u][2]; v[7] += pb1[u][3];
+                                    }
+                                    if (residual) {
+#pragma unroll
+                                        for (int j = 0; j < 8; ++j) v[j] += (float)res[u][j];
+                                    }
+                                    if (silu) {
+#pragma unroll
+                                        for (int j = 0; j < 8; ++j) v[j] = fast_silu(v[j]);
+                                    }
+                                    f16x8 o;
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
+                                    *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(out) + (long)m * d.ldc + ocol) = o;
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // generic (rare, tiny layers): scalar stores, any N, fp32 or fp16 out; GEGLU not supported here
+                    for (int idx = lane; idx < 32 * gw * 32; idx += 64) {
+                        const int row = idx / (gw * 32), col = idx - row * (gw * 32);
+                        const int m = mrow0 + row, n = n0 + wn * WN + c0 * 32 + col;
+                        if (m >= d.M || n >= d.N) continue;
+                        float v = sW[row * STR + col];
+                        if (bias) v += bias[(long)(m / d.bias_rows) * d.ldbias + n];
+                        if (residual) v += (float)residual[(long)m * d.ldr + n];
+                        if (silu) v = fast_silu(v);
+                        if (out_f32) reinterpret_cast<float*>(out)[(long)m * d.ldc + n] = v;
+                        else reinterpret_cast<f16*>(out)[(long)m * d.ldc + n] = (f16)v;
+                    }
+                }
+                wave_sync();
+            }
+        }
+    };
+    if (geglu) {
+        if constexpr (TN % 2 == 0) epilogue(std::true_type{});
+    } else {
+        epilogue(std::false_type{});
     }
     DS_STAMP(4);
 }
@@ -552,10 +598,6 @@ extern "C" int ds_dbg_set_stamps(void* p) {
 }
 #endif
 
-// LDS-DMA ring variant (gemm_ring.hip)
-int dsi_gemm_ring(const void* A, const void* W, const float* bias, const void* residual, void* out,
-                  const ds_gemm_desc* d, hipStream_t st);
-
 extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,
                            const ds_gemm_desc* desc, void* stream) {
     DS_CHECK_ARG(A && W && out && desc, "ds_gemm_f16: null argument");
@@ -582,12 +624,10 @@ extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, cons
         DS_CHECK_ARG(false, "ds_gemm_f16: unknown a_mode %d", d.a_mode);
     }
     if (d.epilogue & DS_EPI_GEGLU) {
-        DS_CHECK_ARG(d.N % 128 == 0, "ds_gemm_f16: GEGLU needs N %% 128 == 0");
+        DS_CHECK_ARG(d.N % 64 == 0, "ds_gemm_f16: GEGLU needs N %% 64 == 0");
         DS_CHECK_ARG(!(d.epilogue & DS_EPI_OUT_F32) && d.ldc % 8 == 0, "ds_gemm_f16: GEGLU needs fp16 out, ldc %% 8 == 0");
     }
     hipStream_t st = (hipStream_t)stream;
-    static const int use_ring = getenv("DS_GEMM_RING") ? atoi(getenv("DS_GEMM_RING")) : 0;
-    if (use_ring) return dsi_gemm_ring(A, W, bias, residual, out, desc, st);
     const int tile = choose_tile(d);
     // 32-bit buffer addressing with offset 2^31 as the 'out of range' marker: an A operand of 2 GiB or more (dense
     // only: e.g. the 2048-wide FF hidden of init_attn at 655k rows) is processed in row chunks.

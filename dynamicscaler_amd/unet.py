@@ -28,12 +28,13 @@ class _Container(nn.Module):
 
 
 def _interleave_geglu(w):
-    """[2*inner, ...] rows (x half | gate half) -> 64-row groups [x_g | gate_g] (DS_EPI_GEGLU layout)."""
+    """[2*inner, ...] rows (x half | gate half) -> 32-row groups [x_g | gate_g] (DS_EPI_GEGLU layout: one 32x32 MFMA
+    tile of x next to the tile of its gates, so the product is formed in registers)."""
     inner = w.shape[0] // 2
-    assert inner % 64 == 0, "GEGLU inner dim must be a multiple of 64"
+    assert inner % 32 == 0, "GEGLU inner dim must be a multiple of 32"
     x, g = w[:inner], w[inner:]
-    xs = x.reshape(inner // 64, 64, *w.shape[1:])
-    gs = g.reshape(inner // 64, 64, *w.shape[1:])
+    xs = x.reshape(inner // 32, 32, *w.shape[1:])
+    gs = g.reshape(inner // 32, 32, *w.shape[1:])
     return torch.cat([xs, gs], dim=1).reshape(w.shape)
 
 

@@ -125,8 +125,8 @@ int ds_resize_latent(const void* in, void* out, int dtype, long planes, int hin,
 
 /* epilogue flags */
 #define DS_EPI_GEGLU 1   /* out[m][j] = (acc[m][x_j]+b) * gelu(acc[m][gate_j]+b)  (attention.py:376-383);
-                            weight rows must be interleaved in 64-row groups [x0..63 | gate0..63] (see
-                            ds_gemm_geglu_row) and N counts x+gate columns; out has N/2 columns            */
+                            weight (and bias) rows must be interleaved in 32-row groups [x0..31 | gate0..31 |
+                            x32..63 | gate32..63 | ...] and N counts x+gate columns; out has N/2 columns    */
 #define DS_EPI_SILU 2    /* out = silu(acc + bias)                                                          */
 #define DS_EPI_OUT_F32 4 /* store fp32 instead of fp16                                                     */
 

@@ -185,8 +185,8 @@ def test_unet_state_dict_keys_and_geglu_interleave():
     assert "input_blocks.1.0.temopral_conv.conv1.0.weight" in sd and "init_attn.0.proj_in.weight" in sd
     w = torch.arange(256).float()
     iw = _interleave_geglu(w)
-    assert iw[:64].tolist() == list(range(0, 64)) and iw[64:128].tolist() == list(range(128, 192))
-    assert iw[128:192].tolist() == list(range(64, 128)) and iw[192:].tolist() == list(range(192, 256))
+    assert iw[:32].tolist() == list(range(0, 32)) and iw[32:64].tolist() == list(range(128, 160))
+    assert iw[64:96].tolist() == list(range(32, 64)) and iw[224:].tolist() == list(range(224, 256))
 
 
 def test_sphere_index_maps_equal_reference_golden_and_winner_rule():
