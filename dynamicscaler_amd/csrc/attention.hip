@@ -30,8 +30,8 @@ __global__ void __launch_bounds__(256)
 attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v, f16* __restrict__ out,
                  int heads, int nq, int nk, int ldq, int ldk, int ldv, int ldo, int kv_batch_div, float scale_log2,
                  int accumulate, int q_tiles) {
-    __shared__ __attribute__((aligned(256))) f16 sK[KT * HD];
-    __shared__ __attribute__((aligned(16))) f16 sVT[HD * VT_STRIDE];
+    __shared__ __attribute__((aligned(256))) f16 sK2[2][KT * HD];          // double-buffered: one barrier per key tile
+    __shared__ __attribute__((aligned(16))) f16 sVT2[2][HD * VT_STRIDE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
@@ -68,42 +68,55 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
             for (int j = 0; j < 16; ++j) o[qb][db][j] = 0.0f;
     }
 
-    // staging: K rows go in as 16-byte chunks (thread -> key row tid/8 (+32), chunk tid%8); V is TRANSPOSED on the
-    // way in: a thread takes the same 8-column chunk of keys 2p and 2p+1 and writes 8 dwords {V[2p][d], V[2p+1][d]}
-    // into V^T[d][2p] (32-bit LDS stores, no sub-dword writes).
+    // Raw buffer loads: a key row past nk lies beyond num_records and reads as zeros in hardware -- no branch, no
+    // select, so the loads of tile t+1 stay in flight behind the MFMAs and the softmax of tile t (a `key < nk ? load : 0`
+    // form made the compiler wait for every load right where it was issued: one full memory latency per tile).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
-    uint4 rk[2], rv[2];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(kp), 0, (int)(((long)(nk - 1) * ldk + HD) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vp), 0, (int)(((long)(nk - 1) * ldv + HD) * 2), 0x00020000);
+    unsigned offk[2], offv[2];     // byte offsets of this thread's rows in tile 0; a tile advances them by KT rows
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offk[i] = (unsigned)((ld_row + 32 * i) * ldk + ld_chunk * 8) * 2u;
+        offv[i] = (unsigned)((2 * ld_row + i) * ldv + ld_chunk * 8) * 2u;
+    }
+    const unsigned tile_k_bytes = (unsigned)(KT * ldk) * 2u, tile_v_bytes = (unsigned)(KT * ldv) * 2u;
+    u32x4 rk[2], rv[2];
     auto load_g = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int key = t * KT + ld_row + 32 * i;
-            rk[i] = key < nk ? *reinterpret_cast<const uint4*>(kp + (long)key * ldk + ld_chunk * 8) : zero4;
-            const int vkey = t * KT + 2 * ld_row + i;
-            rv[i] = vkey < nk ? *reinterpret_cast<const uint4*>(vp + (long)vkey * ldv + ld_chunk * 8) : zero4;
+            rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, offk[i] + (unsigned)t * tile_k_bytes, 0, 0);
+            rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, offv[i] + (unsigned)t * tile_v_bytes, 0, 0);
         }
     };
-    auto store_l = [&]() {
+    // K rows go in as 16-byte chunks (thread -> key row tid/8 (+32), chunk tid%8); V is TRANSPOSED on the way in: a
+    // thread holds the same 8-column chunk of keys 2p and 2p+1 and writes 8 dwords {V[2p][d], V[2p+1][d]} into
+    // V^T[d][2p] (v_perm_b32 pairs the halves; 32-bit LDS stores, no sub-dword writes).
+    auto store_l = [&](int buf) {
+        f16* sK = sK2[buf];
+        f16* sVT = sVT2[buf];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = ld_row + 32 * i;
-            *reinterpret_cast<uint4*>(sK + row * HD + swz_chunk(row, ld_chunk) * 8) = rk[i];
+            *reinterpret_cast<u32x4*>(sK + row * HD + swz_chunk(row, ld_chunk) * 8) = rk[i];
         }
-        const unsigned short* v0 = reinterpret_cast<const unsigned short*>(&rv[0]);
-        const unsigned short* v1 = reinterpret_cast<const unsigned short*>(&rv[1]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            *reinterpret_cast<unsigned*>(sVT + (ld_chunk * 8 + j) * VT_STRIDE + 2 * ld_row) =
-                (unsigned)v0[j] | ((unsigned)v1[j] << 16);
+        for (int j = 0; j < 8; ++j) {
+            const unsigned w = __builtin_amdgcn_perm(rv[1][j >> 1], rv[0][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+            *reinterpret_cast<unsigned*>(sVT + (ld_chunk * 8 + j) * VT_STRIDE + 2 * ld_row) = w;
+        }
     };
 
     const int ntiles = (nk + KT - 1) / KT;
     load_g(0);
-    store_l();
+    store_l(0);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) load_g(t + 1);
+        const f16* sK = sK2[t & 1];
+        const f16* sVT = sVT2[t & 1];
 
         // K fragments for this tile are shared by the wave's QB query blocks
         f16x8 kf[2][4];
@@ -146,19 +159,29 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
             const float mnew = fmaxf(mold, mt);
             mrun[qb] = mnew;
             const float mneg = -mnew * scale_log2;
-            float lsum = 0.0f;
+            // p = 2^(s*scale - m*scale): arguments are <= 0, so the raw v_exp_f32 (no denormal-range fix-up: a result
+            // below 2^-126 flushes to 0, which is what the softmax wants) and packed fp32 math (two scores per
+            // v_pk_fma / v_pk_add).  The kernel is VALU-bound at head_dim 64 -- the MFMAs of a 64-key tile take 512
+            // cycles per wave, the softmax of its 32 scores per lane was ~1200 with libm's exp2f.
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 sc2 = {scale_log2, scale_log2}, mn2 = {mneg, mneg};
+            f32x2 ls2 = {0.0f, 0.0f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const float p = exp2f(fmaf(s[kb][j], scale_log2, mneg));
-                    s[kb][j] = p;
-                    lsum += p;
+                for (int j = 0; j < 16; j += 2) {
+                    f32x2 x = {s[kb][j], s[kb][j + 1]};
+                    x = __builtin_elementwise_fma(x, sc2, mn2);
+                    f32x2 p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    s[kb][j] = p[0];
+                    s[kb][j + 1] = p[1];
+                    ls2 += p;
                 }
+            const float lsum = ls2[0] + ls2[1];
             if (__all(mnew == mold)) {
                 lrun[qb] += lsum;          // no query of this wave moved its max: alpha == 1 everywhere
             } else {
-                const float alpha = exp2f((mold - mnew) * scale_log2);
+                const float alpha = __builtin_amdgcn_exp2f((mold - mnew) * scale_log2);
                 lrun[qb] = lrun[qb] * alpha + lsum;
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
@@ -185,11 +208,8 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
                     }
                 }
         }
+        if (t + 1 < ntiles) store_l((t + 1) & 1);   // the other buffer: last read in iteration t-1, before its barrier
         __syncthreads();
-        if (t + 1 < ntiles) {
-            store_l();
-            __syncthreads();
-        }
     }
 
     // ---- normalise and store: lane owns query fr, d = 32*db + (j&3) + 8*(j>>2) + 4*fh ----
