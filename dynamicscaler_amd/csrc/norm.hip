@@ -14,30 +14,50 @@ namespace {
 
 constexpr int MAX_C = 4096;
 constexpr int GN_CHUNK_ROWS = 256;
+constexpr int GN_LDS_FLOATS = 4096;   // per array: rl*C (<= 2048 + C) when C <= 2048, C otherwise
 
-// partial sums: grid (nchunks, ninst), 256 threads. part[(inst*nchunks + chunk)*groups + g] = (sum, sumsq)
+__device__ __forceinline__ float fast_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// partial sums: grid (nchunks, ninst), 256 threads. part[(inst*nchunks + chunk)*groups + g] = (sum, sumsq).
+// A thread owns one 8-channel vector column and every rl-th row of the chunk; four rows are loaded before they are
+// accumulated (one accumulation chain per channel, in row order: the sums do not depend on the unrolling), so a
+// workgroup keeps ~15 KB in flight instead of one 16-byte load per thread.
 __global__ void __launch_bounds__(256)
 gn_partial_kernel(const f16* __restrict__ x, float2* __restrict__ part, int rows_per_inst, int C, int groups) {
-    __shared__ float csum[MAX_C];
-    __shared__ float csq[MAX_C];
+    __shared__ float csum[GN_LDS_FLOATS];
+    __shared__ float csq[GN_LDS_FLOATS];
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, inst = blockIdx.y, nchunks = gridDim.x;
     const int r0 = chunk * GN_CHUNK_ROWS;
     const int r1 = min(rows_per_inst, r0 + GN_CHUNK_ROWS);
     const int nvec = C / 8;
     const f16* base = x + (long)inst * rows_per_inst * C;
-    const int rl = nvec <= 256 ? 256 / nvec : 1;  // row lanes; rl*C <= 2048 when rl > 1
+    const int rl = nvec <= 256 ? 256 / nvec : 1;  // row lanes; rl*C <= 2048 + C when rl > 1
+    auto accumulate = [&](int col, int rfirst, int rstep, float* s, float* q) {
+        const f16* p = base + col * 8;
+        int r = rfirst;
+        for (; r + 3 * rstep < r1; r += 4 * rstep) {
+            f16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(p + (long)(r + u * rstep) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
+        }
+        for (; r < r1; r += rstep) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(p + (long)r * C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+        }
+    };
     if (nvec <= 256) {
         if (tid < rl * nvec) {
             const int col = tid % nvec, rlane = tid / nvec;
             float s[8], q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
-            for (int r = r0 + rlane; r < r1; r += rl) {
-                const f16x8 v = *reinterpret_cast<const f16x8*>(base + (long)r * C + col * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
-            }
+            accumulate(col, r0 + rlane, rl, s, q);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { csum[rlane * C + col * 8 + j] = s[j]; csq[rlane * C + col * 8 + j] = q[j]; }
         }
@@ -46,11 +66,7 @@ gn_partial_kernel(const f16* __restrict__ x, float2* __restrict__ part, int rows
             float s[8], q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
-            for (int r = r0; r < r1; ++r) {
-                const f16x8 v = *reinterpret_cast<const f16x8*>(base + (long)r * C + col * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
-            }
+            accumulate(col, r0, 1, s, q);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { csum[col * 8 + j] = s[j]; csq[col * 8 + j] = q[j]; }
         }
@@ -82,93 +98,121 @@ __global__ void gn_finalize_kernel(const float2* __restrict__ part, float* __res
     rstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// grid (nchunks, ninst)
+// grid (nchunks, ninst).  Same thread -> (column, row lane) map as the stats kernel: the per-channel scale / shift of a
+// thread's 8 channels live in registers, four rows are in flight per thread.
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                 const float* __restrict__ gamma, const float* __restrict__ beta, f16* __restrict__ y,
                 int rows_per_inst, int C, int groups, int silu) {
-    __shared__ float sa[MAX_C];
-    __shared__ float sb[MAX_C];
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, inst = blockIdx.y;
     const int cpg = C / groups;
-    for (int c = tid; c < C; c += 256) {
-        const int g = c / cpg;
-        const float r = rstd[inst * groups + g], m = mean[inst * groups + g];
-        const float a = r * gamma[c];
-        sa[c] = a;
-        sb[c] = beta[c] - m * a;
-    }
-    __syncthreads();
     const int r0 = chunk * GN_CHUNK_ROWS;
     const int r1 = min(rows_per_inst, r0 + GN_CHUNK_ROWS);
     const int nvec = C / 8;
     const long base = (long)inst * rows_per_inst * C;
-    const int total = (r1 - r0) * nvec;
-    for (int idx = tid; idx < total; idx += 256) {
-        const int r = idx / nvec, col = idx - r * nvec;
-        const long off = base + (long)(r0 + r) * C + col * 8;
-        const f16x8 v = *reinterpret_cast<const f16x8*>(x + off);
-        f16x8 o;
+    const int rl = nvec <= 256 ? 256 / nvec : 1;
+    const int ncolpass = nvec <= 256 ? 1 : (nvec + 255) / 256;
+    for (int cp = 0; cp < ncolpass; ++cp) {
+        const int col = nvec <= 256 ? tid % nvec : tid + cp * 256;
+        const int rlane = nvec <= 256 ? tid / nvec : 0;
+        if (col >= nvec || rlane >= rl) continue;
+        float a[8], b[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j] * sa[col * 8 + j] + sb[col * 8 + j];
-            if (silu) f = f / (1.0f + __expf(-f));
-            o[j] = (f16)f;
+            const int c = col * 8 + j;
+            const int g = c / cpg;
+            const float r = rstd[inst * groups + g], m = mean[inst * groups + g];
+            a[j] = r * gamma[c];
+            b[j] = beta[c] - m * a[j];
         }
-        *reinterpret_cast<f16x8*>(y + off) = o;
+        auto one = [&](const f16x8 v) {
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)v[j] * a[j] + b[j];
+                if (silu) f = fast_silu(f);
+                o[j] = (f16)f;
+            }
+            return o;
+        };
+        const f16* px = x + base + col * 8;
+        f16* py = y + base + col * 8;
+        int r = r0 + rlane;
+        for (; r + 3 * rl < r1; r += 4 * rl) {
+            f16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(px + (long)(r + u * rl) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<f16x8*>(py + (long)(r + u * rl) * C) = one(v[u]);
+        }
+        for (; r < r1; r += rl) *reinterpret_cast<f16x8*>(py + (long)r * C) = one(*reinterpret_cast<const f16x8*>(px + (long)r * C));
     }
 }
 
-// one wave per row; C <= 2560 (5 vectors of 8 per lane)
+// LayerNorm: one wave per row, NV 8-channel vectors per lane (C <= 512*NV), RW rows per wave with all their loads issued
+// before the first reduction (bytes in flight: the 320-channel rows of the first UNet level are only 640 B each).
+template <int NV, int RW>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                  f16* __restrict__ y, int rows, int C, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + wave;
-    if (row >= rows) return;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * RW;
+    if (row0 >= rows) return;
     const int nvec = C / 8;
-    constexpr int MAXV = 5;
-    float v[MAXV][8];
-    float s = 0.0f;
+    f16x8 t[RW][NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int col = lane + 64 * i;
-        if (col < nvec) {
-            const f16x8 t = *reinterpret_cast<const f16x8*>(x + row * C + col * 8);
+    for (int rw = 0; rw < RW; ++rw) {
+        const long row = row0 + rw < rows ? row0 + rw : rows - 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[i][j] = 0.0f;
+        for (int i = 0; i < NV; ++i) {
+            const int col = lane + 64 * i;
+            t[rw][i] = col < nvec ? *reinterpret_cast<const f16x8*>(x + row * C + col * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
+    f32x4 g0[NV], g1[NV], b0[NV], b1[NV];
 #pragma unroll
-    for (int sh = 1; sh < 64; sh <<= 1) s += __shfl_xor(s, sh);
-    const float mean = s / (float)C;
-    float q = 0.0f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int col = lane + 64 * i;
-        if (col < nvec) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
-        }
+        const int c = (col < nvec ? col : 0) * 8;
+        g0[i] = *reinterpret_cast<const f32x4*>(gamma + c); g1[i] = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+        b0[i] = *reinterpret_cast<const f32x4*>(beta + c);  b1[i] = *reinterpret_cast<const f32x4*>(beta + c + 4);
     }
 #pragma unroll
-    for (int sh = 1; sh < 64; sh <<= 1) q += __shfl_xor(q, sh);
-    const float rstd = rsqrtf(q / (float)C + eps);
+    for (int rw = 0; rw < RW; ++rw) {
+        if (row0 + rw >= rows) break;
+        float v[NV][8];
+        float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int col = lane + 64 * i;
-        if (col < nvec) {
-            f16x8 o;
+        for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = col * 8 + j;
-                o[j] = (f16)((v[i][j] - mean) * rstd * gamma[c] + beta[c]);
+            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[rw][i][j]; s += v[i][j]; }
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) s += __shfl_xor(s, sh);
+        const float mean = s / (float)C;
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (lane + 64 * i < nvec) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
             }
-            *reinterpret_cast<f16x8*>(y + row * C + col * 8) = o;
+        }
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) q += __shfl_xor(q, sh);
+        const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = lane + 64 * i;
+            if (col < nvec) {
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gm = j < 4 ? g0[i][j & 3] : g1[i][j & 3], bt = j < 4 ? b0[i][j & 3] : b1[i][j & 3];
+                    o[j] = (f16)((v[i][j] - mean) * rstd * gm + bt);
+                }
+                *reinterpret_cast<f16x8*>(y + (row0 + rw) * C + col * 8) = o;
+            }
         }
     }
 }
@@ -215,7 +259,12 @@ extern "C" int ds_layernorm(const void* x, const float* gamma, const float* beta
     DS_CHECK_ARG(x && gamma && beta && y, "ds_layernorm: null argument");
     DS_CHECK_ARG(rows > 0 && C % 8 == 0 && C <= 2560, "ds_layernorm: rows=%d C=%d unsupported (C %% 8 == 0, C <= 2560)", rows, C);
     hipStream_t st = (hipStream_t)stream;
-    layernorm_kernel<<<(rows + 3) / 4, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps);
+    DS_CHECK_ARG((reinterpret_cast<uintptr_t>(gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(beta) & 15) == 0, "ds_layernorm: gamma/beta must be 16-byte aligned");
+    const int nv = (C / 8 + 63) / 64;
+    if (nv == 1) layernorm_kernel<1, 4><<<(rows + 15) / 16, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps);
+    else if (nv == 2) layernorm_kernel<2, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps);
+    else if (nv == 3) layernorm_kernel<3, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps);
+    else layernorm_kernel<5, 1><<<(rows + 3) / 4, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps);
     DS_CHECK_LAUNCH("ds_layernorm");
     return DS_OK;
 }
