@@ -108,7 +108,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n,
                 unsigned a_bytes, unsigned w_bytes) {
     using Cfg = TileCfg<BM, BN, WGM, WGN>;
-    constexpr int NT = Cfg::NT, WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
+    constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
     constexpr int LROWS = Cfg::LROWS, A_ROWS_PER_THREAD = Cfg::AR, B_ROWS_PER_THREAD = Cfg::BR;
 
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -336,12 +336,6 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             for (int ni = 0; ni < TN; ++ni) bf[0][ni] = read_b(0, ni);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                if (kk + 1 < 4) {
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi) af[(kk + 1) & 1][mi] = read_a(kk + 1, mi);
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni) bf[(kk + 1) & 1][ni] = read_b(kk + 1, ni);
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 const int np = kk == 0 ? P0 : (kk == 1 ? P1 : 0);     // pieces issued inside this k-slice
                 const int stride = np > 0 ? NMF / np : NMF + 1;
@@ -349,6 +343,14 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 for (int idx = 0; idx < NMF; ++idx) {
                     const int ni = idx / TM, mi = idx % TM;
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk & 1][ni], af[kk & 1][mi], acc[ni][mi], 0, 0, 0);
+                    // the fragments of the next k-slice are read one per MFMA (not as a burst in front of the slice):
+                    // right after the barrier only the first slice's reads of the eight waves queue up at the LDS
+                    if (kk + 1 < 4 && idx < TM + TN) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (idx < TM) af[(kk + 1) & 1][idx] = read_a(kk + 1, idx);
+                        else bf[(kk + 1) & 1][idx - TM] = read_b(kk + 1, idx - TM);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (Cfg::DMA && MORE && np > 0 && idx % stride == stride - 1 && idx / stride < np) {
                         __builtin_amdgcn_sched_barrier(0);
                         dma_piece((kk == 0 ? 0 : P0) + idx / stride, buf ^ 1);

@@ -78,3 +78,44 @@ def exchange_level(x_prev_local, x0_local, n_items, group=None):
             x_prev_all[r::world] = recv[r, 0, :counts[r]]
             x0_all[r::world] = recv[r, 1, :counts[r]]
     return x_prev_all, x0_all
+
+
+class StreamPool:
+    """n worker threads, each bound to its own HIP stream: `map(fn, items)` runs fn(item) for up to n items
+    concurrently (item k on stream k), ordered after everything already queued on the caller's stream, and makes the
+    caller's stream wait for all of them.  Tensors returned by fn are handed over to the caller's stream
+    (`record_stream`), so the caching allocator does not recycle them while it still reads them."""
+
+    def __init__(self, device, n):
+        from concurrent.futures import ThreadPoolExecutor
+        self.device, self.n = device, n
+        self.streams = [torch.cuda.Stream(device) for _ in range(n)]
+        self.pool = ThreadPoolExecutor(max_workers=n)
+
+    def map(self, fn, items):
+        outs = []
+        for g in range(0, len(items), self.n):
+            group = items[g:g + self.n]
+            main = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+
+            def work(k, item):
+                torch.cuda.set_device(self.device)
+                s = self.streams[k]
+                s.wait_event(ready)
+                with torch.no_grad(), torch.cuda.stream(s):
+                    out = fn(item)
+                done = torch.cuda.Event()
+                done.record(s)
+                return out, done
+
+            futs = [self.pool.submit(work, k, it) for k, it in enumerate(group)]
+            for f in futs:
+                out, done = f.result()
+                main.wait_event(done)
+                for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
+                outs.append(out)
+        return outs

@@ -55,6 +55,8 @@ class VC2_Pipeline_T2V:
         self._device = None
         self.latent_dtype = torch.float16    # "fp16 latents" (BASELINE.json north_star); torch.float32 for bit-exact tile ops
         self.max_tile_batch = 8              # windows per batched UNet evaluation (x2 with CFG)
+        self.num_streams = 1                 # > 1: tile batches of a level run concurrently on that many HIP streams
+        self._pool = None
         self.verbose = False
 
     # -- the bits of DiffusionPipeline the reference relies on --
@@ -155,6 +157,11 @@ class VC2_Pipeline_T2V:
 
     # ------------------------------------------------------------------ the tile engine shared by all ring loops
     @torch.no_grad()
+    def _stream_pool(self, device):
+        if self._pool is None or self._pool.n != self.num_streams or self._pool.device != device:
+            self._pool = parallel.StreamPool(device, self.num_streams)
+        return self._pool
+
     def _denoise_windows(self, st, i, wins, ctxs, renoise, mask_frame0, merge_prev_ratio=None, use_mask=True):
         """Process the windows of DDIM step i (reference order `wins`) with the reference's sequential semantics:
         levels of pairwise-disjoint windows (parallel.plan_levels), each level = one batched gather -> re-noise/mix
@@ -175,9 +182,7 @@ class VC2_Pipeline_T2V:
         mask = st.mask if use_mask else None
         for level in parallel.plan_levels(wins, st.pano_fhw):
             mine = parallel.rank_share(level, st.rank, st.world)
-            xp_parts, x0_parts = [], []
-            for s in range(0, len(mine), self.max_tile_batch):
-                ids = mine[s:s + self.max_tile_batch]
+            def run_batch(ids):
                 origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
                 tiles, mtiles = ops.ring_gather(pano, origins, st.tile_fhw, mask)
                 prev = tiles.clone() if merge_prev_ratio is not None else None
@@ -203,8 +208,17 @@ class VC2_Pipeline_T2V:
                     # merge-prev (i2v_sphere_panorama_pipeline.py:938-943): mix(x_prev, window_before_renoise, mask, r_i)
                     ops.renoise_mix_(x_prev, mtiles, st.total_shape, 0.0, 1.0, merge_prev_ratio, noise=prev,
                                      mask_frame0=mask_frame0)
-                xp_parts.append(x_prev)
-                x0_parts.append(x0)
+                return x_prev, x0
+
+            # the tile batches of a level are independent (disjoint windows, the panorama is only read until the
+            # scatter below): with num_streams > 1 they run concurrently on separate HIP streams, so the partial last
+            # round of workgroups of one batch's kernels is filled by the other batch's kernels
+            batches = [mine[s:s + self.max_tile_batch] for s in range(0, len(mine), self.max_tile_batch)]
+            if self.num_streams > 1 and len(batches) > 1:
+                parts = self._stream_pool(device).map(run_batch, batches)
+            else:
+                parts = [run_batch(ids) for ids in batches]
+            xp_parts, x0_parts = [p[0] for p in parts], [p[1] for p in parts]
             if st.world > 1:
                 empty = torch.empty((0,) + st.tile_shape[1:], dtype=pano.dtype, device=device)
                 xp_l = torch.cat(xp_parts, 0) if xp_parts else empty
