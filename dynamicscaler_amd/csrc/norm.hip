@@ -99,14 +99,43 @@ __global__ void gn_finalize_kernel(const float2* __restrict__ part, float* __res
 }
 
 // grid (nchunks, ninst).  Same thread -> (column, row lane) map as the stats kernel: the per-channel scale / shift of a
-// thread's 8 channels live in registers, four rows are in flight per thread.
+// thread's 8 channels live in registers, four rows are in flight per thread.  With `part` != nullptr the workgroup first
+// reduces the instance's per-chunk partial sums itself (fp64, fixed order: 8 interleaved slices, then the slices in
+// order) instead of reading mean / rstd -- the separate finalize launch (1300 per DDIM step, each latency-bound) is gone.
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                const float* __restrict__ gamma, const float* __restrict__ beta, f16* __restrict__ y,
-                int rows_per_inst, int C, int groups, int silu) {
+                const float2* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
+                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps) {
+    __shared__ double sred[2][8][32];
+    __shared__ float smean[256], srstd[256];
     const int tid = threadIdx.x;
-    const int chunk = blockIdx.x, inst = blockIdx.y;
+    const int chunk = blockIdx.x, inst = blockIdx.y, nchunks = gridDim.x;
     const int cpg = C / groups;
+    if (part) {
+        for (int g0 = 0; g0 < groups; g0 += 32) {
+            const int g = g0 + (tid & 31), sl = tid >> 5;
+            double s = 0.0, q = 0.0;
+            if (g < groups)
+                for (int c = sl; c < nchunks; c += 8) {
+                    const float2 p = part[((long)inst * nchunks + c) * groups + g];
+                    s += (double)p.x; q += (double)p.y;
+                }
+            sred[0][sl][tid & 31] = s;
+            sred[1][sl][tid & 31] = q;
+            __syncthreads();
+            if (tid < 32 && g < groups) {
+                double ss = 0.0, qq = 0.0;
+                for (int k = 0; k < 8; ++k) { ss += sred[0][k][tid]; qq += sred[1][k][tid]; }
+                const double count = (double)rows_per_inst * cpg;
+                const double m = ss / count;
+                double var = qq / count - m * m;
+                if (var < 0.0) var = 0.0;
+                smean[g] = (float)m;
+                srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+            }
+            __syncthreads();
+        }
+    }
     const int r0 = chunk * GN_CHUNK_ROWS;
     const int r1 = min(rows_per_inst, r0 + GN_CHUNK_ROWS);
     const int nvec = C / 8;
@@ -122,7 +151,7 @@ gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const
         for (int j = 0; j < 8; ++j) {
             const int c = col * 8 + j;
             const int g = c / cpg;
-            const float r = rstd[inst * groups + g], m = mean[inst * groups + g];
+            const float r = part ? srstd[g] : rstd[inst * groups + g], m = part ? smean[g] : mean[inst * groups + g];
             a[j] = r * gamma[c];
             b[j] = beta[c] - m * a[j];
         }
@@ -249,8 +278,23 @@ extern "C" int ds_groupnorm_apply(const void* x, const float* mean, const float*
     DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && C % groups == 0, "ds_groupnorm_apply: C=%d groups=%d unsupported", C, groups);
     hipStream_t st = (hipStream_t)stream;
     const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
-    gn_apply_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, mean, rstd, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu);
+    gn_apply_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, mean, rstd, nullptr, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, 0.0f);
     DS_CHECK_LAUNCH("ds_groupnorm_apply");
+    return DS_OK;
+}
+
+extern "C" int ds_groupnorm_f16(const void* x, const float* gamma, const float* beta, void* y, float* workspace, int ninst,
+                                int rows_per_inst, int C, int groups, float eps, int silu, void* stream) {
+    DS_CHECK_ARG(x && gamma && beta && y && workspace, "ds_groupnorm_f16: null argument");
+    DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0, "ds_groupnorm_f16: ninst/rows_per_inst must be positive");
+    DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_f16: C=%d groups=%d unsupported", C, groups);
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
+    gn_partial_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups);
+    DS_CHECK_LAUNCH("ds_groupnorm_f16(stats)");
+    gn_apply_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, nullptr, nullptr, (const float2*)workspace, gamma, beta,
+                                                          (f16*)y, rows_per_inst, C, groups, silu, eps);
+    DS_CHECK_LAUNCH("ds_groupnorm_f16(apply)");
     return DS_OK;
 }
 

@@ -239,15 +239,32 @@ def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE
 def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None):
     lib = _lib.load()
     st = _stream() if stream is None else stream
+    ws = torch.empty((lib.ds_groupnorm_stats_workspace_floats(ninst, rows_per_inst, groups),), dtype=torch.float32,
+                     device=x.device)
+    y = torch.empty_like(x)
+    check(lib.ds_groupnorm_f16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), ws.data_ptr(), ninst,
+                               rows_per_inst, Cch, groups, float(eps), int(bool(silu)), st), "ds_groupnorm_f16")
+    return y
+
+
+def groupnorm_stats(x, ninst, rows_per_inst, Cch, eps, groups=32, stream=None):
+    """mean, rstd fp32 [ninst*groups] (the two-step C-ABI entry points; `groupnorm` uses the fused ds_groupnorm_f16)."""
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
     stats = torch.empty((2, ninst * groups), dtype=torch.float32, device=x.device)
     ws = torch.empty((lib.ds_groupnorm_stats_workspace_floats(ninst, rows_per_inst, groups),), dtype=torch.float32,
                      device=x.device)
     check(lib.ds_groupnorm_stats(x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(), ninst,
                                  rows_per_inst, Cch, groups, float(eps), st), "ds_groupnorm_stats")
+    return stats[0], stats[1]
+
+
+def groupnorm_apply(x, mean, rstd, gamma, beta, ninst, rows_per_inst, Cch, silu, groups=32, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
     y = torch.empty_like(x)
-    check(lib.ds_groupnorm_apply(x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(),
-                                 beta.data_ptr(), y.data_ptr(), ninst, rows_per_inst, Cch, groups, int(bool(silu)), st),
-          "ds_groupnorm_apply")
+    check(lib.ds_groupnorm_apply(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                 y.data_ptr(), ninst, rows_per_inst, Cch, groups, int(bool(silu)), st), "ds_groupnorm_apply")
     return y
 
 

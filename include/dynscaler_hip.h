@@ -157,9 +157,10 @@ int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* res
                 const ds_gemm_desc* desc, void* stream);
 
 /* GroupNorm statistics: x fp16 [ninst*rows_per_inst][C]; instance i = rows [i*rows_per_inst, (i+1)*...).
- * Writes mean/rstd fp32 [ninst][groups]; `workspace` = caller scratch of
- * ds_groupnorm_stats_workspace_floats(...) floats (per-chunk partial sums; no global atomics -> reproducible).  rows_per_inst = H*W (per-frame GroupNorm, basics.py:76-86,
- * attention.py:238) or T*H*W (5-D GroupNorm over T jointly, openaimodel3d.py:275-292, attention.py:297). */
+ * Writes mean/rstd fp32 [ninst][groups]; `workspace` = caller scratch of ds_groupnorm_stats_workspace_floats(...)
+ * floats (per-chunk partial sums; no global atomics -> reproducible).  rows_per_inst = H*W (per-frame GroupNorm,
+ * basics.py:76-86, attention.py:238) or T*H*W (5-D GroupNorm over T jointly, openaimodel3d.py:275-292,
+ * attention.py:297). */
 size_t ds_groupnorm_stats_workspace_floats(int ninst, int rows_per_inst, int groups);
 int ds_groupnorm_stats(const void* x, float* mean, float* rstd, float* workspace, int ninst, int rows_per_inst,
                        int C, int groups, float eps, void* stream);
@@ -167,6 +168,10 @@ int ds_groupnorm_stats(const void* x, float* mean, float* rstd, float* workspace
 int ds_groupnorm_apply(const void* x, const float* mean, const float* rstd, const float* gamma,
                        const float* beta, void* y, int ninst, int rows_per_inst, int C, int groups, int silu,
                        void* stream);
+/* stats + apply in two launches (the apply reduces the per-chunk partial sums itself; no mean / rstd round trip):
+   y = GroupNorm(x) (+ SiLU).  workspace: ds_groupnorm_stats_workspace_floats(...) floats.                            */
+int ds_groupnorm_f16(const void* x, const float* gamma, const float* beta, void* y, float* workspace, int ninst,
+                     int rows_per_inst, int C, int groups, float eps, int silu, void* stream);
 /* nn.LayerNorm(C) eps 1e-5 over each row (attention.py:199-201). x,y fp16 [rows][C]. */
 int ds_layernorm(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
                  void* stream);

@@ -310,6 +310,12 @@ def test_groupnorm(ninst, rows, C, silu):
         ref = F.silu(ref)
     ref = ref.permute(0, 2, 1).reshape(ninst * rows, C)
     assert relerr(y, ref) < 1e-3
+    # the two-step entry points (stats, apply) give the same normalisation
+    mean, rstd = ops.groupnorm_stats(x.half().to(d), ninst, rows, C, 1e-5)
+    y2 = ops.groupnorm_apply(x.half().to(d), mean, rstd, g.to(d), b.to(d), ninst, rows, C, silu)
+    assert relerr(y2, ref) < 1e-3 and relerr(y2, y.float().cpu()) < 2e-3
+    mref = x.reshape(ninst, rows, 32, C // 32).permute(0, 2, 1, 3).reshape(ninst * 32, -1).mean(1)
+    assert torch.allclose(mean.cpu(), mref, atol=1e-4)
 
 
 @pytest.mark.parametrize("rows,C", [(1000, 320), (77, 1280), (5, 64), (333, 512)])
