@@ -29,19 +29,27 @@ constexpr int BK = 64;  // halfs per K-step (128-byte LDS rows, 8 chunks of 16 b
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-// Epilogue activations.  The kernel is vector-issue bound, so these avoid the IEEE-division sequence (10 VALU ops) and
-// the libm erff polynomial (~40 ops): v_rcp_f32 is accurate to 1 ulp, and erf comes from Abramowitz & Stegun 7.1.26
-// (|error| <= 1.5e-7 absolute) -- both far below the fp16 rounding of the stored result.
+// Epilogue activations.  The epilogue is vector-issue bound, so these avoid the IEEE-division sequence (10 VALU ops;
+// v_rcp_f32 is accurate to 1 ulp) and the libm erff polynomial (~40 ops).
 __device__ __forceinline__ float fast_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-__device__ __forceinline__ float fast_gelu_erf(float g) {
-    const float x = fabsf(g) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-x * x);       // erf(|g|/sqrt2)
-    return 0.5f * g * (1.0f + copysignf(e, g));
+// exact-erf GELU, two values at a time (packed fp32 math):  gelu(g) = g/2 * (1 + erf(g/sqrt2)) and
+// 1 + erf(g/sqrt2) = E(|g|) for g < 0, 2 - E(|g|) otherwise, with E(a) = erfc(a/sqrt2) = 2^-q(a).  q is a degree-6
+// polynomial fitted on [0, 6] (max error 6.5e-5 in q = 4.5e-5 RELATIVE in erfc, so the small negative tail keeps its
+// relative accuracy; |gelu error| <= 6.5e-6 absolute, two orders below the fp16 rounding of the result).  One v_exp_f32
+// and 7 packed ops per pair of values.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fast_gelu_erf2(f32x2 g) {
+    const f32x2 a = {fminf(fabsf(g[0]), 6.0f), fminf(fabsf(g[1]), 6.0f)};
+    f32x2 q = {-2.2990398065303452e-05f, -2.2990398065303452e-05f};
+    q = __builtin_elementwise_fma(q, a, f32x2{0.0006110938265919685f, 0.0006110938265919685f});
+    q = __builtin_elementwise_fma(q, a, f32x2{-0.007195422891527414f, -0.007195422891527414f});
+    q = __builtin_elementwise_fma(q, a, f32x2{0.05118447542190552f, 0.05118447542190552f});
+    q = __builtin_elementwise_fma(q, a, f32x2{0.46127405762672424f, 0.46127405762672424f});
+    q = __builtin_elementwise_fma(q, a, f32x2{1.150172233581543f, 1.150172233581543f});
+    q = __builtin_elementwise_fma(q, a, f32x2{6.5313492086716e-05f, 6.5313492086716e-05f});
+    const f32x2 e = {__builtin_amdgcn_exp2f(-q[0]), __builtin_amdgcn_exp2f(-q[1])};
+    const f32x2 t = {g[0] < 0.0f ? e[0] : 2.0f - e[0], g[1] < 0.0f ? e[1] : 2.0f - e[1]};
+    return (g * f32x2{0.5f, 0.5f}) * t;
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -405,10 +413,13 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const float xv = acc[2 * p2][mi][j] + bxq[j >> 2][j & 3];
-                        const float gv = acc[2 * p2 + 1][mi][j] + bgq[j >> 2][j & 3];
-                        acc[p2][mi][j] = xv * fast_gelu_erf(gv);
+                    for (int j = 0; j < 16; j += 2) {
+                        const f32x2 xv = {acc[2 * p2][mi][j] + bxq[j >> 2][j & 3], acc[2 * p2][mi][j + 1] + bxq[j >> 2][(j & 3) + 1]};
+                        const f32x2 gv = {acc[2 * p2 + 1][mi][j] + bgq[j >> 2][j & 3],
+                                          acc[2 * p2 + 1][mi][j + 1] + bgq[j >> 2][(j & 3) + 1]};
+                        const f32x2 r = xv * fast_gelu_erf2(gv);
+                        acc[p2][mi][j] = r[0];
+                        acc[p2][mi][j + 1] = r[1];
                     }
             }
         }
@@ -497,7 +508,15 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                                     f16x8 o;
 #pragma unroll
                                     for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
+#ifdef DS_EXP_NOSTORE
+                                    asm volatile("" ::"v"(o));
+#else
+#ifdef DS_EXP_NOSTORE   // diagnostic builds only (tools/build_stamps.sh)
+                                    asm volatile("" ::"v"(o));
+#else
                                     *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(out) + (long)m * d.ldc + ocol) = o;
+#endif
+#endif
                                 }
                             }
                         }
