@@ -393,8 +393,10 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     };
-    auto epilogue = [&](auto ge_tag) {
+    auto epilogue = [&](auto ge_tag, auto res_tag, auto pib_tag) {
         constexpr bool GE = decltype(ge_tag)::value;
+        constexpr bool RES = decltype(res_tag)::value;   // residual add
+        constexpr bool PIB = !GE && decltype(pib_tag)::value;   // per-item bias (time-embedding add), never with GEGLU
         constexpr int TNE = GE ? TN / 2 : TN;          // output tiles per wave row (GEGLU halves the columns)
         constexpr int NG = Cfg::NG, STR = Cfg::STR;
         if constexpr (GE) {
@@ -462,62 +464,62 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 }
                 wave_sync();
                 if (fast) {
-                    // the global loads of a batch of sweeps (residual, per-item bias) are issued before any is consumed
-                    constexpr int SB = 4;
+                    // Batches of SB sweeps: first the global loads (residual, per-item bias), then ALL the strip reads of
+                    // the batch, then the arithmetic and the stores -- straight-line code (RES / PIB are compile-time),
+                    // so the LDS and memory latencies of a batch overlap instead of adding up per sweep.
+                    constexpr int SB = TM * TN > 8 ? 2 : 4;   // 160 accumulator registers leave room for two sweeps
                     const int nsw = (32 + rps - 1) / rps;
+                    const long out_step = (long)rps * d.ldc, res_step = (long)rps * d.ldr;
+                    f16* const out_base = reinterpret_cast<f16*>(out) + (long)(mrow0 + r0) * d.ldc + ocol;
+                    const f16* const res_base = RES ? residual + (long)(mrow0 + r0) * d.ldr + ocol : nullptr;
 #pragma unroll
                     for (int sb = 0; sb < 8; sb += SB) {
                         if (sb < nsw) {
                             f16x8 res[SB];
-                            f32x4 pb0[SB], pb1[SB];
+                            f32x4 pb0[SB], pb1[SB], p0[SB], p1[SB];
+                            bool ok[SB];
 #pragma unroll
                             for (int u = 0; u < SB; ++u) {
                                 const int row = (sb + u) * rps + r0;
-                                const int m = mrow0 + row;
-                                const bool ok = col_on && row < 32 && m < d.M;
-                                const long mm = ok ? m : 0;
-                                const long oc = ok ? ocol : 0;
-                                if (residual) res[u] = *reinterpret_cast<const f16x8*>(residual + mm * d.ldr + oc);
-                                if (bias && !shared_bias) {
-                                    const long brow = (long)((int)mm / d.bias_rows) * d.ldbias + (ok ? ncol : 0);
-                                    pb0[u] = *reinterpret_cast<const f32x4*>(bias + brow);
-                                    pb1[u] = *reinterpret_cast<const f32x4*>(bias + brow + 4);
+                                ok[u] = col_on && row < 32 && mrow0 + row < d.M;
+                                if constexpr (RES) res[u] = *reinterpret_cast<const f16x8*>(ok[u] ? res_base + (sb + u) * res_step : residual);
+                                if constexpr (PIB) {
+                                    const int mm = ok[u] ? mrow0 + row : 0;
+                                    const float* bp = bias + (long)(mm / d.bias_rows) * d.ldbias + (ok[u] ? ncol : 0);
+                                    pb0[u] = *reinterpret_cast<const f32x4*>(bp);
+                                    pb1[u] = *reinterpret_cast<const f32x4*>(bp + 4);
                                 }
                             }
 #pragma unroll
                             for (int u = 0; u < SB; ++u) {
-                                const int row = (sb + u) * rps + r0;
-                                const int m = mrow0 + row;
-                                if (col_on && row < 32 && m < d.M) {
-                                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * 8);
-                                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * 8 + 4);
-                                    float v[8] = {p0[0] + bx[0], p0[1] + bx[1], p0[2] + bx[2], p0[3] + bx[3],
-                                                  p1[0] + bx[4], p1[1] + bx[5], p1[2] + bx[6], p1[3] + bx[7]};
-                                    if (!GE && bias && !shared_bias) {
-                                        v[0] += pb0[u][0]; v[1] += pb0[u][1]; v[2] += pb0[u][2]; v[3] += pb0[u][3];
-                                        v[4] += pb1[u][0]; v[5] += pb1[u][1]; v[6] += pb1[u][2]; v[7] += pb1[u][3];
-                                    }
-                                    if (residual) {
+                                const int row = min((sb + u) * rps + r0, 31);
+                                p0[u] = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * 8);
+                                p1[u] = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * 8 + 4);
+                            }
 #pragma unroll
-                                        for (int j = 0; j < 8; ++j) v[j] += (float)res[u][j];
-                                    }
-                                    if (silu) {
-#pragma unroll
-                                        for (int j = 0; j < 8; ++j) v[j] = fast_silu(v[j]);
-                                    }
-                                    f16x8 o;
-#pragma unroll
-                                    for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
-#ifdef DS_EXP_NOSTORE
-                                    asm volatile("" ::"v"(o));
-#else
-#ifdef DS_EXP_NOSTORE   // diagnostic builds only (tools/build_stamps.sh)
-                                    asm volatile("" ::"v"(o));
-#else
-                                    *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(out) + (long)m * d.ldc + ocol) = o;
-#endif
-#endif
+                            for (int u = 0; u < SB; ++u) {
+                                float v[8] = {p0[u][0] + bx[0], p0[u][1] + bx[1], p0[u][2] + bx[2], p0[u][3] + bx[3],
+                                              p1[u][0] + bx[4], p1[u][1] + bx[5], p1[u][2] + bx[6], p1[u][3] + bx[7]};
+                                if constexpr (PIB) {
+                                    v[0] += pb0[u][0]; v[1] += pb0[u][1]; v[2] += pb0[u][2]; v[3] += pb0[u][3];
+                                    v[4] += pb1[u][0]; v[5] += pb1[u][1]; v[6] += pb1[u][2]; v[7] += pb1[u][3];
                                 }
+                                if constexpr (RES) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) v[j] += (float)res[u][j];
+                                }
+                                if (silu) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) v[j] = fast_silu(v[j]);
+                                }
+                                f16x8 o;
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
+#ifdef DS_EXP_NOSTORE   // diagnostic builds only (tools/build_stamps.sh)
+                                asm volatile("" ::"v"(o));
+#else
+                                if (ok[u]) *reinterpret_cast<f16x8*>(out_base + (sb + u) * out_step) = o;
+#endif
                             }
                         }
                     }
@@ -539,10 +541,20 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             }
         }
     };
+    const bool pib = bias && !shared_bias;
+    auto with_bias_mode = [&](auto ge_tag, auto res_tag) {
+        if (pib) epilogue(ge_tag, res_tag, std::true_type{});
+        else epilogue(ge_tag, res_tag, std::false_type{});
+    };
     if (geglu) {
-        if constexpr (TN % 2 == 0) epilogue(std::true_type{});
+        if constexpr (TN % 2 == 0) {
+            if (residual) epilogue(std::true_type{}, std::true_type{}, std::false_type{});
+            else epilogue(std::true_type{}, std::false_type{}, std::false_type{});
+        }
+    } else if (residual) {
+        with_bias_mode(std::false_type{}, std::true_type{});
     } else {
-        epilogue(std::false_type{});
+        with_bias_mode(std::false_type{}, std::false_type{});
     }
     DS_STAMP(4);
 }
