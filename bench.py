@@ -144,10 +144,16 @@ def main():
         shapes = {}
         for name, flops, e0, e1, info in events:
             dt = e0.elapsed_time(e1) * 1e-3
-            for a in (agg.setdefault(name, [0, 0.0, 0.0]), shapes.setdefault((name,) + tuple(info or ()), [0, 0.0, 0.0])):
+            nbytes = 0.0
+            if name == "gemm" and info:   # A + W + out once, fp16 (GEGLU writes N/2 columns)
+                _, M_, N_, K_, epi_ = info
+                kin = K_ // 9 if info[0] == 1 else (K_ // 3 if info[0] == 2 else K_)
+                nbytes = 2.0 * (M_ * kin + N_ * K_ + M_ * (N_ // 2 if epi_ & 1 else N_))
+            for a in (agg.setdefault(name, [0, 0.0, 0.0, 0.0]), shapes.setdefault((name,) + tuple(info or ()), [0, 0.0, 0.0, 0.0])):
                 a[0] += 1
                 a[1] += flops
                 a[2] += dt
+                a[3] += nbytes
         if os.environ.get("DS_BENCH_BREAKDOWN") and rank == 0:   # per-shape table (diagnostics, profiles/)
             with open(os.environ["DS_BENCH_BREAKDOWN"], "w") as f:
                 f.write("kernel,shape,launches,ms_per_step,tflops\n")
@@ -155,10 +161,21 @@ def main():
                     f.write(f"{k[0]},{'x'.join(map(str, k[1:]))},{a[0]},{a[2] * 1e3:.3f},{a[1] / a[2] / 1e12:.1f}\n")
         g = agg["gemm"]
         achieved = g[1] / g[2] / 1e12
+        # HBM bytes per GEMM launch: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_summary.py) cannot
+        # run inside this process; the committed summary of the same workload is quoted, with its source
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            src = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic_v*.json")))[-1]
+            traffic = json.load(open(src))["gemm_f16_kernel(all)"]["hbm_bytes_per_launch"]
+            traffic_src = os.path.relpath(src, REPO)
+        except Exception:
+            pass
         roofline = {
             "bound": "mfma", "kernel": "gemm_f16_kernel (implicit GEMM: linear / conv3x3 / temporal conv)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
-            "frac": round(achieved * 1e12 / MFMA_PEAK_F16, 4), "traffic": None,
+            "frac": round(achieved * 1e12 / MFMA_PEAK_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(g[3] / g[0]),
             "launches_per_step": g[0], "algorithmic_tflop_per_step": round(g[1] / 1e12, 2),
             "avg_launch_us": round(1e6 * g[2] / g[0], 2), "gemm_time_share_of_step": round(g[2] / (elapsed / args.steps), 3),
             "attention_tflops": round(agg["attention"][1] / agg["attention"][2] / 1e12, 2) if "attention" in agg else None,

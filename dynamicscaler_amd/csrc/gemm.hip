@@ -71,7 +71,10 @@ __device__ unsigned long long* ds_dbg_stamps = nullptr;
         unsigned long long t_;                                                                        \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        if (ds_dbg_stamps && threadIdx.x == 0) ds_dbg_stamps[(size_t)blockIdx.x * 8 + (i)] = t_;      \
+        if (ds_dbg_stamps && threadIdx.x == 0) {                                                      \
+            ds_dbg_stamps[(size_t)blockIdx.x * 8 + (i)] = t_;                                         \
+            if ((i) == 0 || (i) == 4) ds_dbg_stamps[(size_t)blockIdx.x * 8 + 5 + (i) / 4] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                             \
     } while (0)
 #else
 #define DS_STAMP(i) do {} while (0)

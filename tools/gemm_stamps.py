@@ -68,8 +68,11 @@ seg = np.diff(s[:, :5], axis=1).astype(np.float64)
 names = ["prologue", "mainloop", "acc->lds", "epilogue"]
 tot = s[:, 4] - s[:, 0]
 span = s[:, 4].max() - s[:, 0].min()
+# in-kernel shader clock: d(s_memtime) / d(s_memrealtime) x 100 MHz, median over workgroups (MI355X_MICROARCH.md)
+rt = (s[:, 6] - s[:, 5]).astype(np.float64)
+clk = np.median((s[:, 4] - s[:, 0])[rt > 0] / rt[rt > 0]) * 100.0
 print(f"shape M={M} N={N} K={K} epi={epi} conv={conv}: {t_plain:.3f} ms/launch unstamped ({2.0*M*N*K/t_plain/1e9:.0f} TFLOP/s), "
-      f"{t_st:.3f} ms stamped; {len(s)} workgroups; kernel span {span} cycles -> clock {span / (t_st * 1e3):.0f} MHz (approx)")
+      f"{t_st:.3f} ms stamped; {len(s)} workgroups; in-kernel shader clock {clk:.0f} MHz")
 for i, n in enumerate(names):
     print(f"  {n:10s} median {np.median(seg[:, i]):9.0f}  mean {seg[:, i].mean():9.0f}  p90 {np.percentile(seg[:, i], 90):9.0f} cycles")
 print(f"  {'total':10s} median {np.median(tot):9.0f}  mean {tot.mean():9.0f}; sum of workgroup cycles / span = {tot.sum() / span:.1f} concurrent workgroups "

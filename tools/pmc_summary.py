@@ -13,7 +13,7 @@ from collections import defaultdict
 
 
 def family(name):
-    m = re.search(r"(gemm_f16_kernel)ILi(\d+)ELi(\d+)ELi(\d)E", name)
+    m = re.search(r"(gemm_f16_kernel)ILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)E", name)
     if m:
         return f"gemm_f16_kernel<{m.group(2)},{m.group(3)},mode{m.group(4)}>"
     for k in ("attention_kernel", "temporal_attention_kernel", "gn_apply_kernel", "gn_partial_kernel", "layernorm_kernel",
