@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tile-batch", type=int, default=int(os.environ.get("DS_TILE_BATCH", "8")))
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DS_STREAMS", "1")))
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("DS_GRAPH", "1")), help="hipGraph replay of the UNet evaluation")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,6 +95,7 @@ def main():
     pipe.to(dev, torch.float16)
     pipe.max_tile_batch = args.tile_batch
     pipe.num_streams = args.streams
+    pipe.use_graph = bool(args.graph)
     init = synth_normal((1, 4, 16, 64, 512), 2333333).to(dev)
     st = pipe.ring_begin(prompt="a synthetic prompt", fps=8, guidance_scale=7.5, init_panorama_latent=init, **GEOM)
 
@@ -137,6 +139,7 @@ def main():
 
         ops.set_timing_hook(hook)
         pipe.num_streams = 1               # per-launch durations are taken with one kernel on the GPU at a time
+        pipe.use_graph = False             # ... and launch by launch
         pipe.ring_step(st, step_idx)
         torch.cuda.synchronize()
         ops.set_timing_hook(None)
@@ -223,7 +226,7 @@ def main():
             "config": {"workload": "t2v_sphere_panorama 4096x512x16f, 8x2 shifted ring windows (16 tiles/step), CFG 7.5, "
                                    "VideoCrafter2 t2v UNet 1.41B, DDIM 50-step schedule",
                        "tiles_per_step": tiles_per_step, "unet_evals_per_step": 2 * tiles_per_step,
-                       "tile_batch": args.tile_batch, "streams": args.streams, "parallelism": f"tiles sharded over {world} GPU(s)",
+                       "tile_batch": args.tile_batch, "streams": args.streams, "hipgraph": bool(args.graph), "parallelism": f"tiles sharded over {world} GPU(s)",
                        "rng": "philox in-kernel (perf mode)"},
             "sec_per_50_step_panorama": 50 * elapsed / args.steps,
             "speedup_vs_cpu_baseline": (steps_per_s / cpu_baseline["value"]) if cpu_baseline else None,

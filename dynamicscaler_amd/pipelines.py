@@ -57,6 +57,8 @@ class VC2_Pipeline_T2V:
         self.max_tile_batch = 8              # windows per batched UNet evaluation (x2 with CFG)
         self.num_streams = 1                 # > 1: tile batches of a level run concurrently on that many HIP streams
         self._pool = None
+        self.use_graph = False               # hipGraph replay of the UNet evaluation (see _eps)
+        self._graphs = {}
         self.verbose = False
 
     # -- the bits of DiffusionPipeline the reference relies on --
@@ -104,12 +106,38 @@ class VC2_Pipeline_T2V:
         return prompt, text_emb, uc_emb
 
     def _eps(self, x, t, ctx_list, fps, frames, **kwargs):
-        """One batched evaluation of pretrained_t2v.model: x [n,C,T,h,w], ctx_list n context tensors [1,L,D]."""
+        """One batched evaluation of pretrained_t2v.model: x [n,C,T,h,w], ctx_list n context tensors [1,L,D].
+        With `use_graph` the evaluation is a hipGraph replay (one graph per input signature, captured on its second
+        use): the ~1250 launches of a forward cost no host time, which is what bounds small tile batches (a rank's
+        share of a level on 4-8 GPUs).  The returned tensor is then the graph's static output buffer: it is
+        overwritten by the next evaluation of the same signature."""
         n = x.shape[0]
-        ts = torch.full((n,), int(t), device=x.device, dtype=torch.long)
         ctx = torch.cat([c.to(x.device) for c in ctx_list], dim=0)
-        return self.pretrained_t2v.model(x, ts, c_crossattn=[ctx], fps=fps, curr_time_steps=ts,
-                                         temporal_length=frames, **kwargs)
+        model = self.pretrained_t2v.model
+        if not (self.use_graph and x.is_cuda and self.num_streams == 1 and isinstance(fps, int)):
+            ts = torch.full((n,), int(t), device=x.device, dtype=torch.long)
+            return model(x, ts, c_crossattn=[ctx], fps=fps, curr_time_steps=ts, temporal_length=frames, **kwargs)
+        key = (tuple(x.shape), x.dtype, tuple(ctx.shape), ctx.dtype, fps, frames, tuple(sorted(kwargs.items())))
+        ent = self._graphs.get(key)
+        if ent is None:                      # first use: eager (loads code objects, sets kernel attributes)
+            self._graphs[key] = "warm"
+            ts = torch.full((n,), int(t), device=x.device, dtype=torch.long)
+            return model(x, ts, c_crossattn=[ctx], fps=fps, curr_time_steps=ts, temporal_length=frames, **kwargs)
+        if ent == "warm":                    # second use: capture
+            sx, sctx = x.clone(), ctx.clone()
+            sts = torch.full((n,), int(t), device=x.device, dtype=torch.long)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = model(sx, sts, c_crossattn=[sctx], fps=fps, curr_time_steps=sts, temporal_length=frames, **kwargs)
+            ent = self._graphs[key] = (g, sx, sts, sctx, out)
+        else:
+            g, sx, sts, sctx, out = ent
+            sx.copy_(x)
+            sts.fill_(int(t))
+            sctx.copy_(ctx)
+        ent[0].replay()
+        return ent[4]
 
     @torch.no_grad()
     def basic_sample(self, prompt=None, height=320, width=512, frames=16, fps=16, guidance_scale=7.5,

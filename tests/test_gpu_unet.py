@@ -146,6 +146,34 @@ def test_pipelines_small_vs_reference_golden():
                 assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"]
 
 
+def test_ring_pipeline_hipgraph_and_streams_equal_eager():
+    """The UNet evaluation as a hipGraph replay (use_graph) and the tile batches of a level on two HIP streams
+    (num_streams) must give the panorama of the plain eager loop bit for bit (same kernels, same order per element)."""
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    d = dev()
+    z = np.load(os.path.join(G, "loops_small.npz"))
+    meta = json.load(open(os.path.join(G, "loops_small_traces.json")))
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    ld = _host(params, 5, T(z["cond"]), T(z["uncond"]), d)
+    cfgd = {"params": {"unet_config": {"params": params}}}
+    outs = {}
+    for mode in ("eager", "graph", "streams"):
+        pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), cfgd).to(d, torch.float16)
+        pipe.use_graph = mode == "graph"
+        if mode == "streams":
+            pipe.num_streams, pipe.max_tile_batch = 2, 2
+        torch.manual_seed(2333333)
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                       **meta["geoms"]["grid4x2"])
+        outs[mode] = (den.float().cpu(), pipe.final_latent.float().cpu())
+        if mode == "graph":
+            assert any(isinstance(v, tuple) for v in pipe._graphs.values()), "no graph was captured"
+    for mode in ("graph", "streams"):
+        assert torch.equal(outs[mode][0], outs["eager"][0]) and torch.equal(outs[mode][1], outs["eager"][1]), mode
+
+
 def _oracle_fake(x, ts, ctx):
     return 0.1 * x + 0.01 * ctx.mean()
 
