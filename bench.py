@@ -11,6 +11,9 @@ with fp32 accumulation.  A "step" = one DDIM step over ALL tiles: ring gather ->
 -> CFG+DDIM -> scatter (+ the per-level tile all-gather when N > 1).  Inputs are resident in HBM before the timed
 region; nothing is skipped.  N > 1 shards the tiles of the SAME panorama over the ranks (strong scaling).
 
+Defaults: the tile batches of a dependency level run on two HIP streams (4 + 4 tiles at N = 1) as hipGraph replays of
+the batched UNet evaluation (`--streams 1 --graph 0` = plain eager loop, same results bit for bit).
+
 One JSON line on rank 0 with the driver's fields plus
   "roofline":     the dominant kernel family (implicit-GEMM MFMA kernel): algorithmic FLOPs of every launch of one
                   step / sum of their HIP-event durations, against the dense fp16 MFMA peak (2.5 PFLOP/s)
@@ -56,7 +59,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tile-batch", type=int, default=int(os.environ.get("DS_TILE_BATCH", "8")))
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DS_STREAMS", "1")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DS_STREAMS", "2")))
     ap.add_argument("--graph", type=int, default=int(os.environ.get("DS_GRAPH", "1")), help="hipGraph replay of the UNet evaluation")
     args = ap.parse_args()
 
@@ -179,6 +182,7 @@ def main():
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / MFMA_PEAK_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(g[3] / g[0]),
+            "measured_with": "per-launch HIP events on one extra step, one stream, eager launches, tile batch %d" % args.tile_batch,
             "launches_per_step": g[0], "algorithmic_tflop_per_step": round(g[1] / 1e12, 2),
             "avg_launch_us": round(1e6 * g[2] / g[0], 2), "gemm_time_share_of_step": round(g[2] / (elapsed / args.steps), 3),
             "attention_tflops": round(agg["attention"][1] / agg["attention"][2] / 1e12, 2) if "attention" in agg else None,

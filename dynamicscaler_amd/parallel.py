@@ -92,7 +92,9 @@ class StreamPool:
         self.streams = [torch.cuda.Stream(device) for _ in range(n)]
         self.pool = ThreadPoolExecutor(max_workers=n)
 
-    def map(self, fn, items):
+    def map(self, fn, items, inline=False, on_slot=None):
+        """inline=True: no worker threads -- the caller's thread enqueues item k on stream k itself (right when every
+        fn(item) only enqueues a few launches, e.g. hipGraph replays); on_slot(k) is called before fn(item)."""
         outs = []
         for g in range(0, len(items), self.n):
             group = items[g:g + self.n]
@@ -105,17 +107,23 @@ class StreamPool:
                 s = self.streams[k]
                 s.wait_event(ready)
                 with torch.no_grad(), torch.cuda.stream(s):
+                    if on_slot is not None:
+                        on_slot(k)
                     out = fn(item)
                 done = torch.cuda.Event()
                 done.record(s)
                 return out, done
 
-            futs = [self.pool.submit(work, k, it) for k, it in enumerate(group)]
-            for f in futs:
-                out, done = f.result()
+            if inline:
+                results = [work(k, it) for k, it in enumerate(group)]
+            else:
+                results = [f.result() for f in [self.pool.submit(work, k, it) for k, it in enumerate(group)]]
+            for out, done in results:
                 main.wait_event(done)
                 for t in (out if isinstance(out, (tuple, list)) else (out,)):
                     if torch.is_tensor(t):
                         t.record_stream(main)
                 outs.append(out)
+        if on_slot is not None:
+            on_slot(0)
         return outs

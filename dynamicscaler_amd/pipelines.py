@@ -59,6 +59,7 @@ class VC2_Pipeline_T2V:
         self._pool = None
         self.use_graph = False               # hipGraph replay of the UNet evaluation (see _eps)
         self._graphs = {}
+        self._slot = 0                       # stream slot of the tile batch being enqueued (one graph set per slot)
         self.verbose = False
 
     # -- the bits of DiffusionPipeline the reference relies on --
@@ -110,14 +111,14 @@ class VC2_Pipeline_T2V:
         With `use_graph` the evaluation is a hipGraph replay (one graph per input signature, captured on its second
         use): the ~1250 launches of a forward cost no host time, which is what bounds small tile batches (a rank's
         share of a level on 4-8 GPUs).  The returned tensor is then the graph's static output buffer: it is
-        overwritten by the next evaluation of the same signature."""
+        overwritten by the next evaluation of the same signature on the same stream slot."""
         n = x.shape[0]
         ctx = torch.cat([c.to(x.device) for c in ctx_list], dim=0)
         model = self.pretrained_t2v.model
-        if not (self.use_graph and x.is_cuda and self.num_streams == 1 and isinstance(fps, int)):
+        if not (self.use_graph and x.is_cuda and isinstance(fps, int)):
             ts = torch.full((n,), int(t), device=x.device, dtype=torch.long)
             return model(x, ts, c_crossattn=[ctx], fps=fps, curr_time_steps=ts, temporal_length=frames, **kwargs)
-        key = (tuple(x.shape), x.dtype, tuple(ctx.shape), ctx.dtype, fps, frames, tuple(sorted(kwargs.items())))
+        key = (self._slot, tuple(x.shape), x.dtype, tuple(ctx.shape), ctx.dtype, fps, frames, tuple(sorted(kwargs.items())))
         ent = self._graphs.get(key)
         if ent is None:                      # first use: eager (loads code objects, sets kernel attributes)
             self._graphs[key] = "warm"
@@ -241,9 +242,15 @@ class VC2_Pipeline_T2V:
             # the tile batches of a level are independent (disjoint windows, the panorama is only read until the
             # scatter below): with num_streams > 1 they run concurrently on separate HIP streams, so the partial last
             # round of workgroups of one batch's kernels is filled by the other batch's kernels
-            batches = [mine[s:s + self.max_tile_batch] for s in range(0, len(mine), self.max_tile_batch)]
+            bsz = self.max_tile_batch
+            if self.num_streams > 1:         # spread this rank's share of the level over the streams
+                bsz = max(1, min(bsz, -(-len(mine) // self.num_streams)))
+            batches = [mine[s:s + bsz] for s in range(0, len(mine), bsz)]
             if self.num_streams > 1 and len(batches) > 1:
-                parts = self._stream_pool(device).map(run_batch, batches)
+                # graph replays are enqueued by this thread (one call per evaluation); eager launches need a host
+                # thread per stream to keep both streams fed
+                parts = self._stream_pool(device).map(run_batch, batches, inline=self.use_graph,
+                                                      on_slot=lambda k: setattr(self, "_slot", k))
             else:
                 parts = [run_batch(ids) for ids in batches]
             xp_parts, x0_parts = [p[0] for p in parts], [p[1] for p in parts]

@@ -159,18 +159,18 @@ def test_ring_pipeline_hipgraph_and_streams_equal_eager():
     ld = _host(params, 5, T(z["cond"]), T(z["uncond"]), d)
     cfgd = {"params": {"unet_config": {"params": params}}}
     outs = {}
-    for mode in ("eager", "graph", "streams"):
+    for mode in ("eager", "graph", "streams", "graph+streams"):
         pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), cfgd).to(d, torch.float16)
-        pipe.use_graph = mode == "graph"
-        if mode == "streams":
+        pipe.use_graph = "graph" in mode
+        if "streams" in mode:
             pipe.num_streams, pipe.max_tile_batch = 2, 2
         torch.manual_seed(2333333)
         _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
                                                        **meta["geoms"]["grid4x2"])
         outs[mode] = (den.float().cpu(), pipe.final_latent.float().cpu())
-        if mode == "graph":
+        if "graph" in mode:
             assert any(isinstance(v, tuple) for v in pipe._graphs.values()), "no graph was captured"
-    for mode in ("graph", "streams"):
+    for mode in ("graph", "streams", "graph+streams"):
         assert torch.equal(outs[mode][0], outs["eager"][0]) and torch.equal(outs[mode][1], outs["eager"][1]), mode
 
 
