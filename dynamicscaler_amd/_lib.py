@@ -46,6 +46,8 @@ SIGNATURES = {
     "ds_cfg_ddim": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, C.POINTER(RingGeom), _i, _vp]),
     "ds_map_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ds_map_scatter3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ds_map_gather_frames": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ds_map_scatter3_frames": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ds_map_splat": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ds_resize_latent": (_i, [_vp, _vp, _i, C.c_long, _i, _i, _i, _i, _i, _vp]),
     "ds_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),

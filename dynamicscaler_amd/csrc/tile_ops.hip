@@ -229,36 +229,50 @@ __global__ void __launch_bounds__(256) cfg_ddim_kernel(const T* __restrict__ x, 
 // Sphere path: perspective view <-> equirect panorama through a host-computed int32 index map
 // (utils/panorama_tensor_utils.py:154-202).  idx[i][p] < 0 = skip (invalid sample / duplicate-target loser).
 // ---------------------------------------------------------------------------------------------
+// Frame windows (RingPanoramaLatentProxy, utils/ring_panorama_tensor_utils.py:262-314): a tile holds tf frames starting
+// at panorama frame f0[i] and wrapping modulo F; tf == F with f0 == nullptr is the plain PanoramaLatentProxy case.
 template <typename T>
 __global__ void __launch_bounds__(256) map_gather_kernel(const T* __restrict__ pano, T* __restrict__ tiles,
-                                                         const int* __restrict__ idx, int CF, int HW, int P, int n) {
-    const long total = (long)n * CF * P;
+                                                         const int* __restrict__ idx, const int* __restrict__ f0, int C,
+                                                         int F, int tf, int HW, int P, int n) {
+    const long total = (long)n * C * tf * P;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int p = (int)(t % P);
-        const long r = t / P;
-        const int cf = (int)(r % CF);
-        const int i = (int)(r / CF);
+        long r = t / P;
+        const int tt = (int)(r % tf);
+        r /= tf;
+        const int c = (int)(r % C);
+        const int i = (int)(r / C);
+        const int fr = ((f0 ? f0[i] : 0) + tt) % F;
         const int src = idx[(long)i * P + p];
-        tiles[t] = src >= 0 ? pano[(long)cf * HW + src] : (T)0;
+        tiles[t] = src >= 0 ? pano[((long)c * F + fr) * HW + src] : (T)0;
     }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) map_scatter3_kernel(T* __restrict__ pano_lat, T* __restrict__ pano_x0,
                                                            uint8_t* __restrict__ mask, const T* __restrict__ xprev,
-                                                           const T* __restrict__ x0t, const int* __restrict__ idx, int CF,
-                                                           int HW, int P, int n) {
-    const long total = (long)n * CF * P;
+                                                           const T* __restrict__ x0t, const int* __restrict__ idx,
+                                                           const int* __restrict__ f0, int C, int F, int tf, int HW, int P,
+                                                           int n, int mask_per_frame) {
+    const long total = (long)n * C * tf * P;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int p = (int)(t % P);
-        const long r = t / P;
-        const int cf = (int)(r % CF);
-        const int i = (int)(r / CF);
+        long r = t / P;
+        const int tt = (int)(r % tf);
+        r /= tf;
+        const int c = (int)(r % C);
+        const int i = (int)(r / C);
         const int dst = idx[(long)i * P + p];
         if (dst < 0) continue;
-        if (pano_lat) pano_lat[(long)cf * HW + dst] = xprev[t];
-        if (pano_x0) pano_x0[(long)cf * HW + dst] = x0t[t];
-        if (mask && cf == 0) mask[dst] = 1;
+        const int fr = ((f0 ? f0[i] : 0) + tt) % F;
+        const long o = ((long)c * F + fr) * HW + dst;
+        if (pano_lat) pano_lat[o] = xprev[t];
+        if (pano_x0) pano_x0[o] = x0t[t];
+        if (mask && c == 0) {
+            if (mask_per_frame) mask[(long)fr * HW + dst] = 1;
+            else if (tt == 0) mask[dst] = 1;
+        }
     }
 }
 
@@ -439,36 +453,61 @@ extern "C" int ds_cfg_ddim(const void* x, const void* eps_c, const void* eps_u, 
     return DS_OK;
 }
 
+static int map_gather_impl(const void* pano, void* tiles, const int32_t* idx, const int32_t* f0, int C, int F, int tf,
+                           int HW, int P, int n, int dtype, void* stream, const char* name) {
+    DS_CHECK_ARG(pano && tiles && idx, "%s: null argument", name);
+    DS_CHECK_ARG(C > 0 && F > 0 && tf > 0 && tf <= F && HW > 0 && P > 0 && n > 0, "%s: sizes must be positive, tf <= F", name);
+    hipStream_t st = (hipStream_t)stream;
+    const long work = (long)n * C * tf * P;
+    if (dtype == DS_F16) map_gather_kernel<f16><<<grid_for(work), 256, 0, st>>>((const f16*)pano, (f16*)tiles, idx, f0, C, F, tf, HW, P, n);
+    else if (dtype == DS_F32) map_gather_kernel<float><<<grid_for(work), 256, 0, st>>>((const float*)pano, (float*)tiles, idx, f0, C, F, tf, HW, P, n);
+    else if (dtype == 2) map_gather_kernel<uint8_t><<<grid_for(work), 256, 0, st>>>((const uint8_t*)pano, (uint8_t*)tiles, idx, f0, C, F, tf, HW, P, n);
+    else DS_CHECK_ARG(false, "%s: bad dtype %d", name, dtype);
+    DS_CHECK_LAUNCH(name);
+    return DS_OK;
+}
+
+static int map_scatter3_impl(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const void* x_prev_tiles,
+                             const void* x0_tiles, const int32_t* idx, const int32_t* f0, int C, int F, int tf, int HW,
+                             int P, int n, int mask_per_frame, int dtype, void* stream, const char* name) {
+    DS_CHECK_ARG(idx, "%s: null index map", name);
+    DS_CHECK_ARG(C > 0 && F > 0 && tf > 0 && tf <= F && HW > 0 && P > 0 && n > 0, "%s: sizes must be positive, tf <= F", name);
+    DS_CHECK_ARG(!pano_latent || x_prev_tiles, "%s: pano_latent without x_prev_tiles", name);
+    DS_CHECK_ARG(!pano_x0 || x0_tiles, "%s: pano_x0 without x0_tiles", name);
+    hipStream_t st = (hipStream_t)stream;
+    const long work = (long)n * C * tf * P;
+    if (dtype == DS_F16)
+        map_scatter3_kernel<f16><<<grid_for(work), 256, 0, st>>>((f16*)pano_latent, (f16*)pano_x0, mask_pano, (const f16*)x_prev_tiles, (const f16*)x0_tiles, idx, f0, C, F, tf, HW, P, n, mask_per_frame);
+    else if (dtype == DS_F32)
+        map_scatter3_kernel<float><<<grid_for(work), 256, 0, st>>>((float*)pano_latent, (float*)pano_x0, mask_pano, (const float*)x_prev_tiles, (const float*)x0_tiles, idx, f0, C, F, tf, HW, P, n, mask_per_frame);
+    else DS_CHECK_ARG(false, "%s: bad dtype %d", name, dtype);
+    DS_CHECK_LAUNCH(name);
+    return DS_OK;
+}
+
 extern "C" int ds_map_gather(const void* pano, void* tiles, const int32_t* idx, int CF, int HW, int P, int n, int dtype,
                              void* stream) {
-    DS_CHECK_ARG(pano && tiles && idx, "ds_map_gather: null argument");
-    DS_CHECK_ARG(CF > 0 && HW > 0 && P > 0 && n > 0, "ds_map_gather: sizes must be positive");
-    hipStream_t st = (hipStream_t)stream;
-    const long work = (long)n * CF * P;
-    if (dtype == DS_F16) map_gather_kernel<f16><<<grid_for(work), 256, 0, st>>>((const f16*)pano, (f16*)tiles, idx, CF, HW, P, n);
-    else if (dtype == DS_F32) map_gather_kernel<float><<<grid_for(work), 256, 0, st>>>((const float*)pano, (float*)tiles, idx, CF, HW, P, n);
-    else if (dtype == 2) map_gather_kernel<uint8_t><<<grid_for(work), 256, 0, st>>>((const uint8_t*)pano, (uint8_t*)tiles, idx, CF, HW, P, n);
-    else DS_CHECK_ARG(false, "ds_map_gather: bad dtype %d", dtype);
-    DS_CHECK_LAUNCH("ds_map_gather");
-    return DS_OK;
+    return map_gather_impl(pano, tiles, idx, nullptr, CF, 1, 1, HW, P, n, dtype, stream, "ds_map_gather");
 }
 
 extern "C" int ds_map_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const void* x_prev_tiles,
                                const void* x0_tiles, const int32_t* idx, int CF, int HW, int P, int n, int dtype,
                                void* stream) {
-    DS_CHECK_ARG(idx, "ds_map_scatter3: null index map");
-    DS_CHECK_ARG(CF > 0 && HW > 0 && P > 0 && n > 0, "ds_map_scatter3: sizes must be positive");
-    DS_CHECK_ARG(!pano_latent || x_prev_tiles, "ds_map_scatter3: pano_latent without x_prev_tiles");
-    DS_CHECK_ARG(!pano_x0 || x0_tiles, "ds_map_scatter3: pano_x0 without x0_tiles");
-    hipStream_t st = (hipStream_t)stream;
-    const long work = (long)n * CF * P;
-    if (dtype == DS_F16)
-        map_scatter3_kernel<f16><<<grid_for(work), 256, 0, st>>>((f16*)pano_latent, (f16*)pano_x0, mask_pano, (const f16*)x_prev_tiles, (const f16*)x0_tiles, idx, CF, HW, P, n);
-    else if (dtype == DS_F32)
-        map_scatter3_kernel<float><<<grid_for(work), 256, 0, st>>>((float*)pano_latent, (float*)pano_x0, mask_pano, (const float*)x_prev_tiles, (const float*)x0_tiles, idx, CF, HW, P, n);
-    else DS_CHECK_ARG(false, "ds_map_scatter3: bad dtype %d", dtype);
-    DS_CHECK_LAUNCH("ds_map_scatter3");
-    return DS_OK;
+    // fused (channel, frame) index, one mask byte per panorama pixel: C = CF "channels" of one frame each
+    return map_scatter3_impl(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, idx, nullptr, CF, 1, 1, HW, P, n, 0,
+                             dtype, stream, "ds_map_scatter3");
+}
+
+extern "C" int ds_map_gather_frames(const void* pano, void* tiles, const int32_t* idx, const int32_t* f0, int C, int F,
+                                    int tf, int HW, int P, int n, int dtype, void* stream) {
+    return map_gather_impl(pano, tiles, idx, f0, C, F, tf, HW, P, n, dtype, stream, "ds_map_gather_frames");
+}
+
+extern "C" int ds_map_scatter3_frames(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const void* x_prev_tiles,
+                                      const void* x0_tiles, const int32_t* idx, const int32_t* f0, int C, int F, int tf,
+                                      int HW, int P, int n, int dtype, void* stream) {
+    return map_scatter3_impl(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, idx, f0, C, F, tf, HW, P, n, 1, dtype,
+                             stream, "ds_map_scatter3_frames");
 }
 
 extern "C" int ds_map_splat(void* pano, const void* view, const int32_t* tgt, const int32_t* row_ptr, const int32_t* src,

@@ -173,6 +173,43 @@ def map_scatter3(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, idx):
                               idx.data_ptr(), Cc * F, H * W, P, n, _DT[ref.dtype], _stream()), "ds_map_scatter3")
 
 
+def map_gather_frames(pano, idx, f0, tf):
+    """pano [1,C,F,H,W] (fp16/fp32) or uint8 mask [F,H,W]; idx int32 device [n,P]; f0 int32 device [n] (first panorama
+    frame of each tile, wraps modulo F) -> tiles [n,C,tf,P] (mask: [n,tf,P])."""
+    _dev(pano, "map_gather_frames")
+    lib = _lib.load()
+    n, P = idx.shape
+    assert idx.dtype == torch.int32 and idx.is_cuda and idx.is_contiguous() and f0.dtype == torch.int32 and f0.numel() == n
+    if pano.dtype == torch.uint8:
+        F, H, W = pano.shape
+        Cc, dt = 1, 2
+        out = torch.empty((n, tf, P), dtype=torch.uint8, device=pano.device)
+    else:
+        _, Cc, F, H, W = pano.shape
+        dt = _DT[pano.dtype]
+        out = torch.empty((n, Cc, tf, P), dtype=pano.dtype, device=pano.device)
+    check(lib.ds_map_gather_frames(pano.data_ptr(), out.data_ptr(), idx.data_ptr(), f0.data_ptr(), Cc, F, tf, H * W, P, n, dt,
+                                   _stream()), "ds_map_gather_frames")
+    return out
+
+
+def map_scatter3_frames(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, idx, f0, tf):
+    """Frame-window scatter; mask_pano uint8 [F,H,W] (set per written frame)."""
+    ref = pano_latent if pano_latent is not None else pano_x0
+    _dev(ref, "map_scatter3_frames")
+    lib = _lib.load()
+    n, P = idx.shape
+    _, Cc, F, H, W = ref.shape
+    for t in (x_prev_tiles, x0_tiles):
+        if t is not None:
+            _dev(t, "map_scatter3_frames(tile)")
+            assert t.dtype == ref.dtype and t.numel() == n * Cc * tf * P and t.is_contiguous()
+    assert mask_pano is None or (mask_pano.dtype == torch.uint8 and mask_pano.numel() == F * H * W)
+    check(lib.ds_map_scatter3_frames(_ptr(pano_latent), _ptr(pano_x0), _ptr(mask_pano), _ptr(x_prev_tiles), _ptr(x0_tiles),
+                                     idx.data_ptr(), f0.data_ptr(), Cc, F, tf, H * W, P, n, _DT[ref.dtype], _stream()),
+          "ds_map_scatter3_frames")
+
+
 def map_splat_(pano, view, tgt, row_ptr, src, wgt):
     """In place bilinear splat of one view [1,C,F,h,w] into pano [1,C,F,H,W] (CSR per target on the device)."""
     _dev(pano, "map_splat")

@@ -103,6 +103,15 @@ int ds_map_gather(const void* pano, void* tiles, const int32_t* idx, int CF, int
                   void* stream);
 int ds_map_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const void* x_prev_tiles,
                     const void* x0_tiles, const int32_t* idx, int CF, int HW, int P, int n, int dtype, void* stream);
+/* Frame-window forms (RingPanoramaLatentProxy, utils/ring_panorama_tensor_utils.py:262-314, used by the i2v sphere loop
+ * pipeline/i2v_sphere_panorama_pipeline.py:330-336,438-471): pano [C][F][HW]; tile i holds tf frames starting at
+ * panorama frame f0[i] (DEVICE int32 [n], NULL = 0), wrapping modulo F.  The mask panorama is [F][HW] here (one byte
+ * per frame and pixel, gathered with C = 1 / dtype 2, set per written frame by the scatter). */
+int ds_map_gather_frames(const void* pano, void* tiles, const int32_t* idx, const int32_t* f0, int C, int F, int tf,
+                         int HW, int P, int n, int dtype, void* stream);
+int ds_map_scatter3_frames(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const void* x_prev_tiles,
+                           const void* x0_tiles, const int32_t* idx, const int32_t* f0, int C, int F, int tf, int HW,
+                           int P, int n, int dtype, void* stream);
 /* set_view_tensor_bilinear (utils/panorama_tensor_utils.py:98-152): 4-tap splat with weight normaliser,
  * pano[t] = sum_j view[src_j] * w_j / sum_j w_j for every panorama pixel t that receives weight.  The host inverts the
  * view's map into a CSR list per target (tgt[ntgt], row_ptr[ntgt+1], src/wgt[nnz], all DEVICE pointers) whose entry

@@ -297,6 +297,40 @@ def i2v_ring_windows(i, *, height, width, frames, total_h, total_w, total_f, num
     return wins
 
 
+def i2v_frame_windows(i, *, frames, total_f, overlap_ratio_f, loop_step_frame=None, dock_at_f=None):
+    """Frame windows [(f_begin, f_end)] of step i, reference order (i2v_sphere_panorama_pipeline.py:256-315; the same
+    arithmetic as :779-854 of the ring loop).  f_begin wraps modulo total_f; f_end = f_begin + frames may exceed total_f."""
+    import math
+    n_f = math.ceil((total_f // frames - 1) / (1 - overlap_ratio_f)) + 1
+    if total_f > frames:
+        off_f = max(int(overlap_ratio_f * frames / loop_step_frame), 1)
+        fr0 = (i % loop_step_frame) * off_f
+        f_ids = list(range(n_f))
+        if dock_at_f:
+            f_ids = [_DOCK_START_INDEX] + f_ids + [_DOCK_END_INDEX]
+    elif total_f == frames:
+        fr0, f_ids = 0, [0]
+    else:
+        raise ValueError(f"total_f {total_f} should >= frames {frames} !")
+    out = []
+    for fi in f_ids:
+        fb = (fr0 + fi * int(frames * (1 - overlap_ratio_f))) % total_f
+        fe = fb + frames
+        if dock_at_f:
+            if fi == _DOCK_START_INDEX:
+                if fr0 == 0:
+                    continue
+                fb, fe = 0, frames
+            if fi == _DOCK_END_INDEX:
+                if fr0 == 0:
+                    continue
+                fb, fe = total_f - frames, total_f
+            if fe > total_f:
+                continue
+        out.append((fb, fe))
+    return out
+
+
 @torch.no_grad()
 def i2v_ring_sample(eps_model, image_embedder, tables: DiffusionTables, text_ctx, uncond_ctx, pano_image, *, height=320,
                     width=512, frames=16, guidance_scale=7.5, total_w, total_h, total_f=None, num_windows_w,

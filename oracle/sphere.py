@@ -181,6 +181,76 @@ def t2v_sphere_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, 
     return pano.clone(), pano_x0.clone()
 
 
+@torch.no_grad()
+def i2v_sphere_sample(eps_model, image_embedder, tables: DiffusionTables, text_ctx, uncond_ctx, pano_image, *, height=320,
+                      width=512, frames=16, guidance_scale=7.5, total_f=None, dock_at_f=None, overlap_ratio_list_f=None,
+                      loop_step_frame=None, equirect_width, equirect_height, phi_theta_dict, view_fov, loop_step_theta,
+                      merge_renoised_overlap_latent_ratio=None, merge_prev_denoised_ratio_list=None,
+                      denoise_to_step=None, paste_on_static=None, static_frame_latent=None, num_inference_steps=4,
+                      init_sphere_latent=None, in_channels=4, trace=None):
+    """basic_sample_shift_shpere_panorama of the i2v pipeline (i2v_sphere_panorama_pipeline.py:31-495), view scale
+    factors 1, output_type='latent'; returns (final_latents, denoised) (:476-495).
+    `image_embedder(crop [1,3,height,width]) -> [1,L,D]` stands for get_image_embeds, `pano_image` [3,H_img,W_img] for
+    the loaded panorama image, `static_frame_latent` [1,C,1,H,W] for tiled_vae_encode_image's result (VAE: SURVEY 8-f N2);
+    uncond_ctx must already contain the image-token part (:123-129)."""
+    from .loops import i2v_frame_windows
+    sched = DDIMSchedule(tables, num_inference_steps)
+    timesteps = np.flip(sched.ddim_timesteps)
+    if denoise_to_step is not None:
+        timesteps = timesteps[:denoise_to_step]
+    total_steps = sched.ddim_timesteps.shape[0]
+    lh, lw = height // VAE_SCALE, width // VAE_SCALE
+    if total_f is None:
+        total_f = frames
+    shape = (1, in_channels, total_f, equirect_height // VAE_SCALE, equirect_width // VAE_SCALE)
+    pano = torch.randn(shape) if init_sphere_latent is None else init_sphere_latent.clone()
+    pano_x0 = torch.zeros_like(pano)
+    img5 = pano_image[None, :, None]                       # [1,3,1,H_img,W_img]: PanoramaTensor of the image (:223)
+    for i, t in enumerate(timesteps):
+        theta_offset = (i % loop_step_theta) * (view_fov // loop_step_theta)
+        mask = torch.zeros_like(pano)                      # reset mask record (:242), full 5-D here
+        temp = None
+        if paste_on_static and i < total_steps - 1:        # :245-254
+            clear = torch.cat([static_frame_latent] * total_f, dim=2)
+            temp = re_noise(sched, clear, 0, total_steps - i - 1)
+        views = []
+        for (fb, fe) in i2v_frame_windows(i, frames=frames, total_f=total_f, overlap_ratio_f=overlap_ratio_list_f[i],
+                                          loop_step_frame=loop_step_frame, dock_at_f=dock_at_f):
+            fidx = torch.arange(fb, fe) % total_f
+            for phi_angle in list(phi_theta_dict.keys()):
+                for theta_angle in phi_theta_dict[phi_angle]:
+                    cphi, cth = phi_angle, theta_angle + theta_offset
+                    views.append((fb, fe, cphi, cth))
+                    view, _ = sphere_gather(pano[:, :, fidx], view_fov, cth, cphi, lw, lh)
+                    prev = view.clone()
+                    vmask, _ = sphere_gather(mask[:, :, fidx], view_fov, cth, cphi, lw, lh)
+                    if merge_renoised_overlap_latent_ratio is not None and i < total_steps - 1:
+                        # RingPanoramaLatentProxy permutes twice (ring_panorama_tensor_utils.py:269,324): its views come
+                        # out contiguous in [B,C,N,h,w], so randn_like is the plain stream for EVERY view (unlike the
+                        # t2v sphere loop, see sphere_renoise_noise)
+                        noised = re_noise(sched, view.clone(), total_steps - i - 2, total_steps - i - 1)
+                        view = mix_latents_with_mask(view, noised, vmask, merge_renoised_overlap_latent_ratio)
+                    crop, _ = sphere_gather(img5, view_fov, cth, cphi, width, height)
+                    ctx = torch.cat([text_ctx, image_embedder(crop[:, :, 0])], dim=1)
+                    ts = torch.full((1,), int(t), dtype=torch.long)
+                    e_c = eps_model(view, ts, ctx)
+                    e = cfg_combine(e_c, eps_model(view, ts, uncond_ctx), guidance_scale) if guidance_scale != 1.0 else e_c
+                    x_prev, x0 = ddim_step(sched, view, e, [total_steps - i - 1] * view.shape[2])
+                    if merge_prev_denoised_ratio_list is not None and i < total_steps - 1:
+                        x_prev = mix_latents_with_mask(x_prev, prev, vmask, merge_prev_denoised_ratio_list[i])
+                    for dst, src in ((pano, x_prev), (temp, x_prev), (pano_x0, x0), (mask, torch.ones_like(x_prev))):
+                        if dst is None:
+                            continue
+                        sub = dst[:, :, fidx].clone()
+                        sphere_scatter_fast(sub, src, view_fov, cth, cphi)
+                        dst[:, :, fidx] = sub
+        if temp is not None:                               # :473-474
+            pano = temp
+        if trace is not None:
+            trace.append((i, int(t), views))
+    return pano.clone(), pano_x0.clone()
+
+
 def sphere_splat_bilinear(pano, view, fov, theta, phi):
     """PanoramaLatentProxy.set_view_tensor_bilinear (utils/panorama_tensor_utils.py:98-152, :281-283): 4-tap splat of a
     view [B,C,N,h,w] into pano [B,C,N,H,W] with weight normaliser; in place.  Same op order as the reference

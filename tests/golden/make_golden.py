@@ -364,8 +364,8 @@ def synth_image_embedder(dim, tokens=16, seed=77):
     pool of the crop projected 3 -> dim by a fixed seeded matrix.  Same function in tests/helpers.py."""
     proj = synth_normal((3, dim), seed)
 
-    def embed(img):
-        pooled = torch.nn.functional.adaptive_avg_pool2d(img.float(), (4, 4))     # [b,3,4,4]
+    def embed(batch_imgs):
+        pooled = torch.nn.functional.adaptive_avg_pool2d(batch_imgs.float(), (4, 4))     # [b,3,4,4]
         return pooled.flatten(2).transpose(1, 2) @ proj                            # [b,16,dim]
     return embed
 
@@ -529,13 +529,93 @@ def g12_sphere():
     print("wrote sphere_traces.json")
 
 
+I2V_SPHERE_GEOMS = {
+    # total_f == frames: one frame window; merge-prev on
+    "base": dict(height=64, width=128, frames=4, total_f=4, equirect_width=512, equirect_height=256, view_fov=120,
+                 loop_step_theta=4, phi_theta_dict={"90": [0], "45": [0, 120, 240], "0": [0, 90, 180, 270], "-60": [0, 180]},
+                 merge_renoised_overlap_latent_ratio=1, merge_prev_denoised_ratio_list=[0.5, 0.4, 0.3, 0.2, 0.1],
+                 overlap_ratio_list_f=[0.0] * 5, loop_step_frame=2, num_inference_steps=5, denoise_to_step=4),
+    # temporal windows with docking (total_f = 2 * frames), ratio < 1
+    "long": dict(height=64, width=128, frames=4, total_f=8, equirect_width=512, equirect_height=256, view_fov=120,
+                 loop_step_theta=3, phi_theta_dict={"90": [0], "0": [0, 120, 240], "-60": [0, 180]},
+                 merge_renoised_overlap_latent_ratio=0.7, merge_prev_denoised_ratio_list=[0.5, 0.3, 0.1, 0.0],
+                 overlap_ratio_list_f=[0.5, 0.5, 0.25, 0.5], loop_step_frame=2, dock_at_f=True, num_inference_steps=4),
+    # paste_on_static: every step the panorama is rebuilt on the re-noised static (image) latent
+    "static": dict(height=64, width=128, frames=4, total_f=4, equirect_width=512, equirect_height=256, view_fov=120,
+                   loop_step_theta=2, phi_theta_dict={"0": [0, 120, 240], "-60": [0, 180]},
+                   merge_renoised_overlap_latent_ratio=1, merge_prev_denoised_ratio_list=[0.5, 0.3, 0.1, 0.0],
+                   overlap_ratio_list_f=[0.0] * 4, loop_step_frame=2, paste_on_static=True, num_inference_steps=4),
+}
+FWIN_RE = re.compile(r"window_latent: f\[(-?\d+) - (-?\d+)\]")
+VIEW2_RE = re.compile(r"window: phi = (-?\d+), theta = (-?\d+), prompt")
+
+
+def g13_i2v_sphere():
+    """P5 (i2v): basic_sample_shift_shpere_panorama of pipeline/i2v_sphere_panorama_pipeline.py:31-495 (RingPanoramaLatentProxy
+    frame windows, per-view image tokens from the perspective crop of the panorama image, merge-prev, paste_on_static).
+    I/O and the VAE are stubbed: the image loader returns a synthetic tensor, tiled_vae_encode_image a synthetic latent."""
+    import pipeline.i2v_sphere_panorama_pipeline as mod
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    cond = synth_normal((1, 77, 64), 61)
+    uncond = synth_normal((1, 77, 64), 62)
+    pano_img = synth_normal((3, 256, 512), 89).clamp(-1, 1)
+    static_latent = synth_normal((1, 4, 1, 32, 64), 90)
+    arrays = {"cond": cond, "uncond": uncond, "pano_img": pano_img, "static_latent": static_latent}
+    traces = {}
+    p_i2v = dict(TINY)
+    p_i2v["use_image_attention"] = True
+    unet_i2v = build_reference_unet(p_i2v, seed=5)
+    embed = synth_image_embedder(64)
+    orig_loader = mod.load_image_tensor_from_path
+    mod.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: pano_img   # I/O stub (cv2 absent)
+    try:
+        for eps_name, eps_mod in (("fake", FakeEps()), ("tiny", WrappedUNet(unet_i2v))):
+            ld = FakeLatentDiffusion(eps_mod, cond, uncond, temporal_length=4)
+            ld.get_image_embeds = embed
+            ld.embedder = object()
+            for gname, geom in I2V_SPHERE_GEOMS.items():
+                if eps_name == "tiny" and gname != "base":
+                    continue
+                g = dict(geom)
+                g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+                pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": p_i2v}}})
+                pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+                pipe.tiled_vae_encode_image = lambda image_path, image_size: static_latent.clone()      # VAE stub (N2)
+                buf = io.StringIO()
+                torch.manual_seed(2333333)
+                with contextlib.redirect_stdout(buf):
+                    final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", img_cond_path="unused.png", fps=8,
+                                                                         guidance_scale=7.5, pano_image_path="unused.png",
+                                                                         output_type="latent", **g)
+                arrays[f"i2vs_{gname}_{eps_name}_final"] = final
+                arrays[f"i2vs_{gname}_{eps_name}_denoised"] = den
+                steps, cur_f = [], None
+                for line in buf.getvalue().splitlines():
+                    m = STEP_RE.match(line.strip())
+                    if m:
+                        steps.append({"i": int(m.group(1)), "t": int(m.group(2)), "views": []})
+                    m = FWIN_RE.search(line)
+                    if m:
+                        cur_f = (int(m.group(1)), int(m.group(2)))
+                    m = VIEW2_RE.search(line)
+                    if m:
+                        steps[-1]["views"].append([cur_f[0], cur_f[1], int(m.group(1)), int(m.group(2))])
+                traces[gname] = steps
+    finally:
+        mod.load_image_tensor_from_path = orig_loader
+    save_npz("sphere_i2v.npz", **arrays)
+    with open(os.path.join(HERE, "sphere_i2v_traces.json"), "w") as f:
+        json.dump({"geoms": I2V_SPHERE_GEOMS, "traces": traces}, f)
+    print("wrote sphere_i2v_traces.json")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size UNet fixture (minutes)")
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere}
     if args.full:
         steps["g10"] = g10_unet_full
     for k, fn in steps.items():

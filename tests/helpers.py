@@ -10,7 +10,7 @@ def synth_image_embedder(dim, tokens=16, seed=77):
     tests/golden/make_golden.py used when it ran the reference."""
     proj = synth_normal((3, dim), seed)
 
-    def embed(img):
-        pooled = torch.nn.functional.adaptive_avg_pool2d(img.float().cpu(), (4, 4))
-        return (pooled.flatten(2).transpose(1, 2) @ proj).to(img.device)
+    def embed(batch_imgs):
+        pooled = torch.nn.functional.adaptive_avg_pool2d(batch_imgs.float().cpu(), (4, 4))
+        return (pooled.flatten(2).transpose(1, 2) @ proj).to(batch_imgs.device)
     return embed

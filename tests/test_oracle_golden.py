@@ -341,3 +341,52 @@ def test_g12_bilinear_splat_bit_exact():
         assert torch.equal(S.sphere_splat_bilinear(pano.clone(), tile, fov, th, ph), T(z[f"splat_after_{n}"])), n
         n += 1
     assert n == 4
+
+
+def test_g13_i2v_sphere_loop_vs_reference_golden():
+    """P5 (i2v): the oracle's sphere loop with frame windows, per-view image tokens, merge-prev and paste_on_static
+    against the reference's own final latents (fake eps: bit-exact) and window traces."""
+    from oracle.sphere import i2v_sphere_sample
+    from oracle.ddim import DiffusionTables
+    from helpers import synth_image_embedder
+    z = np.load(os.path.join(G, "sphere_i2v.npz"))
+    meta = json.load(open(os.path.join(G, "sphere_i2v_traces.json")))
+    cond, uncond, pano_img = T(z["cond"]), T(z["uncond"]), T(z["pano_img"])
+    embed = synth_image_embedder(64)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)      # zero image of the LATENT size (:123-129)
+    fake = lambda x, ts, ctx: 0.1 * x + 0.01 * ctx.mean()
+    for gname, geom in meta["geoms"].items():
+        g = dict(geom)
+        g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+        g.pop("dock_at_f", None)
+        trace = []
+        torch.manual_seed(2333333)
+        final, den = i2v_sphere_sample(fake, embed, DiffusionTables(), cond, uc, pano_img, guidance_scale=7.5,
+                                       dock_at_f=geom.get("dock_at_f"), static_frame_latent=T(z["static_latent"]),
+                                       trace=trace, **g)
+        assert torch.equal(final, T(z[f"i2vs_{gname}_fake_final"])), gname
+        assert torch.equal(den, T(z[f"i2vs_{gname}_fake_denoised"])), gname
+        for (i, t, views), ref in zip(trace, meta["traces"][gname]):
+            assert i == ref["i"] and t == ref["t"] and [list(v) for v in views] == ref["views"], (gname, i)
+
+
+def test_g13_i2v_sphere_loop_tiny_unet():
+    from oracle.sphere import i2v_sphere_sample
+    from helpers import synth_image_embedder
+    z = np.load(os.path.join(G, "sphere_i2v.npz"))
+    meta = json.load(open(os.path.join(G, "sphere_i2v_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    params, _ = _tiny_setup()
+    p2 = dict(params)
+    p2["use_image_attention"] = True
+    sd2 = synth_state_dict(param_shapes(p2), seed=5)
+    embed = synth_image_embedder(64)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
+    g = dict(meta["geoms"]["base"])
+    g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+    torch.manual_seed(2333333)
+    final, den = i2v_sphere_sample(lambda x, ts, ctx: unet_forward(sd2, p2, x, ts, ctx, fps=8), embed, oddim.DiffusionTables(),
+                                   cond, uc, T(z["pano_img"]), guidance_scale=7.5, **g)
+    for got, key in ((final, "i2vs_base_tiny_final"), (den, "i2vs_base_tiny_denoised")):
+        ref = T(z[key])
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-4, key
