@@ -31,7 +31,7 @@ def install():
     _mod("pipeline.t2v_sphere_panorama_pipeline", VC2_Pipeline_T2V_SpherePano=sphere.VC2_Pipeline_T2V_SpherePano)
     _mod("utils.panorama_tensor_utils", PanoramaLatentProxy=sphere.PanoramaLatentProxy)
     _mod("pipeline.i2v_normal_pipeline", VC2_Pipeline_I2V=pipelines_i2v.VC2_Pipeline_I2V)
-    _mod("pipeline.i2v_sphere_panorama_pipeline", VC2_Pipeline_I2V_SpherePano=pipelines_i2v.VC2_Pipeline_I2V_SpherePano)
+    _mod("pipeline.i2v_sphere_panorama_pipeline", VC2_Pipeline_I2V_SpherePano=sphere.VC2_Pipeline_I2V_SpherePano)
     _mod("utils.shift_window_utils", RingLatent=ring.RingLatent, RingImageTensor=pipelines_i2v.RingImageTensor,
          get_dimension_slices_and_sizes=ring.get_dimension_slices_and_sizes)
     _mod("utils.tensor_utils", mix_latents_with_mask=tensor_utils.mix_latents_with_mask)

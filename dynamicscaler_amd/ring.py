@@ -203,3 +203,38 @@ def i2v_ring_windows(i, *, latent_h, latent_w, frames, total_f, step_w, step_h, 
                         continue
                 wins.append((left, left + latent_w, top, top + latent_h, fb, fe))
     return wins
+
+
+def i2v_frame_windows(i, *, frames, total_f, overlap_ratio_f, loop_step_frame=None, dock_at_f=None):
+    """Frame windows [(f_begin, f_end)] of step i of the i2v SPHERE loop, reference order
+    (pipeline/i2v_sphere_panorama_pipeline.py:256-315): f_begin wraps modulo total_f, f_end = f_begin + frames may run
+    past total_f (the window then wraps); with dock_at_f two docking windows are added when the grid is shifted and
+    windows running past total_f are skipped (:302-315)."""
+    import math
+    n_f = math.ceil((total_f // frames - 1) / (1 - overlap_ratio_f)) + 1
+    if total_f > frames:
+        fr0 = (i % loop_step_frame) * max(int(overlap_ratio_f * frames / loop_step_frame), 1)
+        f_ids = list(range(n_f))
+        if dock_at_f:
+            f_ids = [I2V_DOCK_START_INDEX] + f_ids + [I2V_DOCK_END_INDEX]
+    elif total_f == frames:
+        fr0, f_ids = 0, [0]
+    else:
+        raise ValueError(f"total_f {total_f} should >= frames {frames} !")
+    out = []
+    for fi in f_ids:
+        fb = (fr0 + fi * int(frames * (1 - overlap_ratio_f))) % total_f
+        fe = fb + frames
+        if dock_at_f:
+            if fi == I2V_DOCK_START_INDEX:
+                if fr0 == 0:
+                    continue
+                fb, fe = 0, frames
+            if fi == I2V_DOCK_END_INDEX:
+                if fr0 == 0:
+                    continue
+                fb, fe = total_f - frames, total_f
+            if fe > total_f:
+                continue
+        out.append((fb, fe))
+    return out

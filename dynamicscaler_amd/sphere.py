@@ -12,6 +12,8 @@ import torch
 
 from . import ops, parallel
 from .pipelines import VC2_Pipeline_T2V_SpherePano as _RingPipe, _RingState
+from .pipelines_i2v import VC2_Pipeline_I2V_SpherePano as _I2VRingPipe, load_image_tensor_from_path
+from .ring import i2v_frame_windows
 
 
 def view_uv(fov, theta, phi, width, height, W, H, dtype=torch.float32):
@@ -286,6 +288,196 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
             scattered += len(views)
             if step_callback is not None:
                 step_callback(i, int(t), views, st.pano, st.pano_x0)
+        denoised = st.pano_x0.clone()
+        final_latents = st.pano.clone()
+        if output_type == "latent":
+            return final_latents, denoised
+        return self.pretrained_t2v.decode_first_stage_2DAE(denoised), denoised
+
+
+def plan_levels_items(frame_sets, view_keys, pix_conflict):
+    """Dependency levels for (frame window, view) items: an earlier item k constrains j when their frame sets intersect
+    AND their pixel footprints conflict (pix_conflict(view_k, view_j): k writes what j touches, or j writes what k
+    reads).  Same guarantees as parallel.plan_levels."""
+    level = []
+    for j in range(len(view_keys)):
+        lv = 0
+        for k in range(j):
+            if level[k] >= lv and (frame_sets[k] & frame_sets[j]) and pix_conflict(view_keys[k], view_keys[j]):
+                lv = level[k] + 1
+        level.append(lv)
+    out = [[] for _ in range(max(level) + 1)] if level else []
+    for j, lv in enumerate(level):
+        out[lv].append(j)
+    return out
+
+
+class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
+    """Adds the i2v sphere loop to the i2v ring pipeline class (one class in the reference,
+    pipeline/i2v_sphere_panorama_pipeline.py:26)."""
+
+    @torch.no_grad()
+    def basic_sample_shift_shpere_panorama(self, prompt=None, img_cond_path=None, height=320, width=512, frames=16, fps=16,
+                                           guidance_scale=7.5, num_videos_per_prompt=1, generator=None,
+                                           init_sphere_latent=None, pano_image_path=None, total_f=None, dock_at_f=None,
+                                           overlap_ratio_list_f=None, loop_step_frame=None, equirect_width=None,
+                                           equirect_height=None, phi_theta_dict=None, phi_prompt_dict=None, view_fov=None,
+                                           view_get_scale_factor=1, view_set_scale_factor=1, loop_step_theta=None,
+                                           merge_renoised_overlap_latent_ratio=None, merge_prev_denoised_ratio_list=None,
+                                           denoise_to_step=None, paste_on_static=None, latents=None,
+                                           num_inference_steps=4, prompt_embeds=None, output_type="pil",
+                                           downsample_factor_before_vae_decode=None, use_skip_time=False,
+                                           skip_time_step_idx=None, progressive_skip=False, pano_image_tensor=None,
+                                           static_frame_latent=None, step_callback=None, **kwargs):
+        """[sic] name kept from the reference (i2v_sphere_panorama_pipeline.py:31-495).  Frame windows over a ring of
+        total_f frames (RingPanoramaLatentProxy), per-view image tokens from the perspective crop of the panorama image,
+        5-D denoised mask, merge-prev, paste_on_static.  Extensions: `pano_image_tensor` [3,H_img,W_img] instead of a path,
+        `static_frame_latent` [1,C,1,H,W] = the VAE-encoded panorama image for paste_on_static (the reference re-runs the
+        tiled VAE encode every step, :247; the VAE is SURVEY.md 8-f N2, so the caller supplies its result once).
+        Returns (final_latents, denoised) for output_type='latent' (:476-495)."""
+        if view_get_scale_factor != 1 or view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
+            raise NotImplementedError("view / decode scale factors other than 1 (gen_pano_360.py uses 1)")
+        if use_skip_time:
+            raise NotImplementedError("use_skip_time needs the tiled VAE encode (SURVEY.md 8-f N2)")
+        if paste_on_static and static_frame_latent is None:
+            raise NotImplementedError("paste_on_static needs `static_frame_latent` (the VAE-encoded panorama image; the "
+                                      "tiled VAE encode itself is SURVEY.md 8-f N2)")
+        unet_config = self.model_config["params"]["unet_config"]
+        frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
+        vs = self.vae_scale_factor
+        prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
+        if guidance_scale != 1.0 and hasattr(self.pretrained_t2v, "embedder"):   # uncond image tokens (:123-129)
+            uc_img = torch.zeros(1, 3, height // vs, width // vs).to(self.pretrained_t2v.device)
+            uc_emb = torch.cat([uc_emb.to(uc_img.device), self.pretrained_t2v.get_image_embeds(uc_img)], dim=1)
+        self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
+        timesteps = np.flip(self.scheduler.ddim_timesteps)
+        if denoise_to_step is not None:
+            timesteps = timesteps[:denoise_to_step]
+        total_steps = self.scheduler.ddim_timesteps.shape[0]       # the full schedule length (:163)
+        if total_f is None:
+            total_f = frames
+        lat_h, lat_w = height // vs, width // vs
+        H, W = equirect_height // vs, equirect_width // vs
+        shape = (1, unet_config["params"]["in_channels"], total_f, H, W)
+        if init_sphere_latent is None:
+            init_sphere_latent = torch.randn(shape)                # host draw, reference order (:183)
+        else:
+            assert tuple(init_sphere_latent.shape) == shape, \
+                f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_sphere_latent.shape)} does not match desired shape {shape}"
+        assert W == 2 * H                                          # RingPanoramaTensor (:12)
+        st = self._new_state(init_sphere_latent, shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale, text_emb,
+                             uc_emb, merge_renoised_overlap_latent_ratio, kwargs)
+        st.total_steps = total_steps
+        device, sched = st.device, self.scheduler
+        mask = torch.zeros((total_f, H, W), dtype=torch.uint8, device=device)   # one byte per (frame, pixel)
+        image = pano_image_tensor if pano_image_tensor is not None else \
+            load_image_tensor_from_path(pano_image_path, equirect_height, equirect_width)
+        Himg, Wimg = image.shape[-2:]
+        assert Wimg == 2 * Himg                                    # PanoramaTensor of the image (:223)
+        image5 = image.to(device=device, dtype=torch.float32).reshape(1, 3, 1, Himg, Wimg).contiguous()
+        static = None
+        if paste_on_static:
+            static = static_frame_latent.to(device=device, dtype=st.pano.dtype)
+            assert tuple(static.shape) == (1, shape[1], 1, H, W)
+        cache, img_cache = ViewMapCache(device), ViewMapCache(device)
+        emb_cache, prompt_cache, conflict_cache = {}, {}, {}
+        P = lat_h * lat_w
+
+        def pix_conflict(ka, kb):
+            r = conflict_cache.get((ka, kb))
+            if r is None:
+                a, b = cache.get(view_fov, ka[1], ka[0], lat_w, lat_h, W, H), cache.get(view_fov, kb[1], kb[0], lat_w, lat_h, W, H)
+                r = conflict_cache[(ka, kb)] = bool((a.write_set & (b.read_set | b.write_set)).any() or
+                                                    (a.read_set & b.write_set).any())
+            return r
+
+        for i in range(len(timesteps)):
+            t = timesteps[i]
+            theta_offset = (i % loop_step_theta) * (view_fov // loop_step_theta)
+            mask.zero_()                                           # reset mask record (:242)
+            live = i < total_steps - 1
+            temp = None
+            if paste_on_static and live:                           # :245-254 (host randn of the whole panorama first)
+                temp = sched.re_noise(static.expand(1, shape[1], total_f, H, W).contiguous(), 0, total_steps - i - 1)
+            items, ctxs = [], []
+            for (fb, fe) in i2v_frame_windows(i, frames=frames, total_f=total_f, overlap_ratio_f=overlap_ratio_list_f[i],
+                                              loop_step_frame=loop_step_frame, dock_at_f=dock_at_f):
+                for phi_angle in list(phi_theta_dict.keys()):
+                    for theta_angle in phi_theta_dict[phi_angle]:
+                        cphi, cth = phi_angle, theta_angle + theta_offset
+                        items.append((fb, fe, cphi, cth))
+                        cur_text = st.text_emb
+                        if phi_prompt_dict is not None:
+                            cur = phi_prompt_dict[phi_angle]
+                            if cur not in prompt_cache:
+                                prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(device)
+                            cur_text = prompt_cache[cur]
+                        if (cphi, cth) not in emb_cache:           # the same view recurs every loop_step_theta steps
+                            im = img_cache.get(view_fov, cth, cphi, width, height, Wimg, Himg)
+                            crop = ops.map_gather(image5, im.gather[None]).reshape(1, 3, height, width)
+                            emb_cache[(cphi, cth)] = self.pretrained_t2v.get_image_embeds(
+                                batch_imgs=crop.to(self.pretrained_t2v.device)).to(device)
+                        ctxs.append(torch.cat([cur_text, emb_cache[(cphi, cth)].to(cur_text.dtype)], dim=1))
+            maps = [cache.get(view_fov, th, ph, lat_w, lat_h, W, H) for (_, _, ph, th) in items]
+            renoise = st.ratio is not None and live
+            merge_prev = merge_prev_denoised_ratio_list[i] if (merge_prev_denoised_ratio_list is not None and live) else None
+            coef = sched.step_coefficients(total_steps - i - 1)
+            noises = []                                            # host noise in the reference's item order
+            for _ in items:
+                nz = sched.draw_renoise_noise(st.tile_shape, "cpu", torch.float32) if renoise else None
+                sn = sched.draw_step_noise(st.tile_shape, "cpu", torch.float32, coef["sigma"])
+                noises.append((nz, sn))
+            if renoise:
+                c_rn, s_rn = sched.renoise_coefficients(total_steps - i - 2, total_steps - i - 1)
+            fsets = [frozenset(f % total_f for f in range(fb, fe)) for (fb, fe, _, _) in items]
+            for level in plan_levels_items(fsets, [(ph, th) for (_, _, ph, th) in items], pix_conflict):
+                mine = parallel.rank_share(level, st.rank, st.world)
+                xp_parts, x0_parts = [], []
+                for s0 in range(0, len(mine), self.max_tile_batch):
+                    ids = mine[s0:s0 + self.max_tile_batch]
+                    n = len(ids)
+                    g_idx = torch.stack([maps[j].gather for j in ids])
+                    f0 = torch.tensor([items[j][0] for j in ids], dtype=torch.int32, device=device)
+                    tiles = ops.map_gather_frames(st.pano, g_idx, f0, frames).reshape((n,) + st.tile_shape[1:])
+                    prev = tiles.clone() if merge_prev is not None else None
+                    mt = ops.map_gather_frames(mask, g_idx, f0, frames).reshape(n, frames, lat_h, lat_w)
+                    if renoise:
+                        nz = None
+                        if noises[ids[0]][0] is not None:
+                            nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=st.pano.dtype)
+                        ops.renoise_mix_(tiles, mt, shape, c_rn, s_rn, st.ratio, noise=nz, mask_frame0=False,
+                                         seed=sched.philox_seed, offset=(i * len(items) + ids[0]) * tiles[0].numel())
+                    if st.guidance_scale != 1.0:
+                        eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n, fps,
+                                        frames, **st.kwargs)
+                        e_c, e_u = eps[:n], eps[n:]
+                    else:
+                        e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], fps, frames, **st.kwargs), None
+                    sn = None
+                    if coef["sigma"] != 0.0:
+                        sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=st.pano.dtype)
+                    x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, shape, st.guidance_scale, coef, sn)
+                    if merge_prev is not None:                     # :430-436
+                        ops.renoise_mix_(x_prev, mt, shape, 0.0, 1.0, merge_prev, noise=prev, mask_frame0=False)
+                    xp_parts.append(x_prev)
+                    x0_parts.append(x0)
+                if st.world > 1:
+                    empty = torch.empty((0,) + st.tile_shape[1:], dtype=st.pano.dtype, device=device)
+                    xp_all, x0_all = parallel.exchange_level(torch.cat(xp_parts, 0) if xp_parts else empty,
+                                                             torch.cat(x0_parts, 0) if x0_parts else empty, len(level))
+                    order = level
+                else:
+                    xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
+                s_idx = torch.stack([maps[j].scatter for j in order])
+                f0 = torch.tensor([items[j][0] for j in order], dtype=torch.int32, device=device)
+                xp_all, x0_all = xp_all.contiguous(), x0_all.contiguous()
+                ops.map_scatter3_frames(st.pano, st.pano_x0, mask, xp_all, x0_all, s_idx, f0, frames)
+                if temp is not None:                               # :446-454
+                    ops.map_scatter3_frames(temp, None, None, xp_all, None, s_idx, f0, frames)
+            if temp is not None:                                   # :473-474
+                st.pano = temp
+            if step_callback is not None:
+                step_callback(i, int(t), items, st.pano, st.pano_x0)
         denoised = st.pano_x0.clone()
         final_latents = st.pano.clone()
         if output_type == "latent":
