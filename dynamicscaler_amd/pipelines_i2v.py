@@ -10,7 +10,8 @@ and after the DDIM update x_prev is mixed with the window's pre-re-noise content
 
 Out of scope here: the CLIP image encoder / Resampler (`pretrained_t2v.get_image_embeds` is
 called as a black box, once per distinct crop position -- the reference calls it per tile per step) and the tiled
-VAE encode behind `use_skip_time`.
+VAE encode behind `use_skip_time` without a given init latent (with `init_panorama_latent`, the way gen_pano_360.py
+calls it, `use_skip_time` only shortens the schedule).
 """
 import math
 
@@ -77,8 +78,9 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
                                          progressive_skip=False, pano_image_tensor=None, step_callback=None, **kwargs):
         """`pano_image_tensor` ([3,total_h,total_w], optional) is an extension: the panorama image as a tensor
         instead of a path (RingImageTensor accepts both, shift_window_utils.py:211-220)."""
-        if use_skip_time:
-            raise NotImplementedError("use_skip_time needs the tiled VAE encode (SURVEY.md 8-f N2)")
+        if use_skip_time and init_panorama_latent is None:
+            raise NotImplementedError("use_skip_time without init_panorama_latent needs the tiled VAE encode of the panorama "
+                                      "image (SURVEY.md 8-f N2); gen_pano_360.py passes the previous stage's latent")
         unet_config = self.model_config["params"]["unet_config"]
         frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
         vs = self.vae_scale_factor
@@ -89,6 +91,8 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
             uc_emb = torch.cat([uc_emb.to(uc_img.device), self.pretrained_t2v.get_image_embeds(uc_img)], dim=1)
         self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
         timesteps = np.flip(self.scheduler.ddim_timesteps)
+        if use_skip_time and not progressive_skip:     # resume from a partly denoised latent (:673-675)
+            timesteps = timesteps[skip_time_step_idx:]
         if total_f is None:
             total_f = frames * num_windows_f
         lat_h, lat_w = height // vs, width // vs

@@ -337,8 +337,8 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
         Returns (final_latents, denoised) for output_type='latent' (:476-495)."""
         if view_get_scale_factor != 1 or view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
             raise NotImplementedError("view / decode scale factors other than 1 (gen_pano_360.py uses 1)")
-        if use_skip_time:
-            raise NotImplementedError("use_skip_time needs the tiled VAE encode (SURVEY.md 8-f N2)")
+        if use_skip_time and init_sphere_latent is None:
+            raise NotImplementedError("use_skip_time without init_sphere_latent needs the tiled VAE encode (SURVEY.md 8-f N2)")
         if paste_on_static and static_frame_latent is None:
             raise NotImplementedError("paste_on_static needs `static_frame_latent` (the VAE-encoded panorama image; the "
                                       "tiled VAE encode itself is SURVEY.md 8-f N2)")
@@ -351,7 +351,11 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
             uc_emb = torch.cat([uc_emb.to(uc_img.device), self.pretrained_t2v.get_image_embeds(uc_img)], dim=1)
         self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
         timesteps = np.flip(self.scheduler.ddim_timesteps)
+        if use_skip_time and not progressive_skip:                 # :143-145
+            timesteps = timesteps[skip_time_step_idx:]
         if denoise_to_step is not None:
+            assert not (use_skip_time and not progressive_skip), \
+                "should not use denoise_to_step while using Non progressive time step skip"   # :148-149
             timesteps = timesteps[:denoise_to_step]
         total_steps = self.scheduler.ddim_timesteps.shape[0]       # the full schedule length (:163)
         if total_f is None:

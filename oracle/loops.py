@@ -337,12 +337,15 @@ def i2v_ring_sample(eps_model, image_embedder, tables: DiffusionTables, text_ctx
                     num_windows_h, num_windows_f=1, loop_step=8, begin_index_offset=0, dock_at_f=None,
                     overlap_ratio_list_f=None, loop_step_frame=None, num_inference_steps=4, init_panorama_latent=None,
                     merge_renoised_overlap_latent_ratio=1, merge_prev_denoised_ratio_list=None, in_channels=4,
-                    trace=None):
+                    use_skip_time=False, skip_time_step_idx=None, progressive_skip=False, trace=None):
     """output_type='latent'.  `image_embedder(crop [1,3,h,w]) -> [1,L_img,D]` stands for get_image_embeds;
     `pano_image` [3,total_h,total_w] for the RingImageTensor content (utils/shift_window_utils.py:209-276).
     uncond_ctx must already contain the image-token part (i2v_sphere…py:652-658)."""
     sched = DDIMSchedule(tables, num_inference_steps)
     timesteps = np.flip(sched.ddim_timesteps)
+    if use_skip_time and not progressive_skip:       # :673-675; the VAE-encoded start of :706-722 is not restated
+        assert init_panorama_latent is not None
+        timesteps = timesteps[skip_time_step_idx:]
     total_steps = len(timesteps)
     if total_f is None:
         total_f = frames * num_windows_f

@@ -356,6 +356,11 @@ I2V_GEOMS = {
                          num_windows_h=2, num_windows_f=2, loop_step=4, num_inference_steps=5, begin_index_offset=1,
                          overlap_ratio_list_f=[0.5, 0.5, 0.25, 0.5, 0.5], loop_step_frame=2, dock_at_f=True,
                          merge_prev_denoised_ratio_list=[0.5, 0.4, 0.3, 0.2, 0.1]),
+    # the way gen_pano_360.py:291-312 resumes from the previous stage: given init latent + use_skip_time (schedule cut)
+    "skip": dict(height=64, width=128, frames=4, total_w=512, total_h=96, total_f=4, num_windows_w=4, num_windows_h=2,
+                 num_windows_f=1, loop_step=4, num_inference_steps=5, overlap_ratio_list_f=[0.0] * 5,
+                 merge_prev_denoised_ratio_list=[0.5, 0.4, 0.3, 0.2, 0.1], use_skip_time=True, skip_time_step_idx=2,
+                 progressive_skip=False, init_seed=93),
 }
 
 
@@ -414,10 +419,14 @@ def g11_grid_and_i2v():
                 pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
                 buf = io.StringIO()
                 torch.manual_seed(2333333)
+                gk = dict(geom)
+                if "init_seed" in gk:
+                    gk["init_panorama_latent"] = synth_normal((1, 4, gk["total_f"], gk["total_h"] // 8, gk["total_w"] // 8),
+                                                              gk.pop("init_seed"))
                 with contextlib.redirect_stdout(buf):
                     _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", img_cond_path="unused.png", fps=8,
                                                                    guidance_scale=7.5, pano_image_path="unused.png",
-                                                                   output_type="latent", **geom)
+                                                                   output_type="latent", **gk)
                 arrays[f"i2v_{gname}_{eps_name}"] = den
                 traces[f"i2v_{gname}"] = parse_trace(buf.getvalue())
     finally:

@@ -14,3 +14,12 @@ def synth_image_embedder(dim, tokens=16, seed=77):
         pooled = torch.nn.functional.adaptive_avg_pool2d(batch_imgs.float().cpu(), (4, 4))
         return (pooled.flatten(2).transpose(1, 2) @ proj).to(batch_imgs.device)
     return embed
+
+
+def i2v_geom(geom):
+    """Golden geometry dict -> call kwargs: an `init_seed` entry stands for a synthetic init_panorama_latent (the same
+    synth_normal draw make_golden.py handed to the reference)."""
+    g = dict(geom)
+    if "init_seed" in g:
+        g["init_panorama_latent"] = synth_normal((1, 4, g["total_f"], g["total_h"] // 8, g["total_w"] // 8), g.pop("init_seed"))
+    return g

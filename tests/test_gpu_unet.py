@@ -276,7 +276,7 @@ def test_grid_pipeline_vs_reference_golden():
 def test_i2v_ring_pipeline_vs_reference_golden():
     """P3 (i2v_sphere_panorama_pipeline.py:564-996): round() placement, temporal windows + docking, 5-D mask,
     merge-prev, per-window image tokens, begin_index_offset."""
-    from helpers import synth_image_embedder
+    from helpers import synth_image_embedder, i2v_geom
     from oracle import loops as oloops, ddim as oddim
     from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
     from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano
@@ -289,6 +289,7 @@ def test_i2v_ring_pipeline_vs_reference_golden():
     ld = _fake_host(cond, uncond, d, embed)
     cfgd = {"params": {"unet_config": {"params": {"in_channels": 4}}}}
     for gname, geom in meta["i2v_geoms"].items():
+        geom = i2v_geom(geom)
         pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), cfgd).to(d, torch.float32)
         trace = []
         torch.manual_seed(2333333)

@@ -218,13 +218,14 @@ def test_g11_grid_loop_fake_eps_bit_exact_and_traces():
 
 
 def test_g11_i2v_ring_loop_fake_eps_bit_exact_and_traces():
-    from helpers import synth_image_embedder
+    from helpers import synth_image_embedder, i2v_geom
     z = npz("loops_grid_i2v.npz")
     meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
     cond, uncond = T(z["cond"]), T(z["uncond"])
     embed = synth_image_embedder(64)
     uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
     for gname, geom in meta["i2v_geoms"].items():
+        geom = i2v_geom(geom)
         trace = []
         torch.manual_seed(2333333)
         den, _, _ = oloops.i2v_ring_sample(_fake_eps, embed, oddim.DiffusionTables(), cond, uc, T(z["pano_img"]),
