@@ -26,7 +26,7 @@ constexpr int VT_STRIDE = 68;   // halfs per V^T row (64 keys + 4 pad): 34-dword
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 template <int QB>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, QB == 1 ? 3 : 1)
 attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v, f16* __restrict__ out,
                  int heads, int nq, int nk, int ldq, int ldk, int ldv, int ldo, int kv_batch_div, float scale_log2,
                  int accumulate, int q_tiles) {
