@@ -179,6 +179,95 @@ gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const
     }
 }
 
+// Small instances (rows_per_inst <= GN_SMALL_ROWS: the per-frame GroupNorms of the two coarse UNet levels): statistics
+// and normalisation in ONE launch, one 1024-thread workgroup per instance -- the instance (<= 1.3 MB) is read twice,
+// the second time from L2; no partial-sum buffer, no second launch.  Same thread -> (column, row lane) map and the same
+// fixed summation order idea as above (row lanes first, then the channels of a group in order).
+constexpr int GN_SMALL_ROWS = 256;
+constexpr int GN_SMALL_NT = 1024;
+
+__global__ void __launch_bounds__(GN_SMALL_NT)
+gn_small_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps) {
+    __shared__ float csum[GN_LDS_FLOATS + MAX_C];
+    __shared__ float csq[GN_LDS_FLOATS + MAX_C];
+    __shared__ float smean[256], srstd[256];
+    const int tid = threadIdx.x, inst = blockIdx.x;
+    const int nvec = C / 8, cpg = C / groups;
+    const f16* base = x + (long)inst * rows_per_inst * C;
+    f16* ybase = y + (long)inst * rows_per_inst * C;
+    const int rl = nvec <= GN_SMALL_NT ? GN_SMALL_NT / nvec : 1;      // row lanes (nvec <= 512 -> rl >= 2)
+    const int cap = (GN_LDS_FLOATS + MAX_C) / C;                       // rlu*C floats must fit the LDS arrays
+    const int rlu = min(min(rl, 8), cap);
+    const bool on = tid < rlu * nvec;
+    const int col = tid % nvec, rlane = tid / nvec;
+    if (on) {
+        float s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
+        const f16* p = base + col * 8;
+        int r = rlane;
+        for (; r + 3 * rlu < rows_per_inst; r += 4 * rlu) {
+            f16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(p + (long)(r + u * rlu) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
+        }
+        for (; r < rows_per_inst; r += rlu) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(p + (long)r * C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { csum[rlane * C + col * 8 + j] = s[j]; csq[rlane * C + col * 8 + j] = q[j]; }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        double s = 0.0, q = 0.0;
+        for (int l = 0; l < rlu; ++l)
+            for (int j = 0; j < cpg; ++j) { s += (double)csum[l * C + tid * cpg + j]; q += (double)csq[l * C + tid * cpg + j]; }
+        const double count = (double)rows_per_inst * cpg;
+        const double m = s / count;
+        double var = q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        smean[tid] = (float)m;
+        srstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if (!on) return;
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = col * 8 + j, g = c / cpg;
+        a[j] = srstd[g] * gamma[c];
+        b[j] = beta[c] - smean[g] * a[j];
+    }
+    auto one = [&](const f16x8 v) {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j] * a[j] + b[j];
+            if (silu) f = fast_silu(f);
+            o[j] = (f16)f;
+        }
+        return o;
+    };
+    const f16* px = base + col * 8;
+    f16* py = ybase + col * 8;
+    int r = rlane;
+    for (; r + 3 * rlu < rows_per_inst; r += 4 * rlu) {
+        f16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(px + (long)(r + u * rlu) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f16x8*>(py + (long)(r + u * rlu) * C) = one(v[u]);
+    }
+    for (; r < rows_per_inst; r += rlu) *reinterpret_cast<f16x8*>(py + (long)r * C) = one(*reinterpret_cast<const f16x8*>(px + (long)r * C));
+}
+
 // LayerNorm: one wave per row, NV 8-channel vectors per lane (C <= 512*NV), RW rows per wave with all their loads issued
 // before the first reduction (bytes in flight: the 320-channel rows of the first UNet level are only 640 B each).
 template <int NV, int RW>
@@ -289,6 +378,11 @@ extern "C" int ds_groupnorm_f16(const void* x, const float* gamma, const float* 
     DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0, "ds_groupnorm_f16: ninst/rows_per_inst must be positive");
     DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_f16: C=%d groups=%d unsupported", C, groups);
     hipStream_t st = (hipStream_t)stream;
+    if (rows_per_inst <= GN_SMALL_ROWS && C / 8 <= 512 && ninst >= 64) {   // enough instances to fill the chip
+        gn_small_kernel<<<ninst, GN_SMALL_NT, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, eps);
+        DS_CHECK_LAUNCH("ds_groupnorm_f16(small)");
+        return DS_OK;
+    }
     const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
     gn_partial_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups);
     DS_CHECK_LAUNCH("ds_groupnorm_f16(stats)");
