@@ -87,14 +87,15 @@ struct RowInfo {   // per staged A row, computed once
 };
 
 // Compile-time shape of one kernel variant: block tile BM x BN, WGM x WGN waves.
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NS = 2>
 struct TileCfg {
+    static constexpr int NSTAGE = NS;                         // LDS stages of BK halfs (2 = double buffering)
     static constexpr int NT = 64 * WGM * WGN;                 // threads
     static constexpr int WM = BM / WGM, WN = BN / WGN;        // wave tile
     static constexpr int TM = WM / 32, TN = WN / 32;          // 32x32 MFMA tiles per wave
     static constexpr int LROWS = NT / 8;                      // rows staged per sweep (8 lanes x 16 B per 128-B row)
     static constexpr int AR = BM / LROWS, BR = BN / LROWS;    // staged rows per thread
-    static constexpr size_t STAGE = (size_t)2 * (BM + BN) * BK * sizeof(f16);
+    static constexpr size_t STAGE = (size_t)NS * (BM + BN) * BK * sizeof(f16);
     // epilogue: every wave transposes its own accumulators through a private LDS strip of 32 rows x NG MFMA tiles
     // (fp32, +4 floats of padding per row) -- no workgroup barrier after the main loop
     static constexpr int NG = TN <= 4 ? TN : (TN + (TN + 3) / 4 - 1) / ((TN + 3) / 4);   // tiles per column group
@@ -113,18 +114,18 @@ struct TileCfg {
     static_assert(LDS <= 163840, "LDS budget");
 };
 
-template <int BM, int BN, int WGM, int WGN, int AMODE>
-__global__ void __launch_bounds__((TileCfg<BM, BN, WGM, WGN>::NT), (TileCfg<BM, BN, WGM, WGN>::WG_PER_CU))
+template <int BM, int BN, int WGM, int WGN, int AMODE, int NS>
+__global__ void __launch_bounds__((TileCfg<BM, BN, WGM, WGN, NS>::NT), (TileCfg<BM, BN, WGM, WGN, NS>::WG_PER_CU))
 gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const float* __restrict__ bias,
                 const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n,
                 unsigned a_bytes, unsigned w_bytes) {
-    using Cfg = TileCfg<BM, BN, WGM, WGN>;
+    using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
     constexpr int LROWS = Cfg::LROWS, A_ROWS_PER_THREAD = Cfg::AR, B_ROWS_PER_THREAD = Cfg::BR;
 
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
-    f16* sA = reinterpret_cast<f16*>(smem);                 // [2][BM][64]
-    f16* sB = sA + 2 * BM * BK;                             // [2][BN][64]
+    f16* sA = reinterpret_cast<f16*>(smem);                 // [NS][BM][64]
+    f16* sB = sA + NS * BM * BK;                            // [NS][BN][64]
     float* sW = reinterpret_cast<float*>(smem) + (size_t)(threadIdx.x >> 6) * 32 * Cfg::STR;   // this wave's epilogue strip
 
     // ---- XCD-aware block remap (bijective for any grid size) ----
@@ -266,9 +267,13 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 
     // K-step synchronisation.  Register staging: store the staged operands, one barrier.  DMA: wait for this wave's
     // LDS-DMA of the next K-step, one barrier (then every wave's part has landed and the current buffer is free).
+    // NS > 2 (deep variant for grids that leave CUs with a single workgroup): the LDS-DMA of K-step k+NS-1 is issued
+    // during step k, so a lone workgroup still has NS-2 K-steps of loads in flight behind the one it waits for
+    // (counted vmcnt: only the pieces of the step needed next must have landed).
     auto stage_sync = [&](int nbuf, bool more) {
         if constexpr (Cfg::DMA) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_ROWS_PER_THREAD + B_ROWS_PER_THREAD) * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         } else {
@@ -278,8 +283,13 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     };
 
     DS_STAMP(0);
-    load_global(0);
-    stage_sync(0, true);
+    if constexpr (Cfg::DMA) {
+        for (int s0 = 0; s0 < NS - 1 && s0 < d.K / BK; ++s0) load_global(s0);   // NS-1 K-steps in flight
+        stage_sync(0, false);
+    } else {
+        load_global(0);
+        stage_sync(0, true);
+    }
     DS_STAMP(1);
 
     // one LDS-DMA piece (8 rows x 128 B of this wave's share) of the next K-step, and the cursor advance after all pieces
@@ -299,10 +309,13 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     };
 
     auto kstep = [&](int kt, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;   // a next K-step exists: stage it while computing this one
-        const int buf = kt & 1;
+        constexpr bool MORE = decltype(more_tag)::value;   // K-step kt+NS-1 exists: stage it while computing this one
+        const int buf = kt % NS;
+        const int nbuf = (kt + NS - 1) % NS;               // its LDS stage (read last in step kt-1)
         if constexpr (!Cfg::DMA) {
-            if (MORE) load_global(buf ^ 1);
+            if (MORE) load_global(nbuf);
+        } else if constexpr (Cfg::HOIST_ALL) {
+            if (MORE) load_global(nbuf);                   // small wave tiles: the pieces go out in front of the reads
         }
         const f16* a_base = sA + (buf * BM + wm * WM) * BK;
         const f16* b_base_l = sB + (buf * BN + wn * WN) * BK;
@@ -364,7 +377,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                     }
                     if (Cfg::DMA && MORE && np > 0 && idx % stride == stride - 1 && idx / stride < np) {
                         __builtin_amdgcn_sched_barrier(0);
-                        dma_piece((kk == 0 ? 0 : P0) + idx / stride, buf ^ 1);
+                        dma_piece((kk == 0 ? 0 : P0) + idx / stride, nbuf);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -374,10 +387,13 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 if (MORE) advance_k();
             }
         }
-        stage_sync(buf ^ 1, MORE);
+        stage_sync(nbuf, MORE);
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
-    kstep(nk - 1, std::false_type{});
+    {
+        int kt = 0;
+        for (; kt + NS - 1 < nk; ++kt) kstep(kt, std::true_type{});
+        for (; kt < nk; ++kt) kstep(kt, std::false_type{});
+    }
 
     DS_STAMP(2);
     const bool geglu = d.epilogue & DS_EPI_GEGLU;
@@ -562,14 +578,14 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     DS_STAMP(4);
 }
 
-template <int BM, int BN, int WGM, int WGN, int AMODE>
+template <int BM, int BN, int WGM, int WGN, int AMODE, int NS = 2>
 int launch(const void* A, const void* W, const float* bias, const void* residual, void* out,
            const ds_gemm_desc& d, hipStream_t st) {
-    using Cfg = TileCfg<BM, BN, WGM, WGN>;
+    using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
     constexpr size_t lds = Cfg::LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WGM, WGN, AMODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WGM, WGN, AMODE, NS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             ds_set_error("ds_gemm_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -586,7 +602,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
         ds_set_error("ds_gemm_f16: operand of %ld / %ld bytes exceeds the 2 GiB buffer-addressing range; lower the tile batch", a_bytes, w_bytes);
         return DS_EINVAL;
     }
-    gemm_f16_kernel<BM, BN, WGM, WGN, AMODE><<<tiles_m * tiles_n, Cfg::NT, lds, st>>>(
+    gemm_f16_kernel<BM, BN, WGM, WGN, AMODE, NS><<<tiles_m * tiles_n, Cfg::NT, lds, st>>>(
         (const f16*)A, (const f16*)W, bias, (const f16*)residual, out, d, tiles_m, tiles_n, (unsigned)a_bytes, (unsigned)w_bytes);
     DS_CHECK_LAUNCH("ds_gemm_f16");
     return DS_OK;
@@ -595,7 +611,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
 // Tile choice.  256-row tiles halve the operand bytes a CU pulls through its vector-memory path and LDS per MFMA
 // (profiles/r1_notes.md: on 128x128 tiles each of the three -- loads, LDS, MFMA -- is near its limit), but need one
 // workgroup per CU to have work: they are used when the grid still fills the chip.
-enum { TILE_128x64 = 0, TILE_128x128 = 1, TILE_256x256 = 2, TILE_256x320 = 3 };
+enum { TILE_128x64 = 0, TILE_128x128 = 1, TILE_256x256 = 2, TILE_256x320 = 3, TILE_128x128_DEEP = 4, TILE_128x64_DEEP = 5 };
 
 int choose_tile(const ds_gemm_desc& d) {
     static const int forced = getenv("DS_GEMM_TILE") ? atoi(getenv("DS_GEMM_TILE")) : -1;
@@ -607,11 +623,20 @@ int choose_tile(const ds_gemm_desc& d) {
     int big = -1;
     if (d.N % 256 == 0) big = TILE_256x256;
     else if (d.N % 320 == 0 && !geglu) big = TILE_256x320;
-    if (big < 0) return small;
+    // a grid that leaves every CU with at most one 128x128 workgroup: 4-stage LDS-DMA pipeline instead of relying on a
+    // partner workgroup to hide the load latency
+    const long nblk128 = (long)ds_cdiv(d.M, 128) * ds_cdiv(d.N, 128);
+    int small_or_deep = small;
+    if (d.K / BK >= 8 && forced != TILE_128x128 && forced != TILE_128x64) {
+        if (!geglu && nblk128 <= 128) small_or_deep = TILE_128x64_DEEP;          // half the CUs or fewer: narrower tiles, twice the workgroups
+        else if (small == TILE_128x128 && nblk128 <= 256) small_or_deep = TILE_128x128_DEEP;
+    }
+    if (forced == TILE_128x128_DEEP || (forced == TILE_128x64_DEEP && !geglu)) return forced;
+    if (big < 0) return small_or_deep;
     if (forced == TILE_256x256 || forced == TILE_256x320) return big;
     const long nblk = tiles_m256 * (d.N / (big == TILE_256x256 ? 256 : 320));
     static const long big_min = getenv("DS_GEMM_BIG_MIN") ? atol(getenv("DS_GEMM_BIG_MIN")) : 160;
-    return nblk >= big_min ? big : small;
+    return nblk >= big_min ? big : small_or_deep;
 }
 
 template <int AMODE>
@@ -621,6 +646,8 @@ int dispatch(int tile, const void* A, const void* W, const float* bias, const vo
         case TILE_256x256: return launch<256, 256, 2, 4, AMODE>(A, W, bias, residual, out, d, st);
         case TILE_256x320: return launch<256, 320, 4, 2, AMODE>(A, W, bias, residual, out, d, st);
         case TILE_128x128: return launch<128, 128, 2, 2, AMODE>(A, W, bias, residual, out, d, st);
+        case TILE_128x128_DEEP: return launch<128, 128, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st);
+        case TILE_128x64_DEEP: return launch<128, 64, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st);
         default:           return launch<128, 64, 2, 2, AMODE>(A, W, bias, residual, out, d, st);
     }
 }
