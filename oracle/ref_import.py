@@ -37,7 +37,17 @@ def install_stubs():
             import torch, random
             import numpy as np
             random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
-        _module("pytorch_lightning", LightningModule=nn.Module, seed_everything=seed_everything)
+        class LightningModule(nn.Module):
+            """nn.Module plus the two LightningModule properties the reference reads (AutoencoderKL.decode: self.dtype)."""
+            @property
+            def dtype(self):
+                return next(self.parameters()).dtype
+
+            @property
+            def device(self):
+                return next(self.parameters()).device
+
+        _module("pytorch_lightning", LightningModule=LightningModule, seed_everything=seed_everything)
     if "torchvision" not in sys.modules:
         tv = _module("torchvision")
         tv.utils = _module("torchvision.utils", make_grid=lambda *a, **k: None)

@@ -22,6 +22,7 @@ so parity is pinned by what this script captures from the imported reference cod
 Only data is written (inputs, expected outputs, seeds); no reference source text.
 """
 import argparse
+import types
 import contextlib
 import hashlib
 import io
@@ -618,15 +619,61 @@ def g13_i2v_sphere():
     print("wrote sphere_i2v_traces.json")
 
 
+VAE_TINY = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2], num_res_blocks=1,
+                attn_resolutions=[], dropout=0.0)
+VAE_FULL = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                num_res_blocks=2, attn_resolutions=[], dropout=0.0)      # configs/inference_t2v_512_v2.0.yaml:51-70
+
+
+def _build_reference_vae(dd, seed):
+    from lvdm.models.autoencoder import AutoencoderKL
+    from dynamicscaler_amd.vae_spec import decoder_param_shapes
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = AutoencoderKL(ddconfig=dict(dd), lossconfig={"target": "torch.nn.Identity"}, embed_dim=4).eval()
+    shapes = decoder_param_shapes(dd, 4)
+    ref = {k: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
+    assert ref == {k: tuple(v) for k, v in shapes.items()}, "vae_spec != reference state dict"
+    sd = synth_state_dict(shapes, seed)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("encoder.", "quant_conv.")) for k in missing)
+    return m, sd
+
+
+def g14_vae_decode(full=False):
+    """N2 (decode side): AutoencoderKL.decode of the reference on synthetic weights -- toy config, and with --full the
+    real first-stage config on one 40x64 latent frame; also decode_first_stage_2DAE's per-frame loop (ddpm3d.py:556-562)."""
+    from lvdm.models.ddpm3d import LatentDiffusion
+    arrays = {}
+    m, _ = _build_reference_vae(VAE_TINY, seed=21)
+    z = synth_normal((2, 4, 3, 8, 16), 31)                  # [B,C,T,h,w]
+    with torch.no_grad():
+        arrays["tiny_frame"] = m.decode(z[:, :, 0])
+        holder = types.SimpleNamespace(first_stage_model=m, scale_factor=0.18215)
+        arrays["tiny_video"] = LatentDiffusion.decode_first_stage_2DAE(holder, z)
+    arrays["tiny_z"] = z
+    arrays["tiny_dd_json"] = np.frombuffer(json.dumps(VAE_TINY).encode(), dtype=np.uint8)
+    if full:
+        mf, _ = _build_reference_vae(VAE_FULL, seed=22)
+        zf = synth_normal((1, 4, 40, 64), 32)
+        with torch.no_grad():
+            out = mf.decode(zf)
+        arrays["full_z"] = zf
+        arrays["full_frame"] = out.to(torch.float16)        # 3x320x512: stored as fp16 to keep the fixture small
+        arrays["full_dd_json"] = np.frombuffer(json.dumps(VAE_FULL).encode(), dtype=np.uint8)
+        save_npz("vae_full.npz", **{k: v for k, v in arrays.items() if k.startswith("full")})
+    save_npz("vae_tiny.npz", **{k: v for k, v in arrays.items() if k.startswith("tiny")})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size UNet fixture (minutes)")
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode}
     if args.full:
         steps["g10"] = g10_unet_full
+        steps["g14"] = lambda: g14_vae_decode(full=True)
     for k, fn in steps.items():
         if args.only and k != args.only:
             continue

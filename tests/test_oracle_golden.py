@@ -391,3 +391,27 @@ def test_g13_i2v_sphere_loop_tiny_unet():
     for got, key in ((final, "i2vs_base_tiny_final"), (den, "i2vs_base_tiny_denoised")):
         ref = T(z[key])
         assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-4, key
+
+
+def test_g14_vae_decode_vs_reference_golden():
+    """N2 decode side: the oracle's AutoencoderKL.decode / decode_first_stage_2DAE against the reference's modules
+    (toy config exactly up to ATen summation order; the real first-stage config on one 40x64 latent frame, stored fp16)."""
+    from oracle.vae import vae_decode, decode_first_stage_2dae
+    from dynamicscaler_amd.vae_spec import decoder_param_shapes
+    z = npz("vae_tiny.npz")
+    dd = json.loads(bytes(z["tiny_dd_json"]).decode())
+    sd = synth_state_dict(decoder_param_shapes(dd, 4), seed=21)
+    zz = T(z["tiny_z"])
+    out = vae_decode(sd, dd, zz[:, :, 0])
+    ref = T(z["tiny_frame"])
+    assert out.shape == ref.shape and float((out - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+    vid = decode_first_stage_2dae(sd, dd, zz, scale_factor=0.18215)
+    ref = T(z["tiny_video"])
+    assert vid.shape == ref.shape and float((vid - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+    zf = npz("vae_full.npz")
+    ddf = json.loads(bytes(zf["full_dd_json"]).decode())
+    sdf = synth_state_dict(decoder_param_shapes(ddf, 4), seed=22)
+    out = vae_decode(sdf, ddf, T(zf["full_z"]))
+    ref = T(zf["full_frame"]).float()
+    assert out.shape == ref.shape == (1, 3, 320, 512)
+    assert float((out - ref).abs().max()) / float(ref.abs().max()) < 2e-3      # the fixture is rounded to fp16
