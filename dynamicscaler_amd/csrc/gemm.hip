@@ -399,7 +399,10 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const bool geglu = d.epilogue & DS_EPI_GEGLU;
     const bool silu = d.epilogue & DS_EPI_SILU;
     const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;
-    const bool fast = !out_f32 && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (!residual || d.ldr % 8 == 0) &&
+    // fp32 output on the fast path: plain accumulator dump (+ shared bias), e.g. attention scores that go through memory
+    const bool fast32 = out_f32 && !residual && !geglu && !silu && (d.N % 8 == 0) && (d.ldc % 4 == 0) &&
+                        (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    const bool fast = (!out_f32 || fast32) && (d.N % 8 == 0) && (d.ldc % 8 == 0 || fast32) && (!residual || d.ldr % 8 == 0) &&
                       (!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0));
     const bool shared_bias = bias && d.bias_rows >= d.M;
 
@@ -537,7 +540,15 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #ifdef DS_EXP_NOSTORE   // diagnostic builds only (tools/build_stamps.sh)
                                 asm volatile("" ::"v"(o));
 #else
-                                if (ok[u]) *reinterpret_cast<f16x8*>(out_base + (sb + u) * out_step) = o;
+                                if (ok[u]) {
+                                    if (out_f32) {
+                                        float* o32 = reinterpret_cast<float*>(out) + (long)(mrow0 + r0) * d.ldc + ocol + (sb + u) * out_step;
+                                        *reinterpret_cast<f32x4*>(o32) = f32x4{v[0], v[1], v[2], v[3]};
+                                        *reinterpret_cast<f32x4*>(o32 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                                    } else {
+                                        *reinterpret_cast<f16x8*>(out_base + (sb + u) * out_step) = o;
+                                    }
+                                }
 #endif
                             }
                         }

@@ -42,6 +42,73 @@ im2col_in_kernel(const T* __restrict__ x, f16* __restrict__ patches, int B, int 
     }
 }
 
+// The same with a CxC channel mix in front (AutoencoderKL.decode: conv_in(post_quant_conv(z / scale_factor)),
+// autoencoder.py:103-107, ddpm3d.py:559): inside the image the patch value is sum_ci wmat[c][ci] * x[ci] * in_scale + bvec[c],
+// outside it is conv_in's zero padding.  C <= 8.
+template <typename T>
+__global__ void __launch_bounds__(256)
+im2col_in_affine_kernel(const T* __restrict__ x, f16* __restrict__ patches, int B, int C, int Tn, int H, int W, int kpad,
+                        const float* __restrict__ wmat, const float* __restrict__ bvec, float in_scale) {
+    const long total = (long)B * Tn * H * W * kpad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / kpad;
+        const int col = (int)(idx - m * kpad);
+        float v = 0.0f;
+        if (col < 9 * C) {
+            const int tap = col / C, c = col - tap * C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            long r = m;
+            const int xx = (int)(r % W); r /= W;
+            const int yy = (int)(r % H); r /= H;
+            const int t = (int)(r % Tn);
+            const int b = (int)(r / Tn);
+            const int iy = yy + ky - 1, ix = xx + kx - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                v = bvec[c];
+                for (int ci = 0; ci < C; ++ci)
+                    v += wmat[c * C + ci] * ((float)x[((((long)b * C + ci) * Tn + t) * H + iy) * W + ix] * in_scale);
+            }
+        }
+        patches[idx] = (f16)v;
+    }
+}
+
+// Row softmax: p[r][c] = softmax_c(s[r][c] * scale), fp32 in, fp16 out; one wave per row (AttnBlock of the first-stage
+// decoder, ae_modules.py:62-64: the 512-wide single head does not fit the head_dim-64 flash kernel, so its scores go
+// through memory as fp32).
+__global__ void __launch_bounds__(256)
+softmax_rows_kernel(const float* __restrict__ s, f16* __restrict__ p, int rows, int cols, int lds, int ldp, float scale_log2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float* sr = s + row * lds;
+    f16* pr = p + row * ldp;
+    float m = -1e30f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sr + c);
+        m = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) m = fmaxf(m, __shfl_xor(m, sh));
+    const float mneg = -m * scale_log2;
+    float l = 0.0f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sr + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l += __builtin_amdgcn_exp2f(fmaf(v[j], scale_log2, mneg));
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) l += __shfl_xor(l, sh);
+    const float inv = 1.0f / l;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sr + c);
+        f16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (f16)(__builtin_amdgcn_exp2f(fmaf(v[j], scale_log2, mneg)) * inv);
+        *reinterpret_cast<f16x4*>(pr + c) = o;
+    }
+}
+
 template <typename Y, typename O>
 __global__ void __launch_bounds__(256)
 rows_to_ncthw_kernel(const Y* __restrict__ y, int ldy, O* __restrict__ out, int B, int C, int Tn, int H, int W) {
@@ -156,6 +223,31 @@ extern "C" int ds_im2col_in(const void* x, int x_dtype, void* patches, int B, in
     else
         DS_CHECK_ARG(false, "ds_im2col_in: bad dtype %d", x_dtype);
     DS_CHECK_LAUNCH("ds_im2col_in");
+    return DS_OK;
+}
+
+extern "C" int ds_im2col_in_affine(const void* x, int x_dtype, void* patches, int B, int C, int T, int H, int W, int kpad,
+                                   const float* wmat, const float* bvec, float in_scale, void* stream) {
+    DS_CHECK_ARG(x && patches && wmat && bvec, "ds_im2col_in_affine: null argument");
+    DS_CHECK_ARG(B > 0 && C > 0 && C <= 8 && T > 0 && H > 0 && W > 0, "ds_im2col_in_affine: sizes must be positive, C <= 8");
+    DS_CHECK_ARG(kpad >= 9 * C && kpad % 64 == 0, "ds_im2col_in_affine: kpad=%d must be >= 9*C and a multiple of 64", kpad);
+    const long work = (long)B * T * H * W * kpad;
+    if (x_dtype == DS_F16)
+        im2col_in_affine_kernel<f16><<<grid_for(work), 256, 0, (hipStream_t)stream>>>((const f16*)x, (f16*)patches, B, C, T, H, W, kpad, wmat, bvec, in_scale);
+    else if (x_dtype == DS_F32)
+        im2col_in_affine_kernel<float><<<grid_for(work), 256, 0, (hipStream_t)stream>>>((const float*)x, (f16*)patches, B, C, T, H, W, kpad, wmat, bvec, in_scale);
+    else
+        DS_CHECK_ARG(false, "ds_im2col_in_affine: bad dtype %d", x_dtype);
+    DS_CHECK_LAUNCH("ds_im2col_in_affine");
+    return DS_OK;
+}
+
+extern "C" int ds_softmax_rows(const float* s, void* p, int rows, int cols, int lds, int ldp, float scale, void* stream) {
+    DS_CHECK_ARG(s && p, "ds_softmax_rows: null argument");
+    DS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && lds % 4 == 0 && ldp % 4 == 0 && lds >= cols && ldp >= cols,
+                 "ds_softmax_rows: cols / strides must be positive multiples of 4");
+    softmax_rows_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(s, (f16*)p, rows, cols, lds, ldp, scale * 1.4426950408889634f);
+    DS_CHECK_LAUNCH("ds_softmax_rows");
     return DS_OK;
 }
 

@@ -1,9 +1,10 @@
 """Host-side stand-in for the LatentDiffusion object the pipelines read (`pretrained_t2v`).
 
 Only the members on the hot path exist: `.model` (DiffusionWrapper around the HIP UNetModel), the schedule
-buffers of register_schedule (lvdm/models/ddpm3d.py:113-134), `get_learned_conditioning`, and the plain
-attributes the pipelines / scheduler read.  CLIP and the VAE are out of scope: the
-conditioner is any callable prompt-list -> [1, L, context_dim] tensor (synthetic embeddings in tests / bench).
+buffers of register_schedule (lvdm/models/ddpm3d.py:113-134), `get_learned_conditioning`, the plain attributes the
+pipelines / scheduler read, and -- when a `first_stage_config` is given -- the first-stage DECODER
+(`decode_first_stage_2DAE`, ddpm3d.py:556-562, on vae.AutoencoderKLDecoder).  CLIP and the VAE encoder are out of
+scope: the conditioner is any callable prompt-list -> [1, L, context_dim] tensor.
 """
 import importlib
 
@@ -40,7 +41,7 @@ class SyntheticConditioner:
 
 class LatentDiffusionHost(nn.Module):
     def __init__(self, unet_config, timesteps=1000, linear_start=0.00085, linear_end=0.012, uncond_type="empty_seq",
-                 use_scale=False, channels=4, conditioner=None, **_ignored):
+                 use_scale=False, channels=4, conditioner=None, first_stage_config=None, scale_factor=1.0, **_ignored):
         super().__init__()
         params = unet_config["params"] if "params" in unet_config else unet_config
         self.model = DiffusionWrapper(UNetModel(**params), "crossattn")
@@ -53,13 +54,25 @@ class LatentDiffusionHost(nn.Module):
         self.uncond_type = uncond_type
         self.channels = channels
         self.temporal_length = params.get("temporal_length", 16)
+        self.scale_factor = scale_factor
         self.first_stage_model = None
+        if first_stage_config is not None:
+            from .vae import AutoencoderKLDecoder
+            fp = first_stage_config.get("params", first_stage_config)
+            self.first_stage_model = AutoencoderKLDecoder(fp["ddconfig"], fp.get("embed_dim", 4))
         self.cond_stage_model = None
         self.conditioner = conditioner
 
     @property
     def device(self):
         return self.betas.device
+
+    @torch.no_grad()
+    def decode_first_stage_2DAE(self, z, **kwargs):
+        """ddpm3d.py:556-562: z [B,C,T,h,w] -> [B,3,T,H,W], every frame through AutoencoderKL.decode of z / scale_factor."""
+        if self.first_stage_model is None:
+            raise RuntimeError("no first-stage decoder attached (pass first_stage_config, or use output_type='latent')")
+        return self.first_stage_model.decode_frames(z.to(self.device), in_scale=1.0 / self.scale_factor)
 
     def get_learned_conditioning(self, prompts):
         if self.conditioner is None:

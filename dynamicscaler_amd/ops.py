@@ -359,6 +359,30 @@ def im2col_in(x, kpad, stream=None):
     return patches
 
 
+def im2col_in_affine(x, kpad, wmat, bvec, in_scale, stream=None):
+    """conv_in patches of post_quant_conv(x * in_scale) (first-stage decoder); wmat fp32 [C,C], bvec fp32 [C] on the device."""
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    B, Cc, T, H, W = x.shape
+    patches = torch.empty((B * T * H * W, kpad), dtype=torch.float16, device=x.device)
+    check(lib.ds_im2col_in_affine(x.data_ptr(), _DT[x.dtype], patches.data_ptr(), B, Cc, T, H, W, kpad, wmat.data_ptr(),
+                                  bvec.data_ptr(), float(in_scale), st), "ds_im2col_in_affine")
+    return patches
+
+
+def softmax_rows(s, scale, out=None, stream=None):
+    """fp32 scores [rows, cols] -> fp16 softmax(s * scale) over the columns."""
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    rows, cols = s.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float16, device=s.device)
+    assert out.shape[0] == rows and out.shape[1] >= cols
+    check(lib.ds_softmax_rows(s.data_ptr(), out.data_ptr(), rows, cols, s.stride(0), out.stride(0), float(scale), st),
+          "ds_softmax_rows")
+    return out
+
+
 def rows_to_ncthw(y, shape, out_dtype, stream=None):
     lib = _lib.load()
     st = _stream() if stream is None else stream

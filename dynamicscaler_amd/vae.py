@@ -1,0 +1,169 @@
+"""First-stage decoder on the HIP kernels (decode side): drop-in for the decode half of
+lvdm.models.autoencoder.AutoencoderKL (autoencoder.py:103-107) and LatentDiffusion.decode_first_stage_2DAE
+(ddpm3d.py:556-562), same constructor config (`ddconfig`, `embed_dim`) and the reference's state-dict keys
+(`post_quant_conv.*`, `decoder.*`; encoder keys are accepted and ignored).
+
+Layout and kernels are the UNet's: activations are rows x channels fp16 with row = ((b*T + t)*H + y)*W + x, every conv is
+ds_gemm_f16 (3x3 / nearest-x2-upsample folded into the gather, 1x1 = dense), GroupNorm(32, eps 1e-6) + swish is
+ds_groupnorm_f16.  The mid-block attention is a single 512-wide head (ae_modules.py:26-78), which does not fit the
+head_dim-64 flash kernel: per image, scores = Q K^T go through memory as fp32 (ds_gemm_f16 with fp32 output),
+ds_softmax_rows, then P V as a GEMM against V^T (produced directly as Wv X^T, so nothing is transposed); v's bias
+moves into proj_out's (softmax rows sum to 1).  post_quant_conv and the 1/scale_factor are applied while conv_in's
+patches are gathered (ds_im2col_in_affine).  Frames are decoded in chunks of `frames_per_chunk` images.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import DS_A_CONV3, DS_EPI_OUT_F32
+from .vae_spec import decoder_blocks, decoder_param_shapes
+
+
+class AutoencoderKLDecoder(nn.Module):
+    def __init__(self, ddconfig, embed_dim=4, **ignored):
+        super().__init__()
+        self.dd = dict(ddconfig)
+        self.embed_dim = embed_dim
+        assert self.dd["z_channels"] == embed_dim or True
+        self._shapes = decoder_param_shapes(self.dd, embed_dim)
+        self._params = nn.ParameterDict()
+        for key, shape in self._shapes.items():
+            self._params[key.replace(".", "/")] = nn.Parameter(torch.zeros(shape), requires_grad=False)
+        self._packed, self._device = None, None
+        self.frames_per_chunk = 4
+
+    # ---- reference-keyed state dict ----
+    def state_dict(self, *a, **k):
+        return {key: self._params[key.replace(".", "/")].data for key in self._shapes}
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._shapes if k not in sd]
+        unexpected = [k for k in sd if k not in self._shapes and not k.startswith(("encoder.", "quant_conv.", "loss."))]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"AutoencoderKLDecoder.load_state_dict: missing {missing[:4]}, unexpected {unexpected[:4]}")
+        for k in self._shapes:
+            if k in sd:
+                assert tuple(sd[k].shape) == tuple(self._shapes[k]), (k, tuple(sd[k].shape), self._shapes[k])
+                self._params[k.replace(".", "/")].data = sd[k].detach().clone().float()
+        self._packed = None
+        return missing, unexpected
+
+    def prepare(self, device):
+        """Repack to the kernels' layouts (fp16 [N][K], K = tap*Cin + c), once per device."""
+        sd = self.state_dict()
+        dev = torch.device(device)
+        P = {}
+
+        def w16(t):
+            return t.to(dev, torch.float16).contiguous()
+
+        def f32(t):
+            return t.to(dev, torch.float32).contiguous()
+
+        def conv_w(w):      # [O,I,3,3] -> [O][9*I] with k = (ky*3+kx)*I + i
+            return w16(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
+
+        for kind, p, cin, cout in decoder_blocks(self.dd):
+            if kind == "conv_in":
+                w = sd[p + ".weight"].permute(0, 2, 3, 1).reshape(cout, -1)          # [O][9*C]
+                kpad = ((w.shape[1] + 63) // 64) * 64
+                wp = torch.zeros(cout, kpad)
+                wp[:, :w.shape[1]] = w
+                P[p + ".w"], P[p + ".b"], self._kpad_in = w16(wp), f32(sd[p + ".bias"]), kpad
+            elif kind == "res":
+                for n in ("norm1", "norm2"):
+                    P[f"{p}.{n}.g"], P[f"{p}.{n}.be"] = f32(sd[f"{p}.{n}.weight"]), f32(sd[f"{p}.{n}.bias"])
+                for n in ("conv1", "conv2"):
+                    P[f"{p}.{n}.w"], P[f"{p}.{n}.b"] = conv_w(sd[f"{p}.{n}.weight"]), f32(sd[f"{p}.{n}.bias"])
+                if cin != cout:
+                    P[p + ".nin.w"] = w16(sd[p + ".nin_shortcut.weight"].reshape(cout, cin))
+                    P[p + ".nin.b"] = f32(sd[p + ".nin_shortcut.bias"])
+            elif kind == "attn":
+                P[p + ".norm.g"], P[p + ".norm.be"] = f32(sd[p + ".norm.weight"]), f32(sd[p + ".norm.bias"])
+                for n in ("q", "k"):
+                    P[f"{p}.{n}.w"], P[f"{p}.{n}.b"] = w16(sd[f"{p}.{n}.weight"].reshape(cin, cin)), f32(sd[f"{p}.{n}.bias"])
+                P[p + ".v.w"] = w16(sd[p + ".v.weight"].reshape(cin, cin))
+                wp = sd[p + ".proj_out.weight"].reshape(cin, cin).double()
+                P[p + ".proj.w"] = w16(wp.float())
+                # softmax rows sum to 1: P (V + 1 b_v^T) = P V + b_v, so b_v rides on proj_out's bias
+                P[p + ".proj.b"] = f32((sd[p + ".proj_out.bias"].double() + wp @ sd[p + ".v.bias"].double()).float())
+            elif kind == "up":
+                P[p + ".w"], P[p + ".b"] = conv_w(sd[p + ".conv.weight"]), f32(sd[p + ".conv.bias"])
+            elif kind == "norm_out":
+                P[p + ".g"], P[p + ".be"] = f32(sd[p + ".weight"]), f32(sd[p + ".bias"])
+            elif kind == "conv_out":
+                P[p + ".w"], P[p + ".b"] = conv_w(sd[p + ".weight"]), f32(sd[p + ".bias"])
+        P["pq.w"] = f32(sd["post_quant_conv.weight"].reshape(self.dd["z_channels"], self.embed_dim))
+        P["pq.b"] = f32(sd["post_quant_conv.bias"])
+        self._packed, self._device = P, dev
+        return self
+
+    # ---- ops ----
+    def _conv3(self, a, w, b, nimg, hin, win, cin, upsample=0, residual=None, epilogue=0):
+        hl, wl = (2 * hin, 2 * win) if upsample else (hin, win)
+        M = nimg * hl * wl
+        out = ops.gemm(a, w, b, residual, M=M, N=w.shape[0], K=w.shape[1], a_mode=DS_A_CONV3, cin=cin, lda=a.stride(0),
+                       conv=(nimg, hin, win, hl, wl, 1, upsample), epilogue=epilogue)
+        return out, hl, wl
+
+    def _attn(self, x, p, nimg, hw, C):
+        P = self._packed
+        h = ops.groupnorm(x, P[p + ".norm.g"], P[p + ".norm.be"], nimg, hw, C, 1e-6, False)
+        M = nimg * hw
+        q = ops.gemm(h, P[p + ".q.w"], P[p + ".q.b"], None, M=M, N=C, K=C)
+        k = ops.gemm(h, P[p + ".k.w"], P[p + ".k.b"], None, M=M, N=C, K=C)
+        o = torch.empty((M, C), dtype=torch.float16, device=x.device)
+        hwp = (hw + 63) // 64 * 64        # the P V contraction runs over the tokens: padded to the GEMM's K granule
+        s = torch.empty((hw, hw), dtype=torch.float32, device=x.device)
+        pr = torch.zeros((hw, hwp), dtype=torch.float16, device=x.device)      # pad columns stay 0
+        vt = torch.zeros((C, hwp), dtype=torch.float16, device=x.device)
+        for i in range(nimg):
+            rows = slice(i * hw, (i + 1) * hw)
+            ops.gemm(q[rows], k[rows], None, None, M=hw, N=hw, K=C, out=s, epilogue=DS_EPI_OUT_F32)     # q k^T
+            ops.softmax_rows(s, int(C) ** (-0.5), out=pr)
+            ops.gemm(P[p + ".v.w"], h[rows], None, None, M=C, N=hw, K=C, out=vt)                      # V^T = Wv X^T
+            ops.gemm(pr, vt, None, None, M=hw, N=C, K=hwp, out=o[rows])                               # P V
+        return ops.gemm(o, P[p + ".proj.w"], P[p + ".proj.b"], x, M=M, N=C, K=C)
+
+    @torch.no_grad()
+    def decode_frames(self, z, in_scale=1.0):
+        """z [B, z_channels, T, h, w] (HIP device, fp16/fp32) -> [B, out_ch, T, H, W] fp32; every (b, t) is one image."""
+        if not z.is_cuda:
+            raise RuntimeError("AutoencoderKLDecoder: input is on the CPU; this build has no CPU path")
+        if self._packed is None or self._device != z.device:
+            self.prepare(z.device)
+        P = self._packed
+        B, Cz, T, hh, ww = z.shape
+        outs = []
+        for t0 in range(0, T, self.frames_per_chunk):
+            zc = z[:, :, t0:t0 + self.frames_per_chunk].contiguous()
+            Tn = zc.shape[2]
+            nimg, H, W = B * Tn, hh, ww
+            x = None
+            for kind, p, cin, cout in decoder_blocks(self.dd):
+                if kind == "conv_in":
+                    patches = ops.im2col_in_affine(zc, self._kpad_in, P["pq.w"], P["pq.b"], in_scale)
+                    x = ops.gemm(patches, P[p + ".w"], P[p + ".b"], None, M=patches.shape[0], N=cout, K=self._kpad_in)
+                elif kind == "res":
+                    a = ops.groupnorm(x, P[p + ".norm1.g"], P[p + ".norm1.be"], nimg, H * W, cin, 1e-6, True)
+                    h1, _, _ = self._conv3(a, P[p + ".conv1.w"], P[p + ".conv1.b"], nimg, H, W, cin)
+                    a2 = ops.groupnorm(h1, P[p + ".norm2.g"], P[p + ".norm2.be"], nimg, H * W, cout, 1e-6, True)
+                    skip = x if cin == cout else ops.gemm(x, P[p + ".nin.w"], P[p + ".nin.b"], None, M=x.shape[0], N=cout, K=cin)
+                    x, _, _ = self._conv3(a2, P[p + ".conv2.w"], P[p + ".conv2.b"], nimg, H, W, cout, residual=skip)
+                elif kind == "attn":
+                    x = self._attn(x, p, nimg, H * W, cin)
+                elif kind == "up":
+                    x, H, W = self._conv3(x, P[p + ".w"], P[p + ".b"], nimg, H, W, cin, upsample=1)
+                elif kind == "norm_out":
+                    x = ops.groupnorm(x, P[p + ".g"], P[p + ".be"], nimg, H * W, cin, 1e-6, True)
+                elif kind == "conv_out":
+                    y, _, _ = self._conv3(x, P[p + ".w"], P[p + ".b"], nimg, H, W, cin, epilogue=DS_EPI_OUT_F32)
+                    outs.append(ops.rows_to_ncthw(y, (B, cout, Tn, H, W), torch.float32))
+        return torch.cat(outs, dim=2)
+
+    def decode(self, z, **kwargs):
+        """AutoencoderKL.decode: z [B, z_channels, h, w] -> [B, out_ch, H, W]."""
+        return self.decode_frames(z.unsqueeze(2))[:, :, 0]
+
+    def forward(self, z):
+        return self.decode(z)

@@ -206,6 +206,13 @@ int ds_concat_channels(const void* a, const void* b, void* dst, int rows, int c1
  * zero padded borders and columns >= 9*C (openaimodel3d.py:421, 682). */
 int ds_im2col_in(const void* x, int x_dtype, void* patches, int B, int C, int T, int H, int W, int kpad,
                  void* stream);
+/* First-stage decoder (N2): conv_in(post_quant_conv(z * in_scale)) patches -- the CxC channel mix of
+ * AutoencoderKL.decode (lvdm/models/autoencoder.py:103-107; in_scale = 1/scale_factor, ddpm3d.py:559) applied inside the
+ * image, conv_in's zero padding outside.  wmat fp32 [C][C], bvec fp32 [C], C <= 8. */
+int ds_im2col_in_affine(const void* x, int x_dtype, void* patches, int B, int C, int T, int H, int W, int kpad,
+                        const float* wmat, const float* bvec, float in_scale, void* stream);
+/* p[r][c] = softmax_c(s[r][c] * scale): fp32 scores in, fp16 probabilities out (AttnBlock, ae_modules.py:60-64). */
+int ds_softmax_rows(const float* s, void* p, int rows, int cols, int lds, int ldp, float scale, void* stream);
 /* y rows fp32/fp16 [B*T*H*W][ldy] (first C columns) -> out [B][C][T][H][W] (out_dtype)  (openaimodel3d.py:707). */
 int ds_rows_to_ncthw(const void* y, int y_dtype, int ldy, void* out, int out_dtype, int B, int C, int T, int H,
                      int W, void* stream);

@@ -443,3 +443,71 @@ def test_i2v_sphere_pipeline_vs_oracle_and_reference_golden():
     e1, e2 = relerr(final, T(z["i2vs_base_tiny_final"])), relerr(den, T(z["i2vs_base_tiny_denoised"]))
     print(f"i2v sphere base tiny fp16: final rel err {e1:.3e}, denoised rel err {e2:.3e}")
     assert e1 < 3e-2 and e2 < 3e-2
+
+
+def test_vae_decode_vs_reference_golden():
+    """N2 decode side: AutoencoderKLDecoder (HIP) against the reference's AutoencoderKL.decode / decode_first_stage_2DAE:
+    toy config (fp32 golden) and the real first-stage config on one 40x64 latent frame (320x512 image, fp16 fixture).
+    fp16 activations vs the reference's fp32: tolerance 1e-2 rel-L2 on the decoded pixels."""
+    from dynamicscaler_amd.vae import AutoencoderKLDecoder
+    from dynamicscaler_amd.vae_spec import decoder_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    d = dev()
+    z = np.load(os.path.join(G, "vae_tiny.npz"))
+    dd = json.loads(bytes(z["tiny_dd_json"]).decode())
+    m = AutoencoderKLDecoder(dd, 4)
+    m.load_state_dict(synth_state_dict(decoder_param_shapes(dd, 4), seed=21))
+    zz = T(z["tiny_z"]).to(d)
+    frame = m.decode(zz[:, :, 0])
+    e1 = relerr(frame, T(z["tiny_frame"]))
+    vid = m.decode_frames(zz, in_scale=1.0 / 0.18215)
+    e2 = relerr(vid, T(z["tiny_video"]))
+    print(f"vae tiny: frame rel err {e1:.3e}, video rel err {e2:.3e}")
+    assert frame.shape == (2, 3, 16, 32) and vid.shape == (2, 3, 3, 16, 32) and e1 < 1e-2 and e2 < 1e-2
+    zf = np.load(os.path.join(G, "vae_full.npz"))
+    ddf = json.loads(bytes(zf["full_dd_json"]).decode())
+    mf = AutoencoderKLDecoder(ddf, 4)
+    mf.load_state_dict(synth_state_dict(decoder_param_shapes(ddf, 4), seed=22))
+    out = mf.decode(T(zf["full_z"]).to(d))
+    e3 = relerr(out, T(zf["full_frame"]).float())
+    print(f"vae full (1 frame 40x64 -> 320x512): rel err {e3:.3e}")
+    assert out.shape == (1, 3, 320, 512) and e3 < 1e-2
+
+
+def test_decode_tail_seam_safe_with_vae():
+    """P6: output_type != 'latent' runs the seam-padded per-frame decode (t2v_sphere_panorama_pipeline.py:638-655) through
+    the HIP first-stage decoder; checked against the oracle's decoder on the same padded latent."""
+    from oracle.vae import decode_first_stage_2dae
+    from dynamicscaler_amd.host_model import LatentDiffusionHost
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    from dynamicscaler_amd.vae_spec import decoder_param_shapes
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    d = dev()
+    z = np.load(os.path.join(G, "loops_small.npz"))
+    meta = json.load(open(os.path.join(G, "loops_small_traces.json")))
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    dd = json.loads(bytes(np.load(os.path.join(G, "vae_tiny.npz"))["tiny_dd_json"]).decode())
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    ld = LatentDiffusionHost({"params": params}, conditioner=lambda p: uncond if p[0] == "" else cond,
+                             first_stage_config={"params": {"ddconfig": dd, "embed_dim": 4}}, scale_factor=0.18215)
+    ld.model.diffusion_model.load_state_dict(synth_state_dict(param_shapes(params), 5), strict=True)
+    vsd = synth_state_dict(decoder_param_shapes(dd, 4), seed=21)
+    ld.first_stage_model.load_state_dict(vsd)
+    ld.temporal_length = 4
+    ld = ld.to(d).eval()
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}}).to(d, torch.float16)
+    torch.manual_seed(2333333)
+    videos, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="tensor",
+                                                        **meta["geoms"]["grid4x2"])
+    assert videos.shape[:3] == (1, 3, den.shape[2]) and videos.shape[3] == den.shape[3] * 2 and videos.shape[4] == den.shape[4] * 2
+    lat = den.float().cpu()
+    chunks = list(torch.chunk(lat, 16, dim=4))
+    padded = torch.cat([chunks[-1]] + chunks + [chunks[0]], dim=4)
+    ref = decode_first_stage_2dae(vsd, dd, padded, scale_factor=0.18215)
+    ref = torch.cat(torch.chunk(ref, 18, dim=4)[1:-1], dim=4)
+    e = relerr(videos, ref)
+    print(f"seam-safe decode tail: rel err {e:.3e}")
+    assert e < 1e-2
