@@ -30,7 +30,7 @@ class AutoencoderKLDecoder(nn.Module):
         for key, shape in self._shapes.items():
             self._params[key.replace(".", "/")] = nn.Parameter(torch.zeros(shape), requires_grad=False)
         self._packed, self._device = None, None
-        self.frames_per_chunk = 4
+        self.frames_per_chunk = 8
 
     # ---- reference-keyed state dict ----
     def state_dict(self, *a, **k):
