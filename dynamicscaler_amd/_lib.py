@@ -31,7 +31,7 @@ class RingGeom(C.Structure):
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "M", "N", "K", "a_mode", "lda", "cin", "nimg", "hin", "win", "hout", "wout", "stride", "upsample",
-        "t_len", "hw", "ldc", "ldr", "bias_rows", "ldbias", "epilogue")]
+        "t_len", "hw", "ldc", "ldr", "bias_rows", "ldbias", "epilogue", "asym_pad")]
 
 
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t

@@ -165,7 +165,8 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             const int hw = d.hout * d.wout;
             const int img = mm / hw, rem = mm - img * hw;
             const int oy = rem / d.wout;
-            ri[i].a = img; ri[i].b = oy * d.stride - 1; ri[i].c = (rem - oy * d.wout) * d.stride - 1;
+            const int pad = d.asym_pad ? 0 : 1;
+            ri[i].a = img; ri[i].b = oy * d.stride - pad; ri[i].c = (rem - oy * d.wout) * d.stride - pad;
             ri[i].base = (unsigned)(img * d.hin * d.win) * (unsigned)d.lda * 2u;
         } else if constexpr (AMODE == DS_A_TCONV) {
             ri[i].a = (mm / d.hw) % d.t_len; ri[i].b = 0; ri[i].c = 0;

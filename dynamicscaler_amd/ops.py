@@ -252,7 +252,8 @@ def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE
     d.cin = K if cin is None else cin
     d.lda = d.cin if lda is None else lda
     if conv is not None:
-        d.nimg, d.hin, d.win, d.hout, d.wout, d.stride, d.upsample = conv
+        d.nimg, d.hin, d.win, d.hout, d.wout, d.stride, d.upsample = conv[:7]
+        d.asym_pad = conv[7] if len(conv) > 7 else 0
     if tconv is not None:
         d.t_len, d.hw = tconv
     d.ldc = out.stride(0)

@@ -155,6 +155,9 @@ typedef struct ds_gemm_desc {
     int32_t bias_rows;      /* bias index = (m / bias_rows) * ldbias + n ; bias_rows >= M -> one shared vector */
     int32_t ldbias;         /* row stride of the bias table in floats (>= N)                                */
     int32_t epilogue;       /* DS_EPI_* flags                                                               */
+    int32_t asym_pad;       /* CONV3: 0 = zero padding 1 on every side; 1 = no top/left padding, bottom/right only
+                               (F.pad(x, (0,1,0,1)) + stride-2 conv of the first-stage encoder's Downsample,
+                               ae_modules.py:102-106)                                                          */
 } ds_gemm_desc;
 
 /* fp16 x fp16 -> fp32-accumulate MFMA GEMM with fused bias / per-item bias (emb add) / residual / GEGLU /

@@ -625,14 +625,16 @@ VAE_FULL = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_
                 num_res_blocks=2, attn_resolutions=[], dropout=0.0)      # configs/inference_t2v_512_v2.0.yaml:51-70
 
 
-def _build_reference_vae(dd, seed):
+def _build_reference_vae(dd, seed, whole=False):
+    """whole=False: decoder-side synthetic weights only (the fixtures of g14); whole=True: encoder + decoder (g15)."""
     from lvdm.models.autoencoder import AutoencoderKL
-    from dynamicscaler_amd.vae_spec import decoder_param_shapes
+    from dynamicscaler_amd.vae_spec import decoder_param_shapes, vae_param_shapes
     with contextlib.redirect_stdout(io.StringIO()):
         m = AutoencoderKL(ddconfig=dict(dd), lossconfig={"target": "torch.nn.Identity"}, embed_dim=4).eval()
-    shapes = decoder_param_shapes(dd, 4)
-    ref = {k: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
-    assert ref == {k: tuple(v) for k, v in shapes.items()}, "vae_spec != reference state dict"
+    full = vae_param_shapes(dd, 4)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in full.items()}, \
+        "vae_spec != reference state dict"
+    shapes = full if whole else decoder_param_shapes(dd, 4)
     sd = synth_state_dict(shapes, seed)
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all(k.startswith(("encoder.", "quant_conv.")) for k in missing)
@@ -664,16 +666,53 @@ def g14_vae_decode(full=False):
     save_npz("vae_tiny.npz", **{k: v for k, v in arrays.items() if k.startswith("tiny")})
 
 
+VAE_TINY8 = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 1, 2, 2],
+                 num_res_blocks=1, attn_resolutions=[], dropout=0.0)      # 8x down like the real first stage
+
+
+def g15_vae_encode(full=False):
+    """N2 (encode side): AutoencoderKL.encode moments, encode_first_stage_2DAE (seeded posterior sample) and the pipeline's
+    tiled_vae_encode_tensor_simple, run on the reference with synthetic weights."""
+    from lvdm.models.ddpm3d import LatentDiffusion
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    arrays = {}
+    m, _ = _build_reference_vae(VAE_TINY8, seed=23, whole=True)
+    img = synth_normal((1, 3, 2, 64, 128), 41).clamp(-1, 1)          # [B,3,F,H,W]
+    holder = types.SimpleNamespace(first_stage_model=m, scale_factor=0.18215)
+    holder.get_first_stage_encoding = lambda post, noise=None: LatentDiffusion.get_first_stage_encoding(holder, post, noise)
+    with torch.no_grad():
+        arrays["tiny8_moments"] = m.encode(img[:, :, 0]).parameters
+        torch.manual_seed(77)
+        arrays["tiny8_encoded"] = LatentDiffusion.encode_first_stage_2DAE(holder, img)
+        holder.encode_first_stage_2DAE = lambda x: LatentDiffusion.encode_first_stage_2DAE(holder, x)
+        pipe = types.SimpleNamespace(pretrained_t2v=holder, vae_scale_factor=8)
+        big = synth_normal((1, 3, 1, 128, 256), 42).clamp(-1, 1)
+        torch.manual_seed(78)
+        arrays["tiny8_tiled"] = VC2_Pipeline_I2V_SpherePano.tiled_vae_encode_tensor_simple.__wrapped__(
+            pipe, image_tensor=big, h_tile_num=4, w_tile_num=4, overlap_h=2, overlap_w=2)
+    arrays["tiny8_img"], arrays["tiny8_big"] = img, big
+    arrays["tiny8_dd_json"] = np.frombuffer(json.dumps(VAE_TINY8).encode(), dtype=np.uint8)
+    save_npz("vae_enc_tiny.npz", **arrays)
+    if full:
+        mf, _ = _build_reference_vae(VAE_FULL, seed=24, whole=True)
+        imgf = synth_normal((1, 3, 320, 512), 43).clamp(-1, 1)
+        with torch.no_grad():
+            mom = mf.encode(imgf).parameters
+        save_npz("vae_enc_full.npz", full_img=imgf.to(torch.float16), full_moments=mom,
+                 full_dd_json=np.frombuffer(json.dumps(VAE_FULL).encode(), dtype=np.uint8))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size UNet fixture (minutes)")
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode}
     if args.full:
         steps["g10"] = g10_unet_full
         steps["g14"] = lambda: g14_vae_decode(full=True)
+        steps["g15"] = lambda: g15_vae_encode(full=True)
     for k, fn in steps.items():
         if args.only and k != args.only:
             continue

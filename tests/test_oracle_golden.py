@@ -415,3 +415,31 @@ def test_g14_vae_decode_vs_reference_golden():
     ref = T(zf["full_frame"]).float()
     assert out.shape == ref.shape == (1, 3, 320, 512)
     assert float((out - ref).abs().max()) / float(ref.abs().max()) < 2e-3      # the fixture is rounded to fp16
+
+
+def test_g15_vae_encode_vs_reference_golden():
+    """N2 encode side: moments of AutoencoderKL.encode, the seeded posterior sample of encode_first_stage_2DAE and the
+    pipeline's tiled encode against the reference's own outputs (toy 8x config; the real config on a 320x512 image)."""
+    from oracle.vae import vae_encode_moments, encode_first_stage_2dae, tiled_vae_encode
+    from dynamicscaler_amd.vae_spec import vae_param_shapes
+    z = npz("vae_enc_tiny.npz")
+    dd = json.loads(bytes(z["tiny8_dd_json"]).decode())
+    sd = synth_state_dict(vae_param_shapes(dd, 4), seed=23)
+    img = T(z["tiny8_img"])
+    mom = vae_encode_moments(sd, dd, img[:, :, 0])
+    ref = T(z["tiny8_moments"])
+    assert mom.shape == ref.shape and float((mom - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+    torch.manual_seed(77)
+    enc = encode_first_stage_2dae(sd, dd, img, scale_factor=0.18215)
+    ref = T(z["tiny8_encoded"])
+    assert enc.shape == ref.shape and float((enc - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+    torch.manual_seed(78)
+    til = tiled_vae_encode(sd, dd, T(z["tiny8_big"]), scale_factor=0.18215, overlap_h=2, overlap_w=2)
+    ref = T(z["tiny8_tiled"])
+    assert til.shape == ref.shape == (1, 4, 1, 16, 32) and float((til - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+    zf = npz("vae_enc_full.npz")
+    ddf = json.loads(bytes(zf["full_dd_json"]).decode())
+    sdf = synth_state_dict(vae_param_shapes(ddf, 4), seed=24)
+    mom = vae_encode_moments(sdf, ddf, T(zf["full_img"]).float())
+    ref = T(zf["full_moments"])
+    assert mom.shape == ref.shape == (1, 8, 40, 64) and float((mom - ref).abs().max()) / float(ref.abs().max()) < 2e-5
