@@ -62,6 +62,7 @@ SIGNATURES = {
     "ds_im2col_in": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ds_im2col_in_affine": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp]),
     "ds_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ds_posterior_sample": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "ds_rows_to_ncthw": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ds_timestep_embedding": (_i, [_vp, _vp, _i, _i, _vp]),
     "ds_silu_f16": (_i, [_vp, _vp, _sz, _vp]),

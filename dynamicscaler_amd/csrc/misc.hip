@@ -109,6 +109,28 @@ softmax_rows_kernel(const float* __restrict__ s, f16* __restrict__ p, int rows, 
     }
 }
 
+// DiagonalGaussianDistribution.sample() * scale_factor (lvdm/distributions.py:24-40, ddpm3d.py:458-465): moments rows
+// [m][2C] fp32 (mean | logvar), row m = ((b*T + t)*H + y)*W + x -> out [B][C][T][H][W] fp32;
+// noise (same layout as out) may be NULL (= the mode).
+__global__ void __launch_bounds__(256)
+posterior_sample_kernel(const float* __restrict__ mom, int ldm, const float* __restrict__ noise, float* __restrict__ out,
+                        int B, int C, int Tn, int H, int W, float scale) {
+    const long total = (long)B * C * Tn * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H); r /= H;
+        const int t = (int)(r % Tn); r /= Tn;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const long m = (((long)b * Tn + t) * H + y) * W + x;
+        const float mean = mom[m * ldm + c];
+        const float logvar = fminf(fmaxf(mom[m * ldm + C + c], -30.0f), 20.0f);
+        const float stdv = expf(0.5f * logvar);
+        out[idx] = scale * (noise ? mean + stdv * noise[idx] : mean);
+    }
+}
+
 template <typename Y, typename O>
 __global__ void __launch_bounds__(256)
 rows_to_ncthw_kernel(const Y* __restrict__ y, int ldy, O* __restrict__ out, int B, int C, int Tn, int H, int W) {
@@ -248,6 +270,16 @@ extern "C" int ds_softmax_rows(const float* s, void* p, int rows, int cols, int 
                  "ds_softmax_rows: cols / strides must be positive multiples of 4");
     softmax_rows_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(s, (f16*)p, rows, cols, lds, ldp, scale * 1.4426950408889634f);
     DS_CHECK_LAUNCH("ds_softmax_rows");
+    return DS_OK;
+}
+
+extern "C" int ds_posterior_sample(const float* moments, int ldm, const float* noise, float* out, int B, int C, int T, int H,
+                                   int W, float scale, void* stream) {
+    DS_CHECK_ARG(moments && out, "ds_posterior_sample: null argument");
+    DS_CHECK_ARG(B > 0 && C > 0 && T > 0 && H > 0 && W > 0 && ldm >= 2 * C, "ds_posterior_sample: bad sizes");
+    const long work = (long)B * C * T * H * W;
+    posterior_sample_kernel<<<grid_for(work), 256, 0, (hipStream_t)stream>>>(moments, ldm, noise, out, B, C, T, H, W, scale);
+    DS_CHECK_LAUNCH("ds_posterior_sample");
     return DS_OK;
 }
 

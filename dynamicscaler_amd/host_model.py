@@ -57,9 +57,9 @@ class LatentDiffusionHost(nn.Module):
         self.scale_factor = scale_factor
         self.first_stage_model = None
         if first_stage_config is not None:
-            from .vae import AutoencoderKLDecoder
+            from .vae import AutoencoderKL
             fp = first_stage_config.get("params", first_stage_config)
-            self.first_stage_model = AutoencoderKLDecoder(fp["ddconfig"], fp.get("embed_dim", 4))
+            self.first_stage_model = AutoencoderKL(fp["ddconfig"], fp.get("embed_dim", 4))
         self.cond_stage_model = None
         self.conditioner = conditioner
 
@@ -73,6 +73,20 @@ class LatentDiffusionHost(nn.Module):
         if self.first_stage_model is None:
             raise RuntimeError("no first-stage decoder attached (pass first_stage_config, or use output_type='latent')")
         return self.first_stage_model.decode_frames(z.to(self.device), in_scale=1.0 / self.scale_factor)
+
+    @torch.no_grad()
+    def encode_first_stage_2DAE(self, x):
+        """ddpm3d.py:485-490: x [B,3,T,H,W] -> scale_factor * posterior.sample(), frame by frame; the posterior noise is
+        drawn on the host in the reference's order (torch.randn(mean.shape) per frame, lvdm/distributions.py:35-39)."""
+        if self.first_stage_model is None:
+            raise RuntimeError("no first-stage model attached (pass first_stage_config)")
+        x = x.to(self.device)
+        mom, (h, w) = self.first_stage_model.encode_moments(x)
+        B, _, T = x.shape[:3]
+        C = mom.shape[1] // 2
+        noise = torch.stack([torch.randn((B, C, h, w)) for _ in range(T)], dim=2).to(self.device)
+        from . import ops
+        return ops.posterior_sample(mom, (B, C, T, h, w), noise, self.scale_factor)
 
     def get_learned_conditioning(self, prompts):
         if self.conditioner is None:

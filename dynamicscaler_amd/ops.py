@@ -384,6 +384,17 @@ def softmax_rows(s, scale, out=None, stream=None):
     return out
 
 
+def posterior_sample(moments, shape, noise, scale, stream=None):
+    """moments fp32 rows [M, >=2C] -> scale * (mean + std * noise) as [B,C,T,H,W] fp32 (noise None = the mode)."""
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    B, Cc, T, H, W = shape
+    out = torch.empty(shape, dtype=torch.float32, device=moments.device)
+    check(lib.ds_posterior_sample(moments.data_ptr(), moments.stride(0), _ptr(noise), out.data_ptr(), B, Cc, T, H, W,
+                                  float(scale), st), "ds_posterior_sample")
+    return out
+
+
 def rows_to_ncthw(y, shape, out_dtype, stream=None):
     lib = _lib.load()
     st = _stream() if stream is None else stream

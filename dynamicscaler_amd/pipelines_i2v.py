@@ -65,6 +65,35 @@ class VC2_Pipeline_I2V(VC2_Pipeline_T2V):
 
 
 class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
+    def tiled_vae_encode_image(self, image_path=None, image_size=None, image_tensor=None):
+        """i2v_sphere_panorama_pipeline.py:498-503; `image_tensor` [3,H,W] in [-1,1] instead of a path is an extension."""
+        if image_tensor is None:
+            image_tensor = load_image_tensor_from_path(image_path, image_size[0], image_size[1])
+        image_tensor = image_tensor.unsqueeze(1).unsqueeze(0).to(device=self.pretrained_t2v.device, dtype=torch.float32)
+        return self.tiled_vae_encode_tensor_simple(image_tensor=image_tensor)
+
+    @torch.no_grad()
+    def tiled_vae_encode_tensor_simple(self, image_tensor, h_tile_num=4, w_tile_num=4, overlap_h=32, overlap_w=32):
+        """i2v_sphere_panorama_pipeline.py:505-562: image [B,3,F,H,W] -> latent [B,4,F,H/8,W/8] fp32.  Every tile is encoded
+        with its overlap margin (first-stage encoder on the HIP kernels, posterior noise drawn on the host in tile order)
+        and cropped back to its own cell; the cells do not overlap, so the reference's count normaliser is 1 everywhere."""
+        B, _, Fr, H_dec, W_dec = image_tensor.shape
+        sf = self.vae_scale_factor
+        Hl, Wl = H_dec // sf, W_dec // sf
+        th, tw = Hl // h_tile_num, Wl // w_tile_num
+        thi, twi = th * sf, tw * sf
+        ovh, ovw = overlap_h * sf, overlap_w * sf
+        out = torch.zeros((B, 4, Fr, Hl, Wl), dtype=torch.float32, device=image_tensor.device)
+        for i in range(h_tile_num):
+            for j in range(w_tile_num):
+                hs, he, ws, we = i * thi, (i + 1) * thi, j * twi, (j + 1) * twi
+                hso, heo, wso, weo = max(hs - ovh, 0), min(he + ovh, H_dec), max(ws - ovw, 0), min(we + ovw, W_dec)
+                lt = self.pretrained_t2v.encode_first_stage_2DAE(image_tensor[:, :, :, hso:heo, wso:weo])
+                top, left = (hs - hso) // sf, (ws - wso) // sf
+                bottom, right = lt.shape[3] - (heo - he) // sf, lt.shape[4] - (weo - we) // sf
+                out[:, :, :, i * th:(i + 1) * th, j * tw:(j + 1) * tw] = lt[:, :, :, top:bottom, left:right]
+        return out
+
     @torch.no_grad()
     def basic_sample_shift_multi_windows(self, prompt=None, img_cond_path=None, height=320, width=512, frames=16, fps=16,
                                          guidance_scale=7.5, num_videos_per_prompt=1, generator=None,

@@ -1,7 +1,8 @@
-"""First-stage decoder on the HIP kernels (decode side): drop-in for the decode half of
-lvdm.models.autoencoder.AutoencoderKL (autoencoder.py:103-107) and LatentDiffusion.decode_first_stage_2DAE
-(ddpm3d.py:556-562), same constructor config (`ddconfig`, `embed_dim`) and the reference's state-dict keys
-(`post_quant_conv.*`, `decoder.*`; encoder keys are accepted and ignored).
+"""First stage (VAE) on the HIP kernels: drop-in for lvdm.models.autoencoder.AutoencoderKL's
+encode / decode (autoencoder.py:97-107) behind LatentDiffusion.encode_first_stage_2DAE / decode_first_stage_2DAE
+(ddpm3d.py:485-490, 556-562), same constructor config (`ddconfig`, `embed_dim`) and the reference's state-dict keys
+(`encoder.*`, `quant_conv.*`, `post_quant_conv.*`, `decoder.*`; a decoder-only state dict is accepted, encode then
+raises).
 
 Layout and kernels are the UNet's: activations are rows x channels fp16 with row = ((b*T + t)*H + y)*W + x, every conv is
 ds_gemm_f16 (3x3 / nearest-x2-upsample folded into the gather, 1x1 = dense), GroupNorm(32, eps 1e-6) + swish is
@@ -16,7 +17,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import DS_A_CONV3, DS_EPI_OUT_F32
-from .vae_spec import decoder_blocks, decoder_param_shapes
+from .vae_spec import decoder_blocks, decoder_param_shapes, encoder_blocks, vae_param_shapes
 
 
 class AutoencoderKLDecoder(nn.Module):
@@ -25,7 +26,9 @@ class AutoencoderKLDecoder(nn.Module):
         self.dd = dict(ddconfig)
         self.embed_dim = embed_dim
         assert self.dd["z_channels"] == embed_dim or True
-        self._shapes = decoder_param_shapes(self.dd, embed_dim)
+        self._shapes = vae_param_shapes(self.dd, embed_dim)
+        self._dec_keys = set(decoder_param_shapes(self.dd, embed_dim))
+        self._has_encoder = False
         self._params = nn.ParameterDict()
         for key, shape in self._shapes.items():
             self._params[key.replace(".", "/")] = nn.Parameter(torch.zeros(shape), requires_grad=False)
@@ -38,8 +41,12 @@ class AutoencoderKLDecoder(nn.Module):
 
     def load_state_dict(self, sd, strict=True):
         missing = [k for k in self._shapes if k not in sd]
-        unexpected = [k for k in sd if k not in self._shapes and not k.startswith(("encoder.", "quant_conv.", "loss."))]
-        if strict and (missing or unexpected):
+        unexpected = [k for k in sd if k not in self._shapes and not k.startswith("loss.")]
+        self._has_encoder = not any(k not in self._dec_keys for k in missing)
+        dec_missing = [k for k in missing if k in self._dec_keys]
+        enc_partial = [k for k in missing if k not in self._dec_keys] if any(k in sd for k in self._shapes if k not in self._dec_keys) else []
+        if strict and (dec_missing or unexpected or enc_partial):
+            missing = dec_missing + enc_partial
             raise RuntimeError(f"AutoencoderKLDecoder.load_state_dict: missing {missing[:4]}, unexpected {unexpected[:4]}")
         for k in self._shapes:
             if k in sd:
@@ -93,18 +100,93 @@ class AutoencoderKLDecoder(nn.Module):
                 P[p + ".g"], P[p + ".be"] = f32(sd[p + ".weight"]), f32(sd[p + ".bias"])
             elif kind == "conv_out":
                 P[p + ".w"], P[p + ".b"] = conv_w(sd[p + ".weight"]), f32(sd[p + ".bias"])
+        if self._has_encoder:
+            for kind, p, cin, cout in encoder_blocks(self.dd):
+                if kind == "conv_in":
+                    w = sd[p + ".weight"].permute(0, 2, 3, 1).reshape(cout, -1)
+                    kpad = ((w.shape[1] + 63) // 64) * 64
+                    wp = torch.zeros(cout, kpad)
+                    wp[:, :w.shape[1]] = w
+                    P[p + ".w"], P[p + ".b"], self._kpad_enc = w16(wp), f32(sd[p + ".bias"]), kpad
+                elif kind == "res":
+                    for n in ("norm1", "norm2"):
+                        P[f"{p}.{n}.g"], P[f"{p}.{n}.be"] = f32(sd[f"{p}.{n}.weight"]), f32(sd[f"{p}.{n}.bias"])
+                    for n in ("conv1", "conv2"):
+                        P[f"{p}.{n}.w"], P[f"{p}.{n}.b"] = conv_w(sd[f"{p}.{n}.weight"]), f32(sd[f"{p}.{n}.bias"])
+                    if cin != cout:
+                        P[p + ".nin.w"] = w16(sd[p + ".nin_shortcut.weight"].reshape(cout, cin))
+                        P[p + ".nin.b"] = f32(sd[p + ".nin_shortcut.bias"])
+                elif kind == "attn":
+                    P[p + ".norm.g"], P[p + ".norm.be"] = f32(sd[p + ".norm.weight"]), f32(sd[p + ".norm.bias"])
+                    for n in ("q", "k"):
+                        P[f"{p}.{n}.w"], P[f"{p}.{n}.b"] = w16(sd[f"{p}.{n}.weight"].reshape(cin, cin)), f32(sd[f"{p}.{n}.bias"])
+                    P[p + ".v.w"] = w16(sd[p + ".v.weight"].reshape(cin, cin))
+                    wpj = sd[p + ".proj_out.weight"].reshape(cin, cin).double()
+                    P[p + ".proj.w"] = w16(wpj.float())
+                    P[p + ".proj.b"] = f32((sd[p + ".proj_out.bias"].double() + wpj @ sd[p + ".v.bias"].double()).float())
+                elif kind == "down":
+                    P[p + ".w"], P[p + ".b"] = conv_w(sd[p + ".conv.weight"]), f32(sd[p + ".conv.bias"])
+                elif kind == "norm_out":
+                    P[p + ".g"], P[p + ".be"] = f32(sd[p + ".weight"]), f32(sd[p + ".bias"])
+                elif kind == "conv_out":
+                    # quant_conv (1x1, no nonlinearity in between) folds into conv_out exactly: W' = Wq W_out, b' = Wq b_out + b_q
+                    wq = sd["quant_conv.weight"].reshape(sd["quant_conv.weight"].shape[0], -1).double()
+                    wo = sd[p + ".weight"].permute(0, 2, 3, 1).reshape(cout, -1).double()
+                    P[p + ".w"] = w16((wq @ wo).float())
+                    P[p + ".b"] = f32((wq @ sd[p + ".bias"].double() + sd["quant_conv.bias"].double()).float())
         P["pq.w"] = f32(sd["post_quant_conv.weight"].reshape(self.dd["z_channels"], self.embed_dim))
         P["pq.b"] = f32(sd["post_quant_conv.bias"])
         self._packed, self._device = P, dev
         return self
 
     # ---- ops ----
-    def _conv3(self, a, w, b, nimg, hin, win, cin, upsample=0, residual=None, epilogue=0):
+    def _conv3(self, a, w, b, nimg, hin, win, cin, upsample=0, residual=None, epilogue=0, down=False):
         hl, wl = (2 * hin, 2 * win) if upsample else (hin, win)
+        if down:       # Downsample: F.pad(x, (0,1,0,1)) + 3x3 stride-2 conv without padding (ae_modules.py:102-106)
+            hl, wl = (hin - 2) // 2 + 1, (win - 2) // 2 + 1
         M = nimg * hl * wl
         out = ops.gemm(a, w, b, residual, M=M, N=w.shape[0], K=w.shape[1], a_mode=DS_A_CONV3, cin=cin, lda=a.stride(0),
-                       conv=(nimg, hin, win, hl, wl, 1, upsample), epilogue=epilogue)
+                       conv=(nimg, hin, win, hl, wl, 2 if down else 1, upsample, 1 if down else 0), epilogue=epilogue)
         return out, hl, wl
+
+    def _res(self, x, p, nimg, H, W, cin, cout):
+        P = self._packed
+        a = ops.groupnorm(x, P[p + ".norm1.g"], P[p + ".norm1.be"], nimg, H * W, cin, 1e-6, True)
+        h1, _, _ = self._conv3(a, P[p + ".conv1.w"], P[p + ".conv1.b"], nimg, H, W, cin)
+        a2 = ops.groupnorm(h1, P[p + ".norm2.g"], P[p + ".norm2.be"], nimg, H * W, cout, 1e-6, True)
+        skip = x if cin == cout else ops.gemm(x, P[p + ".nin.w"], P[p + ".nin.b"], None, M=x.shape[0], N=cout, K=cin)
+        out, _, _ = self._conv3(a2, P[p + ".conv2.w"], P[p + ".conv2.b"], nimg, H, W, cout, residual=skip)
+        return out
+
+    @torch.no_grad()
+    def encode_moments(self, x):
+        """x [B, 3, T, H, W] image frames (HIP device) -> (moments rows [B*T*h*w, 2*embed] fp32, (h, w)): the parameters of
+        AutoencoderKL.encode's posterior (quant_conv(Encoder(x)), autoencoder.py:97-101), every (b, t) one image."""
+        if not x.is_cuda:
+            raise RuntimeError("AutoencoderKL.encode: input is on the CPU; this build has no CPU path")
+        if self._packed is None or self._device != x.device:
+            self.prepare(x.device)
+        if not self._has_encoder:
+            raise RuntimeError("AutoencoderKL.encode: the loaded state dict had no encoder / quant_conv weights")
+        P = self._packed
+        B, Cin, T, H, W = x.shape
+        nimg = B * T
+        h = None
+        for kind, p, cin, cout in encoder_blocks(self.dd):
+            if kind == "conv_in":
+                patches = ops.im2col_in(x.contiguous(), self._kpad_enc)
+                h = ops.gemm(patches, P[p + ".w"], P[p + ".b"], None, M=patches.shape[0], N=cout, K=self._kpad_enc)
+            elif kind == "res":
+                h = self._res(h, p, nimg, H, W, cin, cout)
+            elif kind == "attn":
+                h = self._attn(h, p, nimg, H * W, cin)
+            elif kind == "down":
+                h, H, W = self._conv3(h, P[p + ".w"], P[p + ".b"], nimg, H, W, cin, down=True)
+            elif kind == "norm_out":
+                h = ops.groupnorm(h, P[p + ".g"], P[p + ".be"], nimg, H * W, cin, 1e-6, True)
+            elif kind == "conv_out":
+                h, _, _ = self._conv3(h, P[p + ".w"], P[p + ".b"], nimg, H, W, cin, epilogue=DS_EPI_OUT_F32)
+        return h, (H, W)
 
     def _attn(self, x, p, nimg, hw, C):
         P = self._packed
@@ -145,11 +227,7 @@ class AutoencoderKLDecoder(nn.Module):
                     patches = ops.im2col_in_affine(zc, self._kpad_in, P["pq.w"], P["pq.b"], in_scale)
                     x = ops.gemm(patches, P[p + ".w"], P[p + ".b"], None, M=patches.shape[0], N=cout, K=self._kpad_in)
                 elif kind == "res":
-                    a = ops.groupnorm(x, P[p + ".norm1.g"], P[p + ".norm1.be"], nimg, H * W, cin, 1e-6, True)
-                    h1, _, _ = self._conv3(a, P[p + ".conv1.w"], P[p + ".conv1.b"], nimg, H, W, cin)
-                    a2 = ops.groupnorm(h1, P[p + ".norm2.g"], P[p + ".norm2.be"], nimg, H * W, cout, 1e-6, True)
-                    skip = x if cin == cout else ops.gemm(x, P[p + ".nin.w"], P[p + ".nin.b"], None, M=x.shape[0], N=cout, K=cin)
-                    x, _, _ = self._conv3(a2, P[p + ".conv2.w"], P[p + ".conv2.b"], nimg, H, W, cout, residual=skip)
+                    x = self._res(x, p, nimg, H, W, cin, cout)
                 elif kind == "attn":
                     x = self._attn(x, p, nimg, H * W, cin)
                 elif kind == "up":
@@ -167,3 +245,6 @@ class AutoencoderKLDecoder(nn.Module):
 
     def forward(self, z):
         return self.decode(z)
+
+
+AutoencoderKL = AutoencoderKLDecoder     # the class covers encode + decode; the old name is kept for decode-only users

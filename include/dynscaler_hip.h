@@ -216,6 +216,11 @@ int ds_im2col_in_affine(const void* x, int x_dtype, void* patches, int B, int C,
                         const float* wmat, const float* bvec, float in_scale, void* stream);
 /* p[r][c] = softmax_c(s[r][c] * scale): fp32 scores in, fp16 probabilities out (AttnBlock, ae_modules.py:60-64). */
 int ds_softmax_rows(const float* s, void* p, int rows, int cols, int lds, int ldp, float scale, void* stream);
+/* First-stage encode tail: scale * DiagonalGaussianDistribution(moments).sample() (lvdm/distributions.py:24-40,
+ * ddpm3d.py:458-465).  moments fp32 rows [m][ldm] = (mean[C] | logvar[C]), m = ((b*T+t)*H+y)*W+x; noise / out fp32
+ * [B][C][T][H][W]; noise NULL -> the mode. */
+int ds_posterior_sample(const float* moments, int ldm, const float* noise, float* out, int B, int C, int T, int H, int W,
+                        float scale, void* stream);
 /* y rows fp32/fp16 [B*T*H*W][ldy] (first C columns) -> out [B][C][T][H][W] (out_dtype)  (openaimodel3d.py:707). */
 int ds_rows_to_ncthw(const void* y, int y_dtype, int ldy, void* out, int out_dtype, int B, int C, int T, int H,
                      int W, void* stream);

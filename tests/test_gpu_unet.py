@@ -511,3 +511,45 @@ def test_decode_tail_seam_safe_with_vae():
     e = relerr(videos, ref)
     print(f"seam-safe decode tail: rel err {e:.3e}")
     assert e < 1e-2
+
+
+def test_vae_encode_vs_reference_golden():
+    """N2 encode side on the HIP kernels: posterior moments (toy 8x config and the real config on a 320x512 image),
+    encode_first_stage_2DAE with the reference's seeded posterior noise, and the pipeline's tiled encode."""
+    from dynamicscaler_amd.host_model import LatentDiffusionHost
+    from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.vae import AutoencoderKL
+    from dynamicscaler_amd.vae_spec import vae_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    d = dev()
+    z = np.load(os.path.join(G, "vae_enc_tiny.npz"))
+    dd = json.loads(bytes(z["tiny8_dd_json"]).decode())
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    ld = LatentDiffusionHost({"params": params}, first_stage_config={"params": {"ddconfig": dd, "embed_dim": 4}},
+                             scale_factor=0.18215)
+    ld.first_stage_model.load_state_dict(synth_state_dict(vae_param_shapes(dd, 4), seed=23))
+    ld = ld.to(d).eval()
+    img = T(z["tiny8_img"]).to(d)
+    mom, (h, w) = ld.first_stage_model.encode_moments(img[:, :, [0]])
+    ref = T(z["tiny8_moments"])                                   # [1,8,h,w]
+    got = mom.reshape(1, h, w, 8).permute(0, 3, 1, 2)
+    e1 = relerr(got, ref)
+    torch.manual_seed(77)
+    enc = ld.encode_first_stage_2DAE(img)
+    e2 = relerr(enc, T(z["tiny8_encoded"]))
+    pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+    torch.manual_seed(78)
+    til = pipe.tiled_vae_encode_tensor_simple(T(z["tiny8_big"]).to(d), overlap_h=2, overlap_w=2)
+    e3 = relerr(til, T(z["tiny8_tiled"]))
+    print(f"vae encode tiny8: moments {e1:.3e}, sampled {e2:.3e}, tiled {e3:.3e}")
+    assert e1 < 1e-2 and e2 < 1e-2 and e3 < 1e-2 and til.shape == (1, 4, 1, 16, 32)
+    zf = np.load(os.path.join(G, "vae_enc_full.npz"))
+    ddf = json.loads(bytes(zf["full_dd_json"]).decode())
+    mf = AutoencoderKL(ddf, 4)
+    mf.load_state_dict(synth_state_dict(vae_param_shapes(ddf, 4), seed=24))
+    mom, (h, w) = mf.encode_moments(T(zf["full_img"]).float().to(d).unsqueeze(2))
+    e4 = relerr(mom.reshape(1, h, w, 8).permute(0, 3, 1, 2), T(zf["full_moments"]))
+    print(f"vae encode full (320x512 -> 40x64): moments rel err {e4:.3e}")
+    assert (h, w) == (40, 64) and e4 < 1e-2
