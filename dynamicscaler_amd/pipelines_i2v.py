@@ -8,10 +8,10 @@ frame windows wrap modulo total_f and can be docked to both ends (:786-854), the
 and after the DDIM update x_prev is mixed with the window's pre-re-noise content under the mask (merge-prev,
 :938-943).  The tile engine is the one of pipelines.py (batched levels of independent windows).
 
-Out of scope here: the CLIP image encoder / Resampler (`pretrained_t2v.get_image_embeds` is
-called as a black box, once per distinct crop position -- the reference calls it per tile per step) and the tiled
-VAE encode behind `use_skip_time` without a given init latent (with `init_panorama_latent`, the way gen_pano_360.py
-calls it, `use_skip_time` only shortens the schedule).
+Out of scope here: the CLIP image encoder / Resampler (`pretrained_t2v.get_image_embeds` is called
+as a black box, once per distinct crop position -- the reference calls it per tile per step).  `use_skip_time` with a
+given `init_panorama_latent` (the way gen_pano_360.py calls it) only shortens the schedule; without one the panorama
+image is encoded by the tiled first-stage encode below and re-noised (:704-722).
 """
 import math
 
@@ -107,9 +107,9 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
                                          progressive_skip=False, pano_image_tensor=None, step_callback=None, **kwargs):
         """`pano_image_tensor` ([3,total_h,total_w], optional) is an extension: the panorama image as a tensor
         instead of a path (RingImageTensor accepts both, shift_window_utils.py:211-220)."""
-        if use_skip_time and init_panorama_latent is None:
-            raise NotImplementedError("use_skip_time without init_panorama_latent needs the tiled VAE encode of the panorama "
-                                      "image (SURVEY.md 8-f N2); gen_pano_360.py passes the previous stage's latent")
+        if use_skip_time and init_panorama_latent is None and getattr(self.pretrained_t2v, "first_stage_model", None) is None:
+            raise NotImplementedError("use_skip_time without init_panorama_latent needs the first-stage encoder "
+                                      "(first_stage_config); gen_pano_360.py passes the previous stage's latent")
         unet_config = self.model_config["params"]["unet_config"]
         frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
         vs = self.vae_scale_factor
@@ -128,6 +128,16 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
         total_shape = (1, unet_config["params"]["in_channels"], total_f, total_h // vs, total_w // vs)
         if init_panorama_latent is None:
             init_panorama_latent = torch.randn(total_shape)  # host draw, reference order
+            if use_skip_time:                                # :704-722: start from the (re-noised) VAE-encoded panorama image
+                frame_0 = self.tiled_vae_encode_image(image_path=pano_image_path, image_size=(total_h, total_w),
+                                                      image_tensor=pano_image_tensor)
+                if progressive_skip:
+                    init_panorama_latent = init_panorama_latent.to(frame_0.device)
+                    for frame_idx, ps in enumerate(list(reversed(range(skip_time_step_idx)))):
+                        init_panorama_latent[:, :, [frame_idx]] = self.scheduler.re_noise(frame_0, 0, num_inference_steps - ps - 1)
+                else:
+                    init_panorama_latent = self.scheduler.re_noise(frame_0.expand(total_shape).contiguous(), 0,
+                                                                   len(timesteps) - 1)
         else:
             assert tuple(init_panorama_latent.shape) == total_shape, \
                 f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_panorama_latent.shape)} " \

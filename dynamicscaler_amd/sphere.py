@@ -337,11 +337,11 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
         Returns (final_latents, denoised) for output_type='latent' (:476-495)."""
         if view_get_scale_factor != 1 or view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
             raise NotImplementedError("view / decode scale factors other than 1 (gen_pano_360.py uses 1)")
-        if use_skip_time and init_sphere_latent is None:
-            raise NotImplementedError("use_skip_time without init_sphere_latent needs the tiled VAE encode (SURVEY.md 8-f N2)")
-        if paste_on_static and static_frame_latent is None:
-            raise NotImplementedError("paste_on_static needs `static_frame_latent` (the VAE-encoded panorama image; the "
-                                      "tiled VAE encode itself is SURVEY.md 8-f N2)")
+        has_vae = getattr(self.pretrained_t2v, "first_stage_model", None) is not None
+        if (use_skip_time and init_sphere_latent is None) or (paste_on_static and static_frame_latent is None):
+            if not has_vae:
+                raise NotImplementedError("use_skip_time without init_sphere_latent / paste_on_static without "
+                                          "static_frame_latent need the first-stage encoder (first_stage_config)")
         unet_config = self.model_config["params"]["unet_config"]
         frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
         vs = self.vae_scale_factor
@@ -363,8 +363,25 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
         lat_h, lat_w = height // vs, width // vs
         H, W = equirect_height // vs, equirect_width // vs
         shape = (1, unet_config["params"]["in_channels"], total_f, H, W)
+        image = pano_image_tensor if pano_image_tensor is not None else \
+            load_image_tensor_from_path(pano_image_path, equirect_height, equirect_width)
+
+        def encode_static():
+            """tiled_vae_encode_image of the panorama image (:186, :247): the reference redoes it at every use, and its
+            posterior sample draws fresh noise each time -- reproduced (same host RNG order)."""
+            return self.tiled_vae_encode_image(image_tensor=image)
+
         if init_sphere_latent is None:
             init_sphere_latent = torch.randn(shape)                # host draw, reference order (:183)
+            if use_skip_time:                                      # :184-208
+                frame_0 = encode_static()
+                if progressive_skip:
+                    init_sphere_latent = init_sphere_latent.to(frame_0.device)
+                    for frame_idx, ps in enumerate(list(reversed(range(skip_time_step_idx)))):
+                        init_sphere_latent[:, :, [frame_idx]] = self.scheduler.re_noise(frame_0, 0, total_steps - ps - 1).to(init_sphere_latent.dtype)
+                else:
+                    init_sphere_latent = self.scheduler.re_noise(frame_0.expand(1, shape[1], total_f, H, W).contiguous(), 0,
+                                                                 total_steps - 1)
         else:
             assert tuple(init_sphere_latent.shape) == shape, \
                 f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_sphere_latent.shape)} does not match desired shape {shape}"
@@ -374,13 +391,11 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
         st.total_steps = total_steps
         device, sched = st.device, self.scheduler
         mask = torch.zeros((total_f, H, W), dtype=torch.uint8, device=device)   # one byte per (frame, pixel)
-        image = pano_image_tensor if pano_image_tensor is not None else \
-            load_image_tensor_from_path(pano_image_path, equirect_height, equirect_width)
         Himg, Wimg = image.shape[-2:]
         assert Wimg == 2 * Himg                                    # PanoramaTensor of the image (:223)
         image5 = image.to(device=device, dtype=torch.float32).reshape(1, 3, 1, Himg, Wimg).contiguous()
         static = None
-        if paste_on_static:
+        if paste_on_static and static_frame_latent is not None:
             static = static_frame_latent.to(device=device, dtype=st.pano.dtype)
             assert tuple(static.shape) == (1, shape[1], 1, H, W)
         cache, img_cache = ViewMapCache(device), ViewMapCache(device)
@@ -402,7 +417,8 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
             live = i < total_steps - 1
             temp = None
             if paste_on_static and live:                           # :245-254 (host randn of the whole panorama first)
-                temp = sched.re_noise(static.expand(1, shape[1], total_f, H, W).contiguous(), 0, total_steps - i - 1)
+                cur_static = static if static is not None else encode_static().to(device=device, dtype=st.pano.dtype)
+                temp = sched.re_noise(cur_static.expand(1, shape[1], total_f, H, W).contiguous(), 0, total_steps - i - 1)
             items, ctxs = [], []
             for (fb, fe) in i2v_frame_windows(i, frames=frames, total_f=total_f, overlap_ratio_f=overlap_ratio_list_f[i],
                                               loop_step_frame=loop_step_frame, dock_at_f=dock_at_f):

@@ -210,8 +210,9 @@ def i2v_sphere_sample(eps_model, image_embedder, tables: DiffusionTables, text_c
         theta_offset = (i % loop_step_theta) * (view_fov // loop_step_theta)
         mask = torch.zeros_like(pano)                      # reset mask record (:242), full 5-D here
         temp = None
-        if paste_on_static and i < total_steps - 1:        # :245-254
-            clear = torch.cat([static_frame_latent] * total_f, dim=2)
+        if paste_on_static and i < total_steps - 1:        # :245-254 (static_frame_latent may be a callable: the reference
+            sfl = static_frame_latent() if callable(static_frame_latent) else static_frame_latent   # re-encodes every step)
+            clear = torch.cat([sfl] * total_f, dim=2)
             temp = re_noise(sched, clear, 0, total_steps - i - 1)
         views = []
         for (fb, fe) in i2v_frame_windows(i, frames=frames, total_f=total_f, overlap_ratio_f=overlap_ratio_list_f[i],

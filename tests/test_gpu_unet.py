@@ -553,3 +553,48 @@ def test_vae_encode_vs_reference_golden():
     e4 = relerr(mom.reshape(1, h, w, 8).permute(0, 3, 1, 2), T(zf["full_moments"]))
     print(f"vae encode full (320x512 -> 40x64): moments rel err {e4:.3e}")
     assert (h, w) == (40, 64) and e4 < 1e-2
+
+
+def test_i2v_sphere_paste_on_static_with_vae_encoder():
+    """S6 end to end: paste_on_static with the panorama image VAE-encoded by the tiled first-stage encode at every step (the
+    reference redraws the posterior noise each time).  Product (HIP encoder + loop) vs the oracle's composition of its
+    pinned parts (tiled_vae_encode + i2v_sphere_sample): the encoder runs in fp16 activations, hence a tolerance."""
+    from helpers import synth_image_embedder
+    from oracle import sphere as S, ddim as oddim
+    from oracle.vae import tiled_vae_encode
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.sphere import VC2_Pipeline_I2V_SpherePano
+    from dynamicscaler_amd.vae import AutoencoderKL
+    from dynamicscaler_amd.vae_spec import vae_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    d = dev()
+    z = np.load(os.path.join(G, "sphere_i2v.npz"))
+    meta = json.load(open(os.path.join(G, "sphere_i2v_traces.json")))
+    dd = json.loads(bytes(np.load(os.path.join(G, "vae_enc_tiny.npz"))["tiny8_dd_json"]).decode())
+    cond, uncond, pano_img = T(z["cond"]), T(z["uncond"]), T(z["pano_img"])
+    embed = synth_image_embedder(64)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
+    ld = _fake_host(cond, uncond, d, embed)
+    vsd = synth_state_dict(vae_param_shapes(dd, 4), seed=23)
+    ld.first_stage_model = AutoencoderKL(dd, 4)
+    ld.first_stage_model.load_state_dict(vsd)
+    ld.scale_factor = 0.18215
+
+    def enc(x):      # LatentDiffusionHost.encode_first_stage_2DAE on the fake host
+        from dynamicscaler_amd.host_model import LatentDiffusionHost
+        return LatentDiffusionHost.encode_first_stage_2DAE(ld, x)
+    ld.encode_first_stage_2DAE = enc
+    g = dict(meta["geoms"]["static"])
+    g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+    pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": {"in_channels": 4}}}})
+    pipe.to(d, torch.float32)
+    torch.manual_seed(2333333)
+    final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                         pano_image_tensor=pano_img, **g)
+    torch.manual_seed(2333333)
+    of, od = S.i2v_sphere_sample(_oracle_fake, embed, oddim.DiffusionTables(), cond, uc, pano_img, guidance_scale=7.5,
+                                 static_frame_latent=lambda: tiled_vae_encode(vsd, dd, pano_img[None, :, None], scale_factor=0.18215),
+                                 **g)
+    e1, e2 = relerr(final, of), relerr(den, od)
+    print(f"paste_on_static with the VAE encoder in the loop: final {e1:.3e}, denoised {e2:.3e}")
+    assert e1 < 1e-2 and e2 < 1e-2
