@@ -382,3 +382,80 @@ def i2v_ring_sample(eps_model, image_embedder, tables: DiffusionTables, text_ctx
             ring_scatter(pano_x0, x0, l, r, tp, dn, fb, fe)
             ring_scatter(mask, torch.ones_like(x_prev), l, r, tp, dn, fb, fe)
     return pano_x0.clone(), pano_x0.clone(), pano
+
+
+def i2v_grid_windows(i, *, height, width, frames, num_windows_h, num_windows_w, num_windows_f, loop_step, dock_at_h=None):
+    """Windows of step i of VC2_Pipeline_I2V.basic_sample_shift_multi_windows (pipeline/i2v_normal_pipeline.py:214-290):
+    non-overlapping tiles shifted by (i % loop_step) * tile/loop_step, order f -> w -> h, docking windows (-100 top,
+    -101 bottom) FIRST in the h list.  Entries: (left, right, top, down, f_begin, f_end, img_left, img_top): latent
+    window + the pixel origin of the image crop (computed separately from the latent one, like the reference)."""
+    lh, lw = height // VAE_SCALE, width // VAE_SCALE
+    img_sw = width // loop_step
+    lat_sw = 0 if num_windows_w == 1 else img_sw // VAE_SCALE
+    img_sh = height // loop_step
+    lat_sh = 0 if num_windows_h == 1 else img_sh // VAE_SCALE
+    lat_sf = 0 if num_windows_f == 1 else frames // loop_step
+    k = i % loop_step
+    total_lh = height * num_windows_h // VAE_SCALE
+    wins = []
+    for fi in range(num_windows_f):
+        for wi in range(num_windows_w):
+            h_ids = list(range(num_windows_h))
+            if dock_at_h:
+                h_ids = [-100, -101] + h_ids
+            for hi in h_ids:
+                img_left, img_top = k * img_sw + wi * width, k * img_sh + hi * height
+                left, top = k * lat_sw + wi * lw, k * lat_sh + hi * lh
+                fb = k * lat_sf + fi * frames
+                if dock_at_h:
+                    if hi in (-100, -101) and k == 0:
+                        continue
+                    if hi == -100:
+                        top, img_top = 0, 0
+                    elif hi == -101:
+                        top, img_top = total_lh - lh, height * num_windows_h - height
+                    if top + lh > total_lh:
+                        continue
+                wins.append((left, left + lw, top, top + lh, fb, fb + frames, img_left, img_top))
+    return wins
+
+
+@torch.no_grad()
+def i2v_grid_sample(eps_model, image_embedder, tables: DiffusionTables, text_ctx, uncond_ctx, pano_image, *, height=320,
+                    width=512, frames=16, guidance_scale=7.5, num_windows_w, num_windows_h, num_windows_f=1, loop_step=8,
+                    dock_at_h=None, num_inference_steps=4, init_panorama_latent=None, merge_renoised_overlap_latent_ratio=1,
+                    use_skip_time=False, skip_time_step_idx=None, progressive_skip=False, in_channels=4, trace=None):
+    """pipeline/i2v_normal_pipeline.py:68-425, output_type='latent': returns (denoised, denoised).  NB total_steps is the
+    FULL schedule length here (:147) even when use_skip_time cuts the timesteps (:139-141)."""
+    sched = DDIMSchedule(tables, num_inference_steps)
+    timesteps = np.flip(sched.ddim_timesteps)
+    if use_skip_time and not progressive_skip:
+        assert init_panorama_latent is not None
+        timesteps = timesteps[skip_time_step_idx:]
+    total_steps = sched.ddim_timesteps.shape[0]
+    total_shape = (1, in_channels, frames * num_windows_f, height * num_windows_h // VAE_SCALE, width * num_windows_w // VAE_SCALE)
+    pano = torch.randn(total_shape) if init_panorama_latent is None else init_panorama_latent.clone()
+    pano_x0 = torch.zeros_like(pano)
+    img5 = pano_image[None, :, None]
+    for i, t in enumerate(timesteps):
+        wins = i2v_grid_windows(i, height=height, width=width, frames=frames, num_windows_h=num_windows_h,
+                                num_windows_w=num_windows_w, num_windows_f=num_windows_f, loop_step=loop_step, dock_at_h=dock_at_h)
+        if trace is not None:
+            trace.append((i, int(t), [w[:6] for w in wins]))
+        mask = torch.zeros_like(pano)
+        for (l, r, tp, dn, fb, fe, il, it) in wins:
+            win = ring_gather(pano, l, r, tp, dn, fb, fe)
+            crop = ring_gather(img5, il, il + width, it, it + height, 0, 1)
+            ctx = torch.cat([text_ctx, image_embedder(crop[:, :, 0])], dim=1)
+            wmask = ring_gather(mask, l, r, tp, dn, fb, fe)
+            if merge_renoised_overlap_latent_ratio is not None and i < total_steps - 1:
+                noised = re_noise(sched, win.clone(), total_steps - i - 2, total_steps - i - 1)
+                win = mix_latents_with_mask(win, noised, wmask[0, 0, [0]], merge_renoised_overlap_latent_ratio)
+            ts = torch.full((1,), int(t), dtype=torch.long)
+            e_c = eps_model(win, ts, ctx)
+            e = cfg_combine(e_c, eps_model(win, ts, uncond_ctx), guidance_scale) if guidance_scale != 1.0 else e_c
+            x_prev, x0 = ddim_step(sched, win, e, [total_steps - i - 1] * win.shape[2])
+            ring_scatter(pano, x_prev, l, r, tp, dn, fb, fe)
+            ring_scatter(pano_x0, x0, l, r, tp, dn, fb, fe)
+            ring_scatter(mask, torch.ones_like(x_prev), l, r, tp, dn, fb, fe)
+    return pano_x0.clone(), pano_x0.clone()

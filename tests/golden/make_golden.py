@@ -365,6 +365,16 @@ I2V_GEOMS = {
 }
 
 
+I2V_GRID_GEOMS = {    # VC2_Pipeline_I2V.basic_sample_shift_multi_windows (i2v_normal_pipeline.py:68-425)
+    "plain": dict(height=64, width=128, frames=4, num_windows_w=2, num_windows_h=2, num_windows_f=1, loop_step=4,
+                  num_inference_steps=5),
+    "dock": dict(height=64, width=128, frames=4, num_windows_w=2, num_windows_h=2, num_windows_f=2, loop_step=2,
+                 num_inference_steps=4, dock_at_h=True, merge_renoised_overlap_latent_ratio=0.6),
+    "skip": dict(height=64, width=128, frames=4, num_windows_w=2, num_windows_h=2, num_windows_f=1, loop_step=4,
+                 num_inference_steps=5, use_skip_time=True, skip_time_step_idx=2, progressive_skip=False, init_seed=94),
+}
+
+
 def synth_image_embedder(dim, tokens=16, seed=77):
     """Deterministic stand-in for get_image_embeds (CLIP image encoder + Resampler are out of scope): a 4x4 average
     pool of the crop projected 3 -> dim by a fixed seeded matrix.  Same function in tests/helpers.py."""
@@ -430,12 +440,38 @@ def g11_grid_and_i2v():
                                                                    output_type="latent", **gk)
                 arrays[f"i2v_{gname}_{eps_name}"] = den
                 traces[f"i2v_{gname}"] = parse_trace(buf.getvalue())
+        # ---- P4 (i2v): non-overlapping grid with per-window image crops (i2v_normal_pipeline.py:68-425) ----
+        from pipeline.i2v_normal_pipeline import VC2_Pipeline_I2V as RefI2V
+        grid_img = synth_normal((3, 128, 256), 87).clamp(-1, 1)
+        swu.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: grid_img
+        for eps_name, eps_mod in (("fake", FakeEps()), ("tiny", WrappedUNet(unet_i2v))):
+            ld = FakeLatentDiffusion(eps_mod, cond, uncond, temporal_length=4)
+            ld.get_image_embeds = embed
+            ld.embedder = object()
+            for gname, geom in I2V_GRID_GEOMS.items():
+                if eps_name == "tiny" and gname != "plain":
+                    continue
+                pipe = RefI2V(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": p_i2v}}})
+                pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: grid_img[None, :, :height, :width]
+                gk = dict(geom)
+                if "init_seed" in gk:
+                    gk["init_panorama_latent"] = synth_normal((1, 4, gk["frames"] * gk["num_windows_f"], gk["height"] * gk["num_windows_h"] // 8,
+                                                               gk["width"] * gk["num_windows_w"] // 8), gk.pop("init_seed"))
+                buf = io.StringIO()
+                torch.manual_seed(2333333)
+                with contextlib.redirect_stdout(buf), torch.no_grad():
+                    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", img_cond_path="unused.png", fps=8,
+                                                                   guidance_scale=7.5, pano_image_path="unused.png",
+                                                                   output_type="latent", **gk)
+                arrays[f"i2vgrid_{gname}_{eps_name}"] = den
+                traces[f"i2vgrid_{gname}"] = parse_trace(buf.getvalue())
+        arrays["grid_img"] = grid_img
     finally:
         swu.load_image_tensor_from_path = orig_loader
     arrays["pano_img"] = pano_img
     save_npz("loops_grid_i2v.npz", **arrays)
     with open(os.path.join(HERE, "loops_grid_i2v_traces.json"), "w") as f:
-        json.dump({"grid_geoms": GRID_GEOMS, "i2v_geoms": I2V_GEOMS, "traces": traces}, f)
+        json.dump({"grid_geoms": GRID_GEOMS, "i2v_geoms": I2V_GEOMS, "i2v_grid_geoms": I2V_GRID_GEOMS, "traces": traces}, f)
     print("wrote loops_grid_i2v_traces.json")
 
 

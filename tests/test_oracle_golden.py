@@ -13,7 +13,7 @@ from oracle import ddim as oddim
 from oracle import loops as oloops
 from oracle.unet import unet_forward
 from dynamicscaler_amd.unet_spec import param_shapes
-from dynamicscaler_amd.synth import synth_state_dict
+from dynamicscaler_amd.synth import synth_state_dict, synth_normal
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -443,3 +443,35 @@ def test_g15_vae_encode_vs_reference_golden():
     mom = vae_encode_moments(sdf, ddf, T(zf["full_img"]).float())
     ref = T(zf["full_moments"])
     assert mom.shape == ref.shape == (1, 8, 40, 64) and float((mom - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+
+
+def test_g11_i2v_grid_loop_vs_reference_golden():
+    """P4 (i2v): VC2_Pipeline_I2V.basic_sample_shift_multi_windows (i2v_normal_pipeline.py:68-425) -- non-overlapping
+    shifted grid, docking windows first in the h list, per-window image crops, use_skip_time with a given init latent."""
+    from helpers import synth_image_embedder
+    z = npz("loops_grid_i2v.npz")
+    meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
+    cond, uncond, img = T(z["cond"]), T(z["uncond"]), T(z["grid_img"])
+    embed = synth_image_embedder(64)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
+    for gname, geom in meta["i2v_grid_geoms"].items():
+        g = dict(geom)
+        if "init_seed" in g:
+            g["init_panorama_latent"] = synth_normal((1, 4, g["frames"] * g["num_windows_f"], g["height"] * g["num_windows_h"] // 8,
+                                                      g["width"] * g["num_windows_w"] // 8), g.pop("init_seed"))
+        trace = []
+        torch.manual_seed(2333333)
+        den, _ = oloops.i2v_grid_sample(_fake_eps, embed, oddim.DiffusionTables(), cond, uc, img, guidance_scale=7.5,
+                                        trace=trace, **g)
+        assert torch.equal(den, T(z[f"i2vgrid_{gname}_fake"])), gname
+        for (i, t, wins), ref in zip(trace, meta["traces"][f"i2vgrid_{gname}"]):
+            assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"], (gname, i)
+    params, _ = _tiny_setup()
+    p2 = dict(params)
+    p2["use_image_attention"] = True
+    sd2 = synth_state_dict(param_shapes(p2), seed=5)
+    torch.manual_seed(2333333)
+    den, _ = oloops.i2v_grid_sample(lambda x, ts, ctx: unet_forward(sd2, p2, x, ts, ctx, fps=8), embed, oddim.DiffusionTables(),
+                                    cond, uc, img, guidance_scale=7.5, **meta["i2v_grid_geoms"]["plain"])
+    ref = T(z["i2vgrid_plain_tiny"])
+    assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4
