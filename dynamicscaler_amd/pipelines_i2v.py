@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .pipelines import VC2_Pipeline_T2V, select_prompt_from_multi_prompt_dict_by_factor
-from .ring import i2v_ring_windows
+from .ring import i2v_ring_windows, i2v_grid_windows
 
 def load_image_tensor_from_path(image_path, height, width, norm_to_1=True):
     """utils/tensor_utils.py:7-16 with PIL's bilinear resize in place of cv2.INTER_LINEAR (cv2 is not in this
@@ -62,6 +62,70 @@ class VC2_Pipeline_I2V(VC2_Pipeline_T2V):
 
     def _load_imgs_from_paths(self, img_path_list, height=320, width=512):
         return torch.stack([load_image_tensor_from_path(p, height, width) for p in img_path_list], dim=0)
+
+    @torch.no_grad()
+    def basic_sample_shift_multi_windows(self, prompt=None, img_cond_path=None, height=320, width=512, frames=16, fps=16,
+                                         guidance_scale=7.5, num_videos_per_prompt=1, generator=None,
+                                         init_panorama_latent=None, num_windows_w=None, num_windows_h=None,
+                                         num_windows_f=None, loop_step=None, pano_image_path=None, dock_at_h=None,
+                                         latents=None, num_inference_steps=4, prompt_embeds=None, output_type="pil",
+                                         merge_renoised_overlap_latent_ratio=1, use_skip_time=False,
+                                         skip_time_step_idx=None, progressive_skip=False, pano_image_tensor=None,
+                                         step_callback=None, **kwargs):
+        """Non-overlapping shifted grid of the i2v base class (pipeline/i2v_normal_pipeline.py:68-425): tiles of the
+        panorama shifted by (i % loop_step) * tile/loop_step (wrap-around), docking windows at the top / bottom edge,
+        0/1 mask re-noise like the t2v ring, image tokens from the RingImageTensor crop under every window.
+        total_steps is the FULL schedule length here (:147) even when use_skip_time cuts the timesteps (:139-141) -- kept.
+        `pano_image_tensor` ([3, H*nh, W*nw]) is an extension (tensor instead of a path)."""
+        if use_skip_time and init_panorama_latent is None:
+            raise NotImplementedError("use_skip_time without init_panorama_latent encodes the panorama image with "
+                                      "encode_images_list_to_latent_tensor (utils/precast_latent_utils.py); pass the latent")
+        unet_config = self.model_config["params"]["unet_config"]
+        frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
+        vs = self.vae_scale_factor
+        prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
+        if guidance_scale != 1.0 and hasattr(self.pretrained_t2v, "embedder"):      # :143-149
+            uc_img = torch.zeros(1, 3, height // vs, width // vs).to(self.pretrained_t2v.device)
+            uc_emb = torch.cat([uc_emb.to(uc_img.device), self.pretrained_t2v.get_image_embeds(uc_img)], dim=1)
+        self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
+        timesteps = np.flip(self.scheduler.ddim_timesteps)
+        if use_skip_time and not progressive_skip:
+            timesteps = timesteps[skip_time_step_idx:]
+        total_steps = self.scheduler.ddim_timesteps.shape[0]
+        lat_h, lat_w = height // vs, width // vs
+        total_h, total_w = height * num_windows_h, width * num_windows_w
+        total_shape = (1, unet_config["params"]["in_channels"], frames * num_windows_f, total_h // vs, total_w // vs)
+        if init_panorama_latent is None:
+            init_panorama_latent = torch.randn(total_shape)  # host draw, reference order
+        else:
+            assert tuple(init_panorama_latent.shape) == total_shape, \
+                f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_panorama_latent.shape)} " \
+                f"does not match desired shape {total_shape}"
+        assert num_windows_f == 1 or frames // loop_step > 0, \
+            f"[basic_sample_shift_multi_windows] loop_step {loop_step} > frames {frames} while num_windows_f {num_windows_f} > 0"
+        ring_image = RingImageTensor(image_path=pano_image_path, image_tensor=pano_image_tensor, height=total_h, width=total_w)
+        st = self._new_state(init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
+                             text_emb, uc_emb, merge_renoised_overlap_latent_ratio, kwargs)
+        st.total_steps = total_steps
+        img_cache = {}
+        with self.progress_bar(total=len(timesteps)) as bar:
+            for i in range(len(timesteps)):
+                st.mask.zero_()                                     # reset mask record (:227)
+                wins, crops = i2v_grid_windows(i, height=height, width=width, frames=frames, num_windows_h=num_windows_h,
+                                               num_windows_w=num_windows_w, num_windows_f=num_windows_f, loop_step=loop_step,
+                                               dock_at_h=dock_at_h)
+                ctxs = []
+                for (il, it) in crops:
+                    if (il, it) not in img_cache:
+                        img_cache[(il, it)] = ring_image.get_encoded_image_cond(self.pretrained_t2v, il, il + width, it,
+                                                                                it + height).to(st.device)
+                    ctxs.append(torch.cat([st.text_emb, img_cache[(il, it)].to(st.text_emb.dtype)], dim=1))
+                renoise = st.ratio is not None and i < total_steps - 1
+                self._denoise_windows(st, i, wins, ctxs, renoise=renoise, mask_frame0=True)
+                if step_callback is not None:
+                    step_callback(i, int(timesteps[i]), wins, st.pano, st.pano_x0)
+                bar.update()
+        return self._finish(st, output_type, total_shape[2], seam_safe=False)
 
 
 class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):

@@ -238,3 +238,41 @@ def i2v_frame_windows(i, *, frames, total_f, overlap_ratio_f, loop_step_frame=No
                 continue
         out.append((fb, fe))
     return out
+
+
+def i2v_grid_windows(i, *, height, width, frames, num_windows_h, num_windows_w, num_windows_f, loop_step, dock_at_h=None):
+    """Windows of step i of VC2_Pipeline_I2V.basic_sample_shift_multi_windows (pipeline/i2v_normal_pipeline.py:214-290):
+    non-overlapping tiles shifted by (i % loop_step) * tile/loop_step, order f -> w -> h with the two docking windows
+    (-100 top edge, -101 bottom edge) FIRST in the h list (:233-235).  Returns (latent windows (left, right, top, down,
+    f_begin, f_end), image crop origins (img_left, img_top) in pixels -- computed from the pixel step like the reference)."""
+    vs = VAE_SCALE_FACTOR
+    lh, lw = height // vs, width // vs
+    img_sw = width // loop_step
+    lat_sw = 0 if num_windows_w == 1 else img_sw // vs
+    img_sh = height // loop_step
+    lat_sh = 0 if num_windows_h == 1 else img_sh // vs
+    lat_sf = 0 if num_windows_f == 1 else frames // loop_step
+    k = i % loop_step
+    total_lh = height * num_windows_h // vs
+    wins, crops = [], []
+    for fi in range(num_windows_f):
+        for wi in range(num_windows_w):
+            h_ids = list(range(num_windows_h))
+            if dock_at_h:
+                h_ids = [-100, -101] + h_ids
+            for hi in h_ids:
+                img_left, img_top = k * img_sw + wi * width, k * img_sh + hi * height
+                left, top = k * lat_sw + wi * lw, k * lat_sh + hi * lh
+                fb = k * lat_sf + fi * frames
+                if dock_at_h:
+                    if hi in (-100, -101) and k == 0:
+                        continue
+                    if hi == -100:
+                        top, img_top = 0, 0
+                    elif hi == -101:
+                        top, img_top = total_lh - lh, height * num_windows_h - height
+                    if top + lh > total_lh:
+                        continue
+                wins.append((left, left + lw, top, top + lh, fb, fb + frames))
+                crops.append((img_left, img_top))
+    return wins, crops

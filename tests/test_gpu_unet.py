@@ -598,3 +598,55 @@ def test_i2v_sphere_paste_on_static_with_vae_encoder():
     e1, e2 = relerr(final, of), relerr(den, od)
     print(f"paste_on_static with the VAE encoder in the loop: final {e1:.3e}, denoised {e2:.3e}")
     assert e1 < 1e-2 and e2 < 1e-2
+
+
+def test_i2v_grid_pipeline_vs_reference_golden():
+    """P4 (i2v): VC2_Pipeline_I2V.basic_sample_shift_multi_windows (i2v_normal_pipeline.py:68-425): fp32 + fake eps bit-exact
+    vs the oracle on this host (plain / docking + two frame windows / use_skip_time), window traces equal to the
+    reference's, toy i2v UNet in fp16 within tolerance of the reference's panorama."""
+    from helpers import synth_image_embedder
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V
+    from dynamicscaler_amd.synth import synth_normal
+    from oracle import loops as oloops, ddim as oddim
+    d = dev()
+    z = np.load(os.path.join(G, "loops_grid_i2v.npz"))
+    meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
+    cond, uncond, img = T(z["cond"]), T(z["uncond"]), T(z["grid_img"])
+    embed = synth_image_embedder(64)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
+    ld = _fake_host(cond, uncond, d, embed)
+    cfgd = {"params": {"unet_config": {"params": {"in_channels": 4}}}}
+
+    def geom_of(name):
+        g = dict(meta["i2v_grid_geoms"][name])
+        if "init_seed" in g:
+            g["init_panorama_latent"] = synth_normal((1, 4, g["frames"] * g["num_windows_f"], g["height"] * g["num_windows_h"] // 8,
+                                                      g["width"] * g["num_windows_w"] // 8), g.pop("init_seed"))
+        return g
+    for gname in meta["i2v_grid_geoms"]:
+        g = geom_of(gname)
+        pipe = VC2_Pipeline_I2V(ld, lvdm_DDIM_Scheduler(ld), cfgd).to(d, torch.float32)
+        trace = []
+        torch.manual_seed(2333333)
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                       pano_image_tensor=img,
+                                                       step_callback=lambda i, t, w, p, p0: trace.append((i, t, w)), **g)
+        torch.manual_seed(2333333)
+        oref, _ = oloops.i2v_grid_sample(_oracle_fake, embed, oddim.DiffusionTables(), cond, uc, img, guidance_scale=7.5, **g)
+        assert torch.equal(den.cpu(), oref), (gname, float((den.cpu() - oref).abs().max()))
+        assert relerr(den, T(z[f"i2vgrid_{gname}_fake"])) < 1e-4
+        for (i, t, wins), ref in zip(trace, meta["traces"][f"i2vgrid_{gname}"]):
+            assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"], (gname, i)
+    zt = np.load(os.path.join(G, "unet_tiny_i2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    ldu = _host(params, 5, cond, uncond, d)
+    ldu.get_image_embeds = embed
+    ldu.embedder = object()
+    pipe = VC2_Pipeline_I2V(ldu, lvdm_DDIM_Scheduler(ldu), {"params": {"unet_config": {"params": params}}}).to(d, torch.float16)
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                   pano_image_tensor=img, **geom_of("plain"))
+    e = relerr(den, T(z["i2vgrid_plain_tiny"]))
+    print(f"i2v grid tiny fp16: rel err {e:.3e}")
+    assert e < 3e-2
