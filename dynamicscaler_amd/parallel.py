@@ -52,10 +52,11 @@ def share_counts(n_items, world):
     return [len(range(r, n_items, world)) for r in range(world)]
 
 
-def exchange_level(x_prev_local, x0_local, n_items, group=None):
+def exchange_level(x_prev_local, x0_local, n_items, group=None, force=False):
     """All-gather the tiles of one level.  x_prev_local / x0_local: [n_local, C, tf, th, tw] of this rank's
-    share (strided assignment).  Returns (x_prev_all, x0_all) [n_items, ...] in level order on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    share (strided assignment).  Returns (x_prev_all, x0_all) [n_items, ...] in level order on every rank.
+    force=True runs the collective even in a one-rank group (tests: the RCCL call pattern on a single GPU)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return x_prev_local, x0_local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)

@@ -2,6 +2,7 @@
 restatement of the same op, on seeded inputs.  Bit-exact for the data-movement and fp32 tile ops; within a stated
 fp16 tolerance for the MFMA paths."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -396,3 +397,25 @@ def test_bilinear_splat_and_resize_vs_reference_golden():
     for key, (h, w) in {"bicubic_x2": (32, 64), "bicubic_odd": (24, 40)}.items():
         got = resize_video_latent(lat.to(d), h, w, mode="bicubic").cpu()
         assert float((got - torch.from_numpy(z[f"resize_{key}"])).abs().max()) < 2e-6, key
+
+
+def test_rccl_level_exchange_single_rank():
+    """The per-level tile all-gather (parallel.exchange_level) through RCCL on device tensors, in a one-rank group: the
+    call pattern the N > 1 bench uses (world_size-2 logic is covered on CPU with gloo, tests/test_parallel_gloo.py)."""
+    import torch.distributed as dist
+    from dynamicscaler_amd import parallel
+    d = dev()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=d)
+    try:
+        xp = rnd((8, 4, 4, 8, 16), 1).half().to(d)
+        x0 = rnd((8, 4, 4, 8, 16), 2).half().to(d)
+        a, b = parallel.exchange_level(xp, x0, 8, force=True)
+        torch.cuda.synchronize()
+        assert torch.equal(a, xp) and torch.equal(b, x0)
+    finally:
+        if created:
+            dist.destroy_process_group()
