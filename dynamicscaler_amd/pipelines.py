@@ -129,8 +129,15 @@ class VC2_Pipeline_T2V:
             sts = torch.full((n,), int(t), device=x.device, dtype=torch.long)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = model(sx, sts, c_crossattn=[sctx], fps=fps, curr_time_steps=sts, temporal_length=frames, **kwargs)
+            try:
+                with torch.cuda.graph(g):
+                    out = model(sx, sts, c_crossattn=[sctx], fps=fps, curr_time_steps=sts, temporal_length=frames, **kwargs)
+            except Exception as e:           # capture is an optimisation: fall back to the eager launches, loudly
+                import warnings
+                warnings.warn(f"hipGraph capture of the UNet evaluation failed ({type(e).__name__}: {e}); running eagerly")
+                torch.cuda.synchronize()
+                self.use_graph = False
+                return model(sx, sts, c_crossattn=[sctx], fps=fps, curr_time_steps=sts, temporal_length=frames, **kwargs)
             ent = self._graphs[key] = (g, sx, sts, sctx, out)
         else:
             g, sx, sts, sctx, out = ent
