@@ -650,3 +650,67 @@ def test_i2v_grid_pipeline_vs_reference_golden():
     e = relerr(den, T(z["i2vgrid_plain_tiny"]))
     print(f"i2v grid tiny fp16: rel err {e:.3e}")
     assert e < 3e-2
+
+
+def test_gen_pano_360_stage_chain_runs():
+    """The stage chain of gen_pano_360.py:227-370 on toy sizes, every stage on the HIP path: i2v sphere loop with
+    paste_on_static (tiled VAE encode each step) and denoise_to_step -> nearest resize -> i2v ring loop resumed with
+    use_skip_time -> bicubic x2 + re_noise -> i2v ring loop at 2x -> seam-safe VAE decode.  No golden for the chain (each
+    stage is pinned on its own); this checks that the hand-offs compose: shapes, finiteness, and that the last stage's
+    decode equals the oracle's decoder on the same latent."""
+    from helpers import synth_image_embedder
+    from oracle.vae import decode_first_stage_2dae
+    from dynamicscaler_amd.host_model import LatentDiffusionHost
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.sphere import VC2_Pipeline_I2V_SpherePano
+    from dynamicscaler_amd.tensor_utils import resize_video_latent
+    from dynamicscaler_amd.vae_spec import vae_param_shapes
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict, synth_normal
+    d = dev()
+    zt = np.load(os.path.join(G, "unet_tiny_i2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    dd = json.loads(bytes(np.load(os.path.join(G, "vae_enc_tiny.npz"))["tiny8_dd_json"]).decode())
+    cond, uncond = synth_normal((1, 77, 64), 61), synth_normal((1, 77, 64), 62)
+    embed = synth_image_embedder(64)
+    ld = LatentDiffusionHost({"params": params}, conditioner=lambda p: uncond if p[0] == "" else cond,
+                             first_stage_config={"params": {"ddconfig": dd, "embed_dim": 4}}, scale_factor=0.18215)
+    ld.model.diffusion_model.load_state_dict(synth_state_dict(param_shapes(params), 5), strict=True)
+    vsd = synth_state_dict(vae_param_shapes(dd, 4), seed=23)
+    ld.first_stage_model.load_state_dict(vsd)
+    ld.temporal_length = 4
+    ld.get_image_embeds = embed
+    ld.embedder = object()
+    ld = ld.to(d).eval()
+    pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}}).to(d, torch.float16)
+    pano_img = synth_normal((3, 256, 512), 89).clamp(-1, 1)
+    N, stop = 6, 3
+    torch.manual_seed(1)
+    sphere_lat, _ = pipe.basic_sample_shift_shpere_panorama(
+        prompt="a prompt", height=64, width=128, frames=4, fps=8, guidance_scale=7.5, pano_image_tensor=pano_img, total_f=4,
+        overlap_ratio_list_f=[0.0] * N, loop_step_frame=2, equirect_width=512, equirect_height=256, view_fov=120,
+        loop_step_theta=2, phi_theta_dict={0: [0, 120, 240], -60: [0, 180], 60: [0, 180]}, merge_renoised_overlap_latent_ratio=1,
+        merge_prev_denoised_ratio_list=[0.3] * N, denoise_to_step=stop, paste_on_static=True, num_inference_steps=N,
+        output_type="latent")
+    assert sphere_lat.shape == (1, 4, 4, 32, 64) and bool(torch.isfinite(sphere_lat.float()).all())
+    lat1 = resize_video_latent(sphere_lat.clone(), target_height=32, target_width=64, mode="nearest")
+    ring_args = dict(prompt="a prompt", height=64, width=128, frames=4, fps=8, guidance_scale=7.5, num_windows_f=1, loop_step=4,
+                     total_f=4, overlap_ratio_list_f=[0.0] * N, loop_step_frame=2, merge_prev_denoised_ratio_list=[0.3] * N,
+                     num_inference_steps=N, use_skip_time=True, skip_time_step_idx=stop, progressive_skip=False)
+    _, lat2 = pipe.basic_sample_shift_multi_windows(init_panorama_latent=lat1, total_h=256, total_w=512, num_windows_h=2 + 3,
+                                                    num_windows_w=5, pano_image_tensor=pano_img, output_type="latent", **ring_args)
+    assert lat2.shape == lat1.shape and bool(torch.isfinite(lat2.float()).all())
+    up = resize_video_latent(lat2.clone(), target_height=64, target_width=128, mode="bicubic")
+    pipe.scheduler.make_schedule(N)
+    mixed = pipe.scheduler.re_noise(up, 0, N - stop)
+    big_img = synth_normal((3, 512, 1024), 90).clamp(-1, 1)
+    videos, lat3 = pipe.basic_sample_shift_multi_windows(init_panorama_latent=mixed, total_h=512, total_w=1024, num_windows_h=9,
+                                                         num_windows_w=9, pano_image_tensor=big_img, output_type="tensor", **ring_args)
+    assert lat3.shape == (1, 4, 4, 64, 128) and videos.shape == (1, 3, 4, 512, 1024) and bool(torch.isfinite(videos).all())
+    lat = lat3.float().cpu()
+    chunks = list(torch.chunk(lat, 16, dim=4))
+    padded = torch.cat([chunks[-1]] + chunks + [chunks[0]], dim=4)
+    ref = torch.cat(torch.chunk(decode_first_stage_2dae(vsd, dd, padded, scale_factor=0.18215), 18, dim=4)[1:-1], dim=4)
+    e = relerr(videos, ref)
+    print(f"stage chain: final decode rel err vs the oracle decoder {e:.3e}")
+    assert e < 1e-2
