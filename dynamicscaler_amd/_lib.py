@@ -66,6 +66,12 @@ SIGNATURES = {
     "ds_rows_to_ncthw": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ds_timestep_embedding": (_i, [_vp, _vp, _i, _i, _vp]),
     "ds_silu_f16": (_i, [_vp, _vp, _sz, _vp]),
+    "ds_attention_enc_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "ds_gelu_f16": (_i, [_vp, _vp, _sz, _vp]),
+    "ds_embed_tokens": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ds_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ds_clip_preprocess": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ds_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

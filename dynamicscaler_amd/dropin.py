@@ -23,10 +23,14 @@ def _mod(name, **attrs):
 
 
 def install():
-    from . import unet, scheduler, pipelines, pipelines_i2v, ring, tensor_utils, host_model, sphere, vae
+    from . import unet, scheduler, pipelines, pipelines_i2v, ring, tensor_utils, host_model, sphere, vae, encoders
     _mod("lvdm.modules.networks.openaimodel3d", UNetModel=unet.UNetModel)
-    _mod("lvdm.models.ddpm3d", DiffusionWrapper=unet.DiffusionWrapper, LatentDiffusion=host_model.LatentDiffusionHost)
-    _mod("lvdm.models.autoencoder", AutoencoderKL=vae.AutoencoderKLDecoder)      # decode half only
+    _mod("lvdm.models.ddpm3d", DiffusionWrapper=unet.DiffusionWrapper, LatentDiffusion=host_model.LatentDiffusionHost,
+         LatentVisualDiffusion=host_model.LatentDiffusionHost)
+    _mod("lvdm.models.autoencoder", AutoencoderKL=vae.AutoencoderKL)
+    _mod("lvdm.modules.encoders.condition", FrozenOpenCLIPEmbedder=encoders.FrozenOpenCLIPEmbedder,
+         FrozenOpenCLIPImageEmbedderV2=encoders.FrozenOpenCLIPImageEmbedderV2)
+    _mod("lvdm.modules.encoders.ip_resampler", Resampler=encoders.Resampler)
     _mod("pipeline.scheduler", lvdm_DDIM_Scheduler=scheduler.lvdm_DDIM_Scheduler)
     _mod("pipeline.t2v_normal_pipeline", VC2_Pipeline_T2V=pipelines.VC2_Pipeline_T2V)
     _mod("pipeline.t2v_sphere_panorama_pipeline", VC2_Pipeline_T2V_SpherePano=sphere.VC2_Pipeline_T2V_SpherePano)

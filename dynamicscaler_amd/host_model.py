@@ -2,9 +2,12 @@
 
 Only the members on the hot path exist: `.model` (DiffusionWrapper around the HIP UNetModel), the schedule
 buffers of register_schedule (lvdm/models/ddpm3d.py:113-134), `get_learned_conditioning`, the plain attributes the
-pipelines / scheduler read, and -- when a `first_stage_config` is given -- the first-stage DECODER
-(`decode_first_stage_2DAE`, ddpm3d.py:556-562, on vae.AutoencoderKLDecoder).  CLIP and the VAE encoder are out of
-scope: the conditioner is any callable prompt-list -> [1, L, context_dim] tensor.
+pipelines / scheduler read, and -- when the configs are given -- the first stage (`first_stage_config`:
+`decode_first_stage_2DAE` / `encode_first_stage_2DAE`, ddpm3d.py:485-490, 556-562, on vae.AutoencoderKL) and the
+conditioning producers of SURVEY.md 8-f N3 (`cond_stage_config`: the OpenCLIP text tower behind
+`get_learned_conditioning`, ddpm3d.py:446-456; `cond_img_config` + `finegrained`: image tower + Resampler behind
+`get_image_embeds`, ddpm3d.py:659-693).  Without a `cond_stage_config` the conditioner is any callable
+prompt-list -> [1, L, context_dim] tensor.
 """
 import importlib
 
@@ -41,7 +44,8 @@ class SyntheticConditioner:
 
 class LatentDiffusionHost(nn.Module):
     def __init__(self, unet_config, timesteps=1000, linear_start=0.00085, linear_end=0.012, uncond_type="empty_seq",
-                 use_scale=False, channels=4, conditioner=None, first_stage_config=None, scale_factor=1.0, **_ignored):
+                 use_scale=False, channels=4, conditioner=None, first_stage_config=None, scale_factor=1.0,
+                 cond_stage_config=None, cond_img_config=None, finegrained=False, **_ignored):
         super().__init__()
         params = unet_config["params"] if "params" in unet_config else unet_config
         self.model = DiffusionWrapper(UNetModel(**params), "crossattn")
@@ -61,7 +65,25 @@ class LatentDiffusionHost(nn.Module):
             fp = first_stage_config.get("params", first_stage_config)
             self.first_stage_model = AutoencoderKL(fp["ddconfig"], fp.get("embed_dim", 4))
         self.cond_stage_model = None
+        if cond_stage_config is not None:                                    # ddpm3d.py:427-444 (frozen, eval)
+            self.cond_stage_model = self._instantiate_encoder(cond_stage_config)
+        if cond_img_config is not None:                                      # LatentVisualDiffusion, ddpm3d.py:659-686
+            from .encoders import Resampler
+            self.embedder = self._instantiate_encoder(cond_img_config)
+            if not finegrained:
+                raise NotImplementedError("ImageProjModel (finegrained=False) is not used by the reference's i2v configs")
+            self.image_proj_model = Resampler(dim=1024, depth=4, dim_head=64, heads=12, num_queries=16,
+                                              embedding_dim=1280, output_dim=1024, ff_mult=4)
         self.conditioner = conditioner
+
+    @staticmethod
+    def _instantiate_encoder(config):
+        """yaml `target:` strings of the reference (lvdm.modules.encoders.condition.*) resolve to encoders.py."""
+        from . import encoders
+        name = config["target"].rsplit(".", 1)[1]
+        if not hasattr(encoders, name):
+            raise NotImplementedError(f"conditioning encoder {config['target']} is not built")
+        return getattr(encoders, name)(**config.get("params", dict()))
 
     @property
     def device(self):
@@ -89,7 +111,16 @@ class LatentDiffusionHost(nn.Module):
         return ops.posterior_sample(mom, (B, C, T, h, w), noise, self.scale_factor)
 
     def get_learned_conditioning(self, prompts):
+        """ddpm3d.py:446-456."""
+        if self.cond_stage_model is not None:
+            return self.cond_stage_model.encode(prompts)
         if self.conditioner is None:
-            raise RuntimeError("no conditioner attached: CLIP is outside the hot-path scope (SURVEY.md 8-f N3); "
-                               "attach a callable prompts -> [1, L, context_dim] tensor")
+            raise RuntimeError("no conditioner attached: pass cond_stage_config (the OpenCLIP text tower, token ids in) "
+                               "or a callable prompts -> [1, L, context_dim] tensor")
         return self.conditioner(prompts)
+
+    def get_image_embeds(self, batch_imgs):
+        """ddpm3d.py:689-693: batch_imgs [b,3,H,W] in [-1,1] -> image tower tokens -> Resampler -> [b,16,1024]."""
+        if getattr(self, "embedder", None) is None:
+            raise RuntimeError("no image embedder attached (pass cond_img_config and finegrained=True)")
+        return self.image_proj_model(self.embedder(batch_imgs.to(self.device)))

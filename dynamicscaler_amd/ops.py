@@ -306,11 +306,11 @@ def groupnorm_apply(x, mean, rstd, gamma, beta, ninst, rows_per_inst, Cch, silu,
     return y
 
 
-def layernorm(x, gamma, beta, eps=1e-5, stream=None):
+def layernorm(x, gamma, beta, eps=1e-5, stream=None, out=None):
     lib = _lib.load()
     st = _stream() if stream is None else stream
     rows, Cch = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     check(lib.ds_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, Cch, float(eps), st),
           "ds_layernorm")
     return y
@@ -420,3 +420,69 @@ def silu(x, stream=None):
     y = torch.empty_like(x)
     check(lib.ds_silu_f16(x.data_ptr(), y.data_ptr(), x.numel(), st), "ds_silu_f16")
     return y
+
+
+# ------------------------------------------------------------------------------------------------ encoder ops (N3)
+def attention_enc(q, k, v, out, *, batch, heads, nq, nk, ldq, ldk, ldv, ldo, head_dim, scale, causal=False, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    check(lib.ds_attention_enc_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), batch, heads, nq, nk, ldq,
+                                   ldk, ldv, ldo, head_dim, float(scale), int(bool(causal)), st), "ds_attention_enc_f16")
+    return out
+
+
+def gelu_(x, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    check(lib.ds_gelu_f16(x.data_ptr(), x.data_ptr(), x.numel(), st), "ds_gelu_f16")
+    return x
+
+
+def embed_tokens(tokens, table, pos, stream=None):
+    """tokens int32 [b, ctx] -> fp16 [b*ctx, width] = table[tokens] + pos."""
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    _dev(tokens, "tokens")
+    assert tokens.dtype == torch.int32 and tokens.is_contiguous()
+    b, ctx = tokens.shape
+    vocab, width = table.shape
+    out = torch.empty((b * ctx, width), dtype=torch.float16, device=tokens.device)
+    check(lib.ds_embed_tokens(tokens.data_ptr(), table.data_ptr(), pos.data_ptr(), out.data_ptr(), b * ctx, ctx, width,
+                              vocab, st), "ds_embed_tokens")
+    return out
+
+
+def vit_assemble(patches, cls, pos, nimg, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    width = patches.shape[1]
+    grid2 = patches.shape[0] // nimg
+    out = torch.empty((nimg * (grid2 + 1), width), dtype=torch.float16, device=patches.device)
+    check(lib.ds_vit_assemble(patches.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), nimg, grid2, width, st),
+          "ds_vit_assemble")
+    return out
+
+
+def clip_preprocess(img, size, mean, std, antialias=True, stream=None):
+    """img [n,3,H,W] fp32/fp16 in [-1,1] on the device -> fp32 [n,3,size,size]."""
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    img = _dev(img.contiguous(), "image")
+    n, c, H, W = img.shape
+    out = torch.empty((n, c, size, size), dtype=torch.float32, device=img.device)
+    m3 = (C.c_float * 3)(*[float(x) for x in mean])
+    s3 = (C.c_float * 3)(*[float(x) for x in std])
+    check(lib.ds_clip_preprocess(img.data_ptr(), _DT[img.dtype], out.data_ptr(), n, c, H, W, size, int(bool(antialias)),
+                                 C.cast(m3, C.c_void_p), C.cast(s3, C.c_void_p), st), "ds_clip_preprocess")
+    return out
+
+
+def patchify(img, patch, kpad, stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    n, c, S, _ = img.shape
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    g = S // patch
+    rows = torch.empty((n * g * g, kpad), dtype=torch.float16, device=img.device)
+    check(lib.ds_patchify(img.data_ptr(), rows.data_ptr(), n, c, S, patch, kpad, st), "ds_patchify")
+    return rows

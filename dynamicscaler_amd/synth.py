@@ -51,3 +51,26 @@ def synth_normal(shape, seed, scale=1.0):
     g = torch.Generator(device="cpu")
     g.manual_seed(int(seed))
     return (torch.randn(tuple(shape), generator=g) * scale).half().float()
+
+
+def synth_encoder_state_dict(shapes, seed=0):
+    """Synthetic weights for the CLIP towers / Resampler (encoder_spec.py): like synth_state_dict, with the keys that do
+    not follow the `.weight` / `.bias` naming handled by role -- packed attention projections as Linear weights,
+    embeddings / queries at CLIP-like scale."""
+    out = {}
+    for k, shape in shapes.items():
+        g = _gen(seed, k)
+        shape = tuple(shape)
+        if k.endswith("in_proj_weight"):
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(shape[1])
+        elif k.endswith("in_proj_bias"):
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(shape[0] // 3)
+        elif k.endswith(("positional_embedding", "class_embedding")):
+            t = 0.05 * torch.randn(shape, generator=g)
+        elif k.endswith("latents"):
+            t = torch.randn(shape, generator=g) / math.sqrt(shape[-1])
+        else:
+            out[k] = synth_tensor(k, shape, shapes, seed)
+            continue
+        out[k] = t.half().float()
+    return out

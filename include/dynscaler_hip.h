@@ -229,6 +229,33 @@ int ds_timestep_embedding(const int64_t* t, void* out, int n, int dim, void* str
 /* y = silu(x), fp16 elementwise (emb_layers SiLU, openaimodel3d.py:172-178). */
 int ds_silu_f16(const void* x, void* y, size_t n, void* stream);
 
+/* ---- conditioning producers: OpenCLIP ViT-H/14 towers and the IP-Adapter Resampler ---- */
+/* softmax(q k^T * scale [+ causal mask]) v for head_dim 64 (text tower, open_clip Transformer behind
+ * condition.py:216-224; Resampler, ip_resampler.py:62-90) or 80 (image tower, condition.py:358-360); layout as in
+ * ds_attention_f16 with head h at column h*head_dim.  causal != 0: key j visible to query i iff j <= i (the text
+ * tower's attn_mask, condition.py:220); needs nq == nk. */
+int ds_attention_enc_f16(const void* q, const void* k, const void* v, void* out, int batch, int heads, int nq, int nk,
+                         int ldq, int ldk, int ldv, int ldo, int head_dim, float scale, int causal, void* stream);
+/* y = gelu(x) with the exact erf (nn.GELU: ip_resampler.py:29, open_clip's mlp), fp16 elementwise. */
+int ds_gelu_f16(const void* x, void* y, size_t n, void* stream);
+/* out fp16 [ntok][width] = table[tokens[i]] + pos[i % ctx]  (condition.py:217-218); table fp16 [vocab][width],
+ * pos fp32 [ctx][width]. */
+int ds_embed_tokens(const int32_t* tokens, const void* table, const float* pos, void* out, int ntok, int ctx, int width,
+                    int vocab, void* stream);
+/* out fp16 [nimg*(grid2+1)][width]: token 0 = cls + pos[0], token 1+i = patches[img*grid2 + i] + pos[1+i]
+ * (condition.py:346-350); patches fp16, cls / pos fp32. */
+int ds_vit_assemble(const void* patches, const float* cls, const float* pos, void* out, int nimg, int grid2, int width,
+                    void* stream);
+/* FrozenOpenCLIPImageEmbedderV2.preprocess (condition.py:324-332): img [nimg][3][H][W] (fp32 or fp16, values in
+ * [-1,1]) -> out fp32 [nimg][3][S][S] = normalize((resize(img) + 1)/2, mean, std); resize = kornia.geometry.resize
+ * (bicubic, align_corners=True, antialias: Gaussian pre-blur of sigma (in/out-1)/2 when an axis shrinks).
+ * mean / stdv: HOST arrays of 3 floats. */
+int ds_clip_preprocess(const void* img, int dtype, float* out, int nimg, int C, int H, int W, int S, int antialias,
+                       const float* mean, const float* stdv, void* stream);
+/* conv1 (patch embedding, kernel = stride = P, no bias; condition.py:342) as a GEMM: rows fp16 [nimg*(S/P)^2][kpad],
+ * column c*P*P + py*P + px (the flattened conv weight's order), columns >= C*P*P zero. */
+int ds_patchify(const float* img, void* rows, int nimg, int C, int S, int P, int kpad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,10 @@ so parity is pinned by what this script captures from the imported reference cod
                              gather/scatter round trips (duplicate winners), t2v sphere loop (P5), fake eps + tiny UNet
   G10 unet_full_t2v.npz      (--full) full-size t2v UNet eps at tile [1,4,16,40,64] (2 forwards, ~2 min)
 
+  G16 encoders_{toy,full}.npz  Resampler (the reference's module, ip_resampler.py) and the CLIP ViT-H/14 text / image
+                             towers -- open_clip is absent, so the tower vectors come from transformers' CLIP
+                             implementation carrying the same synthetic weights (independent anchor, not the reference)
+
 Only data is written (inputs, expected outputs, seeds); no reference source text.
 """
 import argparse
@@ -738,17 +742,151 @@ def g15_vae_encode(full=False):
                  full_dd_json=np.frombuffer(json.dumps(VAE_FULL).encode(), dtype=np.uint8))
 
 
+# ---------------------------------------------------------------------------------------------- g16: encoders (N3)
+RESAMPLER_TOY = dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=4, embedding_dim=192, output_dim=128, ff_mult=4)
+CLIP_TOY = dict(vision=dict(image_size=56, layers=2, width=320, head_width=80, patch_size=14, mlp_ratio=4.0),
+                text=dict(context_length=77, vocab_size=1000, width=128, heads=2, layers=3, mlp_ratio=4.0))
+
+
+@contextlib.contextmanager
+def _without_reference_stubs():
+    """transformers probes optional packages with importlib.util.find_spec, which rejects the spec-less stub modules
+    oracle/ref_import.py installs for the reference (torchvision, ...): hide them while transformers is imported."""
+    hidden = {k: sys.modules.pop(k) for k in list(sys.modules)
+              if k.split(".")[0] in ("torchvision", "cv2", "kornia", "open_clip", "imageio", "diffusers", "omegaconf",
+                                     "pytorch_lightning", "xformers", "decord", "av")
+              and getattr(sys.modules[k], "__spec__", None) is None}
+    try:
+        yield
+    finally:
+        sys.modules.update(hidden)
+
+
+def _hf_block_map(sd, src, dst, W):
+    out = {}
+    for nm, sl in (("q_proj", slice(0, W)), ("k_proj", slice(W, 2 * W)), ("v_proj", slice(2 * W, 3 * W))):
+        out[f"{dst}.self_attn.{nm}.weight"] = sd[f"{src}.attn.in_proj_weight"][sl]
+        out[f"{dst}.self_attn.{nm}.bias"] = sd[f"{src}.attn.in_proj_bias"][sl]
+    for a, b in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"),
+                 ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+        out[f"{dst}.{b}.weight"] = sd[f"{src}.{a}.weight"]
+        out[f"{dst}.{b}.bias"] = sd[f"{src}.{a}.bias"]
+    return out
+
+
+def _hf_text(text, sd):
+    """transformers' CLIPTextModel carrying the open_clip-keyed synthetic weights (independent implementation)."""
+    with _without_reference_stubs():
+        from transformers import CLIPTextConfig, CLIPTextModel
+    W = text["width"]
+    cfg = CLIPTextConfig(vocab_size=text["vocab_size"], hidden_size=W, intermediate_size=int(W * text["mlp_ratio"]),
+                         num_hidden_layers=text["layers"], num_attention_heads=text["heads"],
+                         max_position_embeddings=text["context_length"], hidden_act="gelu", layer_norm_eps=1e-5,
+                         bos_token_id=0, eos_token_id=2, pad_token_id=1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = CLIPTextModel(cfg).eval()
+    hf = {"text_model.embeddings.token_embedding.weight": sd["model.token_embedding.weight"],
+          "text_model.embeddings.position_embedding.weight": sd["model.positional_embedding"],
+          "text_model.final_layer_norm.weight": sd["model.ln_final.weight"],
+          "text_model.final_layer_norm.bias": sd["model.ln_final.bias"]}
+    for i in range(text["layers"]):
+        hf.update(_hf_block_map(sd, f"model.transformer.resblocks.{i}", f"text_model.encoder.layers.{i}", W))
+    if not any(k.startswith("text_model.") for k in m.state_dict()):      # newer transformers: no wrapper prefix
+        hf = {k[len("text_model."):]: v for k, v in hf.items()}
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    return m
+
+
+def _hf_vision(vision, sd):
+    with _without_reference_stubs():
+        from transformers import CLIPVisionConfig, CLIPVisionModel
+    W = vision["width"]
+    cfg = CLIPVisionConfig(hidden_size=W, intermediate_size=int(W * vision["mlp_ratio"]), num_hidden_layers=vision["layers"],
+                           num_attention_heads=W // vision["head_width"], image_size=vision["image_size"],
+                           patch_size=vision["patch_size"], hidden_act="gelu", layer_norm_eps=1e-5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = CLIPVisionModel(cfg).eval()
+    hf = {"vision_model.embeddings.class_embedding": sd["model.visual.class_embedding"],
+          "vision_model.embeddings.patch_embedding.weight": sd["model.visual.conv1.weight"],
+          "vision_model.embeddings.position_embedding.weight": sd["model.visual.positional_embedding"],
+          "vision_model.pre_layrnorm.weight": sd["model.visual.ln_pre.weight"],
+          "vision_model.pre_layrnorm.bias": sd["model.visual.ln_pre.bias"]}
+    for i in range(vision["layers"]):
+        hf.update(_hf_block_map(sd, f"model.visual.transformer.resblocks.{i}", f"vision_model.encoder.layers.{i}", W))
+    if not any(k.startswith("vision_model.") for k in m.state_dict()):
+        hf = {k[len("vision_model."):]: v for k, v in hf.items()}
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected and all(("post_layernorm" in k or "position_ids" in k) for k in missing), (missing, unexpected)
+    return m
+
+
+def g16_encoders(full=False):
+    """N3.  Resampler: the reference's own module (ip_resampler.py) on synthetic weights -- toy and the i2v config of
+    ddpm3d.py:683-685.  CLIP towers: open_clip is absent, so the anchor is transformers' CLIP implementation carrying
+    the same weights: text = final_layer_norm(hidden_states[-2]) (the 'penultimate' + ln_final of condition.py:216-234),
+    vision = the last block's tokens before post_layernorm (condition.py:336-365)."""
+    from lvdm.modules.encoders.ip_resampler import Resampler
+    from dynamicscaler_amd.encoder_spec import (CLIP_VIT_H_14, RESAMPLER_I2V, clip_text_param_shapes,
+                                                clip_vision_param_shapes, resampler_param_shapes)
+    from dynamicscaler_amd.synth import synth_encoder_state_dict
+    with _without_reference_stubs():
+        import transformers
+        from transformers import CLIPTextModel, CLIPVisionModel  # noqa: F401  (resolve the lazy modules now)
+    arrays = {"transformers_version": np.frombuffer(transformers.__version__.encode(), dtype=np.uint8)}
+
+    def resampler(tag, cfg, seed, x):
+        m = Resampler(**cfg).eval()
+        shapes = resampler_param_shapes(**cfg)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+        m.load_state_dict(synth_encoder_state_dict(shapes, seed))
+        with torch.no_grad():
+            arrays[f"{tag}_resampler_out"] = m(x)
+        arrays[f"{tag}_resampler_x"] = x
+
+    def towers(tag, spec, seed, batch):
+        text, vision = spec["text"], spec["vision"]
+        tsd = synth_encoder_state_dict(clip_text_param_shapes(text), seed)
+        g = torch.Generator().manual_seed(seed + 1)
+        tokens = torch.randint(3, text["vocab_size"], (batch, text["context_length"]), generator=g)
+        tokens[:, 0] = 0
+        with torch.no_grad():
+            tm = _hf_text(text, tsd)
+            hs = tm(input_ids=tokens, output_hidden_states=True)
+            arrays[f"{tag}_text_out"] = getattr(tm, "text_model", tm).final_layer_norm(hs.hidden_states[-2])
+            del tm
+        arrays[f"{tag}_text_tokens"] = tokens.to(torch.int32)
+        vsd = synth_encoder_state_dict(clip_vision_param_shapes(vision), seed + 2)
+        pix = synth_normal((batch, 3, vision["image_size"], vision["image_size"]), seed + 3)
+        with torch.no_grad():
+            vs = _hf_vision(vision, vsd)(pixel_values=pix, output_hidden_states=True)
+        arrays[f"{tag}_vision_out"] = vs.hidden_states[-1]
+        arrays[f"{tag}_vision_pixels"] = pix
+
+    resampler("toy", RESAMPLER_TOY, 51, synth_normal((2, 17, 192), 52))
+    towers("toy", CLIP_TOY, 53, 2)
+    arrays["toy_cfg_json"] = np.frombuffer(json.dumps(dict(resampler=RESAMPLER_TOY, clip=CLIP_TOY)).encode(), dtype=np.uint8)
+    save_npz("encoders_toy.npz", **{k: v for k, v in arrays.items() if k.startswith(("toy", "transformers"))})
+    if full:
+        resampler("full", RESAMPLER_I2V, 61, synth_normal((1, 257, 1280), 62))
+        towers("full", CLIP_VIT_H_14, 63, 1)
+        keep = {k: (v.to(torch.float16) if torch.is_tensor(v) and v.dtype == torch.float32 and v.numel() > 65536 else v)
+                for k, v in arrays.items() if k.startswith(("full", "transformers"))}
+        save_npz("encoders_full.npz", **keep)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size UNet fixture (minutes)")
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders}
     if args.full:
         steps["g10"] = g10_unet_full
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
+        steps["g16"] = lambda: g16_encoders(full=True)
     for k, fn in steps.items():
         if args.only and k != args.only:
             continue

@@ -475,3 +475,59 @@ def test_g11_i2v_grid_loop_vs_reference_golden():
                                     cond, uc, img, guidance_scale=7.5, **meta["i2v_grid_geoms"]["plain"])
     ref = T(z["i2vgrid_plain_tiny"])
     assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4
+
+
+def _enc_cfg(z):
+    return json.loads(bytes(z["toy_cfg_json"]).decode())
+
+
+def test_g16_resampler_vs_reference_golden():
+    """N3: oracle Resampler == the reference's ip_resampler.Resampler on the same synthetic weights (toy, and the i2v
+    configuration of ddpm3d.py:683-685 on 257 image tokens)."""
+    from oracle.encoders import resampler_forward
+    from dynamicscaler_amd.encoder_spec import RESAMPLER_I2V, resampler_param_shapes
+    from dynamicscaler_amd.synth import synth_encoder_state_dict
+    z = npz("encoders_toy.npz")
+    r = _enc_cfg(z)["resampler"]
+    out = resampler_forward(synth_encoder_state_dict(resampler_param_shapes(**r), 51), T(z["toy_resampler_x"]),
+                            depth=r["depth"], heads=r["heads"])
+    assert torch.equal(out, T(z["toy_resampler_out"]))
+    zf = npz("encoders_full.npz")
+    r = RESAMPLER_I2V
+    out = resampler_forward(synth_encoder_state_dict(resampler_param_shapes(**r), 61), T(zf["full_resampler_x"]).float(),
+                            depth=r["depth"], heads=r["heads"])
+    ref = T(zf["full_resampler_out"]).float()
+    assert out.shape == (1, 16, 1024) and float((out - ref).abs().max()) < 2e-5
+
+
+def test_g16_clip_towers_vs_independent_implementation():
+    """N3, parity UNPINNED against open_clip (absent): the oracle's towers against transformers' CLIP carrying the same
+    weights -- toy sizes here, the ViT-H/14 sizes in the -m gpu suite's fixtures."""
+    from oracle.encoders import clip_text_encode, clip_vision_tokens
+    from dynamicscaler_amd.encoder_spec import clip_text_param_shapes, clip_vision_param_shapes
+    from dynamicscaler_amd.synth import synth_encoder_state_dict
+    z = npz("encoders_toy.npz")
+    c = _enc_cfg(z)["clip"]
+    t, v = c["text"], c["vision"]
+    out = clip_text_encode(synth_encoder_state_dict(clip_text_param_shapes(t), 53), T(z["toy_text_tokens"]),
+                           heads=t["heads"], layers=t["layers"], layer_idx=1)
+    assert float((out - T(z["toy_text_out"])).abs().max()) < 2e-5
+    out = clip_vision_tokens(synth_encoder_state_dict(clip_vision_param_shapes(v), 55), T(z["toy_vision_pixels"]),
+                             heads=v["width"] // v["head_width"], layers=v["layers"])
+    assert out.shape == (2, 17, v["width"]) and float((out - T(z["toy_vision_out"])).abs().max()) < 2e-5
+
+
+def test_g16_clip_preprocess_properties():
+    """kornia's resize restated (unpinned): without shrinking it is F.interpolate(bicubic, align_corners=True); a
+    constant image stays constant through blur + resize; output is normalised with the CLIP mean / std."""
+    import torch.nn.functional as F
+    from oracle.encoders import clip_preprocess
+    from dynamicscaler_amd.encoder_spec import CLIP_MEAN, CLIP_STD
+    x = synth_normal((1, 3, 20, 24), 9).clamp(-1, 1)
+    up = clip_preprocess(x, 32)
+    ref = (F.interpolate(x, size=(32, 32), mode="bicubic", align_corners=True) + 1) / 2
+    ref = (ref - torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)) / torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    assert torch.allclose(up, ref, atol=1e-6)
+    const = clip_preprocess(torch.full((1, 3, 96, 160), 0.25), 32)
+    want = ((0.25 + 1) / 2 - torch.tensor(CLIP_MEAN)) / torch.tensor(CLIP_STD)
+    assert torch.allclose(const, want.view(1, 3, 1, 1).expand_as(const), atol=1e-5)
