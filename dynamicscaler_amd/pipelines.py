@@ -129,8 +129,11 @@ class VC2_Pipeline_T2V:
             sts = torch.full((n,), int(t), device=x.device, dtype=torch.long)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            # with a process group up, RCCL's watchdog thread polls events concurrently: only this thread's calls
+            # may invalidate the capture then
+            multi = torch.distributed.is_available() and torch.distributed.is_initialized()
             try:
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local" if multi else "global"):
                     out = model(sx, sts, c_crossattn=[sctx], fps=fps, curr_time_steps=sts, temporal_length=frames, **kwargs)
             except Exception as e:           # capture is an optimisation: fall back to the eager launches, loudly
                 import warnings

@@ -174,6 +174,44 @@ def test_ring_pipeline_hipgraph_and_streams_equal_eager():
         assert torch.equal(outs[mode][0], outs["eager"][0]) and torch.equal(outs[mode][1], outs["eager"][1]), mode
 
 
+def test_ring_pipeline_hipgraph_under_process_group():
+    """hipGraph capture of the UNet evaluation while an RCCL process group (its watchdog thread) is alive -- the state
+    the N > 1 bench runs in: capture uses the thread-local error mode then, and the panorama equals the eager one."""
+    import torch.distributed as dist
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    d = dev()
+    z = np.load(os.path.join(G, "loops_small.npz"))
+    meta = json.load(open(os.path.join(G, "loops_small_traces.json")))
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    ld = _host(params, 5, T(z["cond"]), T(z["uncond"]), d)
+    cfgd = {"params": {"unet_config": {"params": params}}}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=d)
+    try:
+        outs = {}
+        for mode in ("eager", "graph"):
+            t = torch.ones(4, device=d)
+            dist.all_reduce(t)                                   # in-flight collective work for the watchdog to poll
+            pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), cfgd).to(d, torch.float16)
+            pipe.use_graph = mode == "graph"
+            torch.manual_seed(2333333)
+            _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5,
+                                                           output_type="latent", **meta["geoms"]["grid4x2"])
+            dist.barrier()
+            outs[mode] = (den.float().cpu(), pipe.final_latent.float().cpu())
+            if mode == "graph":
+                assert pipe.use_graph and any(isinstance(v, tuple) for v in pipe._graphs.values()), "capture fell back"
+        assert torch.equal(outs["graph"][0], outs["eager"][0]) and torch.equal(outs["graph"][1], outs["eager"][1])
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def _oracle_fake(x, ts, ctx):
     return 0.1 * x + 0.01 * ctx.mean()
 
