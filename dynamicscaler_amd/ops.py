@@ -105,10 +105,21 @@ def ring_scatter3(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, origi
                                C.byref(g), arr, n, _stream()), "ds_ring_scatter3")
 
 
-def renoise_mix_(tiles, mask_tiles, pano_shape, c, s, mix_ratio, noise=None, mask_frame0=True, seed=0, offset=0):
-    """In place: tiles <- mix(tiles, c*tiles + s*noise, mask, mix_ratio)."""
+def renoise_mix_(tiles, mask_tiles, pano_shape, c, s, mix_ratio, noise=None, mask_frame0=True, seed=0, offset=0,
+                 tile_ids=None):
+    """In place: tiles <- mix(tiles, c*tiles + s*noise, mask, mix_ratio).
+    In-kernel Philox mode (noise None): the launch draws the counters offset, offset+1, ... (one counter = 4 normals).
+    With `tile_ids` (the tiles' numbers within the step) tile k draws from counter offset + tile_ids[k]*numel on,
+    whatever batch / rank it is processed in (one launch per tile; numel counters are reserved per tile), so no two
+    tiles of a step share noise and the result does not depend on the batching."""
     _dev(tiles, "renoise_mix")
     _dev(mask_tiles, "renoise_mix(mask)")
+    if noise is None and tile_ids is not None:
+        numel = tiles[0].numel()
+        for k, j in enumerate(tile_ids):
+            renoise_mix_(tiles[k:k + 1], mask_tiles[k:k + 1], pano_shape, c, s, mix_ratio, None, mask_frame0, seed,
+                         offset + j * numel)
+        return tiles
     lib = _lib.load()
     n = tiles.shape[0]
     g = _geom(pano_shape, tuple(tiles.shape[2:]), tiles.dtype)

@@ -231,7 +231,7 @@ class VC2_Pipeline_T2V:
                         nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=pano.dtype)
                     ops.renoise_mix_(tiles, mtiles, st.total_shape, c_rn, s_rn, st.ratio, noise=nz,
                                      mask_frame0=mask_frame0, seed=sched.philox_seed,
-                                     offset=(i * len(wins) + ids[0]) * tiles[0].numel())
+                                     offset=i * len(wins) * tiles[0].numel(), tile_ids=ids)
                 n = len(ids)
                 if st.guidance_scale != 1.0:
                     eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n,

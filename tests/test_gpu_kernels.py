@@ -127,6 +127,16 @@ def test_renoise_philox_statistics():
     out2 = ops.renoise_mix_(torch.zeros_like(x), m, (1, 4, 16, 64, 512), 0.0, 1.0, 1.0, noise=None, mask_frame0=False,
                             seed=7, offset=0)
     assert torch.equal(out, out2)                          # counter-based: reproducible
+    # tile_ids: a tile's noise depends on its number within the step only, not on the batch / rank it is processed in
+    args = ((1, 4, 16, 64, 512), 0.0, 1.0, 1.0)
+    whole = ops.renoise_mix_(torch.zeros_like(x), m, *args, seed=7, offset=5, tile_ids=list(range(8)), mask_frame0=False)
+    ids = [1, 3, 4, 7]
+    part = ops.renoise_mix_(torch.zeros_like(x[:4]), m[:4], *args, seed=7, offset=5, tile_ids=ids, mask_frame0=False)
+    assert torch.equal(part, whole[ids])
+    flat = whole.float().cpu().reshape(8, -1)
+    assert abs(float(flat.std()) - 1.0) < 5e-3
+    corr = torch.corrcoef(flat)                              # distinct tiles: independent streams
+    assert float((corr - torch.eye(8)).abs().max()) < 0.02
 
 
 @pytest.mark.parametrize("dtype,edt", [(torch.float32, torch.float32), (torch.float16, torch.float32),

@@ -212,6 +212,30 @@ def test_ring_pipeline_hipgraph_under_process_group():
             dist.destroy_process_group()
 
 
+def test_device_rng_panorama_independent_of_tile_batching():
+    """rng_mode="device" (in-kernel Philox, the bench's mode): a tile's re-noise stream is keyed by (step, tile number),
+    so the panorama does not depend on how tiles are batched or sharded -- max_tile_batch 1 == 8, bit for bit."""
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    d = dev()
+    z = np.load(os.path.join(G, "loops_small.npz"))
+    meta = json.load(open(os.path.join(G, "loops_small_traces.json")))
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    ld = _host(params, 5, T(z["cond"]), T(z["uncond"]), d)
+    cfgd = {"params": {"unet_config": {"params": params}}}
+    outs = []
+    for tb in (1, 8):
+        pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="device"), cfgd).to(d, torch.float16)
+        pipe.max_tile_batch = tb
+        torch.manual_seed(2333333)
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                       **meta["geoms"]["grid4x2"])
+        outs.append((den.float().cpu(), pipe.final_latent.float().cpu()))
+        assert torch.isfinite(outs[-1][0]).all()
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+
+
 def _oracle_fake(x, ts, ctx):
     return 0.1 * x + 0.01 * ctx.mean()
 
