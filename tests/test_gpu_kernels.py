@@ -211,6 +211,69 @@ def test_gemm_epilogues():
     assert out.shape == (M, inner) and relerr(out, ref) < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,what", [
+    (161 * 256 - 219, 320, 320, "256x320"),        # >= 160 workgroups of 256x320, ragged last row tile
+    (160 * 256 + 5, 256, 192, "256x256"),
+    (81 * 256 - 1, 640, 128, "256x320 two N tiles"),
+    (1024, 1024, 1024, "128x64 deep (4-stage)"),   # <= 128 blocks of 128x128 and K/64 >= 8
+    (2048 - 77, 2048, 512, "128x128 deep (4-stage)"),
+])
+def test_gemm_big_and_deep_tiles(M, N, K, what):
+    """The one-workgroup-per-CU tile variants (LDS-DMA, source-side swizzle, hardware zero-fill of tail rows), which the
+    small shapes above never select: bias + residual, per-item bias, SiLU, fp32 output, and an exact integer check."""
+    from dynamicscaler_amd import ops, _lib
+    d = dev()
+    A, W = _h(rnd((M, K), 1)), _h(rnd((N, K), 2, 0.1))
+    b, R = rnd((N,), 3), _h(rnd((M, N), 4))
+    Ad, Wd = A.half().to(d), W.half().to(d)
+    base = A @ W.t()
+    out = ops.gemm(Ad, Wd, b.to(d), R.half().to(d), M=M, N=N, K=K)
+    assert relerr(out, base + b + R) < 1e-3, what
+    items = 7
+    rows = -(-M // items)
+    table = rnd((items, N + 64), 5)
+    out = ops.gemm(Ad, Wd, table.to(d)[:, 64:], None, M=M, N=N, K=K, bias_rows=rows, ldbias=N + 64)
+    ref = base + table[:, 64:].repeat_interleave(rows, 0)[:M]
+    assert relerr(out, ref) < 1e-3, what
+    out = ops.gemm(Ad, Wd, b.to(d), None, M=M, N=N, K=K, epilogue=_lib.DS_EPI_SILU)
+    assert relerr(out, F.silu(base + b)) < 1e-3, what
+    out = ops.gemm(Ad, Wd, b.to(d), None, M=M, N=N, K=K, epilogue=_lib.DS_EPI_OUT_F32)
+    assert out.dtype == torch.float32 and relerr(out, base + b) < 1e-5, what
+    Ai = torch.zeros((M, K)); Ai[torch.arange(M), torch.arange(M) % K] = 1.0          # row m selects column m % K of W
+    Wi = (torch.arange(N * K).reshape(N, K) % 17 - 8).float()
+    out = ops.gemm(Ai.half().to(d), Wi.half().to(d), None, None, M=M, N=N, K=K)
+    assert torch.equal(out.float().cpu(), Ai @ Wi.t()), what
+
+
+def test_gemm_big_tiles_geglu_and_conv():
+    """GEGLU on the 256x256 tile (32-row [x | gate] interleave across a wave's tile pairs) with a ragged M, and the 3x3
+    implicit GEMM (stride 1 and 2, padding taps zero-filled by the buffer loads) at a size that selects 256x320."""
+    from dynamicscaler_amd import ops, _lib
+    from dynamicscaler_amd.unet import _interleave_geglu
+    d = dev()
+    M, K, inner = 160 * 256 - 100, 128, 256
+    A = _h(rnd((M, K), 1))
+    Wg, bg = _h(rnd((2 * inner, K), 6, 0.1)), rnd((2 * inner,), 7)
+    out = ops.gemm(A.half().to(d), _interleave_geglu(Wg).half().to(d), _interleave_geglu(bg).to(d), None, M=M,
+                   N=2 * inner, K=K, epilogue=_lib.DS_EPI_GEGLU)
+    xg = A @ Wg.t() + bg
+    assert out.shape == (M, inner) and relerr(out, xg[:, :inner] * F.gelu(xg[:, inner:])) < 1e-3
+    for stride, nimg, hin, win in ((1, 17, 40, 64), (2, 66, 40, 64)):
+        cin, cout = 64, 320
+        x = _h(rnd((nimg, cin, hin, win), 1))
+        w = _h(rnd((cout, cin, 3, 3), 2, 0.05))
+        b = rnd((cout,), 3)
+        ref = F.conv2d(x, w, b, stride=stride, padding=1)
+        hout, wout = ref.shape[-2:]
+        assert nimg * hout * wout >= 160 * 256
+        a = x.permute(0, 2, 3, 1).reshape(-1, cin).half().to(d)
+        wp = w.permute(0, 2, 3, 1).reshape(cout, -1).half().to(d)
+        out = ops.gemm(a, wp, b.to(d), None, M=nimg * hout * wout, N=cout, K=9 * cin, a_mode=_lib.DS_A_CONV3, cin=cin,
+                       lda=cin, conv=(nimg, hin, win, hout, wout, stride, 0))
+        got = out.float().cpu().reshape(nimg, hout, wout, cout).permute(0, 3, 1, 2)
+        assert relerr(got, ref) < 1e-3, stride
+
+
 @pytest.mark.parametrize("stride,upsample,hin,win", [(1, 0, 10, 12), (2, 0, 10, 12), (2, 0, 5, 8), (1, 1, 5, 6)])
 def test_gemm_conv3x3(stride, upsample, hin, win):
     from dynamicscaler_amd import ops, _lib

@@ -217,3 +217,48 @@ def test_sphere_index_maps_equal_reference_golden_and_winner_rule():
                     assert (lvl[a] < lvl[b]) if dep else True
                     assert lvl[a] != lvl[b] or not dep
             assert lvl[0] == lvl[1] == 0          # the two polar caps (phi = +90 / -90) are disjoint -> batched together
+
+
+def test_encoder_state_dicts_and_cpu_behaviour():
+    """N3 host side: reference state-dict keys (open_clip's / ip_resampler's), the checkpoint's unused keys are
+    ignored, yaml-style construction through LatentDiffusionHost, and no CPU path."""
+    from dynamicscaler_amd import _lib
+    from dynamicscaler_amd.encoders import FrozenOpenCLIPEmbedder, FrozenOpenCLIPImageEmbedderV2, Resampler
+    from dynamicscaler_amd.encoder_spec import clip_text_param_shapes, clip_vision_param_shapes
+    from dynamicscaler_amd.host_model import LatentDiffusionHost
+    from dynamicscaler_amd.synth import synth_encoder_state_dict
+    text = dict(context_length=77, vocab_size=50, width=128, heads=2, layers=2, mlp_ratio=4.0)
+    m = FrozenOpenCLIPEmbedder(layer="penultimate", model_cfg=text)
+    sd = synth_encoder_state_dict(clip_text_param_shapes(text), 1)
+    assert "model.transformer.resblocks.1.attn.in_proj_weight" in sd and "model.token_embedding.weight" in sd
+    extra = dict(sd)
+    extra["model.text_projection"] = torch.zeros(128, 64)
+    extra["model.logit_scale"] = torch.zeros(())
+    assert m.load_state_dict(extra) == ([], [])
+    assert torch.equal(m.state_dict()["model.ln_final.weight"], sd["model.ln_final.weight"])
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({**sd, "model.bogus": torch.zeros(1)})
+    with pytest.raises(_lib.DsError, match="no CPU fallback"):
+        m.encode_with_transformer(torch.zeros((1, 77), dtype=torch.long))
+    with pytest.raises(RuntimeError, match="tokenizer"):
+        m(["a prompt"])
+    vision = dict(image_size=28, layers=1, width=160, head_width=80, patch_size=14, mlp_ratio=4.0)
+    v = FrozenOpenCLIPImageEmbedderV2(model_cfg=vision)
+    vsd = synth_encoder_state_dict(clip_vision_param_shapes(vision), 2)
+    assert v.load_state_dict({**vsd, "model.visual.ln_post.weight": torch.zeros(160), "model.visual.proj": torch.zeros(160, 64),
+                              "model.token_embedding.weight": torch.zeros(5, 8)}) == ([], [])
+    with pytest.raises(NotImplementedError):
+        FrozenOpenCLIPImageEmbedderV2(layer="penultimate", model_cfg=vision)          # as the reference (condition.py:314-316)
+    r = Resampler(dim=128, depth=1, dim_head=64, heads=2, num_queries=4, embedding_dim=192, output_dim=128)
+    assert set(r.state_dict()) >= {"latents", "proj_in.weight", "layers.0.0.to_kv.weight", "layers.0.1.3.weight", "norm_out.bias"}
+    with pytest.raises(_lib.DsError, match="no CPU fallback"):
+        r(torch.zeros(1, 5, 192))
+    params = json.loads(bytes(np.load(os.path.join(G, "unet_tiny_t2v.npz"))["params_json"]).decode())
+    ld = LatentDiffusionHost({"params": params}, finegrained=True,
+        cond_stage_config={"target": "lvdm.modules.encoders.condition.FrozenOpenCLIPEmbedder",
+                           "params": {"freeze": True, "layer": "penultimate", "model_cfg": text}},
+        cond_img_config={"target": "lvdm.modules.encoders.condition.FrozenOpenCLIPImageEmbedderV2",
+                         "params": {"freeze": True, "model_cfg": vision}})
+    assert isinstance(ld.cond_stage_model, FrozenOpenCLIPEmbedder) and isinstance(ld.embedder, FrozenOpenCLIPImageEmbedderV2)
+    assert ld.image_proj_model.cfg["num_queries"] == 16 and ld.image_proj_model.cfg["heads"] == 12      # ddpm3d.py:683-685
+
