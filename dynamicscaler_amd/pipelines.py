@@ -311,7 +311,7 @@ class VC2_Pipeline_T2V:
         if not seam_safe:
             return self.pretrained_t2v.decode_first_stage_2DAE(denoised), denoised
         # seam-safe decode (t2v_sphere_panorama_pipeline.py:638-655): pad W with wrapped 1/16 chunks, decode per
-        # frame, crop.  The VAE itself is the caller's.
+        # frame, crop (vae.AutoencoderKL behind decode_first_stage_2DAE).
         chunks = list(torch.chunk(denoised, 16, dim=4))
         padded = torch.cat([chunks[-1]] + chunks + [chunks[0]], dim=4)
         frames_out = [self.pretrained_t2v.decode_first_stage_2DAE(padded[:, :, [f]]) for f in range(total_frames)]

@@ -8,8 +8,8 @@ frame windows wrap modulo total_f and can be docked to both ends (:786-854), the
 and after the DDIM update x_prev is mixed with the window's pre-re-noise content under the mask (merge-prev,
 :938-943).  The tile engine is the one of pipelines.py (batched levels of independent windows).
 
-Out of scope here: the CLIP image encoder / Resampler (`pretrained_t2v.get_image_embeds` is called
-as a black box, once per distinct crop position -- the reference calls it per tile per step).  `use_skip_time` with a
+`pretrained_t2v.get_image_embeds` (CLIP image tower + Resampler, encoders.py) is called once per distinct crop
+position -- the reference calls it per tile per step.  `use_skip_time` with a
 given `init_panorama_latent` (the way gen_pano_360.py calls it) only shortens the schedule; without one the panorama
 image is encoded by the tiled first-stage encode below and re-noised (:704-722).
 """

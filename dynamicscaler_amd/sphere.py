@@ -332,8 +332,8 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
         """[sic] name kept from the reference (i2v_sphere_panorama_pipeline.py:31-495).  Frame windows over a ring of
         total_f frames (RingPanoramaLatentProxy), per-view image tokens from the perspective crop of the panorama image,
         5-D denoised mask, merge-prev, paste_on_static.  Extensions: `pano_image_tensor` [3,H_img,W_img] instead of a path,
-        `static_frame_latent` [1,C,1,H,W] = the VAE-encoded panorama image for paste_on_static (the reference re-runs the
-        tiled VAE encode every step, :247; the VAE is SURVEY.md 8-f N2, so the caller supplies its result once).
+        `static_frame_latent` [1,C,1,H,W] = a VAE-encoded panorama image to reuse for paste_on_static; without it the tiled
+        VAE encode runs every step like the reference's (:247, fresh posterior noise each time).
         Returns (final_latents, denoised) for output_type='latent' (:476-495)."""
         if view_get_scale_factor != 1 or view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
             raise NotImplementedError("view / decode scale factors other than 1 (gen_pano_360.py uses 1)")
