@@ -266,7 +266,7 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
                                          seed=sched.philox_seed, offset=i * len(views) * tiles[0].numel(), tile_ids=ids)
                     if st.guidance_scale != 1.0:
                         eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n, fps,
-                                        frames, **st.kwargs)
+                                        frames, cfg_pairs=n, **st.kwargs)
                         e_c, e_u = eps[:n], eps[n:]
                     else:
                         e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], fps, frames, **st.kwargs), None
@@ -469,7 +469,7 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                                          seed=sched.philox_seed, offset=i * len(items) * tiles[0].numel(), tile_ids=ids)
                     if st.guidance_scale != 1.0:
                         eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n, fps,
-                                        frames, **st.kwargs)
+                                        frames, cfg_pairs=n, **st.kwargs)
                         e_c, e_u = eps[:n], eps[n:]
                     else:
                         e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], fps, frames, **st.kwargs), None

@@ -232,8 +232,10 @@ class UNetModel(nn.Module):
                        bias_rows=bias_rows, ldbias=ldbias, epilogue=epilogue)
         return out, (hout, wout)
 
-    def _transformer_block(self, x, p, heads, spatial, geo, ctx):
-        """x [M, inner].  spatial: attention over H*W per frame (+ cross-attention to ctx); else over T per pixel."""
+    def _transformer_block(self, x, p, heads, spatial, geo, ctx, dup=None):
+        """x [M, inner].  spatial: attention over H*W per frame (+ cross-attention to ctx); else over T per pixel.
+        dup (spatial only): x holds ONE copy of a [cond | uncond] pair batch; attn1 (which does not see the context) runs
+        on it, then dup(x) doubles the batch for the cross-attention and everything after (see forward, cfg_pairs)."""
         P = self._packed
         B, T, H, W = geo
         M, inner = x.shape
@@ -254,6 +256,9 @@ class UNetModel(nn.Module):
             return self._linear(o, f"{p}.{name}.to_out.0", residual=xin)
 
         x = self_attn("attn1", x)
+        if dup is not None:
+            x = dup(x)
+            B, M = 2 * B, 2 * M
         if spatial:
             n2 = ops.layernorm(x, P[f"{p}.norm2.g"], P[f"{p}.norm2.be"])
             q = ops.gemm(n2, P[f"{p}.attn2.to_q.w"], None, None, M=M, N=inner, K=inner)
@@ -277,7 +282,7 @@ class UNetModel(nn.Module):
         g = ops.gemm(n3, w1, P[f"{p}.ff1.b"], None, M=M, N=w1.shape[0], K=w1.shape[1], epilogue=DS_EPI_GEGLU)
         return self._linear(g, f"{p}.ff.net.2", residual=x)
 
-    def _transformer(self, h, prefix, heads, depth, spatial, geo, ctx):
+    def _transformer(self, h, prefix, heads, depth, spatial, geo, ctx, dup=None):
         B, T, H, W = geo
         C = h.shape[1]
         if spatial:
@@ -286,7 +291,10 @@ class UNetModel(nn.Module):
             a = self._gn(h, prefix + ".norm", B, T * H * W, C, 1e-6, False)
         x = self._linear(a, prefix + ".proj_in")
         for d in range(depth):
-            x = self._transformer_block(x, f"{prefix}.transformer_blocks.{d}", heads, spatial, geo, ctx)
+            x = self._transformer_block(x, f"{prefix}.transformer_blocks.{d}", heads, spatial, geo, ctx,
+                                        dup=dup if d == 0 else None)
+            if dup is not None and d == 0:
+                h, geo = dup(h), (2 * B, T, H, W)
         return self._linear(x, prefix + ".proj_out", residual=h)
 
     def _resblock(self, h, b, geo, emb_all):
@@ -316,7 +324,14 @@ class UNetModel(nn.Module):
     @torch.no_grad()
     def forward(self, x, timesteps, context=None, features_adapter=None, fps=16, timestep_cond=None, **kwargs):
         """x [b,C,t,h,w] (fp16|fp32, HIP device), timesteps int64 [b], context [b,L,context_dim].
-        Returns eps [b,C_out,t,h,w] fp32 (the reference UNet computes and returns fp32)."""
+        Returns eps [b,C_out,t,h,w] fp32 (the reference UNet computes and returns fp32).
+
+        cfg_pairs=n (extension): the batch is [x_1..x_n | x_1..x_n] with the same timesteps / fps in both halves and only
+        the CONTEXT differing (classifier-free guidance: cond | uncond of the same tiles).  Everything up to the first
+        cross-attention -- conv_in, init_attn, the first ResBlock, and GroupNorm / proj_in / self-attention of the first
+        SpatialTransformer -- never sees the context, so it is evaluated once on n items and duplicated.  Same kernels on
+        the same numbers: the result is bit-identical to the plain 2n forward (a batch equals its separate forwards)."""
+        pairs = kwargs.pop("cfg_pairs", None)
         if features_adapter is not None or timestep_cond is not None:
             raise NotImplementedError("features_adapter / timestep_cond are not used by the DynamicScaler pipelines")
         if not x.is_cuda:
@@ -360,17 +375,27 @@ class UNetModel(nn.Module):
         else:
             ctx = (context.to(torch.float16).reshape(B * L, -1).contiguous(), None, L, 0)
 
+        shared = bool(pairs)                      # still on the context-free prefix of a [cond | uncond] pair batch
+        if shared and (2 * pairs != B or not any(b.kind == "st" for g in self._inputs for b in g)):
+            raise ValueError(f"cfg_pairs={pairs} needs a batch of {2 * pairs} (got {B}) and a SpatialTransformer in the input path")
+
+        def dup(t):
+            return torch.cat([t, t], 0)
+
         def run(group, h, geo):
+            nonlocal shared
             for b in group:
                 Bq, Tq, Hq, Wq = geo
                 if b.kind == "conv_in":
-                    patches = ops.im2col_in(x, self._kpad_in)
+                    patches = ops.im2col_in(x[:pairs] if shared else x, self._kpad_in)
                     w = P[b.prefix + ".w"]
                     h = ops.gemm(patches, w, P[b.prefix + ".b"], None, M=patches.shape[0], N=w.shape[0], K=w.shape[1])
                 elif b.kind == "res":
                     h = self._resblock(h, b, geo, emb_all)
                 elif b.kind == "st":
-                    h = self._transformer(h, b.prefix, b.heads, b.depth, True, geo, ctx)
+                    h = self._transformer(h, b.prefix, b.heads, b.depth, True, geo, ctx, dup=dup if shared else None)
+                    if shared:
+                        shared, geo = False, (2 * Bq, Tq, Hq, Wq)
                 elif b.kind == "tt":
                     h = self._transformer(h, b.prefix, b.heads, b.depth, False, geo, ctx)
                 elif b.kind == "down":
@@ -381,14 +406,14 @@ class UNetModel(nn.Module):
                     geo = (Bq, Tq, ho, wo)
             return h, geo
 
-        geo = (B, T, H, W)
+        geo = (pairs if shared else B, T, H, W)
         h = None
         hs = []
         for gi, group in enumerate(self._inputs):
             h, geo = run(group, h, geo)
             if gi == 0 and cfg["addition_attention"]:
                 h = self._transformer(h, "init_attn.0", 8, cfg["transformer_depth"], False, geo, ctx)
-            hs.append((h, geo))
+            hs.append((dup(h), (B,) + geo[1:]) if shared else (h, geo))
         h, geo = run(self._middle, h, geo)
         for group in self._outputs:
             skip, sgeo = hs.pop()

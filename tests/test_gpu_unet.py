@@ -57,6 +57,52 @@ def test_unet_tiny_vs_reference_golden(name):
             assert e < EPS_TOL
 
 
+@pytest.mark.parametrize("name", ["t2v", "i2v"])
+def test_unet_cfg_pair_prefix_sharing_is_bit_identical(name):
+    """cfg_pairs=n: the context-free prefix of a [cond | uncond] batch (conv_in, init_attn, first ResBlock, GroupNorm /
+    proj_in / self-attention of the first SpatialTransformer) evaluated once and duplicated == the plain 2n forward,
+    bit for bit; and the pipelines' switch (share_cfg_prefix) does not change a panorama."""
+    d = dev()
+    z = np.load(os.path.join(G, f"unet_tiny_{name}.npz"))
+    params = json.loads(bytes(z["params_json"]).decode())
+    m = build_unet(params, 5, d)
+    from dynamicscaler_amd.synth import synth_normal
+    x0, c0 = T(z["x_0"]), T(z["ctx_0"])
+    for n in (1, 3):
+        x = torch.cat([x0] + [synth_normal(x0.shape, 100 + k) for k in range(1, n)], 0).to(d, torch.float16)
+        t = T(z["t_0"]).to(d).reshape(-1)[:1].expand(2 * n).contiguous()
+        ctx_c = torch.cat([c0] + [synth_normal(c0.shape, 200 + k) for k in range(1, n)], 0)
+        ctx_u = torch.cat([synth_normal(c0.shape, 300 + k) for k in range(n)], 0)
+        ctx = torch.cat([ctx_c, ctx_u], 0).to(d)
+        x2 = torch.cat([x, x], 0)
+        plain = m(x2, t, context=ctx, fps=int(z["fps_0"]))
+        shared = m(x2, t, context=ctx, fps=int(z["fps_0"]), cfg_pairs=n)
+        assert torch.equal(plain, shared), (name, n)
+        assert not torch.equal(plain[:n], plain[n:])          # the contexts do differ
+    with pytest.raises(ValueError):
+        m(x2, t, context=ctx, fps=8, cfg_pairs=2)
+
+
+def test_ring_pipeline_cfg_prefix_sharing_same_panorama():
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    d = dev()
+    z = np.load(os.path.join(G, "loops_small.npz"))
+    meta = json.load(open(os.path.join(G, "loops_small_traces.json")))
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    ld = _host(params, 5, T(z["cond"]), T(z["uncond"]), d)
+    outs = []
+    for share in (False, True):
+        pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}}).to(d, torch.float16)
+        pipe.share_cfg_prefix = share
+        torch.manual_seed(2333333)
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                       **meta["geoms"]["grid4x2"])
+        outs.append((den.float().cpu(), pipe.final_latent.float().cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_unet_batch_equals_separate_forwards():
     d = dev()
     z = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
