@@ -17,7 +17,7 @@ so parity is pinned by what this script captures from the imported reference cod
                              windows + docking, 5-D mask, merge-prev, per-window image tokens), fake eps + tiny UNet
   G12 sphere.npz             _get_uv index maps (gen_pano_360 view set, one view at all 10 theta offsets), sphere
                              gather/scatter round trips (duplicate winners), t2v sphere loop (P5), fake eps + tiny UNet
-  G10 unet_full_t2v.npz      (--full) full-size t2v UNet eps at tile [1,4,16,40,64] (2 forwards, ~2 min)
+  G10 unet_full_{t2v,i2v}.npz (--full) full-size t2v / i2v UNet eps at tile [1,4,16,40,64] (3 forwards, ~3 min)
 
   G16 encoders_{toy,full}.npz  Resampler (the reference's module, ip_resampler.py) and the CLIP ViT-H/14 text / image
                              towers -- open_clip is absent, so the tower vectors come from transformers' CLIP
@@ -344,6 +344,21 @@ def g10_unet_full():
         arrays[f"eps_{name}"] = eps
         print(name, float(eps.abs().mean()), float(eps.std()))
     save_npz("unet_full_t2v.npz", **arrays)
+
+
+def g10_unet_full_i2v():
+    """The model gen_pano_360.py runs: the i2v 512 UNet (image cross-attention, 77 text + 16 image tokens) at tile
+    [1,4,16,40,64], one forward of the reference on CPU."""
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_i2v_512_v1.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(os.cpu_count())
+    m = build_reference_unet(params, seed=3)
+    x = synth_normal((1, 4, 16, 40, 64), 2333334)
+    ctx = synth_normal((1, 77 + 16, 1024), 4)
+    with torch.no_grad():
+        eps = m(x, torch.tensor([321]), context=ctx, fps=16)
+    print("i2v full", float(eps.abs().mean()), float(eps.std()))
+    save_npz("unet_full_i2v.npz", x=x, t=np.int64(321), fps=np.int64(16), ctx=ctx, eps=eps)
 
 
 GRID_GEOMS = {
@@ -884,6 +899,7 @@ if __name__ == "__main__":
              "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders}
     if args.full:
         steps["g10"] = g10_unet_full
+        steps["g10i"] = g10_unet_full_i2v
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)

@@ -147,6 +147,22 @@ def test_unet_full_size_vs_reference_golden():
     assert l1 < LATENT_TOL
 
 
+def test_unet_full_size_i2v_vs_reference_golden():
+    """The model gen_pano_360.py runs -- the i2v 512 UNet with image cross-attention (77 text + 16 image tokens) -- at
+    the real tile, against the reference's fp32 CPU forward (tests/golden/unet_full_i2v.npz)."""
+    import yaml
+    d = dev()
+    z = np.load(os.path.join(G, "unet_full_i2v.npz"))
+    repo = os.path.dirname(os.path.dirname(G))
+    params = yaml.safe_load(open(os.path.join(repo, "dynamicscaler_amd", "configs", "i2v_512_v1_unet.yaml")))
+    m = build_unet(params, 3, d)
+    eps = m(T(z["x"]).to(d, torch.float16), torch.tensor([int(z["t"])], device=d), context=T(z["ctx"]).to(d),
+            fps=int(z["fps"]))
+    e = relerr(eps, T(z["eps"]))
+    print(f"full i2v UNet eps rel err: {e:.3e}")
+    assert eps.shape == (1, 4, 16, 40, 64) and e < EPS_TOL
+
+
 def _host(params, seed, cond, uncond, device, temporal_length=4):
     from dynamicscaler_amd.host_model import LatentDiffusionHost
     from dynamicscaler_amd.unet_spec import param_shapes
