@@ -329,6 +329,39 @@ def test_ring_pipeline_fake_eps_bit_exact_fp32():
         assert relerr(den, T(z[f"ring_{gname}_fake"])) < 1e-4          # and the reference's own panorama (other host's RNG)
 
 
+@pytest.mark.parametrize("name", ["cfg2_2048x512", "cfg3_4096x512", "cfg3_overlap_nw10", "cfg5_8192x1024x24"])
+def test_ring_pipeline_baseline_geometries_fake_eps_bit_exact(name):
+    """BASELINE.json's full-size geometries (configs 2, 3, 3 with W overlap, 5: up to an 8192x1024x24f panorama, 64 tiles
+    per step) through the HIP tile engine with the fake eps-model in fp32: the final pred-x0 panorama EQUALS the CPU
+    oracle's run on this host (which is pinned to the reference's SHA-256 in the build container,
+    test_oracle_golden.py::test_g9_baseline_geometry_final_panorama_sha); 50-step schedules are cut to 6 steps of the
+    same shifted-window sequence."""
+    import hashlib
+    from oracle import loops as oloops, ddim as oddim
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    d = dev()
+    rec = json.load(open(os.path.join(G, "loop_traces.json")))[name]
+    geom = dict(rec["geom"])
+    full_schedule = geom["num_inference_steps"] <= 10
+    if not full_schedule:
+        geom["num_inference_steps"] = 6
+    z = np.load(os.path.join(G, "loops_small.npz"))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    ld = _fake_host(cond, uncond, d)
+    ld.temporal_length = geom["frames"]
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": {"in_channels": 4}}}})
+    pipe.to(d, torch.float32)
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent", **geom)
+    torch.manual_seed(2333333)
+    ref, _, _ = oloops.t2v_ring_sample(_oracle_fake, oddim.DiffusionTables(), cond, uncond, guidance_scale=7.5, **geom)
+    assert list(den.shape) == rec["shape"]
+    assert torch.equal(den.cpu(), ref), (name, float((den.cpu() - ref).abs().max()))
+    if full_schedule and hashlib.sha256(ref.numpy().tobytes()).hexdigest() == rec["denoised_sha256"]:
+        print(f"{name}: this host's CPU normal stream matches the build container's: panorama SHA-256 == the reference's")
+
+
 # ------------------------------------------------------------------------------------------------ P4 / P3
 class _FakeModel(torch.nn.Module):
     """The survey's fake eps-model 0.1*x + 0.01*mean(ctx); the mean is taken on the host over the same [1,L,D] shape
