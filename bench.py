@@ -71,11 +71,20 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU over RCCL.  DS_BENCH_DEVICE / DS_DIST_BACKEND exist for the single-GPU rehearsal of the N > 1 path
+    # (tests/test_gpu_multirank.py: two ranks share cuda:0 and exchange through gloo); the driver never sets them.
+    dev_index = int(os.environ.get("DS_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+            from dynamicscaler_amd import parallel
+            parallel.host_staged_collectives(True)
 
     from dynamicscaler_amd import ops
     from dynamicscaler_amd.host_model import LatentDiffusionHost, SyntheticConditioner

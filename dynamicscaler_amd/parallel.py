@@ -52,6 +52,16 @@ def share_counts(n_items, world):
     return [len(range(r, n_items, world)) for r in range(world)]
 
 
+_HOST_STAGED = False
+
+
+def host_staged_collectives(on=True):
+    """Rehearsal mode (a backend without device collectives, e.g. gloo with several ranks on one GPU): the level
+    all-gather goes through host buffers.  RCCL runs never enable it."""
+    global _HOST_STAGED
+    _HOST_STAGED = bool(on)
+
+
 def exchange_level(x_prev_local, x0_local, n_items, group=None, force=False):
     """All-gather the tiles of one level.  x_prev_local / x0_local: [n_local, C, tf, th, tw] of this rank's
     share (strided assignment).  Returns (x_prev_all, x0_all) [n_items, ...] in level order on every rank.
@@ -70,7 +80,12 @@ def exchange_level(x_prev_local, x0_local, n_items, group=None, force=False):
         send[1, :n_local] = x0_local
     # output = concatenation along dim 0 (the form both RCCL and gloo accept), viewed back as [world, 2, cmax, ...]
     recv = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    if _HOST_STAGED and send.is_cuda:
+        recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(recv_h, send.cpu(), group=group)
+        recv.copy_(recv_h)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view((world,) + tuple(send.shape))
     x_prev_all = torch.empty((n_items,) + tile_shape, dtype=send.dtype, device=send.device)
     x0_all = torch.empty_like(x_prev_all)

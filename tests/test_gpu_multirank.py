@@ -1,0 +1,64 @@
+"""-m gpu: rehearsal of the N > 1 path on ONE GPU.  Two ranks (torch.distributed.run) share cuda:0 and exchange
+through gloo with host-staged buffers -- RCCL refuses two ranks on one device -- so everything except the transport is
+what the driver's multi-GPU run executes: level planning, the strided share of a rank, the per-level all-gather,
+every rank scattering all tiles into its replica, hipGraph replays under a live process group, bench.py's rank logic."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(nproc, script_and_args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_port())] + script_and_args
+    return subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("geom,rng", [("grid4x2", "reference"), ("overlapw", "device")])
+def test_two_ranks_equal_single_process(tmp_path, geom, rng):
+    """Both replicas of a rank-sharded run equal the single-process panorama bit for bit (host RNG with the same seed on
+    every rank, or the in-kernel Philox streams keyed by tile number)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    worker = os.path.join(REPO, "tests", "multirank_worker.py")
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    r = subprocess.run([sys.executable, worker, str(one), geom, rng], cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = _torchrun(2, [worker, str(two), geom, rng])
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = np.load(one / "rank0.npz")
+    for rank in (0, 1):
+        got = np.load(two / f"rank{rank}.npz")
+        assert np.array_equal(got["den"], ref["den"]) and np.array_equal(got["final"], ref["final"]), (geom, rank)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, RANK / WORLD_SIZE from the env), rehearsed on
+    one GPU: one JSON line from rank 0 with n_gpus 2 and a finite whole-job value."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    r = _torchrun(2, ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline"],
+                  env_extra={"DS_DIST_BACKEND": "gloo", "DS_BENCH_DEVICE": "0"}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "strong" and j["cpu_baseline"] is None
+    assert np.isfinite(j["value"]) and j["value"] > 0 and j["unit"] == "denoising-steps/sec"
