@@ -167,8 +167,13 @@ def test_clip_image_tower():
     v = cfg["clip"]["vision"]
     m = FrozenOpenCLIPImageEmbedderV2(model_cfg=v)
     m.load_state_dict(synth_encoder_state_dict(clip_vision_param_shapes(v), 55))
-    out = m.encode_pixels(T(z["toy_vision_pixels"]).to(d))
+    pix = T(z["toy_vision_pixels"]).to(d)
+    out = m.encode_pixels(pix)                                   # eager (first use)
     e1 = relerr(out, T(z["toy_vision_out"]))
+    cap, rep = m.encode_pixels(pix), m.encode_pixels(pix * 0.5)  # hipGraph capture, then a replay on other pixels
+    m.use_graph = False
+    assert torch.equal(cap, out) and torch.equal(rep, m.encode_pixels(pix * 0.5)) and not torch.equal(rep, out)
+    m.use_graph = True
     zf = np.load(os.path.join(G, "encoders_full.npz"))
     vf = CLIP_VIT_H_14["vision"]
     mf = FrozenOpenCLIPImageEmbedderV2()

@@ -10,8 +10,8 @@ from dynamicscaler_amd.synth import synth_encoder_state_dict, synth_normal
 d = torch.device("cuda:0")
 
 
-def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=20):
+    fn(); fn(); fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
         fn()
