@@ -24,6 +24,7 @@ def _port():
 
 def _torchrun(nproc, script_and_args, env_extra=None, timeout=900):
     env = dict(os.environ)
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")      # the box's hostname may not resolve; everything here is one node
     env.update(env_extra or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
            "127.0.0.1", "--master-port", str(_port())] + script_and_args
