@@ -188,6 +188,46 @@ __global__ void __launch_bounds__(256) renoise_mix_kernel(T* __restrict__ tiles,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Per-step residual merge of the non-overlapping grid loop (t2v_normal_pipeline.py:445-468):
+//   dense : out = curr*r + noised*(1-r)
+//   sparse: out = curr, except (p = step parity, rows / columns of each [H][W] plane)
+//           out[p::2, ::2]     = r*curr[(1-p)::2, ::2] + (1-r)*noised[::2, ::2]
+//           out[(1-p)::2, 1::2] = r*curr[p::2, 1::2]    + (1-r)*noised[::2, ::2]
+// Same fp32 operations in the same order as the reference's tensor expressions (two products, one sum).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) residual_merge_kernel(const T* __restrict__ curr, const T* __restrict__ noised,
+                                                              T* __restrict__ out, long planes, int H, int W, float r,
+                                                              float one_minus_r, int parity, int sparse) {
+    const long total = planes * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const long q = idx / W;
+        const int y = (int)(q % H);
+        const long base = (q / H) * (long)H * W;
+        float v;
+        if (!sparse) {
+            const float t1 = ldf(curr, idx) * r;
+            const float t2 = ldf(noised, idx) * one_minus_r;
+            v = t1 + t2;
+        } else if ((y & 1) == parity && (x & 1) == 0) {
+            const int k = y >> 1;                                     // y = parity + 2k
+            const float t1 = r * ldf(curr, base + (long)((1 - parity) + 2 * k) * W + x);
+            const float t2 = one_minus_r * ldf(noised, base + (long)(2 * k) * W + x);
+            v = t1 + t2;
+        } else if ((y & 1) == 1 - parity && (x & 1) == 1) {
+            const int k = y >> 1;                                     // y = (1-parity) + 2k
+            const float t1 = r * ldf(curr, base + (long)(parity + 2 * k) * W + x);
+            const float t2 = one_minus_r * ldf(noised, base + (long)(2 * k) * W + (x - 1));
+            v = t1 + t2;
+        } else {
+            v = ldf(curr, idx);
+        }
+        stf(out, idx, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // CFG + DDIM
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename E>
@@ -406,6 +446,21 @@ extern "C" int ds_ring_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_
         }
     }
     DS_CHECK_LAUNCH("ds_ring_scatter3");
+    return DS_OK;
+}
+
+extern "C" int ds_residual_merge(const void* curr, const void* noised, void* out, int dtype, long planes, int H, int W,
+                                 float r, float one_minus_r, int parity, int sparse, void* stream) {
+    DS_CHECK_ARG(curr && noised && out && out != curr && out != noised, "ds_residual_merge: null or aliased argument");
+    DS_CHECK_ARG(planes > 0 && H > 0 && W > 0, "ds_residual_merge: sizes must be positive");
+    DS_CHECK_ARG(!sparse || (H % 2 == 0 && W % 2 == 0), "ds_residual_merge: the sparse pattern needs even H and W (got %dx%d)", H, W);
+    DS_CHECK_ARG(parity == 0 || parity == 1, "ds_residual_merge: parity must be 0 or 1");
+    const long work = planes * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DS_F16) residual_merge_kernel<f16><<<grid_for(work), 256, 0, st>>>((const f16*)curr, (const f16*)noised, (f16*)out, planes, H, W, r, one_minus_r, parity, sparse);
+    else if (dtype == DS_F32) residual_merge_kernel<float><<<grid_for(work), 256, 0, st>>>((const float*)curr, (const float*)noised, (float*)out, planes, H, W, r, one_minus_r, parity, sparse);
+    else DS_CHECK_ARG(false, "ds_residual_merge: bad dtype %d", dtype);
+    DS_CHECK_LAUNCH("ds_residual_merge");
     return DS_OK;
 }
 

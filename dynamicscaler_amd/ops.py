@@ -248,6 +248,19 @@ def resize_latent(x, target_height, target_width, mode="nearest"):
     return out
 
 
+def residual_merge(curr, noised, ratio, step, sparse=True):
+    """t2v_normal_pipeline.py:445-468 on [B,C,F,H,W] panoramas; returns the merged panorama (new tensor)."""
+    _dev(curr, "residual_merge")
+    _dev(noised, "residual_merge(noised)")
+    assert curr.shape == noised.shape and curr.dtype == noised.dtype
+    out = torch.empty_like(curr)
+    H, W = curr.shape[-2:]
+    check(_lib.load().ds_residual_merge(curr.data_ptr(), noised.data_ptr(), out.data_ptr(), _DT[curr.dtype],
+                                        curr.numel() // (H * W), H, W, float(ratio), float(1.0 - ratio), int(step) % 2,
+                                        int(bool(sparse)), _stream()), "ds_residual_merge")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ UNet ops
 def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE, lda=None, cin=None,
          conv=None, tconv=None, bias_rows=None, ldbias=None, epilogue=0, stream=None):

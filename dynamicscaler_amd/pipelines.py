@@ -200,6 +200,21 @@ class VC2_Pipeline_T2V:
         return videos, denoised
 
 
+    @torch.no_grad()
+    def _basic_denoise_one_step(self, latent, t, i, total_steps, text_emb, uc_emb, guidance_scale, fps, frames, kwargs):
+        """t2v_normal_pipeline.py:572-615: one CFG + DDIM step of a single tile at schedule index total_steps - i - 1."""
+        kwargs = dict(kwargs)
+        kwargs.update({"clean_cond": True})
+        if guidance_scale != 1.0:
+            eps = self._eps(torch.cat([latent, latent], 0), t, [text_emb, uc_emb], fps, frames, cfg_pairs=latent.shape[0],
+                            **kwargs)
+            e_c, e_u = eps[:1].contiguous(), eps[1:].contiguous()
+        else:
+            e_c, e_u = self._eps(latent, t, [text_emb], fps, frames, **kwargs), None
+        coef = self.scheduler.step_coefficients(total_steps - i - 1)
+        noise = self.scheduler.draw_step_noise(tuple(latent.shape), latent.device, latent.dtype, coef["sigma"])
+        return ops.cfg_ddim(latent, e_c, e_u, (1,) + tuple(latent.shape[1:]), guidance_scale, coef, noise)
+
     # ------------------------------------------------------------------ the tile engine shared by all ring loops
     @torch.no_grad()
     def _stream_pool(self, device):
@@ -340,21 +355,69 @@ class VC2_Pipeline_T2V:
         """Non-overlapping shifted grid (pipeline/t2v_normal_pipeline.py:213-568): the panorama is exactly
         num_windows_h x num_windows_w tiles; every step the grid is shifted by (i % loop_step) * tile/loop_step in
         W, H and F (wrap-around), optionally jumped by half the panorama on odd steps and docked to the borders.
-        No mask / re-noise in this variant.  The pre-denoise branch (VAE encode of a resized clip, :345-412) is outside
-        the hot-path scope."""
-        if use_pre_denoise or use_skip_time or random_shuffle_init_frame_stride:
-            raise NotImplementedError("pre-denoise / skip-time / frame shuffle need the VAE stage hand-off (SURVEY.md 8-f N1/N2)")
+        No mask / re-noise in this variant.  Pre-denoise start (:345-412): one tile denoised for `pre_denoise_steps`
+        steps (or `clear_pre_denoised_latent`), resized bicubically to the panorama, `_add_noise`d -- with
+        `use_skip_time` the schedule is cut (non-progressive) or the first frames get progressively lower noise levels;
+        per step the panorama is merged with that resized latent re-noised to the step's level, densely or on the
+        reference's sparse checkerboard (:445-468, `ds_residual_merge`)."""
+        if random_shuffle_init_frame_stride:
+            raise NotImplementedError("random_shuffle_init_frame_stride: the reference indexes the H axis with frame "
+                                      "indices there (t2v_normal_pipeline.py:337) and fails for panoramas lower than "
+                                      "their frame count; no driver uses it")
+        if clear_pre_denoised_video_tensor is not None:
+            raise NotImplementedError("clear_pre_denoised_video_tensor (resize + VAE encode of a clip, :363-368): "
+                                      "encode it with encode_first_stage_2DAE and pass clear_pre_denoised_latent")
         unet_config = self.model_config["params"]["unet_config"]
         frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
         prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
         self.scheduler.make_schedule(num_inference_steps, verbose=self.verbose)
-        timesteps = np.flip(self.scheduler.ddim_timesteps)
+        full_timesteps = np.flip(self.scheduler.ddim_timesteps)
+        if use_skip_time and not progressive_skip:
+            timesteps = full_timesteps[skip_time_step_idx - skip_steps_after_pre_denoise:]       # :299-301
+        else:
+            timesteps = full_timesteps
+        total_steps = len(timesteps)
         vs = self.vae_scale_factor
         lat_h, lat_w = height // vs, width // vs
-        total_shape = (1, unet_config["params"]["in_channels"], frames * num_windows_f, lat_h * num_windows_h,
-                       lat_w * num_windows_w)
+        c_lat = unet_config["params"]["in_channels"]
+        total_shape = (1, c_lat, frames * num_windows_f, lat_h * num_windows_h, lat_w * num_windows_w)
+        resized = None
         if init_panorama_latent is None:
             init_panorama_latent = torch.randn(total_shape)  # host draw, reference order
+            if use_skip_time:
+                assert use_pre_denoise and pre_denoise_steps > 0, \
+                    "[basic_sample_shift_multi_windows] skip ts should be used with pre denoise if init_panorama_latent is not provided "
+                assert skip_time_step_idx >= skip_steps_after_pre_denoise, \
+                    f"[basic_sample_shift_multi_windows] skip_time_step_idx {skip_time_step_idx} should >=skip_steps_after_pre_denoise {skip_steps_after_pre_denoise}"
+            if use_pre_denoise and pre_denoise_steps > 0:
+                if (num_windows_h != 1 or num_windows_w != 1) and num_windows_f != 1:
+                    raise NotImplementedError()
+                device = self._execution_device
+                basic_shape = (1, c_lat, frames, lat_h, lat_w)
+                latent = torch.randn(basic_shape)            # drawn in every branch (:358)
+                if clear_pre_denoised_latent is not None:
+                    assert tuple(clear_pre_denoised_latent.shape) == basic_shape, \
+                        f"[basic_sample_shift_multi_windows] clear_pre_denoised_latent shape :{tuple(clear_pre_denoised_latent.shape)}" \
+                        f"not equal to _basic_latent_shape: {basic_shape}"
+                    latent = clear_pre_denoised_latent.clone()
+                latent = latent.to(device=device, dtype=self.latent_dtype).contiguous()
+                if clear_pre_denoised_latent is None:
+                    self._log(f"[basic_sample_shift_multi_windows] Pre Denosing {pre_denoise_steps} Steps...")
+                    for i, t in enumerate(full_timesteps[:pre_denoise_steps]):
+                        latent, _ = self._basic_denoise_one_step(latent, t, i, total_steps, text_emb, uc_emb,
+                                                                 guidance_scale, fps, frames, kwargs)
+                from .tensor_utils import resize_video_latent
+                resized = resize_video_latent(latent, lat_h * num_windows_h, lat_w * num_windows_w, mode="bicubic")
+                # `resized` is a permuted view in the reference: its randn_like draws follow frames-major strides
+                init_panorama_latent = self.scheduler.add_noise(resized, total_steps - 1, frames_major_strides=True)
+                if use_skip_time:
+                    if progressive_skip:
+                        for frame_idx, progs_skip_idx in enumerate(list(reversed(range(skip_time_step_idx)))):
+                            noised = self.scheduler.add_noise(resized[:, :, [frame_idx]].contiguous(),
+                                                              total_steps - progs_skip_idx - 1)
+                            init_panorama_latent[:, :, [frame_idx]] = noised
+                    else:
+                        init_panorama_latent = self.scheduler.add_noise(resized, total_steps - 1, frames_major_strides=True)
         else:
             assert tuple(init_panorama_latent.shape) == total_shape, \
                 f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_panorama_latent.shape)} " \
@@ -365,6 +428,11 @@ class VC2_Pipeline_T2V:
         st = self._new_state(init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
                              text_emb, uc_emb, None, kwargs)
         for i in range(len(timesteps)):
+            if use_pre_denoise and merge_predenoise_ratio_list is not None and resized is not None:       # :445-468
+                assert len(merge_predenoise_ratio_list) == len(timesteps), \
+                    f"merge_predenoise_ratio_list ({len(merge_predenoise_ratio_list)}) should have same length as timesteps({len(timesteps)})"
+                noised_resized = self.scheduler.re_noise(resized, 0, total_steps - i - 1, frames_major_strides=True)
+                st.pano = ops.residual_merge(st.pano, noised_resized, merge_predenoise_ratio_list[i], i, sparse_add_residual)
             wins = t2v_grid_windows(i, latent_h=lat_h, latent_w=lat_w, frames=frames, num_windows_w=num_windows_w,
                                     num_windows_h=num_windows_h, num_windows_f=num_windows_f, loop_step=loop_step,
                                     shift_jump_odd_w=shift_jump_odd_w, shift_jump_odd_h=shift_jump_odd_h,

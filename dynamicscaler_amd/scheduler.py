@@ -138,12 +138,28 @@ class lvdm_DDIM_Scheduler(object):
         return x_prev, x0
 
     @torch.no_grad()
-    def re_noise(self, x_a, step_a, step_b):
-        """scheduler.py:98-110: x_b = c*x_a + s*randn_like(x_a) (mask of ones, ratio 1 in the fused kernel)."""
+    def add_noise(self, clear, index, frames_major_strides=False):
+        """VC2_Pipeline_T2V._add_noise (t2v_normal_pipeline.py:619-625): sqrt(a)*x + sqrt(1-a)*randn_like(x) with
+        a = ddim_alphas[index] (fp32), through the same fused kernel as re_noise.  frames_major_strides: the reference's
+        tensor is the output of resize_video_latent, a permuted view of [B,F,C,H,W] storage (diffusion_utils.py:30-31),
+        and randn_like follows its strides (see draw_renoise_noise)."""
+        alpha = torch.as_tensor(self.ddim_alphas[index], dtype=torch.float32)
+        c, s = float(alpha ** 0.5), float((1 - alpha) ** 0.5)
+        x = clear.contiguous().clone()
+        noise = self.draw_renoise_noise(tuple(x.shape), x.device, x.dtype, "later" if frames_major_strides else None)
+        ones = torch.ones((x.shape[0],) + tuple(x.shape[2:]), dtype=torch.uint8, device=x.device)
+        ops.renoise_mix_(x, ones, (1,) + tuple(x.shape[1:]), c, s, 1.0, noise=noise, mask_frame0=False,
+                         seed=self.philox_seed, offset=self.next_philox_offset(x.numel()))
+        return x
+
+    @torch.no_grad()
+    def re_noise(self, x_a, step_a, step_b, frames_major_strides=False):
+        """scheduler.py:98-110: x_b = c*x_a + s*randn_like(x_a) (mask of ones, ratio 1 in the fused kernel).
+        frames_major_strides: x_a is (a clone of) a resize_video_latent output in the reference, see add_noise."""
         c, s = self.renoise_coefficients(step_a, step_b)
         x = x_a.contiguous().clone()
         n = x.shape[0]
-        noise = self.draw_renoise_noise(tuple(x.shape), x.device, x.dtype)
+        noise = self.draw_renoise_noise(tuple(x.shape), x.device, x.dtype, "later" if frames_major_strides else None)
         ones = torch.ones((n,) + tuple(x.shape[2:]), dtype=torch.uint8, device=x.device)
         pano_shape = (1,) + tuple(x.shape[1:])
         ops.renoise_mix_(x, ones, pano_shape, c, s, 1.0, noise=noise, mask_frame0=False, seed=self.philox_seed,

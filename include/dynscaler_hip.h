@@ -118,6 +118,13 @@ int ds_map_scatter3_frames(void* pano_latent, void* pano_x0, uint8_t* mask_pano,
  * order is the reference's index_add_ order, so the kernel needs no atomics and reproduces the CPU sums bit for bit. */
 int ds_map_splat(void* pano, const void* view, const int32_t* tgt, const int32_t* row_ptr, const int32_t* src,
                  const float* wgt, int CF, int HW, int P, int ntgt, int dtype, void* stream);
+/* Per-step residual merge of the non-overlapping grid loop (VC2_Pipeline_T2V.basic_sample_shift_multi_windows,
+ * pipeline/t2v_normal_pipeline.py:445-468): curr = the panorama latent, noised = the resized pre-denoised latent re-noised
+ * to the step's level, both [planes][H][W] (planes = B*C*F).  sparse == 0: out = curr*r + noised*(1-r).  sparse != 0
+ * (parity = step & 1, even H and W): out[p::2, ::2] = r*curr[(1-p)::2, ::2] + (1-r)*noised[::2, ::2] and
+ * out[(1-p)::2, 1::2] = r*curr[p::2, 1::2] + (1-r)*noised[::2, ::2], the rest copied.  out must not alias the inputs. */
+int ds_residual_merge(const void* curr, const void* noised, void* out, int dtype, long planes, int H, int W, float r,
+                      float one_minus_r, int parity, int sparse, void* stream);
 /* resize_video_latent (utils/diffusion_utils.py:21-33; stage hand-off gen_pano_360.py:287-289,345-347): F.interpolate
  * over H,W of `planes` = B*C*F images.  mode 0 'nearest', mode 1 'bicubic' (align_corners=False, A=-0.75). */
 int ds_resize_latent(const void* in, void* out, int dtype, long planes, int hin, int win, int hout, int wout, int mode,

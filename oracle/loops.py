@@ -212,30 +212,97 @@ def t2v_grid_windows(i, *, latent_h, latent_w, frames, num_windows_w, num_window
 
 
 @torch.no_grad()
+def resize_video_latent(x, target_height, target_width, mode="bicubic"):
+    """utils/diffusion_utils.py:21-33: F.interpolate per frame."""
+    import torch.nn.functional as F
+    b, c, f, h, w = x.shape
+    y = F.interpolate(x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w), size=(target_height, target_width), mode=mode,
+                      align_corners=None if mode == "nearest" else False)
+    return y.view(b, f, c, target_height, target_width).permute(0, 2, 1, 3, 4)
+
+
+def _add_noise(sched, clear, index):
+    """VC2_Pipeline_T2V._add_noise (t2v_normal_pipeline.py:619-625): sqrt(a) x + sqrt(1-a) randn_like(x), a = ddim_alphas[index]."""
+    alpha = torch.as_tensor(sched.ddim_alphas[index], dtype=torch.float32)
+    beta = 1 - alpha
+    return (alpha ** 0.5) * clear.clone() + (beta ** 0.5) * torch.randn_like(clear)
+
+
 def t2v_grid_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, *, height=320, width=512, frames=16,
                     guidance_scale=7.5, num_windows_w, num_windows_h, num_windows_f=1, loop_step=8,
-                    num_inference_steps=50, init_panorama_latent=None, in_channels=4, trace=None, **grid_kw):
-    """Returns (denoised, denoised) for output_type='latent' (t2v_normal_pipeline.py:561-568)."""
+                    num_inference_steps=50, init_panorama_latent=None, in_channels=4, trace=None,
+                    use_pre_denoise=False, pre_denoise_steps=None, skip_steps_after_pre_denoise=0,
+                    clear_pre_denoised_latent=None, merge_predenoise_ratio_list=None, sparse_add_residual=True,
+                    use_skip_time=False, skip_time_step_idx=None, progressive_skip=False, **grid_kw):
+    """Returns (denoised, denoised) for output_type='latent' (t2v_normal_pipeline.py:561-568).  Includes the pre-denoise
+    start (:345-412: a single tile denoised for a few steps or given, resized bicubically to the panorama, re-noised,
+    optionally with a per-frame progressive noise level) and the per-step sparse / dense residual merge (:445-468)."""
     sched = DDIMSchedule(tables, num_inference_steps)
-    timesteps = np.flip(sched.ddim_timesteps)
+    full_timesteps = np.flip(sched.ddim_timesteps)
+    if use_skip_time and not progressive_skip:
+        timesteps = full_timesteps[skip_time_step_idx - skip_steps_after_pre_denoise:]          # :299-301
+    else:
+        timesteps = full_timesteps
     total_steps = len(timesteps)
     lh, lw = height // VAE_SCALE, width // VAE_SCALE
     total_shape = (1, in_channels, frames * num_windows_f, lh * num_windows_h, lw * num_windows_w)
-    pano = torch.randn(total_shape) if init_panorama_latent is None else init_panorama_latent.clone()
+    resized = None
+
+    def basic_step(latent, t, i):                                                           # _basic_denoise_one_step :572-615
+        ts = torch.full((1,), int(t), dtype=torch.long)
+        e_c = eps_model(latent, ts, cond_ctx)
+        e = cfg_combine(e_c, eps_model(latent, ts, uncond_ctx), guidance_scale) if guidance_scale != 1.0 else e_c
+        return ddim_step(sched, latent, e, [total_steps - i - 1] * latent.shape[2])
+
+    if init_panorama_latent is None:
+        pano = torch.randn(total_shape)
+        if use_skip_time:
+            assert use_pre_denoise and pre_denoise_steps > 0 and skip_time_step_idx >= skip_steps_after_pre_denoise
+        if use_pre_denoise and pre_denoise_steps > 0:
+            if (num_windows_h != 1 or num_windows_w != 1) and num_windows_f != 1:
+                raise NotImplementedError()
+            latent = torch.randn((1, in_channels, frames, lh, lw))                            # drawn in every branch (:358)
+            if clear_pre_denoised_latent is not None:
+                latent = clear_pre_denoised_latent.clone()
+            else:
+                for i, t in enumerate(full_timesteps[:pre_denoise_steps]):
+                    latent, _ = basic_step(latent, t, i)
+            resized = resize_video_latent(latent.clone(), lh * num_windows_h, lw * num_windows_w, "bicubic")
+            pano = _add_noise(sched, resized, total_steps - 1)
+            if use_skip_time:
+                if progressive_skip:
+                    for frame_idx, progs in enumerate(list(reversed(range(skip_time_step_idx)))):
+                        pano[:, :, [frame_idx]] = _add_noise(sched, resized[:, :, [frame_idx]], total_steps - progs - 1).clone()
+                else:
+                    pano = _add_noise(sched, resized, total_steps - 1)
+    else:
+        pano = init_panorama_latent.clone()
     pano_x0 = torch.zeros_like(pano)
     for i, t in enumerate(timesteps):
+        if use_pre_denoise and merge_predenoise_ratio_list is not None and resized is not None:
+            assert len(merge_predenoise_ratio_list) == len(timesteps)
+            r = merge_predenoise_ratio_list[i]
+            curr = pano.clone()
+            noised = re_noise(sched, resized.clone(), 0, total_steps - i - 1)
+            if sparse_add_residual:
+                mixed = curr.clone()
+                mixed[..., i % 2::2, ::2] = r * curr[..., (i + 1) % 2::2, ::2] + (1.0 - r) * noised[..., ::2, ::2]
+                mixed[..., (i + 1) % 2::2, 1::2] = r * curr[..., i % 2::2, 1::2] + (1.0 - r) * noised[..., ::2, ::2]
+            else:
+                mixed = curr * r + noised * (1.0 - r)
+            pano = mixed.clone()
         wins = t2v_grid_windows(i, latent_h=lh, latent_w=lw, frames=frames, num_windows_w=num_windows_w,
                                 num_windows_h=num_windows_h, num_windows_f=num_windows_f, loop_step=loop_step, **grid_kw)
         if trace is not None:
             trace.append((i, int(t), wins))
-        for (l, r, tp, dn, fb, fe) in wins:
-            win = ring_gather(pano, l, r, tp, dn, fb, fe)
+        for (l, r_, tp, dn, fb, fe) in wins:
+            win = ring_gather(pano, l, r_, tp, dn, fb, fe)
             ts = torch.full((1,), int(t), dtype=torch.long)
             e_c = eps_model(win, ts, cond_ctx)
             e = cfg_combine(e_c, eps_model(win, ts, uncond_ctx), guidance_scale) if guidance_scale != 1.0 else e_c
             x_prev, x0 = ddim_step(sched, win, e, [total_steps - i - 1] * win.shape[2])
-            ring_scatter(pano, x_prev, l, r, tp, dn, fb, fe)
-            ring_scatter(pano_x0, x0, l, r, tp, dn, fb, fe)
+            ring_scatter(pano, x_prev, l, r_, tp, dn, fb, fe)
+            ring_scatter(pano_x0, x0, l, r_, tp, dn, fb, fe)
     return pano_x0.clone(), pano_x0.clone()
 
 

@@ -368,6 +368,20 @@ GRID_GEOMS = {
     "dock": dict(num_windows_w=3, num_windows_h=2, num_windows_f=2, loop_step=4, num_inference_steps=6,
                  docking_w=True, docking_h=True, docking_f=True, docking_step_range=[1, 2, 4]),
 }
+# the pre-denoise start and the per-step residual merge of the same method (t2v_normal_pipeline.py:345-412, 445-468)
+GRID_PRE_GEOMS = {
+    "pre_sparse": dict(num_windows_w=2, num_windows_h=2, num_windows_f=1, loop_step=4, num_inference_steps=5,
+                       use_pre_denoise=True, pre_denoise_steps=2, merge_predenoise_ratio_list=[0.9, 0.8, 0.7, 0.6, 0.5]),
+    "pre_dense_skip": dict(num_windows_w=2, num_windows_h=2, num_windows_f=1, loop_step=4, num_inference_steps=6,
+                           use_pre_denoise=True, pre_denoise_steps=3, skip_steps_after_pre_denoise=1, use_skip_time=True,
+                           skip_time_step_idx=2, merge_predenoise_ratio_list=[0.9, 0.8, 0.7, 0.6, 0.5],
+                           sparse_add_residual=False),
+    "pre_progressive": dict(num_windows_w=2, num_windows_h=1, num_windows_f=1, loop_step=4, num_inference_steps=5,
+                            use_pre_denoise=True, pre_denoise_steps=2, use_skip_time=True, skip_time_step_idx=3,
+                            progressive_skip=True),
+    "clear": dict(num_windows_w=2, num_windows_h=2, num_windows_f=1, loop_step=4, num_inference_steps=5,
+                  use_pre_denoise=True, pre_denoise_steps=1, clear_seed=71),
+}
 I2V_GEOMS = {
     "ring": dict(height=64, width=128, frames=4, total_w=512, total_h=96, total_f=4, num_windows_w=4, num_windows_h=2,
                  num_windows_f=1, loop_step=4, num_inference_steps=5, overlap_ratio_list_f=[0.0] * 5,
@@ -429,6 +443,19 @@ def g11_grid_and_i2v():
                                                                **geom)
             arrays[f"grid_{gname}_{eps_name}"] = den
             traces[f"grid_{gname}"] = parse_trace(buf.getvalue())
+        for gname, geom in GRID_PRE_GEOMS.items():
+            if eps_name == "tiny" and gname != "pre_sparse":
+                continue
+            gk = dict(geom)
+            if "clear_seed" in gk:
+                gk["clear_pre_denoised_latent"] = synth_normal((1, 4, 4, 8, 16), gk.pop("clear_seed"))
+            gk.setdefault("skip_time_step_idx", 0)
+            pipe = VC2_Pipeline_T2V(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": dict(TINY)}}})
+            torch.manual_seed(2333333)
+            with contextlib.redirect_stdout(io.StringIO()):
+                _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=64, width=128, frames=4, fps=8,
+                                                               guidance_scale=7.5, output_type="latent", **gk)
+            arrays[f"gridpre_{gname}_{eps_name}"] = den
     # ---- P3: i2v overlapped ring (i2v_sphere_panorama_pipeline.py:564-996) ----
     p_i2v = dict(TINY)
     p_i2v["use_image_attention"] = True
@@ -490,7 +517,7 @@ def g11_grid_and_i2v():
     arrays["pano_img"] = pano_img
     save_npz("loops_grid_i2v.npz", **arrays)
     with open(os.path.join(HERE, "loops_grid_i2v_traces.json"), "w") as f:
-        json.dump({"grid_geoms": GRID_GEOMS, "i2v_geoms": I2V_GEOMS, "i2v_grid_geoms": I2V_GRID_GEOMS, "traces": traces}, f)
+        json.dump({"grid_geoms": GRID_GEOMS, "grid_pre_geoms": GRID_PRE_GEOMS, "i2v_geoms": I2V_GEOMS, "i2v_grid_geoms": I2V_GRID_GEOMS, "traces": traces}, f)
     print("wrote loops_grid_i2v_traces.json")
 
 

@@ -472,6 +472,27 @@ def test_bilinear_splat_and_resize_vs_reference_golden():
         assert float((got - torch.from_numpy(z[f"resize_{key}"])).abs().max()) < 2e-6, key
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_residual_merge_bit_exact(dtype):
+    """ds_residual_merge against the reference's tensor expressions (t2v_normal_pipeline.py:456-467), both parities,
+    sparse and dense; fp16 = the same fp32 arithmetic on fp16 inputs, rounded once."""
+    from dynamicscaler_amd import ops, _lib
+    d = dev()
+    curr, noised = rnd((1, 4, 3, 8, 12), 1).to(dtype), rnd((1, 4, 3, 8, 12), 2).to(dtype)
+    for i, r in ((0, 0.9), (1, 0.35), (4, 0.5), (7, 1.0)):
+        c32, n32 = curr.float(), noised.float()
+        mixed = c32.clone()
+        mixed[..., i % 2::2, ::2] = r * c32[..., (i + 1) % 2::2, ::2] + (1.0 - r) * n32[..., ::2, ::2]
+        mixed[..., (i + 1) % 2::2, 1::2] = r * c32[..., i % 2::2, 1::2] + (1.0 - r) * n32[..., ::2, ::2]
+        got = ops.residual_merge(curr.to(d), noised.to(d), r, i, sparse=True)
+        assert torch.equal(got.cpu(), mixed.to(dtype)), (i, r)
+        dense = c32 * r + n32 * (1.0 - r)
+        got = ops.residual_merge(curr.to(d), noised.to(d), r, i, sparse=False)
+        assert torch.equal(got.cpu(), dense.to(dtype)), (i, r)
+    with pytest.raises(_lib.DsError, match="even H and W"):
+        ops.residual_merge(curr[..., :7, :].contiguous().to(d), noised[..., :7, :].contiguous().to(d), 0.5, 0)
+
+
 def test_rccl_level_exchange_single_rank():
     """The per-level tile all-gather (parallel.exchange_level) through RCCL on device tensors, in a one-rank group: the
     call pattern the N > 1 bench uses (world_size-2 logic is covered on CPU with gloo, tests/test_parallel_gloo.py)."""

@@ -430,6 +430,51 @@ def test_grid_pipeline_vs_reference_golden():
     assert e < 3e-2
 
 
+def test_grid_pipeline_pre_denoise_and_residual_merge():
+    """R11's pre-denoise start / skip-time / progressive skip / given clear latent and the per-step sparse and dense
+    residual merge (t2v_normal_pipeline.py:345-412, 445-468) on the HIP path, fake eps in fp32: the oracle on this host
+    (bit-exact vs the reference in the build container) within the bicubic kernel's round-off, the reference's
+    panoramas within the cross-host RNG bound; toy UNet in fp16 within the usual tolerance."""
+    from oracle import loops as oloops, ddim as oddim
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V
+    from dynamicscaler_amd.synth import synth_normal
+    d = dev()
+    z = np.load(os.path.join(G, "loops_grid_i2v.npz"))
+    meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    ld = _fake_host(cond, uncond, d)
+    cfgd = {"params": {"unet_config": {"params": {"in_channels": 4}}}}
+    for gname, geom in meta["grid_pre_geoms"].items():
+        gk = dict(geom)
+        if "clear_seed" in gk:
+            gk["clear_pre_denoised_latent"] = synth_normal((1, 4, 4, 8, 16), gk.pop("clear_seed"))
+        pipe = VC2_Pipeline_T2V(ld, lvdm_DDIM_Scheduler(ld), cfgd).to(d, torch.float32)
+        torch.manual_seed(2333333)
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=64, width=128, frames=4, fps=8,
+                                                       guidance_scale=7.5, output_type="latent", **gk)
+        torch.manual_seed(2333333)
+        oref, _ = oloops.t2v_grid_sample(_oracle_fake, oddim.DiffusionTables(), cond, uncond, height=64, width=128, frames=4,
+                                         guidance_scale=7.5, **gk)
+        e_o, e_r = relerr(den, oref), relerr(den, T(z[f"gridpre_{gname}_fake"]))
+        print(f"grid {gname}: vs oracle {e_o:.2e}, vs reference golden {e_r:.2e}")
+        assert e_o < 2e-6 and e_r < 1e-4, gname
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    ldu = _host(params, 5, cond, uncond, d)
+    pipe = VC2_Pipeline_T2V(ldu, lvdm_DDIM_Scheduler(ldu), {"params": {"unet_config": {"params": params}}}).to(d, torch.float16)
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=64, width=128, frames=4, fps=8,
+                                                   guidance_scale=7.5, output_type="latent", **meta["grid_pre_geoms"]["pre_sparse"])
+    e = relerr(den, T(z["gridpre_pre_sparse_tiny"]))
+    print(f"grid pre_sparse tiny fp16: rel err {e:.3e}")
+    assert e < 3e-2
+    with pytest.raises(NotImplementedError):
+        pipe.basic_sample_shift_multi_windows(prompt="a", height=64, width=128, frames=4, num_windows_w=1, num_windows_h=1,
+                                              num_windows_f=2, loop_step=2, num_inference_steps=3, output_type="latent",
+                                              random_shuffle_init_frame_stride=2)
+
+
 def test_i2v_ring_pipeline_vs_reference_golden():
     """P3 (i2v_sphere_panorama_pipeline.py:564-996): round() placement, temporal windows + docking, 5-D mask,
     merge-prev, per-window image tokens, begin_index_offset."""

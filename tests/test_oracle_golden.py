@@ -531,3 +531,28 @@ def test_g16_clip_preprocess_properties():
     const = clip_preprocess(torch.full((1, 3, 96, 160), 0.25), 32)
     want = ((0.25 + 1) / 2 - torch.tensor(CLIP_MEAN)) / torch.tensor(CLIP_STD)
     assert torch.allclose(const, want.view(1, 3, 1, 1).expand_as(const), atol=1e-5)
+
+
+def test_g11_grid_pre_denoise_and_residual_merge_vs_reference_golden():
+    """R11's remaining branches (t2v_normal_pipeline.py:345-412, 445-468): pre-denoise start (tile denoised for a few
+    steps or given, bicubic resize, _add_noise, non-progressive and progressive skip) and the per-step sparse / dense
+    residual merge -- oracle == the reference's panoramas, bit for bit with the fake eps-model, and with the toy UNet."""
+    z = npz("loops_grid_i2v.npz")
+    meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    for gname, geom in meta["grid_pre_geoms"].items():
+        gk = dict(geom)
+        if "clear_seed" in gk:
+            gk["clear_pre_denoised_latent"] = synth_normal((1, 4, 4, 8, 16), gk.pop("clear_seed"))
+        torch.manual_seed(2333333)
+        den, _ = oloops.t2v_grid_sample(_fake_eps, oddim.DiffusionTables(), cond, uncond, height=64, width=128, frames=4,
+                                        guidance_scale=7.5, **gk)
+        assert torch.equal(den, T(z[f"gridpre_{gname}_fake"])), (gname, float((den - T(z[f"gridpre_{gname}_fake"])).abs().max()))
+    params = json.loads(bytes(npz("unet_tiny_t2v.npz")["params_json"]).decode())
+    sd = synth_state_dict(param_shapes(params), 5)
+    eps = lambda x, t, c: unet_forward(sd, params, x, t, c, fps=8)
+    torch.manual_seed(2333333)
+    den, _ = oloops.t2v_grid_sample(eps, oddim.DiffusionTables(), cond, uncond, height=64, width=128, frames=4,
+                                    guidance_scale=7.5, **meta["grid_pre_geoms"]["pre_sparse"])
+    ref = T(z["gridpre_pre_sparse_tiny"])
+    assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4
