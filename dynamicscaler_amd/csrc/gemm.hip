@@ -14,10 +14,9 @@
 //   * v_mfma_f32_32x32x16_f16 with the WEIGHT fragment as the A operand and the ACTIVATION fragment as B:
 //     D[i=n][j=m], so a lane owns one output row m (lane&31) and 4 consecutive columns n per register quad
 //     -> float4 LDS stores in the epilogue.
-//   * epilogue through per-wave LDS strips: rows are read back as 8-column chunks, per-item bias (time-embedding
-//     add) / residual / SiLU / GEGLU applied in fp32, one rounding to fp16, 16-byte coalesced stores.  A shared
-//     bias starts in the accumulators; launches without residual / per-item bias use fp16 strips (half the LDS
-//     bytes: the epilogue is LDS-bandwidth bound).
+//   * epilogue through LDS (fp32 tile, stride BN+4): rows are read back as 8-column chunks, bias / per-item
+//     bias (time-embedding add) / residual / SiLU / GEGLU applied in fp32, one rounding to fp16, 16-byte
+//     coalesced stores.
 //   * blockIdx is remapped so that the blocks that share an XCD (bid % 8) walk neighbouring N tiles of the same
 //     A row panel (L2 reuse; performance only).
 #include <type_traits>
@@ -55,7 +54,6 @@ __device__ __forceinline__ f32x2 fast_gelu_erf2(f32x2 g) {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
-
 
 // LDS-DMA: 16 bytes per lane, lane l lands at dst + 16*l (dst wave-uniform).  Kept in a __device__ helper: with the
 // builtin written directly inside the templated kernel, clang's host pass silently drops the kernel's launch stub.
@@ -103,9 +101,7 @@ struct TileCfg {
     static constexpr int NG = TN <= 4 ? TN : (TN + (TN + 3) / 4 - 1) / ((TN + 3) / 4);   // tiles per column group
     static constexpr int STR = 32 * NG + 4;                    // floats per strip row
     static constexpr size_t EPI = (size_t)(NT / 64) * 32 * STR * sizeof(float);
-    // + per wave WN floats: the wave's slice of a shared bias vector, read back in the accumulator layout (acc init)
-    static constexpr size_t BIAS_OFF = STAGE > EPI ? STAGE : EPI;
-    static constexpr size_t LDS = BIAS_OFF + (size_t)(NT / 64) * WN * sizeof(float);
+    static constexpr size_t LDS = STAGE > EPI ? STAGE : EPI;
     static constexpr int WG_PER_CU = LDS <= 81920 && NT <= 256 ? 2 : 1;
     // fragment scheduling: all four k-slices of a K-step up front when that is <= 16 fragments, else one k-slice
     // ahead (double-buffered fragment registers)
@@ -259,24 +255,16 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         }
     };
 
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[ni][mi][j] = 0.0f;
+
     const int nk = d.K / BK;
     const int fr = lane & 31, fh = lane >> 5;
-
-    const bool geglu = d.epilogue & DS_EPI_GEGLU;
-    const bool silu = d.epilogue & DS_EPI_SILU;
-    const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;
-    // fp32 output on the fast path: plain accumulator dump (+ shared bias), e.g. attention scores that go through memory
-    const bool fast32 = out_f32 && !residual && !geglu && !silu && (d.N % 8 == 0) && (d.ldc % 4 == 0) &&
-                        (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    const bool fast = (!out_f32 || fast32) && (d.N % 8 == 0) && (d.ldc % 8 == 0 || fast32) && (!residual || d.ldr % 8 == 0) &&
-                      (!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0));
-    const bool shared_bias = bias && d.bias_rows >= d.M;
-    // A bias DECLARED shared (bias_rows > M) starts in the accumulators; a per-item table that happens to cover the launch
-    // with one item (bias_rows == M: a batch of one evaluation) is added at the end like the per-item case, so that a
-    // batch stays bit-identical to its separate forwards.
-    const bool bias_in_acc = shared_bias && fast && d.bias_rows > d.M;
-
-    f32x16 acc[TN][TM];
 
     // K-step synchronisation.  Register staging: store the staged operands, one barrier.  DMA: wait for this wave's
     // LDS-DMA of the next K-step, one barrier (then every wave's part has landed and the current buffer is free).
@@ -298,41 +286,11 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     DS_STAMP(0);
     if constexpr (Cfg::DMA) {
         for (int s0 = 0; s0 < NS - 1 && s0 < d.K / BK; ++s0) load_global(s0);   // NS-1 K-steps in flight
+        stage_sync(0, false);
     } else {
         load_global(0);
+        stage_sync(0, true);
     }
-    // Accumulators start at the (shared) bias instead of zero: the wave's WN bias values go global -> LDS once (40 lanes x
-    // 16 bytes) and come back in the accumulator layout -- quad g of tile ni holds columns 32 ni + 8 g + 4 (lane>>5) .. +3,
-    // two distinct addresses per read, i.e. LDS broadcasts -- while the first K-step's loads are in flight.  The epilogue
-    // then has no bias work at all (the fp16-strip path below depends on that).  Per-item bias stays in the epilogue.
-    if (bias_in_acc) {
-        float* sBias = reinterpret_cast<float*>(smem + Cfg::BIAS_OFF) + wave * WN;
-        for (int i = lane; i < WN / 4; i += 64) {
-            const int col = n0 + wn * WN + 4 * i;
-            *reinterpret_cast<f32x4*>(sBias + 4 * i) = col < d.N ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0, 0, 0, 0};
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(sBias + ni * 32 + 8 * g + 4 * fh);
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] = b[j];
-            }
-    } else {
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc[ni][mi][j] = 0.0f;
-    }
-    if constexpr (Cfg::DMA) stage_sync(0, false);
-    else stage_sync(0, true);
     DS_STAMP(1);
 
     // one LDS-DMA piece (8 rows x 128 B of this wave's share) of the next K-step, and the cursor advance after all pieces
@@ -439,6 +397,15 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     }
 
     DS_STAMP(2);
+    const bool geglu = d.epilogue & DS_EPI_GEGLU;
+    const bool silu = d.epilogue & DS_EPI_SILU;
+    const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;
+    // fp32 output on the fast path: plain accumulator dump (+ shared bias), e.g. attention scores that go through memory
+    const bool fast32 = out_f32 && !residual && !geglu && !silu && (d.N % 8 == 0) && (d.ldc % 4 == 0) &&
+                        (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    const bool fast = (!out_f32 || fast32) && (d.N % 8 == 0) && (d.ldc % 8 == 0 || fast32) && (!residual || d.ldr % 8 == 0) &&
+                      (!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0));
+    const bool shared_bias = bias && d.bias_rows >= d.M;
 
     // ---- epilogue.  D[i][j] of an MFMA tile: j = lane&31 is the output row m, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     //      the column n.  Each wave moves its own tiles through its private LDS strip (32 rows x up to NG tiles, fp32),
@@ -457,15 +424,24 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         constexpr int NG = Cfg::NG, STR = Cfg::STR;
         if constexpr (GE) {
             // GEGLU in registers: weight rows are interleaved in 32-row groups [x | gate], so tile 2p holds x and tile
-            // 2p+1 the gate of the same 32 outputs (bias included: accumulator init); acc[p] <- x * gelu(gate)
+            // 2p+1 the gate of the same 32 outputs; acc[p] <- (x + b) * gelu(gate + b)
 #pragma unroll
             for (int p2 = 0; p2 < TNE; ++p2) {
+                const int nx = n0 + wn * WN + 2 * p2 * 32 + 4 * fh;   // + 8g : x column of quad g
+                f32x4 bxq[4], bgq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bool okn = nx + 8 * g + 32 < d.N && bias;
+                    bxq[g] = okn ? *reinterpret_cast<const f32x4*>(bias + nx + 8 * g) : f32x4{0, 0, 0, 0};
+                    bgq[g] = okn ? *reinterpret_cast<const f32x4*>(bias + nx + 8 * g + 32) : f32x4{0, 0, 0, 0};
+                }
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int j = 0; j < 16; j += 2) {
-                        const f32x2 xv = {acc[2 * p2][mi][j], acc[2 * p2][mi][j + 1]};
-                        const f32x2 gv = {acc[2 * p2 + 1][mi][j], acc[2 * p2 + 1][mi][j + 1]};
+                        const f32x2 xv = {acc[2 * p2][mi][j] + bxq[j >> 2][j & 3], acc[2 * p2][mi][j + 1] + bxq[j >> 2][(j & 3) + 1]};
+                        const f32x2 gv = {acc[2 * p2 + 1][mi][j] + bgq[j >> 2][j & 3],
+                                          acc[2 * p2 + 1][mi][j + 1] + bgq[j >> 2][(j & 3) + 1]};
                         const f32x2 r = xv * fast_gelu_erf2(gv);
                         acc[p2][mi][j] = r[0];
                         acc[p2][mi][j + 1] = r[1];
@@ -473,75 +449,6 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             }
         }
         DS_STAMP(3);
-        // fp16 strips (no residual, no per-item bias, fp16 output: QKV / GEGLU / proj_in / most temporal convs): the bias is
-        // already in the accumulators, SiLU is applied in the accumulator layout, the value is rounded to fp16 there -- the
-        // same fp32 operations and the same single rounding as the fp32-strip path below, so the bits are identical -- and
-        // the strip carries halfs: half the LDS bytes (the epilogue of a
-        // 256x320 tile moves 655 KB through the LDS in fp32), twice the tiles per strip, and a sweep is one 16-byte read
-        // and one 16-byte store with nothing in between, so all sweeps of a group are in flight together.
-        if constexpr (!RES && !PIB) {
-            if (fast && !out_f32 && (!bias || bias_in_acc)) {
-                constexpr int NGH_ = TNE < 2 * NG ? TNE : 2 * NG;      // tiles per group in the same strip bytes,
-                constexpr int NGH = NGH_ < 4 ? NGH_ : 4;               // at most 4: 16 chunks per row, 8 sweeps of 4 rows
-                constexpr int STRH = 32 * NGH + 8;                     // halfs per strip row (16-byte aligned chunks)
-                static_assert(STRH <= 2 * STR, "fp16 strip must fit the fp32 strip");
-                f16* const sH = reinterpret_cast<f16*>(sW);
-#pragma unroll
-                for (int c0 = 0; c0 < TNE; c0 += NGH) {
-                    const int gw = (TNE - c0) < NGH ? (TNE - c0) : NGH;
-                    const int cpr = gw * 4, rps = 64 / cpr;
-                    const int ch = lane % cpr, r0 = lane / cpr;
-                    const bool lane_on = lane < rps * cpr;
-                    const int ncol = GE ? n0 + wn * WN + 2 * (c0 * 32 + ch * 8 - (ch * 8) % 32) + (ch * 8) % 32
-                                        : n0 + wn * WN + c0 * 32 + ch * 8;
-                    const long ocol = GE ? (long)tile_n * (BN / 2) + wn * (WN / 2) + c0 * 32 + ch * 8 : (long)ncol;
-                    const bool col_on = lane_on && (GE ? ncol + 32 < d.N : ncol < d.N);
-                    const int nsw = (32 + rps - 1) / rps;
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi) {
-                        const int mrow0 = m0 + wm * WM + mi * 32;
-#pragma unroll
-                        for (int t = 0; t < NGH; ++t) {
-                            if (t < gw) {
-#pragma unroll
-                                for (int g = 0; g < 4; ++g) {
-                                    const f32x16& a = acc[c0 + t][mi];
-                                    f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-                                    if constexpr (!GE) {
-                                        if (silu) {
-#pragma unroll
-                                            for (int j = 0; j < 4; ++j) v[j] = fast_silu(v[j]);
-                                        }
-                                    }
-                                    const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                                    *reinterpret_cast<f16x4*>(sH + fr * STRH + t * 32 + 8 * g + 4 * fh) = h;
-                                }
-                            }
-                        }
-                        wave_sync();
-                        f16* const out_base = reinterpret_cast<f16*>(out) + (long)(mrow0 + r0) * d.ldc + ocol;
-                        const long out_step = (long)rps * d.ldc;
-                        u32x4 hv[8];
-#pragma unroll
-                        for (int sw = 0; sw < 8; ++sw)
-                            if (sw < nsw) hv[sw] = *reinterpret_cast<const u32x4*>(sH + min(sw * rps + r0, 31) * STRH + ch * 8);
-#pragma unroll
-                        for (int sw = 0; sw < 8; ++sw) {
-                            if (sw < nsw) {
-                                const int row = sw * rps + r0;
-#ifdef DS_EXP_NOSTORE
-                                asm volatile("" ::"v"(hv[sw]));
-#else
-                                if (col_on && row < 32 && mrow0 + row < d.M) *reinterpret_cast<u32x4*>(out_base + sw * out_step) = hv[sw];
-#endif
-                            }
-                        }
-                        wave_sync();
-                    }
-                }
-                return;
-            }
-        }
 #pragma unroll
         for (int c0 = 0; c0 < TNE; c0 += NG) {
             const int gw = (TNE - c0) < NG ? (TNE - c0) : NG;   // tiles in this column group (compile-time after unroll)
@@ -557,7 +464,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             float bx[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) bx[j] = 0.0f;
-            if (!GE && shared_bias && !bias_in_acc && fast && col_on) {
+            if (!GE && shared_bias && fast && col_on) {
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + ncol);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + ncol + 4);
                 bx[0] = b0[0]; bx[1] = b0[1]; bx[2] = b0[2]; bx[3] = b0[3];
@@ -794,9 +701,6 @@ extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, cons
     if (d.epilogue & DS_EPI_GEGLU) {
         DS_CHECK_ARG(d.N % 64 == 0, "ds_gemm_f16: GEGLU needs N %% 64 == 0");
         DS_CHECK_ARG(!(d.epilogue & DS_EPI_OUT_F32) && d.ldc % 8 == 0, "ds_gemm_f16: GEGLU needs fp16 out, ldc %% 8 == 0");
-        DS_CHECK_ARG(!bias || (d.bias_rows > d.M && d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
-                     "ds_gemm_f16: GEGLU takes a shared (bias_rows > M), 16-byte aligned bias vector");
-        DS_CHECK_ARG(!residual || d.ldr % 8 == 0, "ds_gemm_f16: GEGLU residual needs ldr %% 8 == 0");
     }
     hipStream_t st = (hipStream_t)stream;
     const int tile = choose_tile(d);

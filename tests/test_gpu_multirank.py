@@ -63,3 +63,26 @@ def test_bench_two_ranks_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "strong" and j["cpu_baseline"] is None
     assert np.isfinite(j["value"]) and j["value"] > 0 and j["unit"] == "denoising-steps/sec"
+
+
+def test_graph_and_streams_repeatable_across_processes():
+    """Two hipGraph replays running concurrently on two streams (the bench's mode) must give the same bits in every
+    process.  An epilogue variant of the GEMM once passed every in-process equality test and still produced panoramas
+    that differed in the last fp16 bit from run to run in exactly this mode (profiles/r1_notes.md) -- this test is the
+    guard: the parent holds a busy GPU context, five fresh processes must agree."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import hashlib
+    import tempfile
+    x = torch.randn(1 << 24, device="cuda:0")
+    _ = float((x * 2).sum())
+    worker = os.path.join(REPO, "tests", "multirank_worker.py")
+    hashes = []
+    for _k in range(5):
+        dd = tempfile.mkdtemp()
+        r = subprocess.run([sys.executable, worker, dd, "grid4x2", "reference"], cwd=REPO, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        o = np.load(os.path.join(dd, "rank0.npz"))
+        hashes.append(hashlib.sha256(o["den"].tobytes() + o["final"].tobytes()).hexdigest()[:12])
+    assert len(set(hashes)) == 1, hashes

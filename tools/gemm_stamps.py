@@ -35,7 +35,7 @@ d.M, d.N, d.K, d.a_mode, d.cin, d.lda = M, N, K, (_lib.DS_A_CONV3 if conv else _
 if conv:
     H, Wd = int(sys.argv[6]), int(sys.argv[7])
     d.nimg, d.hin, d.win, d.hout, d.wout, d.stride, d.upsample = M // (H * Wd), H, Wd, H, Wd, 1, 0
-d.ldc, d.ldr, d.bias_rows, d.ldbias, d.epilogue = n_out, 0, 0x7FFFFFFF, N, epi
+d.ldc, d.ldr, d.bias_rows, d.ldbias, d.epilogue = n_out, 0, M, N, epi
 nblk = ((M + 127) // 128) * ((N + 63) // 64)  # upper bound over all tile shapes
 stamps = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
