@@ -449,6 +449,77 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             }
         }
         DS_STAMP(3);
+        // fp16 strips for launches without bias / residual / per-item bias and fp16 output (QKV and q projections, GEGLU:
+        // its bias is added in the stage above): SiLU is applied in the ACCUMULATOR layout and the value rounded to fp16
+        // there -- the same fp32 operations and the same single rounding as the fp32-strip path below, so the bits are
+        // identical -- and the strip carries halfs: half the LDS bytes (the epilogue of a 256x320 tile moves 655 KB
+        // through the LDS in fp32 and is LDS-bandwidth bound), and a sweep is one 16-byte read and one 16-byte store
+        // with nothing in between, so all sweeps of a group are in flight together.  (Launches WITH a shared bias stay on
+        // the fp32 strips: moving the bias into the accumulators was not repeatable under concurrent graph replays,
+        // profiles/r1_notes.md.)
+        if constexpr (!RES && !PIB) {
+            if (fast && !out_f32 && (!bias || GE)) {
+                constexpr int NGH_ = TNE < 2 * NG ? TNE : 2 * NG;      // tiles per group in the same strip bytes,
+                constexpr int NGH = NGH_ < 4 ? NGH_ : 4;               // at most 4: 16 chunks per row, 8 sweeps of 4 rows
+                constexpr int STRH = 32 * NGH + 8;                     // halfs per strip row (16-byte aligned chunks)
+                static_assert(STRH <= 2 * STR, "fp16 strip must fit the fp32 strip");
+                f16* const sH = reinterpret_cast<f16*>(sW);
+#pragma unroll
+                for (int c0 = 0; c0 < TNE; c0 += NGH) {
+                    const int gw = (TNE - c0) < NGH ? (TNE - c0) : NGH;
+                    const int cpr = gw * 4, rps = 64 / cpr;
+                    const int ch = lane % cpr, r0 = lane / cpr;
+                    const bool lane_on = lane < rps * cpr;
+                    const int ncol = GE ? n0 + wn * WN + 2 * (c0 * 32 + ch * 8 - (ch * 8) % 32) + (ch * 8) % 32
+                                        : n0 + wn * WN + c0 * 32 + ch * 8;
+                    const long ocol = GE ? (long)tile_n * (BN / 2) + wn * (WN / 2) + c0 * 32 + ch * 8 : (long)ncol;
+                    const bool col_on = lane_on && (GE ? ncol + 32 < d.N : ncol < d.N);
+                    const int nsw = (32 + rps - 1) / rps;
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        const int mrow0 = m0 + wm * WM + mi * 32;
+#pragma unroll
+                        for (int t = 0; t < NGH; ++t) {
+                            if (t < gw) {
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const f32x16& a = acc[c0 + t][mi];
+                                    f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+                                    if constexpr (!GE) {
+                                        if (silu) {
+#pragma unroll
+                                            for (int j = 0; j < 4; ++j) v[j] = fast_silu(v[j]);
+                                        }
+                                    }
+                                    const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                                    *reinterpret_cast<f16x4*>(sH + fr * STRH + t * 32 + 8 * g + 4 * fh) = h;
+                                }
+                            }
+                        }
+                        wave_sync();
+                        f16* const out_base = reinterpret_cast<f16*>(out) + (long)(mrow0 + r0) * d.ldc + ocol;
+                        const long out_step = (long)rps * d.ldc;
+                        u32x4 hv[8];
+#pragma unroll
+                        for (int sw = 0; sw < 8; ++sw)
+                            if (sw < nsw) hv[sw] = *reinterpret_cast<const u32x4*>(sH + min(sw * rps + r0, 31) * STRH + ch * 8);
+#pragma unroll
+                        for (int sw = 0; sw < 8; ++sw) {
+                            if (sw < nsw) {
+                                const int row = sw * rps + r0;
+#ifdef DS_EXP_NOSTORE
+                                asm volatile("" ::"v"(hv[sw]));
+#else
+                                if (col_on && row < 32 && mrow0 + row < d.M) *reinterpret_cast<u32x4*>(out_base + sw * out_step) = hv[sw];
+#endif
+                            }
+                        }
+                        wave_sync();
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int c0 = 0; c0 < TNE; c0 += NG) {
             const int gw = (TNE - c0) < NG ? (TNE - c0) : NG;   // tiles in this column group (compile-time after unroll)
