@@ -3,20 +3,21 @@
 // One kernel serves nn.Linear, Conv2d 1x1 / 3x3 (stride 1|2, nearest-x2 upsample folded into the gather)
 // and Conv3d (3,1,1): the modes differ only in how a row of the A tile is addressed (DS_A_*).
 //
-// Structure (CDNA4, wave64):
-//   * workgroup = 256 threads = 4 waves in a 2x2 grid; block tile BM x BN (128x128 or 128x64), K-step 64.
-//   * operands staged global -> VGPR -> LDS (the A rows are a gather with zero padding, so register staging;
-//     the next K-tile's global loads are issued before the MFMAs of the current one), double-buffered LDS,
-//     one barrier per K-step.
+// Structure (CDNA4, wave64; DESIGN.md section 4 has the measurements behind each choice):
+//   * tile variants (TileCfg, choose_tile): 256x256 (8 waves as 2x4) and 256x320 (4x2) with ONE workgroup per CU and
+//     LDS-DMA staging (buffer_load ... lds, 16 B per lane, the XOR swizzle applied to the SOURCE address, padding taps /
+//     tail rows zero-filled by out-of-range offsets), the DMA pieces of K-step k+1 issued between the MFMAs of k;
+//     128x128 / 128x64 (4 waves, 2x2) with TWO workgroups per CU and register staging for small launches; 4-stage
+//     LDS-DMA forms of those two for grids that leave CUs with a single workgroup.  K-step 64, one barrier per K-step.
 //   * LDS tiles are [rows][64 halfs] (128-byte rows) with the 16-byte chunk index XOR-swizzled by
 //     ((row >> 1) & 7): every ds_read_b128 lane group of a 32-row fragment read hits 16 distinct 16-byte slots
 //     of the 256-byte bank row (conflict-free), and the staging ds_write_b128 (8 lanes per row) is too.
 //   * v_mfma_f32_32x32x16_f16 with the WEIGHT fragment as the A operand and the ACTIVATION fragment as B:
-//     D[i=n][j=m], so a lane owns one output row m (lane&31) and 4 consecutive columns n per register quad
-//     -> float4 LDS stores in the epilogue.
-//   * epilogue through LDS (fp32 tile, stride BN+4): rows are read back as 8-column chunks, bias / per-item
-//     bias (time-embedding add) / residual / SiLU / GEGLU applied in fp32, one rounding to fp16, 16-byte
-//     coalesced stores.
+//     D[i=n][j=m], so a lane owns one output row m (lane&31) and 4 consecutive columns n per register quad.
+//   * epilogue per wave through a private LDS strip, no workgroup barrier: rows are read back as 8-column chunks, bias /
+//     per-item bias (time-embedding add) / residual / SiLU applied in fp32, one rounding to fp16, 16-byte stores; GEGLU
+//     in registers before the strips; launches without bias / residual transpose fp16 instead of fp32 (the epilogue is
+//     LDS-bandwidth bound).
 //   * blockIdx is remapped so that the blocks that share an XCD (bid % 8) walk neighbouring N tiles of the same
 //     A row panel (L2 reuse; performance only).
 #include <type_traits>
