@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- denoising-steps/sec of the tiled panoramic denoising loop on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks itself: the parent -- which never
+touches the GPU -- runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+bench.py <same arguments>` as a CHILD process, relays rank 0's JSON line and exits with the child's return code.
 
 Workload (BASELINE.json metric: 4096x512x16f): t2v overlapped-ring panorama, P = [1,4,16,64,512], 8x2 windows of
 512x320x16f (16 tiles / DDIM step, shifted every step), CFG 7.5 (2 UNet evaluations per tile), 50-step DDIM schedule,
@@ -32,10 +36,55 @@ import yaml
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-F_UNET_T2V = 12580.6e9       # FLOPs (2*MAC) per UNet evaluation at tile [1,4,16,40,64]
 MFMA_PEAK_F16 = 2500e12      # dense fp16 MFMA peak, MI355X_MICROARCH.md
-GEOM = dict(height=320, width=512, frames=16, total_w=4096, total_h=512, num_windows_w=8, num_windows_h=2,
-            num_windows_f=1, loop_step=8, num_inference_steps=50)
+# BASELINE.json configs 2-5 (config 1 is the CPU plumbing case: a parity test, tests/test_gpu_unet.py).  f_unet = FLOPs
+# (2*MAC) of one UNet evaluation at the config's tile; geometry as in SURVEY.md 8-d / BASELINE.md 3.
+CONFIGS = {
+    "cfg2": dict(model="t2v", f_unet=12580.6e9, ctx_len=77, label="t2v_sphere_panorama 2048x512x16f, 4x2 shifted ring windows (8 tiles/step)",
+                 size="2048x512x16f",
+                 geom=dict(height=320, width=512, frames=16, total_w=2048, total_h=512, num_windows_w=4, num_windows_h=2,
+                           num_windows_f=1, loop_step=8, num_inference_steps=50)),
+    "cfg3": dict(model="t2v", f_unet=12580.6e9, ctx_len=77, label="t2v_sphere_panorama 4096x512x16f, 8x2 shifted ring windows (16 tiles/step)",
+                 size="4096x512x16f",
+                 geom=dict(height=320, width=512, frames=16, total_w=4096, total_h=512, num_windows_w=8, num_windows_h=2,
+                           num_windows_f=1, loop_step=8, num_inference_steps=50)),
+    "cfg4": dict(model="i2v", f_unet=12601.1e9, ctx_len=93, label="i2v_sphere_panorama 4096x512x16f from a synthetic panorama image, 8x2 shifted "
+                 "ring windows (16 tiles/step), 77 text + 16 image tokens per window", size="4096x512x16f",
+                 geom=dict(height=320, width=512, frames=16, total_w=4096, total_h=512, num_windows_w=8, num_windows_h=2,
+                           num_windows_f=1, loop_step=8, num_inference_steps=50)),
+    "cfg5": dict(model="t2v", f_unet=18884.0e9, ctx_len=77, label="t2v_sphere_panorama 8192x1024x24f, 16x4 shifted ring windows (64 tiles/step), "
+                 "UNet at T=24", size="8192x1024x24f",
+                 geom=dict(height=320, width=512, frames=24, total_w=8192, total_h=1024, num_windows_w=16, num_windows_h=4,
+                           num_windows_f=1, loop_step=8, num_inference_steps=50)),
+}
+
+
+def self_launch(argv, n):
+    """Start the n ranks as a child `torch.distributed.run` and relay rank 0's line.  Called before anything in this
+    process has touched the GPU (no torch.cuda call above): the parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in p.stdout:
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc != 0 or line is None:
+        sys.stderr.write(f"bench.py: the {n}-rank child exited with code {rc}" + ("" if line else " and printed no result line") + "\n")
+        raise SystemExit(rc if rc != 0 else 1)
+    raise SystemExit(0)
 
 
 def usable_cpus():
@@ -56,6 +105,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3",
+                    help="BASELINE.json configuration (default cfg3 = the 4096x512x16f panorama the metric is quoted on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tile-batch", type=int, default=int(os.environ.get("DS_TILE_BATCH", "8")))
@@ -67,8 +118,13 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(sys.argv[1:], args.gpus)          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    cfg = CONFIGS[args.config]
+    GEOM, F_UNET = cfg["geom"], cfg["f_unet"]
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # one rank per GPU over RCCL.  DS_BENCH_DEVICE / DS_DIST_BACKEND exist for the single-GPU rehearsal of the N > 1 path
@@ -89,11 +145,11 @@ def main():
     from dynamicscaler_amd import ops
     from dynamicscaler_amd.host_model import LatentDiffusionHost, SyntheticConditioner
     from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
-    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
     from dynamicscaler_amd.unet_spec import param_shapes
     from dynamicscaler_amd.synth import synth_state_dict, synth_normal
 
-    params = yaml.safe_load(open(os.path.join(REPO, "dynamicscaler_amd", "configs", "t2v_512_v2_unet.yaml")))
+    yaml_name = {"t2v": "t2v_512_v2_unet.yaml", "i2v": "i2v_512_v1_unet.yaml"}[cfg["model"]]
+    params = yaml.safe_load(open(os.path.join(REPO, "dynamicscaler_amd", "configs", yaml_name)))
     t0 = time.time()
     sd = synth_state_dict(param_shapes(params), seed=0)
     ld = LatentDiffusionHost({"params": params}, conditioner=SyntheticConditioner(77, params["context_dim"]))
@@ -105,14 +161,34 @@ def main():
     setup_s = time.time() - t0
 
     sched = lvdm_DDIM_Scheduler(ld, rng_mode="device")   # Philox noise in-kernel: no host RNG in the timed loop
-    pipe = VC2_Pipeline_T2V_SpherePano(ld, sched, {"params": {"unet_config": {"params": params}}})
+    vs = 8
+    pano_shape = (1, 4, GEOM["frames"] * GEOM["num_windows_f"], GEOM["total_h"] // vs, GEOM["total_w"] // vs)
+    init = synth_normal(pano_shape, 2333333).to(dev)
+    extra = {}
+    if cfg["model"] == "i2v":
+        # config 4: input/pano_surfing_1.png is absent from the reference tree, so the panorama image is
+        # synthetic; every window takes the 16 image tokens of the crop under it.  The image tower + Resampler are the
+        # next-row components (N3); here a seeded stand-in maps a crop to [1,16,1024] tokens so that the measured path is
+        # the denoising loop with its 93-token contexts, cached per crop position like the product pipeline does.
+        from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano as Pipe
+
+        def image_tokens(batch_imgs):
+            seed = 1000 + int(batch_imgs.float().abs().sum().item() * 16) % 100000
+            return synth_normal((batch_imgs.shape[0], 16, params["context_dim"]), seed).to(dev)
+
+        ld.embedder = True                                   # marks the host as image-conditioned (uncond image tokens)
+        ld.get_image_embeds = image_tokens
+        extra = dict(pano_image_tensor=synth_normal((3, GEOM["total_h"], GEOM["total_w"]), 77).clamp(-1, 1),
+                     overlap_ratio_list_f=[0.0] * GEOM["num_inference_steps"])
+    else:
+        from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano as Pipe
+    pipe = Pipe(ld, sched, {"params": {"unet_config": {"params": params}}})
     pipe.to(dev, torch.float16)
     pipe.max_tile_batch = args.tile_batch
     pipe.num_streams = args.streams
     pipe.use_graph = bool(args.graph)
     pipe.share_cfg_prefix = bool(args.share_cfg_prefix)
-    init = synth_normal((1, 4, 16, 64, 512), 2333333).to(dev)
-    st = pipe.ring_begin(prompt="a synthetic prompt", fps=8, guidance_scale=7.5, init_panorama_latent=init, **GEOM)
+    st = pipe.ring_begin(prompt="a synthetic prompt", fps=8, guidance_scale=7.5, init_panorama_latent=init, **GEOM, **extra)
 
     def barrier():
         if world > 1:
@@ -139,7 +215,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     steps_per_s = args.steps / elapsed
     tiles_per_step = GEOM["num_windows_w"] * GEOM["num_windows_h"]
-    flops_per_step = tiles_per_step * 2 * F_UNET_T2V
+    flops_per_step = tiles_per_step * 2 * F_UNET
 
     # ---- roofline of the dominant kernel: per-launch HIP events on one extra (untimed) step, this rank's share ----
     roofline = None
@@ -234,38 +310,41 @@ def main():
         from oracle import ring as oring, ddim as oddim
         ncpu = usable_cpus()
         torch.set_num_threads(ncpu)
-        x = synth_normal((1, 4, 16, 40, 64), 7)
-        ctx = synth_normal((1, 77, 1024), 1)
+        T_ = GEOM["frames"]
+        x = synth_normal((1, 4, T_, 40, 64), 7)
+        ctx = synth_normal((1, cfg["ctx_len"], 1024), 1)
         tc = time.perf_counter()
         e = unet_forward(sd, params, x, torch.tensor([499]), ctx, fps=8)
         t_fwd = time.perf_counter() - tc
-        pano_c = synth_normal((1, 4, 16, 64, 512), 3)
+        pano_c = synth_normal(pano_shape, 3)
         osched = oddim.DDIMSchedule(oddim.DiffusionTables(), 50)
         tc = time.perf_counter()
         for _ in range(3):
-            w = oring.ring_gather(pano_c, 8, 72, 3, 43, 0, 16)
-            m = oring.ring_gather(torch.zeros_like(pano_c), 8, 72, 3, 43, 0, 16)
+            w = oring.ring_gather(pano_c, 8, 72, 3, 43, 0, T_)
+            m = oring.ring_gather(torch.zeros_like(pano_c), 8, 72, 3, 43, 0, T_)
             w = oddim.mix_latents_with_mask(w, oddim.re_noise(osched, w, 24, 25), m[0, 0, [0]], 1)
-            xp, x0 = oddim.ddim_step(osched, w, oddim.cfg_combine(e, e, 7.5), [25] * 16)
+            xp, x0 = oddim.ddim_step(osched, w, oddim.cfg_combine(e, e, 7.5), [25] * T_)
             for dst in (pano_c, pano_c, pano_c):
-                oring.ring_scatter(dst, xp, 8, 72, 3, 43, 0, 16)
+                oring.ring_scatter(dst, xp, 8, 72, 3, 43, 0, T_)
         t_ops = (time.perf_counter() - tc) / 3
         t_step = tiles_per_step * (2 * t_fwd + t_ops)
         cpu_baseline = {
             "value": 1.0 / t_step, "unit": "denoising-steps/sec", "cores": ncpu, "kind": "port",
-            "sample": f"1 fp32 UNet evaluation of one 512x320x16f tile ({t_fwd:.1f} s) = 1/32 of a step + the tile ops of "
-                      f"one tile ({t_ops * 1e3:.1f} ms); step time extrapolated as 16 tiles x (2 x UNet + tile ops)",
+            "sample": f"1 fp32 UNet evaluation of one 512x320x{T_}f tile ({t_fwd:.1f} s) = 1/{2 * tiles_per_step} of a step + the "
+                      f"tile ops of one tile ({t_ops * 1e3:.1f} ms); step time extrapolated as {tiles_per_step} tiles x "
+                      f"(2 x UNet + tile ops)",
             "sec_per_step": round(t_step, 1),
         }
 
     if rank == 0:
         line = {
-            "metric": "denoising-steps/sec (whole node), 4096x512x16f panorama", "value": steps_per_s,
+            "metric": f"denoising-steps/sec (whole node), {cfg['size']} panorama", "value": steps_per_s,
             "unit": "denoising-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "t2v_sphere_panorama 4096x512x16f, 8x2 shifted ring windows (16 tiles/step), CFG 7.5, "
-                                   "VideoCrafter2 t2v UNet 1.41B, DDIM 50-step schedule",
+            "config": {"workload": f"{args.config}: {cfg['label']}, CFG 7.5, VideoCrafter {cfg['model']} UNet "
+                                   f"({'1.41' if cfg['model'] == 't2v' else '1.44'} B parameters), DDIM 50-step schedule",
+                       "baseline_config": args.config,
                        "tiles_per_step": tiles_per_step, "unet_evals_per_step": 2 * tiles_per_step,
                        "tile_batch": args.tile_batch, "streams": args.streams, "hipgraph": bool(args.graph), "cfg_prefix_shared": bool(args.share_cfg_prefix), "parallelism": f"tiles sharded over {world} GPU(s)",
                        "rng": "philox in-kernel (perf mode)"},

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdynscaler_hip.so")
+# DS_HIP_LIBRARY: a diagnostic build of the same ABI (tests/hazard_probe.py); the product always loads the in-tree library
+LIB_PATH = os.environ.get("DS_HIP_LIBRARY") or os.path.join(HERE, "libdynscaler_hip.so")
 
 DS_F16, DS_F32 = 0, 1
 DS_A_DENSE, DS_A_CONV3, DS_A_TCONV = 0, 1, 2
@@ -73,6 +74,7 @@ SIGNATURES = {
     "ds_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ds_clip_preprocess": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ds_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ds_dbg_poison_cu_state": (_i, [_vp]),
 }
 
 _lib = None

@@ -27,7 +27,17 @@ def _newer(src_list, target):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def build(force=False, verbose=True):
+# diagnostic variants of the library (same ABI, loaded through DS_HIP_LIBRARY by tests/hazard_probe.py only)
+VARIANTS = {"accinit": ["-DDS_EXP_BIAS_ACC_INIT"]}
+
+
+def build(force=False, verbose=True, variant=None):
+    global OBJ, LIB
+    extra = []
+    if variant is not None:
+        extra = VARIANTS[variant]
+        OBJ = os.path.join(HERE, "_build_" + variant)
+        LIB = os.path.join(HERE, f"libdynscaler_hip_{variant}.so")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "dynscaler_hip.h")]
     jobs = []
@@ -37,7 +47,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _newer([src] + headers, obj):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):
@@ -60,4 +70,5 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    print(build(force="--force" in sys.argv, variant=v))

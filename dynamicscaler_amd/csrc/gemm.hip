@@ -256,16 +256,41 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         }
     };
 
-    f32x16 acc[TN][TM];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[ni][mi][j] = 0.0f;
-
     const int nk = d.K / BK;
     const int fr = lane & 31, fh = lane >> 5;
+
+    f32x16 acc[TN][TM];
+#ifdef DS_EXP_BIAS_ACC_INIT
+    // DIAGNOSTIC BUILD ONLY (tests/hazard_probe.py, `python -m dynamicscaler_amd.build --variant accinit`): a shared bias
+    // starts in the accumulators instead of being added after the K sum.  Valid arithmetic in a DIFFERENT summation order
+    // (bias + p1 + p2 + ... instead of (p1 + p2 + ...) + bias), i.e. results that differ from the product build in the
+    // last bit -- this is the variant of round 1 whose panoramas were not repeatable from process to process.
+    const bool bias_in_acc = bias && d.bias_rows >= d.M && (d.N % 8 == 0) && (d.ldbias % 4 == 0) &&
+                             (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && !(d.epilogue & DS_EPI_OUT_F32);
+    if (bias_in_acc) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + wn * WN + ni * 32 + 8 * g + 4 * fh;
+                const f32x4 b = col < d.N ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] = b[j];
+            }
+    } else
+#else
+    constexpr bool bias_in_acc = false;
+#endif
+    {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[ni][mi][j] = 0.0f;
+    }
 
     // K-step synchronisation.  Register staging: store the staged operands, one barrier.  DMA: wait for this wave's
     // LDS-DMA of the next K-step, one barrier (then every wave's part has landed and the current buffer is free).
@@ -432,7 +457,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 f32x4 bxq[4], bgq[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const bool okn = nx + 8 * g + 32 < d.N && bias;
+                    const bool okn = nx + 8 * g + 32 < d.N && bias && !bias_in_acc;
                     bxq[g] = okn ? *reinterpret_cast<const f32x4*>(bias + nx + 8 * g) : f32x4{0, 0, 0, 0};
                     bgq[g] = okn ? *reinterpret_cast<const f32x4*>(bias + nx + 8 * g + 32) : f32x4{0, 0, 0, 0};
                 }
@@ -459,7 +484,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         // the fp32 strips: moving the bias into the accumulators was not repeatable under concurrent graph replays,
         // profiles/r1_notes.md.)
         if constexpr (!RES && !PIB) {
-            if (fast && !out_f32 && (!bias || GE)) {
+            if (fast && !out_f32 && (!bias || GE || bias_in_acc)) {
                 constexpr int NGH_ = TNE < 2 * NG ? TNE : 2 * NG;      // tiles per group in the same strip bytes,
                 constexpr int NGH = NGH_ < 4 ? NGH_ : 4;               // at most 4: 16 chunks per row, 8 sweeps of 4 rows
                 constexpr int STRH = 32 * NGH + 8;                     // halfs per strip row (16-byte aligned chunks)
@@ -536,7 +561,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             float bx[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) bx[j] = 0.0f;
-            if (!GE && shared_bias && fast && col_on) {
+            if (!GE && shared_bias && fast && col_on && !bias_in_acc) {
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + ncol);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + ncol + 4);
                 bx[0] = b0[0]; bx[1] = b0[1]; bx[2] = b0[2]; bx[3] = b0[3];

@@ -60,6 +60,7 @@ class VC2_Pipeline_T2V:
         self.use_graph = False               # hipGraph replay of the UNet evaluation (see _eps)
         self.share_cfg_prefix = True         # [cond | uncond] pairs: context-free UNet prefix evaluated once (UNetModel.forward)
         self._graphs = {}
+        self._graph_generation = None        # UNetModel._generation the cached graphs were captured with
         self._slot = 0                       # stream slot of the tile batch being enqueued (one graph set per slot)
         self.verbose = False
 
@@ -120,9 +121,21 @@ class VC2_Pipeline_T2V:
         model = self.pretrained_t2v.model
         if cfg_pairs and self.share_cfg_prefix and hasattr(getattr(model, "diffusion_model", None), "_transformer_block"):
             kwargs = dict(kwargs, cfg_pairs=int(cfg_pairs))
-        if not (self.use_graph and x.is_cuda and isinstance(fps, int)):
+        # graph replay only for signatures that a key can identify: python scalars in the kwargs (a tensor-valued kwarg would
+        # be baked into the graph by pointer), an int fps
+        scalar_kw = all(v is None or isinstance(v, (bool, int, float, str)) for v in kwargs.values())
+        if not (self.use_graph and x.is_cuda and isinstance(fps, int) and scalar_kw):
             ts = torch.full((n,), int(t), device=x.device, dtype=torch.long)
             return model(x, ts, c_crossattn=[ctx], fps=fps, curr_time_steps=ts, temporal_length=frames, **kwargs)
+        # the captured graphs hold the packed-weight pointers of ONE prepare(): a reload / .to() / invalidate() of the UNet
+        # repacks into new buffers (generation + 1) and every older graph is dropped
+        unet = getattr(model, "diffusion_model", None)
+        if unet is not None and hasattr(unet, "prepare"):
+            unet.prepare(x.device)           # no-op when packed; never inside a capture (the eager warm call comes first)
+        gen = getattr(unet, "_generation", 0)
+        if gen != self._graph_generation:
+            self._graphs.clear()
+            self._graph_generation = gen
         key = (self._slot, tuple(x.shape), x.dtype, tuple(ctx.shape), ctx.dtype, fps, frames, tuple(sorted(kwargs.items())))
         ent = self._graphs.get(key)
         if ent is None:                      # first use: eager (loads code objects, sets kernel attributes)
@@ -252,7 +265,7 @@ class VC2_Pipeline_T2V:
                         nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=pano.dtype)
                     ops.renoise_mix_(tiles, mtiles, st.total_shape, c_rn, s_rn, st.ratio, noise=nz,
                                      mask_frame0=mask_frame0, seed=sched.philox_seed,
-                                     offset=i * len(wins) * tiles[0].numel(), tile_ids=ids)
+                                     offset=sched.tile_philox_offset(i, tiles[0].numel()), tile_ids=ids)
                 n = len(ids)
                 if st.guidance_scale != 1.0:
                     eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n,
@@ -302,6 +315,11 @@ class VC2_Pipeline_T2V:
     def _new_state(self, init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
                    text_emb, uc_emb, ratio, kwargs):
         device = self._execution_device
+        # weights are repacked here, on the caller's stream and followed by a device synchronisation, never lazily by
+        # whichever side stream happens to run the first evaluation
+        unet = getattr(getattr(self.pretrained_t2v, "model", None), "diffusion_model", None)
+        if unet is not None and hasattr(unet, "prepare"):
+            unet.prepare(device)
         st = _RingState()
         st.in_device = init_panorama_latent.device
         st.pano = init_panorama_latent.to(device=device, dtype=self.latent_dtype).contiguous().clone()

@@ -171,6 +171,33 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
                                          progressive_skip=False, pano_image_tensor=None, step_callback=None, **kwargs):
         """`pano_image_tensor` ([3,total_h,total_w], optional) is an extension: the panorama image as a tensor
         instead of a path (RingImageTensor accepts both, shift_window_utils.py:211-220)."""
+        st = self.ring_begin(prompt=prompt, height=height, width=width, frames=frames, fps=fps, guidance_scale=guidance_scale,
+                             init_panorama_latent=init_panorama_latent, total_w=total_w, total_h=total_h, total_f=total_f,
+                             num_windows_w=num_windows_w, num_windows_h=num_windows_h, num_windows_f=num_windows_f,
+                             loop_step=loop_step, begin_index_offset=begin_index_offset, dock_at_f=dock_at_f,
+                             overlap_ratio_list_f=overlap_ratio_list_f, loop_step_frame=loop_step_frame,
+                             pano_image_path=pano_image_path, num_inference_steps=num_inference_steps,
+                             prompt_embeds=prompt_embeds, merge_renoised_overlap_latent_ratio=merge_renoised_overlap_latent_ratio,
+                             merge_prev_denoised_ratio_list=merge_prev_denoised_ratio_list,
+                             window_multi_prompt_dict=window_multi_prompt_dict, use_skip_time=use_skip_time,
+                             skip_time_step_idx=skip_time_step_idx, progressive_skip=progressive_skip,
+                             pano_image_tensor=pano_image_tensor, **kwargs)
+        with self.progress_bar(total=st.total_steps) as bar:
+            for i in range(st.total_steps):
+                wins = self.ring_step(st, i)
+                if step_callback is not None:
+                    step_callback(i, int(st.timesteps[i]), wins, st.pano, st.pano_x0)
+                bar.update()
+        return self.ring_finish(st, output_type)
+
+    # ---- the loop in three pieces (like the t2v ring, pipelines.py) so a caller (bench.py) can time single DDIM steps ----
+    @torch.no_grad()
+    def ring_begin(self, prompt=None, height=320, width=512, frames=16, fps=16, guidance_scale=7.5, init_panorama_latent=None,
+                   total_w=None, total_h=None, total_f=None, num_windows_w=None, num_windows_h=None, num_windows_f=None,
+                   loop_step=None, begin_index_offset=0, dock_at_f=None, overlap_ratio_list_f=None, loop_step_frame=None,
+                   pano_image_path=None, num_inference_steps=4, prompt_embeds=None, merge_renoised_overlap_latent_ratio=1,
+                   merge_prev_denoised_ratio_list=None, window_multi_prompt_dict=None, use_skip_time=False,
+                   skip_time_step_idx=None, progressive_skip=False, pano_image_tensor=None, **kwargs):
         if use_skip_time and init_panorama_latent is None and getattr(self.pretrained_t2v, "first_stage_model", None) is None:
             raise NotImplementedError("use_skip_time without init_panorama_latent needs the first-stage encoder "
                                       "(first_stage_config); gen_pano_360.py passes the previous stage's latent")
@@ -219,39 +246,47 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
         step_f = 0 if total_f == frames else frames // loop_step
         assert step_f > 0 or total_f == frames, \
             f"[basic_sample_shift_multi_windows] loop_step {loop_step} > frames {frames} while total_f {total_f} > frame"
-        ring_image = RingImageTensor(image_path=pano_image_path, image_tensor=pano_image_tensor, height=total_h, width=total_w)
         st = self._new_state(init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
                              text_emb, uc_emb, merge_renoised_overlap_latent_ratio, kwargs)
-        img_cache, prompt_cache = {}, {}
-        total_steps = len(timesteps)
-        with self.progress_bar(total=total_steps) as bar:
-            for i in range(total_steps):
-                st.mask.zero_()  # reset denoised mask record (:810)
-                wins = i2v_ring_windows(i, latent_h=lat_h, latent_w=lat_w, frames=frames, total_f=total_f, step_w=step_w,
-                                        step_h=step_h, off_w=off_w, off_h=off_h, num_windows_w=num_windows_w,
-                                        num_windows_h=num_windows_h, loop_step=loop_step,
-                                        overlap_ratio_f=overlap_ratio_list_f[i], loop_step_frame=loop_step_frame,
-                                        dock_at_f=dock_at_f, begin_index_offset=begin_index_offset)
-                ctxs = []
-                for (left, _r, top, _d, _fb, _fe) in wins:
-                    cur_text = st.text_emb
-                    if window_multi_prompt_dict is not None:
-                        cur = select_prompt_from_multi_prompt_dict_by_factor(window_multi_prompt_dict,
-                                                                              (top * vs + height) / total_h)
-                        if cur not in prompt_cache:
-                            prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(st.device)
-                        cur_text = prompt_cache[cur]
-                    key = (left, top)
-                    if key not in img_cache:   # same crop position recurs every loop_step steps
-                        img_cache[key] = ring_image.get_encoded_image_cond(
-                            self.pretrained_t2v, left * vs, left * vs + width, top * vs, top * vs + height).to(st.device)
-                    ctxs.append(torch.cat([cur_text, img_cache[key].to(cur_text.dtype)], dim=1))
-                renoise = st.ratio is not None and i < total_steps - 1
-                merge_prev = None
-                if merge_prev_denoised_ratio_list is not None and i < total_steps - 1:
-                    merge_prev = merge_prev_denoised_ratio_list[i]
-                self._denoise_windows(st, i, wins, ctxs, renoise=renoise, mask_frame0=False, merge_prev_ratio=merge_prev)
-                if step_callback is not None:
-                    step_callback(i, int(timesteps[i]), wins, st.pano, st.pano_x0)
-                bar.update()
-        return self._finish(st, output_type, total_f, seam_safe=True)
+        st.ring_image = RingImageTensor(image_path=pano_image_path, image_tensor=pano_image_tensor, height=total_h, width=total_w)
+        st.img_cache, st.prompt_cache = {}, {}
+        st.win_args = dict(latent_h=lat_h, latent_w=lat_w, frames=frames, total_f=total_f, step_w=step_w, step_h=step_h,
+                           off_w=off_w, off_h=off_h, num_windows_w=num_windows_w, num_windows_h=num_windows_h,
+                           loop_step=loop_step, loop_step_frame=loop_step_frame, dock_at_f=dock_at_f,
+                           begin_index_offset=begin_index_offset)
+        st.overlap_ratio_list_f = overlap_ratio_list_f
+        st.merge_prev_denoised_ratio_list = merge_prev_denoised_ratio_list
+        st.window_multi_prompt_dict = window_multi_prompt_dict
+        st.height, st.width, st.total_h, st.total_f = height, width, total_h, total_f
+        return st
+
+    @torch.no_grad()
+    def ring_step(self, st, i):
+        """One DDIM step over all windows (i2v_sphere_panorama_pipeline.py:806-960)."""
+        vs = self.vae_scale_factor
+        st.mask.zero_()  # reset denoised mask record (:810)
+        wins = i2v_ring_windows(i, overlap_ratio_f=st.overlap_ratio_list_f[i], **st.win_args)
+        ctxs = []
+        for (left, _r, top, _d, _fb, _fe) in wins:
+            cur_text = st.text_emb
+            if st.window_multi_prompt_dict is not None:
+                cur = select_prompt_from_multi_prompt_dict_by_factor(st.window_multi_prompt_dict,
+                                                                      (top * vs + st.height) / st.total_h)
+                if cur not in st.prompt_cache:
+                    st.prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(st.device)
+                cur_text = st.prompt_cache[cur]
+            key = (left, top)
+            if key not in st.img_cache:   # same crop position recurs every loop_step steps
+                st.img_cache[key] = st.ring_image.get_encoded_image_cond(
+                    self.pretrained_t2v, left * vs, left * vs + st.width, top * vs, top * vs + st.height).to(st.device)
+            ctxs.append(torch.cat([cur_text, st.img_cache[key].to(cur_text.dtype)], dim=1))
+        renoise = st.ratio is not None and i < st.total_steps - 1
+        merge_prev = None
+        if st.merge_prev_denoised_ratio_list is not None and i < st.total_steps - 1:
+            merge_prev = st.merge_prev_denoised_ratio_list[i]
+        self._denoise_windows(st, i, wins, ctxs, renoise=renoise, mask_frame0=False, merge_prev_ratio=merge_prev)
+        return wins
+
+    @torch.no_grad()
+    def ring_finish(self, st, output_type="latent"):
+        return self._finish(st, output_type, st.total_f, seam_safe=True)

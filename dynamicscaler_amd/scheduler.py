@@ -48,7 +48,21 @@ class lvdm_DDIM_Scheduler(object):
         self.counter = 0
         self.rng_mode = rng_mode
         self._philox_offset = 0
-        self.philox_seed = 0
+        self.philox_seed = 0                 # settable: Philox key of the in-kernel draws (rng_mode "device")
+
+    # Philox counter spaces (rng_mode "device").  Tile draws of the step loops: key = philox_seed, counter =
+    # tile_philox_offset(step, tile, numel) -- a fixed stride of PHILOX_TILES_PER_STEP tiles is reserved per step, so the
+    # counters of two steps never overlap whatever their window counts (docking adds windows on some steps only).
+    # Panorama-sized draws of add_noise / re_noise: a different KEY (aux_philox_seed), so they can never meet a tile's.
+    PHILOX_TILES_PER_STEP = 1 << 16
+
+    @classmethod
+    def tile_philox_offset(cls, step, numel):
+        return int(step) * cls.PHILOX_TILES_PER_STEP * int(numel)
+
+    @property
+    def aux_philox_seed(self):
+        return (int(self.philox_seed) ^ 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
         if ddim_discretize != "uniform":
@@ -149,7 +163,7 @@ class lvdm_DDIM_Scheduler(object):
         noise = self.draw_renoise_noise(tuple(x.shape), x.device, x.dtype, "later" if frames_major_strides else None)
         ones = torch.ones((x.shape[0],) + tuple(x.shape[2:]), dtype=torch.uint8, device=x.device)
         ops.renoise_mix_(x, ones, (1,) + tuple(x.shape[1:]), c, s, 1.0, noise=noise, mask_frame0=False,
-                         seed=self.philox_seed, offset=self.next_philox_offset(x.numel()))
+                         seed=self.aux_philox_seed, offset=self.next_philox_offset(x.numel()))
         return x
 
     @torch.no_grad()
@@ -162,6 +176,6 @@ class lvdm_DDIM_Scheduler(object):
         noise = self.draw_renoise_noise(tuple(x.shape), x.device, x.dtype, "later" if frames_major_strides else None)
         ones = torch.ones((n,) + tuple(x.shape[2:]), dtype=torch.uint8, device=x.device)
         pano_shape = (1,) + tuple(x.shape[1:])
-        ops.renoise_mix_(x, ones, pano_shape, c, s, 1.0, noise=noise, mask_frame0=False, seed=self.philox_seed,
+        ops.renoise_mix_(x, ones, pano_shape, c, s, 1.0, noise=noise, mask_frame0=False, seed=self.aux_philox_seed,
                          offset=self.next_philox_offset(x.numel()))
         return x

@@ -263,7 +263,7 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
                         if noises[ids[0]][0] is not None:
                             nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=st.pano.dtype)
                         ops.renoise_mix_(tiles, mt, shape, c_rn, s_rn, st.ratio, noise=nz, mask_frame0=True,
-                                         seed=sched.philox_seed, offset=i * len(views) * tiles[0].numel(), tile_ids=ids)
+                                         seed=sched.philox_seed, offset=sched.tile_philox_offset(i, tiles[0].numel()), tile_ids=ids)
                     if st.guidance_scale != 1.0:
                         eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n, fps,
                                         frames, cfg_pairs=n, **st.kwargs)
@@ -466,7 +466,7 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                         if noises[ids[0]][0] is not None:
                             nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=st.pano.dtype)
                         ops.renoise_mix_(tiles, mt, shape, c_rn, s_rn, st.ratio, noise=nz, mask_frame0=False,
-                                         seed=sched.philox_seed, offset=i * len(items) * tiles[0].numel(), tile_ids=ids)
+                                         seed=sched.philox_seed, offset=sched.tile_philox_offset(i, tiles[0].numel()), tile_ids=ids)
                     if st.guidance_scale != 1.0:
                         eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n, fps,
                                         frames, cfg_pairs=n, **st.kwargs)

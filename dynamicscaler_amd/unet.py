@@ -12,6 +12,7 @@ Beyond the reference (which only runs batch 1): a batch of b inde
 separate b=1 forwards.
 """
 import math
+import threading
 
 import torch
 import torch.nn as nn
@@ -68,6 +69,9 @@ class UNetModel(nn.Module):
                 node = getattr(node, p)
             node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape), requires_grad=False))
         self._packed = None
+        self._tap = None                     # optional callable(name, rows [M,C] fp16, (B,T,H,W)) after every block (tests)
+        self._generation = 0                 # bumped by every prepare(): identifies the packed buffers (hipGraph cache keys)
+        self._prepare_lock = threading.Lock()
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, *a, **k):
@@ -84,9 +88,21 @@ class UNetModel(nn.Module):
 
     @torch.no_grad()
     def prepare(self, device=None):
-        """Repack parameters for the kernels (fp16 GEMM operands, fp32 biases / norm affine)."""
+        """Repack parameters for the kernels (fp16 GEMM operands, fp32 biases / norm affine).
+        The repack kernels run on the caller's current stream; the call returns after a device synchronisation, so any
+        stream (the pipelines' side streams, hipGraph captures) may read the packed buffers afterwards.  Serialised by a
+        lock: two threads racing into the first forward repack once."""
+        with self._prepare_lock:
+            dev = torch.device(device) if device is not None else next(self.parameters()).device
+            if dev.type == "cuda" and dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            if self._packed is not None and self._device == dev:
+                return self
+            return self._prepare_locked(dev)
+
+    def _prepare_locked(self, device):
         sd = dict(self.named_parameters())
-        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        dev = device
         if dev.type != "cuda":
             raise RuntimeError("UNetModel runs on an MI355X only (no CPU path): move the model / inputs to a HIP device")
         P = {}
@@ -202,8 +218,10 @@ class UNetModel(nn.Module):
         P["emb_all.w"] = w16(torch.cat(emb_w, 0))
         P["emb_all.b"] = f32(torch.cat(emb_b, 0))
         self._emb_total = off
-        self._packed = P
+        torch.cuda.synchronize(dev)          # the packed buffers are complete before any other stream can see them
         self._device = dev
+        self._generation += 1
+        self._packed = P
         return self
 
     # ------------------------------------------------------------------ forward program
@@ -404,6 +422,8 @@ class UNetModel(nn.Module):
                 elif b.kind == "up":
                     h, (ho, wo) = self._conv3(h, b.prefix + ".conv", (Bq * Tq, Hq, Wq), b.cin, upsample=1)
                     geo = (Bq, Tq, ho, wo)
+                if self._tap is not None:
+                    self._tap(b.prefix, h, geo)
             return h, geo
 
         geo = (pairs if shared else B, T, H, W)
@@ -413,6 +433,8 @@ class UNetModel(nn.Module):
             h, geo = run(group, h, geo)
             if gi == 0 and cfg["addition_attention"]:
                 h = self._transformer(h, "init_attn.0", 8, cfg["transformer_depth"], False, geo, ctx)
+                if self._tap is not None:
+                    self._tap("init_attn.0", h, geo)
             hs.append((dup(h), (B,) + geo[1:]) if shared else (h, geo))
         h, geo = run(self._middle, h, geo)
         for group in self._outputs:

@@ -235,6 +235,11 @@ int ds_rows_to_ncthw(const void* y, int y_dtype, int ldy, void* out, int out_dty
 int ds_timestep_embedding(const int64_t* t, void* out, int n, int dim, void* stream);
 /* y = silu(x), fp16 elementwise (emb_layers SiLU, openaimodel3d.py:172-178). */
 int ds_silu_f16(const void* x, void* y, size_t n, void* stream);
+/* Diagnostic (no reference counterpart): fill every CU's LDS and vector / accumulator register files with NaN
+ * patterns.  The test suite runs the UNet program with this launch in front of every kernel and demands bit-identical
+ * results, i.e. no kernel reads LDS or registers it has not written (state that would otherwise depend on what ran on
+ * the CU before -- timing, once two hipGraphs replay concurrently). */
+int ds_dbg_poison_cu_state(void* stream);
 
 /* ---- conditioning producers: OpenCLIP ViT-H/14 towers and the IP-Adapter Resampler ---- */
 /* softmax(q k^T * scale [+ causal mask]) v for head_dim 64 (text tower, open_clip Transformer behind

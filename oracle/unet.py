@@ -133,6 +133,7 @@ class _Net:
         self.sd = sd
         self.layout = unet_layout(params)
         self.c = self.layout["cfg"]
+        self.tap = None   # optional callable(name, h [b*t, C, H, W]) after every block (layer-wise error budget tests)
 
     def p(self, key):
         return self.sd[key]
@@ -286,14 +287,18 @@ class _Net:
                 h = F.conv2d(h, self.p(p + ".conv.weight"), self.p(p + ".conv.bias"), padding=1)
             else:
                 raise AssertionError(kind)
+            if self.tap is not None:
+                self.tap(p, h)
         return h
 
 
 @torch.no_grad()
-def unet_forward(sd, params, x, timesteps, context, fps=16):
+def unet_forward(sd, params, x, timesteps, context, fps=16, tap=None):
     """UNetModel.forward (openaimodel3d.py:657-708).  x [b,C,t,h,w] fp32, timesteps int64 [b],
-    context [b,L,context_dim], fps python int or int64 tensor [b].  Returns eps [b,C_out,t,h,w]."""
+    context [b,L,context_dim], fps python int or int64 tensor [b].  Returns eps [b,C_out,t,h,w].
+    tap(name, h): called with the activation [b*t, C, H, W] after every block (names = state-dict prefixes)."""
     net = _Net(sd, params)
+    net.tap = tap
     c = net.c
     mc = c["model_channels"]
     t_emb = timestep_embedding(timesteps, mc)
@@ -317,6 +322,8 @@ def unet_forward(sd, params, x, timesteps, context, fps=16):
             # init_attn: n_heads=8, d_head=num_head_channels, depth=transformer_depth (openaimodel3d.py:425-439)
             h5 = net.temporal_transformer(h5, "init_attn.0", 8, c["transformer_depth"])
             h = h5.permute(0, 2, 1, 3, 4).reshape(bt, ch, h2, w2)
+            if tap is not None:
+                tap("init_attn.0", h)
         hs.append(h)
     h = net.run_layers(h, lay["middle"], "middle_block", emb, context, b)
     for i, layers in enumerate(lay["output"]):

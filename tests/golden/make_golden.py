@@ -18,6 +18,8 @@ so parity is pinned by what this script captures from the imported reference cod
   G12 sphere.npz             _get_uv index maps (gen_pano_360 view set, one view at all 10 theta offsets), sphere
                              gather/scatter round trips (duplicate winners), t2v sphere loop (P5), fake eps + tiny UNet
   G10 unet_full_{t2v,i2v}.npz (--full) full-size t2v / i2v UNet eps at tile [1,4,16,40,64] (3 forwards, ~3 min)
+  G17 cfg1_full_t2v.npz      (--full) BASELINE config 1: basic_sample, real t2v UNet, 512x320x16f, 4 steps, CFG 7.5;
+                             per-step x_t / e_t / x_prev / pred_x0 (8 forwards, ~8 min)
 
   G16 encoders_{toy,full}.npz  Resampler (the reference's module, ip_resampler.py) and the CLIP ViT-H/14 text / image
                              towers -- open_clip is absent, so the tower vectors come from transformers' CLIP
@@ -359,6 +361,46 @@ def g10_unet_full_i2v():
         eps = m(x, torch.tensor([321]), context=ctx, fps=16)
     print("i2v full", float(eps.abs().mean()), float(eps.std()))
     save_npz("unet_full_i2v.npz", x=x, t=np.int64(321), fps=np.int64(16), ctx=ctx, eps=eps)
+
+
+
+def g17_cfg1_full():
+    """BASELINE config 1 as written: VC2_Pipeline_T2V.basic_sample (pipeline/t2v_normal_pipeline.py:69-210) with the real
+    t2v yaml UNet (1.41 B parameters), one 512x320x16f tile, 4 DDIM steps, CFG 7.5 -- 8 forwards of the reference on CPU.
+    The init latent is passed in (fp16-representable, `latents=`), so a fp16-latent build starts from identical numbers.
+    Per step: the guided prediction e_t, x_prev and pred_x0 (the latent that went in is x_init / the previous x_prev) as the reference's own
+    lvdm_DDIM_Scheduler.ddim_step (pipeline/scheduler.py:60-96) returned them."""
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(os.cpu_count())
+    unet = build_reference_unet(params, seed=0)
+    cond, uncond = synth_normal((1, 77, 1024), 1), synth_normal((1, 77, 1024), 2)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    sched = lvdm_DDIM_Scheduler(ld)
+    pipe = VC2_Pipeline_T2V(ld, sched, {"params": {"unet_config": {"params": params}}})
+    x_init = synth_normal((1, 4, 16, 40, 64), 2333333)
+    rec = []
+    orig_step = sched.ddim_step
+
+    def recording_step(sample, noise_pred, indices):
+        x_prev, pred_x0 = orig_step(sample=sample, noise_pred=noise_pred, indices=indices)
+        rec.append((sample.clone(), noise_pred.clone(), x_prev.clone(), pred_x0.clone(), int(indices[0])))
+        print(f"step {len(rec)}: index {indices[0]} |e_t| {float(noise_pred.std()):.4f} |x_prev| {float(x_prev.std()):.4f} "
+              f"|x0| {float(pred_x0.std()):.4f}", flush=True)
+        return x_prev, pred_x0
+
+    sched.ddim_step = recording_step
+    torch.manual_seed(2333333)
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, den = pipe.basic_sample(prompt="a prompt", height=320, width=512, frames=16, fps=8, guidance_scale=7.5,
+                                   num_inference_steps=4, output_type="latent", latents=x_init.clone())
+    arrays = {"x_init": x_init, "denoised": den, "fps": np.int64(8), "guidance": np.float32(7.5),
+              "timesteps": np.flip(sched.ddim_timesteps).copy()}
+    for i, (x_t, e_t, x_prev, x0, idx) in enumerate(rec):
+        assert torch.equal(x_t, x_init if i == 0 else rec[i - 1][2])     # x_t of step i is x_prev of step i-1: stored once
+        arrays.update({f"e_t_{i}": e_t, f"x_prev_{i}": x_prev, f"pred_x0_{i}": x0, f"index_{i}": np.int64(idx)})
+    assert torch.equal(den, rec[-1][3])
+    save_npz("cfg1_full_t2v.npz", **arrays)
 
 
 GRID_GEOMS = {
@@ -927,6 +969,7 @@ if __name__ == "__main__":
     if args.full:
         steps["g10"] = g10_unet_full
         steps["g10i"] = g10_unet_full_i2v
+        steps["g17"] = g17_cfg1_full
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)
