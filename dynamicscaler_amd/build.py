@@ -27,8 +27,9 @@ def _newer(src_list, target):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-# diagnostic variants of the library (same ABI, loaded through DS_HIP_LIBRARY by tests/hazard_probe.py only)
-VARIANTS = {"accinit": ["-DDS_EXP_BIAS_ACC_INIT"]}
+# diagnostic variants of the library (same ABI, loaded through DS_HIP_LIBRARY by tests/hazard_probe.py only):
+# "barebarrier" = round 1's K-step barrier without the lgkmcnt(0) in front of it (profiles/r2_notes.md)
+VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"]}
 
 
 def build(force=False, verbose=True, variant=None):

@@ -240,23 +240,27 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Temporal attention, T <= 16, on the matrix cores: one wave per (batch, pixel, head) item.
-//   S^T = K Q^T   : two v_mfma_f32_16x16x32_f16 (K and Q fragments straight from global memory, 16 B per lane);
-//                   a lane then owns ONE query (lane&15) and four keys (4*(lane>>4)..+3): softmax = 4 values in
-//                   registers + two cross-lane steps (xor 16, 32);
-//   O^T = V^T P^T : four v_mfma_f32_16x16x16f16; the S^T accumulator, converted to fp16 in place, IS the B operand;
-//                   V is transposed on its way into a per-wave LDS strip (v_perm pairs, 32-bit stores);
+// Temporal attention on the matrix cores, T <= 16 * NB (NB = 1: the UNet's 16 frames; NB = 2: up to 32 frames, BASELINE
+// config 5 runs the UNet at T = 24): one wave per (batch, pixel, head) item, tokens in NB blocks of 16.
+//   S^T = K Q^T   : per (key block, query block) two v_mfma_f32_16x16x32_f16 (K and Q fragments straight from global
+//                   memory, 16 B per lane); a lane then owns ONE query per query block (lane&15) and four keys per key
+//                   block (4*(lane>>4)..+3): softmax = 4*NB values in registers + two cross-lane steps (xor 16, 32);
+//   O^T = V^T P^T : per query block four d-blocks x NB v_mfma_f32_16x16x16f16; the S^T accumulator, converted to fp16 in
+//                   place, IS the B operand; V is transposed on its way into a per-wave LDS strip (v_perm pairs, 32-bit
+//                   stores);
 //   O goes back through a per-wave LDS strip so that rows leave as 16-byte chunks.
-// ~120 vector ops per item instead of ~1250 in the VALU kernel below (which had capped the kernel at 3.3 TB/s).
+// ~120 vector ops per item (NB = 1) instead of ~1250 in the VALU kernel below (which had capped the kernel at 3.3 TB/s).
 // ---------------------------------------------------------------------------------------------------------
+template <int NB>
 __global__ void __launch_bounds__(256)
-temporal_attention16_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
-                            f16* __restrict__ out, long nseq_total, int T, int hw, int heads, int ldq, int ldk, int ldv,
-                            int ldo, float scale_log2) {
-    constexpr int VTS = 20;   // halfs per V^T row (16 keys + 4 pad)
-    constexpr int OS = 72;    // halfs per O row (64 d + 8 pad)
+temporal_attention_mfma_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+                               f16* __restrict__ out, long nseq_total, int T, int hw, int heads, int ldq, int ldk, int ldv,
+                               int ldo, float scale_log2) {
+    constexpr int TP = 16 * NB;   // token slots
+    constexpr int VTS = TP + 4;   // halfs per V^T row (TP keys + 4 pad)
+    constexpr int OS = 72;        // halfs per O row (64 d + 8 pad)
     __shared__ __attribute__((aligned(16))) f16 sVT[4][HD * VTS];
-    __shared__ __attribute__((aligned(16))) f16 sO[4][16 * OS];
+    __shared__ __attribute__((aligned(16))) f16 sO[4][TP * OS];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long item = (long)blockIdx.x * 4 + wave;
@@ -270,17 +274,21 @@ temporal_attention16_kernel(const f16* __restrict__ q, const f16* __restrict__ k
     f16* vt = sVT[wave];
     f16* so = sO[wave];
 
-    // fragments: token = lane&15 (clamped: T may be < 16), 8 consecutive d at 32*kh + 8*(lane>>4)
-    const long rowt = row0 + (long)min(r16, T - 1) * hw;
-    f16x8 qf[2], kf[2];
+    // fragments: token = 16*block + (lane&15) (clamped: T may be < TP), 8 consecutive d at 32*kh + 8*(lane>>4)
+    f16x8 qf[NB][2], kf[NB][2];
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-        qf[kh] = *reinterpret_cast<const f16x8*>(q + rowt * ldq + head * HD + 32 * kh + 8 * c16);
-        kf[kh] = *reinterpret_cast<const f16x8*>(k + rowt * ldk + head * HD + 32 * kh + 8 * c16);
+    for (int blk = 0; blk < NB; ++blk) {
+        const long rowt = row0 + (long)min(16 * blk + r16, T - 1) * hw;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            qf[blk][kh] = *reinterpret_cast<const f16x8*>(q + rowt * ldq + head * HD + 32 * kh + 8 * c16);
+            kf[blk][kh] = *reinterpret_cast<const f16x8*>(k + rowt * ldk + head * HD + 32 * kh + 8 * c16);
+        }
     }
-    // V: lane -> (key pair lane>>3, 8-column chunk lane&7); V^T[d][2*pair] = {V[2*pair][d], V[2*pair+1][d]}
-    {
-        const int pr = lane >> 3, ch = lane & 7;
+    // V: lane -> (key pair 8*blk + (lane>>3), 8-column chunk lane&7); V^T[d][2*pair] = {V[2*pair][d], V[2*pair+1][d]}
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        const int pr = 8 * blk + (lane >> 3), ch = lane & 7;
         const u32x4 v0 = *reinterpret_cast<const u32x4*>(v + (row0 + (long)min(2 * pr, T - 1) * hw) * ldv + head * HD + ch * 8);
         const u32x4 v1 = *reinterpret_cast<const u32x4*>(v + (row0 + (long)min(2 * pr + 1, T - 1) * hw) * ldv + head * HD + ch * 8);
 #pragma unroll
@@ -289,42 +297,62 @@ temporal_attention16_kernel(const f16* __restrict__ q, const f16* __restrict__ k
             *reinterpret_cast<unsigned*>(vt + (ch * 8 + j) * VTS + 2 * pr) = w;
         }
     }
-    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
-    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], s, 0, 0, 0);
-    // lane: query lane&15, keys 4*(lane>>4) + r
+    // scores: s[qb][kb], lane: query 16*qb + (lane&15), keys 16*kb + 4*(lane>>4) + r
+    f16x4 pf[NB][NB];
+    float inv[NB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (4 * c16 + r >= T) s[r] = -1e30f;
-    float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    const float mneg = -m * scale_log2;
-    float pr4[4], l = 0.0f;
+    for (int qb = 0; qb < NB; ++qb) {
+        f32x4 s[NB];
+        float m = -1e30f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        pr4[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2, mneg));
-        l += pr4[r];
+        for (int kb = 0; kb < NB; ++kb) {
+            s[kb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], s[kb], 0, 0, 0);
+            s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[qb][1], s[kb], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * kb + 4 * c16 + r >= T) s[kb][r] = -1e30f;
+            m = fmaxf(m, fmaxf(fmaxf(s[kb][0], s[kb][1]), fmaxf(s[kb][2], s[kb][3])));
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float mneg = -m * scale_log2;
+        float l = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            float pr4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr4[r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], scale_log2, mneg));
+                l += pr4[r];
+            }
+            pf[qb][kb] = f16x4{(f16)pr4[0], (f16)pr4[1], (f16)pr4[2], (f16)pr4[3]};
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        inv[qb] = __builtin_amdgcn_rcpf(l);
     }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const f16x4 pf = {(f16)pr4[0], (f16)pr4[1], (f16)pr4[2], (f16)pr4[3]};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's V^T strip is complete (LDS ops of a wave are ordered)
     __builtin_amdgcn_wave_barrier();
-    const float inv = __builtin_amdgcn_rcpf(l);
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
-        const f16x4 vf = *reinterpret_cast<const f16x4*>(vt + (16 * db + r16) * VTS + 4 * c16);
-        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-        o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, o, 0, 0, 0);
-        // O^T[d][q]: lane holds q = lane&15, d = 16*db + 4*(lane>>4) + r
-        const f16x4 w = {(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
-        *reinterpret_cast<f16x4*>(so + r16 * OS + 16 * db + 4 * c16) = w;
+        f16x4 vf[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) vf[kb] = *reinterpret_cast<const f16x4*>(vt + (16 * db + r16) * VTS + 16 * kb + 4 * c16);
+#pragma unroll
+        for (int qb = 0; qb < NB; ++qb) {
+            f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[kb], pf[qb][kb], o, 0, 0, 0);
+            // O^T[d][q]: lane holds q = 16*qb + (lane&15), d = 16*db + 4*(lane>>4) + r
+            const f16x4 w = {(f16)(o[0] * inv[qb]), (f16)(o[1] * inv[qb]), (f16)(o[2] * inv[qb]), (f16)(o[3] * inv[qb])};
+            *reinterpret_cast<f16x4*>(so + (16 * qb + r16) * OS + 16 * db + 4 * c16) = w;
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2 * NB; ++i) {
         const int idx = lane + 64 * i, tq = idx >> 3, ch = idx & 7;
         if (tq < T)
             *reinterpret_cast<u32x4*>(out + (row0 + (long)tq * hw) * ldo + head * HD + ch * 8) =
@@ -475,7 +503,9 @@ extern "C" int ds_temporal_attention_f16(const void* q, const void* k, const voi
     const int grid = (int)((items + 3) / 4);
     static const int valu_kernel = getenv("DS_TATTN_VALU") ? atoi(getenv("DS_TATTN_VALU")) : 0;   // diagnostic
     if (T <= 16 && !valu_kernel)
-        temporal_attention16_kernel<<<grid, 256, 0, st>>>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, items, T, hw, heads, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f);
+        temporal_attention_mfma_kernel<1><<<grid, 256, 0, st>>>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, items, T, hw, heads, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f);
+    else if (!valu_kernel)
+        temporal_attention_mfma_kernel<2><<<grid, 256, 0, st>>>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, items, T, hw, heads, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f);
     else if (T <= 16)
         temporal_attention_kernel<16><<<grid, 256, 0, st>>>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, items, T, hw, heads, ldq, ldk, ldv, ldo, scale);
     else

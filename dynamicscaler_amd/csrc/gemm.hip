@@ -260,13 +260,16 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const int fr = lane & 31, fh = lane >> 5;
 
     f32x16 acc[TN][TM];
-#ifdef DS_EXP_BIAS_ACC_INIT
-    // DIAGNOSTIC BUILD ONLY (tests/hazard_probe.py, `python -m dynamicscaler_amd.build --variant accinit`): a shared bias
-    // starts in the accumulators instead of being added after the K sum.  Valid arithmetic in a DIFFERENT summation order
-    // (bias + p1 + p2 + ... instead of (p1 + p2 + ...) + bias), i.e. results that differ from the product build in the
-    // last bit -- this is the variant of round 1 whose panoramas were not repeatable from process to process.
-    const bool bias_in_acc = bias && d.bias_rows >= d.M && (d.N % 8 == 0) && (d.ldbias % 4 == 0) &&
-                             (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && !(d.epilogue & DS_EPI_OUT_F32);
+    // A bias vector DECLARED shared (bias_rows > M, e.g. INT32_MAX: one vector for every row) starts in the accumulators:
+    // the epilogue then has no bias work, and launches without residual / per-item bias transpose fp16 strips (below).
+    // The sum is bias + p1 + p2 + ... instead of (p1 + p2 + ...) + bias -- the same value up to fp32 rounding, chosen per
+    // LAYER (never per batch size), so a batch stays bit-identical to its separate forwards; a per-item table
+    // (bias_rows <= M, also when it covers the launch with ONE item) is always added after the K sum.
+    // Each lane reads the 4 columns of its register quads straight from global memory (two addresses per wave-instruction,
+    // L2-resident) while the first K-steps' loads are in flight.
+    const bool bias_in_acc = bias && d.bias_rows > d.M && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.ldbias % 4 == 0) &&
+                             (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && !(d.epilogue & DS_EPI_OUT_F32) &&
+                             (!residual || d.ldr % 8 == 0);
     if (bias_in_acc) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
@@ -279,11 +282,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] = b[j];
             }
-    } else
-#else
-    constexpr bool bias_in_acc = false;
-#endif
-    {
+    } else {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -297,10 +296,24 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     // NS > 2 (deep variant for grids that leave CUs with a single workgroup): the LDS-DMA of K-step k+NS-1 is issued
     // during step k, so a lone workgroup still has NS-2 K-steps of loads in flight behind the one it waits for
     // (counted vmcnt: only the pieces of the step needed next must have landed).
+    // lgkmcnt(0) IN FRONT OF THE BARRIER IS LOAD-BEARING.  A bare s_barrier orders nothing: gfx950 does not drain the memory
+    // counters at a barrier, and the machine scheduler is free to hoist it above the MFMAs of the K-step (it does: in the
+    // 4-stage tiles the barrier lands right behind the first MFMA).  Without the wait, fragment reads (ds_read) of this
+    // K-step can still be in flight when a faster wave leaves the barrier and issues the LDS-DMA of the next K-step INTO
+    // THE STAGE THOSE READS ARE FETCHING FROM (nbuf of step kt+1 is the stage read in step kt) -- or, after the last
+    // K-step, writes its epilogue strip over it.  The window only opens when the reads are delayed beyond a DMA round trip,
+    // i.e. with another kernel contending for the CU's LDS: this was round 1's "not repeatable under two concurrently
+    // replaying hipGraphs" (profiles/r2_notes.md: found with tests/hazard_probe.py, ISA evidence, the static check
+    // tests/test_host_cpu.py::test_gemm_isa_no_lds_reads_in_flight_at_barriers).
     auto stage_sync = [&](int nbuf, bool more) {
         if constexpr (Cfg::DMA) {
+#ifdef DS_EXP_BARE_BARRIER   // round 1's form, kept ONLY so that the static ISA check can show that it detects it (never built into a library)
             if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_ROWS_PER_THREAD + B_ROWS_PER_THREAD) * (NS - 2)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+            if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((A_ROWS_PER_THREAD + B_ROWS_PER_THREAD) * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         } else {
@@ -431,7 +444,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                         (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     const bool fast = (!out_f32 || fast32) && (d.N % 8 == 0) && (d.ldc % 8 == 0 || fast32) && (!residual || d.ldr % 8 == 0) &&
                       (!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0));
-    const bool shared_bias = bias && d.bias_rows >= d.M;
+    const bool shared_bias = bias && d.bias_rows >= d.M;   // (bias_rows == M: a per-item table covering the launch with one item)
 
     // ---- epilogue.  D[i][j] of an MFMA tile: j = lane&31 is the output row m, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     //      the column n.  Each wave moves its own tiles through its private LDS strip (32 rows x up to NG tiles, fp32),
@@ -480,9 +493,8 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         // there -- the same fp32 operations and the same single rounding as the fp32-strip path below, so the bits are
         // identical -- and the strip carries halfs: half the LDS bytes (the epilogue of a 256x320 tile moves 655 KB
         // through the LDS in fp32 and is LDS-bandwidth bound), and a sweep is one 16-byte read and one 16-byte store
-        // with nothing in between, so all sweeps of a group are in flight together.  (Launches WITH a shared bias stay on
-        // the fp32 strips: moving the bias into the accumulators was not repeatable under concurrent graph replays,
-        // profiles/r1_notes.md.)
+        // with nothing in between, so all sweeps of a group are in flight together.  A shared bias is already in the
+        // accumulators (bias_in_acc above).
         if constexpr (!RES && !PIB) {
             if (fast && !out_f32 && (!bias || GE || bias_in_acc)) {
                 constexpr int NGH_ = TNE < 2 * NG ? TNE : 2 * NG;      // tiles per group in the same strip bytes,

@@ -282,7 +282,7 @@ def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE
         d.t_len, d.hw = tconv
     d.ldc = out.stride(0)
     d.ldr = residual.stride(0) if residual is not None else 0
-    d.bias_rows = M if bias_rows is None else bias_rows
+    d.bias_rows = 0x7FFFFFFF if bias_rows is None else bias_rows      # > M: one shared bias vector (summed first)
     d.ldbias = N if ldbias is None else ldbias
     d.epilogue = epilogue
     st = _stream() if stream is None else stream

@@ -159,7 +159,10 @@ typedef struct ds_gemm_desc {
     int32_t t_len, hw;      /* TCONV: frames per sequence, rows per frame (M == nseq*t_len*hw)              */
     int32_t ldc;            /* output row stride in elements                                                */
     int32_t ldr;            /* residual row stride (elements)                                               */
-    int32_t bias_rows;      /* bias index = (m / bias_rows) * ldbias + n ; bias_rows >= M -> one shared vector */
+    int32_t bias_rows;      /* bias index = (m / bias_rows) * ldbias + n ; bias_rows >= M -> one shared vector.  A vector
+                             * DECLARED shared with bias_rows > M (e.g. INT32_MAX) is summed FIRST (the accumulators start
+                             * at it); bias_rows <= M is added after the K sum, so a per-item table gives the same bits
+                             * whether a launch covers one item or many. */
     int32_t ldbias;         /* row stride of the bias table in floats (>= N)                                */
     int32_t epilogue;       /* DS_EPI_* flags                                                               */
     int32_t asym_pad;       /* CONV3: 0 = zero padding 1 on every side; 1 = no top/left padding, bottom/right only

@@ -107,9 +107,11 @@ def t2v_ring_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, *,
                     frames=16, guidance_scale=7.5, total_w, total_h, num_windows_w, num_windows_h,
                     num_windows_f=1, loop_step=8, dock_at_h=None, num_inference_steps=4,
                     init_panorama_latent=None, merge_renoised_overlap_latent_ratio=1, in_channels=4,
-                    trace=None, on_tile=None):
+                    trace=None, on_tile=None, window_multi_prompt_dict=None, get_learned_conditioning=None):
     """VC2_Pipeline_T2V_SpherePano.basic_sample_shift_multi_windows, output_type='latent'
-    (t2v_sphere_panorama_pipeline.py:316-660).  Returns (denoised, denoised, final_latent)."""
+    (t2v_sphere_panorama_pipeline.py:316-660).  Returns (denoised, denoised, final_latent).
+    window_multi_prompt_dict / get_learned_conditioning: the per-window prompt (:561-566, utils/multi_prompt_utils.py:1-7):
+    the prompt of the first key >= window_down / total_latent_h, re-encoded for every window."""
     sched = DDIMSchedule(tables, num_inference_steps)
     timesteps = np.flip(sched.ddim_timesteps)
     total_steps = len(timesteps)
@@ -136,6 +138,12 @@ def t2v_ring_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, *,
                 wmask3 = wmask[0, 0, [0]]  # :555 -> [1,h,w]
                 win = mix_latents_with_mask(win, noised, wmask3, merge_renoised_overlap_latent_ratio)
             ts = torch.full((1,), int(t), dtype=torch.long)
+            if window_multi_prompt_dict is not None:
+                factor = dn / (total_h // VAE_SCALE)
+                assert 0.0 <= factor <= 1.0, f"select_prompt: input factor {factor} not legal"   # multi_prompt_utils.py:2
+                keys = sorted(window_multi_prompt_dict.keys())
+                chosen = next((window_multi_prompt_dict[k] for k in keys if factor <= k), window_multi_prompt_dict[keys[-1]])
+                cond_ctx = get_learned_conditioning([chosen])   # stays bound for the following windows, like `text_emb` (:565)
             e_c = eps_model(win, ts, cond_ctx)
             if guidance_scale != 1.0:
                 e_u = eps_model(win, ts, uncond_ctx)

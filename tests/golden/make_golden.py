@@ -18,6 +18,9 @@ so parity is pinned by what this script captures from the imported reference cod
   G12 sphere.npz             _get_uv index maps (gen_pano_360 view set, one view at all 10 theta offsets), sphere
                              gather/scatter round trips (duplicate winners), t2v sphere loop (P5), fake eps + tiny UNet
   G10 unet_full_{t2v,i2v}.npz (--full) full-size t2v / i2v UNet eps at tile [1,4,16,40,64] (3 forwards, ~3 min)
+  G18 unet_t24.npz           (--full) the UNet at T = 24 (config 5): toy config and the real t2v UNet, one forward each
+  G19 loops_multiprompt.npz  per-window prompt selection (window_multi_prompt_dict) on the toy dock geometry
+  G20 loop_trace_cfg4_i2v.json  BASELINE config 4 geometry through the reference's i2v ring loop (fake eps): trace + SHA-256
   G17 cfg1_full_t2v.npz      (--full) BASELINE config 1: basic_sample, real t2v UNet, 512x320x16f, 4 steps, CFG 7.5;
                              per-step x_t / e_t / x_prev / pred_x0 (8 forwards, ~8 min)
 
@@ -401,6 +404,107 @@ def g17_cfg1_full():
         arrays.update({f"e_t_{i}": e_t, f"x_prev_{i}": x_prev, f"pred_x0_{i}": x0, f"index_{i}": np.int64(idx)})
     assert torch.equal(den, rec[-1][3])
     save_npz("cfg1_full_t2v.npz", **arrays)
+
+
+
+def g18_unet_t24(full=False):
+    """BASELINE config 5 runs the UNet at T = 24 (`frames=24`, t2v_sphere_panorama_pipeline.py:411 -> UNetModel.forward with
+    a 24-frame tile, openaimodel3d.py:657-708): one forward of the reference at T = 24, toy config and (--full) the real
+    t2v UNet at tile [1,4,24,40,64]."""
+    arrays = {}
+    p = dict(TINY)
+    m = build_reference_unet(p, seed=5)
+    x = synth_normal((1, 4, 24, 8, 16), 70)
+    ctx = synth_normal((1, 77, 64), 71)
+    with torch.no_grad():
+        arrays.update(tiny_x=x, tiny_ctx=ctx, tiny_t=np.int64(640), tiny_fps=np.int64(8),
+                      tiny_eps=m(x, torch.tensor([640]), context=ctx, fps=8))
+    arrays["tiny_params_json"] = np.frombuffer(json.dumps(p).encode(), dtype=np.uint8)
+    if full:
+        params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+        params = params["model"]["params"]["unet_config"]["params"]
+        torch.set_num_threads(os.cpu_count())
+        m = build_reference_unet(params, seed=0)
+        x = synth_normal((1, 4, 24, 40, 64), 2333335)
+        ctx = synth_normal((1, 77, 1024), 1)
+        with torch.no_grad():
+            eps = m(x, torch.tensor([777]), context=ctx, fps=8)
+        print("t24 full", float(eps.abs().mean()), float(eps.std()))
+        arrays.update(full_x=x, full_t=np.int64(777), full_fps=np.int64(8), full_eps=eps)
+    save_npz("unet_t24.npz", **arrays)
+
+
+
+def g19_multi_prompt():
+    """R13: per-window prompt selection (`window_multi_prompt_dict`, t2v_sphere_panorama_pipeline.py:561-566,
+    utils/multi_prompt_utils.py:1-7) on the toy `dock` geometry (dock_at_h keeps every window's lower edge inside the
+    panorama; without it the reference's own factor assert fires as soon as a window wraps in H -- recorded as
+    `grid4x2_raises`).  Prompts map to seeded embeddings; fake eps and the tiny UNet."""
+    prompts = {"a prompt": synth_normal((1, 77, 64), 61), "": synth_normal((1, 77, 64), 62),
+               "sky": synth_normal((1, 77, 64), 63), "ground": synth_normal((1, 77, 64), 64)}
+
+    class PromptLD(FakeLatentDiffusion):
+        def get_learned_conditioning(self, p):
+            return prompts[p[0]]
+
+    mp = {0.7: "sky", 1.0: "ground"}
+    unet = build_reference_unet(dict(TINY), seed=5)
+    arrays = {f"emb_{k or 'empty'}".replace(" ", "_"): v for k, v in prompts.items()}
+    out = {"multi_prompt_dict": {str(k): v for k, v in mp.items()}, "geom": "dock"}
+    for eps_name, eps_mod in (("fake", FakeEps()), ("tiny", WrappedUNet(unet))):
+        ld = PromptLD(eps_mod, prompts["a prompt"], prompts[""], temporal_length=4)
+        den, trace = run_ring_pipeline(ld, dict(TINY), 2333333, fps=8, guidance_scale=7.5, window_multi_prompt_dict=mp,
+                                       **SMALL_GEOMS["dock"])
+        arrays[f"ring_dock_multiprompt_{eps_name}"] = den
+        out["trace"] = trace
+    ld = PromptLD(FakeEps(), prompts["a prompt"], prompts[""], temporal_length=4)
+    try:
+        run_ring_pipeline(ld, dict(TINY), 2333333, fps=8, guidance_scale=7.5, window_multi_prompt_dict=mp, **SMALL_GEOMS["grid4x2"])
+        out["grid4x2_raises"] = None
+    except AssertionError as e:
+        out["grid4x2_raises"] = str(e)
+    save_npz("loops_multiprompt.npz", **arrays)
+    with open(os.path.join(HERE, "loops_multiprompt.json"), "w") as f:
+        json.dump(out, f)
+    print("multi-prompt:", out["grid4x2_raises"])
+
+
+
+CFG4_GEOM = dict(height=320, width=512, frames=16, total_w=4096, total_h=512, total_f=16, num_windows_w=8, num_windows_h=2,
+                 num_windows_f=1, loop_step=8, num_inference_steps=8, overlap_ratio_list_f=[0.0] * 8,
+                 merge_prev_denoised_ratio_list=[0.5, 0.45, 0.4, 0.35, 0.3, 0.25, 0.2, 0.15])
+
+
+def g20_cfg4_geometry():
+    """BASELINE config 4 (i2v_sphere_panorama 4096x512x16f, 8x2 windows): the reference's i2v overlapped-ring loop
+    (i2v_sphere_panorama_pipeline.py:564-996) at the full-size geometry with the fake eps-model, a synthetic panorama image
+    (input/pano_surfing_1.png is absent from the reference tree) and the synthetic image embedder (77 + 16 = 93 tokens per
+    window): window trace + SHA-256 of the final pred-x0 panorama, 8 of the 50 steps' shifted-window sequence."""
+    import utils.shift_window_utils as swu
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    cond, uncond = synth_normal((1, 77, 64), 61), synth_normal((1, 77, 64), 62)
+    embed = synth_image_embedder(64)
+    pano_img = synth_normal((3, 512, 4096), 188).clamp(-1, 1)
+    orig_loader = swu.load_image_tensor_from_path
+    swu.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: pano_img   # I/O stub (cv2 absent)
+    try:
+        ld = FakeLatentDiffusion(FakeEps(), cond, uncond, temporal_length=16)
+        ld.get_image_embeds = embed
+        ld.embedder = object()
+        pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": {"in_channels": 4}}}})
+        pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+        buf = io.StringIO()
+        torch.manual_seed(2333333)
+        with contextlib.redirect_stdout(buf):
+            _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", img_cond_path="unused.png", fps=8, guidance_scale=7.5,
+                                                           pano_image_path="unused.png", output_type="latent", **CFG4_GEOM)
+    finally:
+        swu.load_image_tensor_from_path = orig_loader
+    out = {"geom": CFG4_GEOM, "trace": parse_trace(buf.getvalue()), "denoised_sha256": sha(den), "shape": list(den.shape),
+           "pano_img_seed": 188, "embedder_dim": 64}
+    with open(os.path.join(HERE, "loop_trace_cfg4_i2v.json"), "w") as f:
+        json.dump(out, f)
+    print("cfg4 i2v ring: tiles/step", sorted({len(s["windows"]) for s in out["trace"]}), out["denoised_sha256"][:12])
 
 
 GRID_GEOMS = {
@@ -965,11 +1069,12 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry}
     if args.full:
         steps["g10"] = g10_unet_full
         steps["g10i"] = g10_unet_full_i2v
         steps["g17"] = g17_cfg1_full
+        steps["g18"] = lambda: g18_unet_t24(full=True)
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)

@@ -7,8 +7,9 @@ gave panoramas that differed in the last fp16 bit from process to process.
     python tests/hazard_probe.py poison            every kernel preceded by the LDS / register poison launch
     python tests/hazard_probe.py pipe   [runs]     the toy ring pipeline (2 streams x graphs) repeated in this process
 
-DS_HIP_LIBRARY=dynamicscaler_amd/libdynscaler_hip_accinit.so selects the diagnostic build whose different summation
-order made the instability visible (python -m dynamicscaler_amd.build --variant accinit).
+DS_HIP_LIBRARY=dynamicscaler_amd/libdynscaler_hip_barebarrier.so selects the diagnostic build with round 1's bare K-step
+barrier (python -m dynamicscaler_amd.build --variant barebarrier): the root cause found with this probe
+(profiles/r2_notes.md).
 Writes one JSON line per finding to stdout.
 """
 import hashlib
@@ -91,16 +92,16 @@ def probe_unet(rounds):
                 out = m(x, ts, context=ctx, fps=8, cfg_pairs=n)
             rec.on = False
             kept = list(rec.log) + [("final:eps", out)]
-            graphs.append((g, kept))
+            graphs.append((g, kept, (x, ctx, ts)))     # the static inputs stay alive with the graph
         # serial references
         refs = []
-        for slot, (g, kept) in enumerate(graphs):
+        for slot, (g, kept, _in) in enumerate(graphs):
             with torch.cuda.stream(streams[slot]):
                 g.replay()
             torch.cuda.synchronize()
             refs.append([t.clone() for _, t in kept])
         # serial repeatability first
-        for slot, (g, kept) in enumerate(graphs):
+        for slot, (g, kept, _in) in enumerate(graphs):
             with torch.cuda.stream(streams[slot]):
                 g.replay()
             torch.cuda.synchronize()
@@ -119,7 +120,7 @@ def probe_unet(rounds):
                     for _ in range(reps):
                         graphs[slot][0].replay()
             torch.cuda.synchronize()
-            for slot, (g, kept) in enumerate(graphs):
+            for slot, (g, kept, _in) in enumerate(graphs):
                 bad = [(i, nm) for i, ((nm, t), rf) in enumerate(zip(kept, refs[slot])) if not torch.equal(t, rf)]
                 if bad:
                     nbad += 1

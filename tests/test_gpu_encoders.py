@@ -12,7 +12,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(__file__), "golden")
-TOL = 1e-2          # fp16 activations / fp32 accumulation vs fp32 CPU, rel-L2 over the output tokens
+TOL = 3.2e-3        # fp16 activations / fp32 accumulation vs fp32 CPU, rel-L2 over the output tokens: 2x the largest
+                    # measured value (image tower 1.6e-3; text tower 1.2e-3, Resampler 8.5e-4, crop chain 7.7e-4)
 
 
 def dev():

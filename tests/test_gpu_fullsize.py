@@ -70,11 +70,20 @@ def full_host(d):
 
 
 # Measured on MI355X (round 2, gpurun_out/measured_parity.jsonl -> DESIGN.md section 5); asserted at <= 2x measured.
+# Per DDIM step of the 4-step schedule (t = 999, 666, 333, 0), fp16 latents (fp32 latents are never worse):
+#   measured e_t (CFG-combined eps)   1.01e-2  7.2e-3  6.8e-3  6.7e-3      (single forward: 1.66e-3; CFG 7.5 amplifies 4-6x)
+#   measured x_prev, teacher-forced   3.70e-3  4.3e-4  3.2e-4  2.1e-4
+#   measured pred_x0, teacher-forced  4.45e-3  5.4e-4  3.2e-4  3.0e-4
+#   measured free-running x_prev / pred_x0: 3.7e-3 / 4.4e-3 at step 0, then 3.7e-3 (the step-0 error carried along)
+# The north-star 1e-3 holds for every step but the first, whose update x_prev = 2.8 x - 1.9 e_t (alpha 0.005 -> 0.18)
+# multiplies the eps error; DESIGN.md section 5 shows why fp16 matrix-core operands cannot reach 1e-3 there.
 CFG1_TOL = {
-    # (latent dtype, quantity): tolerance per step index 0..3
-    "teacher_x_prev": 1.0e-2, "teacher_pred_x0": 1.0e-2, "teacher_e_t": 2.0e-2,
-    "free_x_prev": 2.0e-2, "free_pred_x0": 2.0e-2,
+    "teacher_e_t": [2.0e-2, 1.45e-2, 1.4e-2, 1.35e-2],
+    "teacher_x_prev": [7.4e-3, 8.6e-4, 6.4e-4, 4.2e-4],
+    "teacher_pred_x0": [8.9e-3, 1.0e-3, 6.5e-4, 6.0e-4],
+    "free_x_prev": [7.4e-3] * 4, "free_pred_x0": [8.9e-3, 7.4e-3, 7.4e-3, 7.4e-3],
 }
+NORTH_STAR = 1e-3
 
 
 @pytest.mark.parametrize("latent_dtype", [torch.float16, torch.float32])
@@ -111,8 +120,10 @@ def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype):
                  x_prev=relerr(xp, T(z[f"x_prev_{i}"])), pred_x0=relerr(x0, T(z[f"pred_x0_{i}"])))
         print(r)
         record(**r)
-        assert r["e_t"] < CFG1_TOL["teacher_e_t"] and r["x_prev"] < CFG1_TOL["teacher_x_prev"] \
-            and r["pred_x0"] < CFG1_TOL["teacher_pred_x0"], r
+        assert r["e_t"] < CFG1_TOL["teacher_e_t"][i] and r["x_prev"] < CFG1_TOL["teacher_x_prev"][i] \
+            and r["pred_x0"] < CFG1_TOL["teacher_pred_x0"][i], r
+        if i > 0:       # the north-star tolerance itself, on x_prev AND pred_x0, for every step after the first
+            assert r["x_prev"] < NORTH_STAR and r["pred_x0"] < NORTH_STAR, r
     # ---- free-running: the pipeline's own loop from the same init latent ----
     lat = T(z["x_init"]).to(d, latent_dtype)
     for i, t in enumerate(timesteps):
@@ -121,12 +132,12 @@ def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype):
                  pred_x0=relerr(den, T(z[f"pred_x0_{i}"])))
         print(r)
         record(**r)
-        assert r["x_prev"] < CFG1_TOL["free_x_prev"] and r["pred_x0"] < CFG1_TOL["free_pred_x0"], r
+        assert r["x_prev"] < CFG1_TOL["free_x_prev"][i] and r["pred_x0"] < CFG1_TOL["free_pred_x0"][i], r
     # basic_sample itself (the drop-in entry point) returns the same thing bit for bit
     _, den2 = pipe.basic_sample(prompt="a prompt", height=320, width=512, frames=16, fps=int(z["fps"]), guidance_scale=g,
                                 num_inference_steps=4, output_type="latent", latents=T(z["x_init"]))
     assert torch.equal(den2, den)
-    assert relerr(den2, T(z["denoised"])) < CFG1_TOL["free_pred_x0"]
+    assert relerr(den2, T(z["denoised"])) < CFG1_TOL["free_pred_x0"][3]
 
 
 def test_error_budget_layerwise_full_size():
@@ -172,7 +183,8 @@ def test_error_budget_layerwise_full_size():
     for row in table:
         assert row["rel_l2"] < 3 * max(prev, 2e-4) + 1e-3, f"error jumps at {row['block']}: {prev:.2e} -> {row['rel_l2']:.2e}"
         prev = row["rel_l2"]
-    assert table[-1]["rel_l2"] < 5e-3
+    assert max(r["rel_l2"] for r in table) < 5.0e-3      # measured: peaks at 2.5e-3 (output_blocks.2.1)
+    assert table[-1]["rel_l2"] < 3.4e-3                   # measured 1.66e-3
 
 
 @pytest.mark.parametrize("size", ["toy", "full"])
@@ -239,3 +251,116 @@ def test_no_kernel_reads_uninitialised_cu_state(size):
         assert bool(torch.isfinite(clean).all())
         assert torch.equal(clean, dirty), f"{size} {shape}: {int((clean != dirty).sum())} elements changed by the poison run " \
                                           f"(nan: {bool(torch.isnan(dirty).any())})"
+
+
+T24_TOL = {"tiny": 1.0e-2, "full": 1.0e-2}   # tightened to <= 2x measured below once measured
+
+
+@pytest.mark.parametrize("size", ["tiny", "full"])
+def test_unet_t24_vs_reference_golden(size):
+    """BASELINE config 5 runs the UNet at T = 24 (temporal attention over 24 tokens: the two-block MFMA kernel; joint-T
+    GroupNorm and the (3,1,1) convolutions over 24 frames): one forward against the reference's own
+    (tests/golden/unet_t24.npz, make_golden.py g18)."""
+    from dynamicscaler_amd.synth import synth_normal, synth_state_dict
+    from dynamicscaler_amd.unet import UNetModel
+    from dynamicscaler_amd.unet_spec import param_shapes
+    d = dev()
+    z = np.load(os.path.join(G, "unet_t24.npz"))
+    if size == "tiny":
+        params = json.loads(bytes(z["tiny_params_json"]).decode())
+        m = UNetModel(**params)
+        m.load_state_dict(synth_state_dict(param_shapes(params), 5), strict=True)
+        m = m.to(d).eval()
+        ctx = T(z["tiny_ctx"])
+    else:
+        ld, params, _ = full_host(d)
+        m = ld.model.diffusion_model
+        ctx = synth_normal((1, 77, 1024), 1)
+    x, t, fps = T(z[f"{size}_x"]), int(z[f"{size}_t"]), int(z[f"{size}_fps"])
+    assert x.shape[2] == 24
+    eps = m(x.to(d, torch.float16), torch.tensor([t], device=d), context=ctx.to(d), fps=fps)
+    e = relerr(eps, T(z[f"{size}_eps"]))
+    r = dict(test="unet_t24", size=size, eps=e)
+    print(r)
+    record(**r)
+    assert eps.shape == x.shape and e < T24_TOL[size]
+
+
+@pytest.mark.parametrize("size", ["toy", "full"])
+def test_concurrent_graph_replays_repeatable(size):
+    """Two hipGraphs of the batched UNet evaluation replaying CONCURRENTLY on two streams (bench.py's default mode) with
+    random relative delays: every replay must reproduce the serial replay bit for bit -- at the toy size (4-stage LDS-DMA
+    tiles, the ones that raced in round 1's withdrawn build) with every kernel's output compared, and at full size (the
+    256-row one-workgroup-per-CU tiles) on the final eps.  The withdrawn build fails this in about 1 round of 20
+    (gpurun_out/s3, profiles/r2_notes.md); the deterministic form of the same check is the ISA test in test_host_cpu.py."""
+    from dynamicscaler_amd import ops
+    from dynamicscaler_amd.synth import synth_normal, synth_state_dict
+    from dynamicscaler_amd.unet import UNetModel
+    from dynamicscaler_amd.unet_spec import param_shapes
+    d = dev()
+    if size == "toy":
+        zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+        params = json.loads(bytes(zt["params_json"]).decode())
+        m = UNetModel(**params)
+        m.load_state_dict(synth_state_dict(param_shapes(params), 5), strict=True)
+        m = m.to(d).eval()
+        m.prepare(d)
+        shape, cdim, n, rounds = (2, 4, 4, 8, 16), 64, 2, 120
+    else:
+        ld, params, _ = full_host(d)
+        m = ld.model.diffusion_model
+        shape, cdim, n, rounds = (1, 4, 16, 40, 64), 1024, 1, 12
+    names = ["gemm", "groupnorm", "layernorm", "attention", "temporal_attention", "concat_channels", "rows_to_ncthw"]
+    orig = {k: getattr(ops, k) for k in names}
+    log = []
+    keep = size == "toy"
+
+    def wrap(k):
+        def f(*a, **kw):
+            out = orig[k](*a, **kw)
+            if keep:
+                log.append((f"{len(log)}:{k} M{kw.get('M')} N{kw.get('N')} K{kw.get('K')}", out))
+            return out
+        return f
+
+    streams = [torch.cuda.Stream(d), torch.cuda.Stream(d)]
+    graphs = []
+    try:
+        for k in names:
+            setattr(ops, k, wrap(k))
+        for slot in range(2):
+            tiles = synth_normal(shape, 100 + slot).to(d, torch.float16)
+            x = torch.cat([tiles, tiles], 0)
+            ctx = torch.cat([synth_normal((1, 77, cdim), 61)] * n + [synth_normal((1, 77, cdim), 62)] * n, 0).to(d)
+            ts = torch.full((2 * n,), 500 + slot, device=d, dtype=torch.long)
+            with torch.cuda.stream(streams[slot]):
+                m(x, ts, context=ctx, fps=8, cfg_pairs=n)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            del log[:]
+            with torch.cuda.graph(g):
+                out = m(x, ts, context=ctx, fps=8, cfg_pairs=n)
+            graphs.append((g, list(log) + [("final:eps", out)], (x, ctx, ts)))
+    finally:
+        for k in names:
+            setattr(ops, k, orig[k])
+    refs = []
+    for slot, (g, kept, _in) in enumerate(graphs):
+        with torch.cuda.stream(streams[slot]):
+            g.replay()
+        torch.cuda.synchronize()
+        refs.append([t.clone() for _, t in kept])
+    gen = torch.Generator().manual_seed(5)
+    for r in range(rounds):
+        reps = 1 + int(torch.randint(0, 3, (1,), generator=gen))
+        delay = int(torch.randint(0, 200000, (1,), generator=gen))
+        for slot in ((0, 1) if r % 2 == 0 else (1, 0)):
+            with torch.cuda.stream(streams[slot]):
+                if slot == r % 2:
+                    torch.cuda._sleep(delay)
+                for _ in range(reps):
+                    graphs[slot][0].replay()
+        torch.cuda.synchronize()
+        for slot, (g, kept, _in) in enumerate(graphs):
+            bad = [nm for (nm, t), rf in zip(kept, refs[slot]) if not torch.equal(t, rf)]
+            assert not bad, f"{size}: round {r}, slot {slot}: first diverging kernel {bad[0]} ({len(bad)} of {len(kept)} outputs)"

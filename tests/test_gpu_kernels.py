@@ -352,7 +352,7 @@ def test_attention_matches_softmax_reference(nq, nk, batch, heads, kvdiv):
     assert relerr(out.float().cpu().reshape(batch, nq, C), 2 * ref) < 3e-3
 
 
-@pytest.mark.parametrize("T", [16, 4, 24])
+@pytest.mark.parametrize("T", [16, 4, 24, 17, 32, 1])
 def test_temporal_attention(T):
     from dynamicscaler_amd import ops
     d = dev()

@@ -11,10 +11,17 @@ pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
-# fp16 activations / fp32 accumulation vs the reference's fp32 CPU path.  BASELINE.json's north_star asks for
-# 1e-3 rel on fp16 LATENTS (x_prev / pred_x0 after a DDIM update); eps itself is compared with EPS_TOL.
-EPS_TOL = 1e-2
-LATENT_TOL = 1e-3
+# fp16 activations / fp32 accumulation vs the reference's fp32 CPU path.  Every tolerance below is <= 2x the value
+# measured on MI355X in round 2 (gpurun_out/s2/gputest_verbose.log; DESIGN.md section 5 has the table and the error
+# budget that explains the numbers).  BASELINE.json's north_star asks for 1e-3 rel on fp16 LATENTS.
+EPS_TOL_TINY = 4.4e-3   # toy UNet eps, measured 2.0e-3 .. 2.2e-3
+EPS_TOL = 3.5e-3        # full-size t2v / i2v UNet eps, measured 1.66e-3 / 1.70e-3 / 1.72e-3
+LATENT_TOL = 7.2e-4     # x_prev after CFG 7.5 + one DDIM update of the 50-step schedule (index 25), measured 3.6e-4
+PRED_X0_TOL = 8e-3      # pred_x0 of the same update, measured 3.9e-3: (x - sqrt(1-a) e_t)/sqrt(a) amplifies the CFG-combined
+                        # eps error by sqrt((1-a)/a); see DESIGN.md section 5 for why 1e-3 is out of reach of fp16 operands
+PIPE_TOL = 9e-3         # toy pipelines end to end (4-6 DDIM steps, CFG 7.5, tiny UNet), fp16 or fp32 latents: measured
+PIPE_TOL_F16 = PIPE_TOL  # 3.7e-3 .. 4.4e-3
+VAE_TOL = 5.4e-3        # first stage: decode 1.4e-3 (toy) / 2.6e-3 (real config), encode moments 8.8e-4 / 1.0e-3
 
 
 def dev():
@@ -54,7 +61,7 @@ def test_unet_tiny_vs_reference_golden(name):
             e = relerr(eps, T(z[f"eps_{case}"]))
             print(f"tiny {name} case {case} {xdt}: eps rel err {e:.3e}")
             assert eps.shape == tuple(z[f"eps_{case}"].shape) and eps.dtype == torch.float32
-            assert e < EPS_TOL
+            assert e < EPS_TOL_TINY
 
 
 @pytest.mark.parametrize("name", ["t2v", "i2v"])
@@ -144,7 +151,7 @@ def test_unet_full_size_vs_reference_golden():
                           sched.step_coefficients(index))
     l1, l2 = relerr(xp, rxp), relerr(x0, rx0)
     print(f"after CFG 7.5 + DDIM step {index}/50: x_prev rel err {l1:.3e}, pred_x0 rel err {l2:.3e}")
-    assert l1 < LATENT_TOL
+    assert l1 < LATENT_TOL and l2 < PRED_X0_TOL
 
 
 def test_unet_full_size_i2v_vs_reference_golden():
@@ -186,7 +193,7 @@ def test_pipelines_small_vs_reference_golden():
     cond, uncond = T(z["cond"]), T(z["uncond"])
     ld = _host(params, 5, cond, uncond, d)
     cfgd = {"params": {"unet_config": {"params": params}}}
-    for dt, tol in ((torch.float32, 2e-2), (torch.float16, 3e-2)):
+    for dt, tol in ((torch.float32, PIPE_TOL), (torch.float16, PIPE_TOL)):
         pipe = VC2_Pipeline_T2V(ld, lvdm_DDIM_Scheduler(ld), cfgd).to(d, dt)
         torch.manual_seed(2333333)
         _, den = pipe.basic_sample(prompt="a prompt", height=64, width=128, frames=4, fps=8, guidance_scale=7.5,
@@ -329,6 +336,54 @@ def test_ring_pipeline_fake_eps_bit_exact_fp32():
         assert relerr(den, T(z[f"ring_{gname}_fake"])) < 1e-4          # and the reference's own panorama (other host's RNG)
 
 
+def test_ring_pipeline_multi_prompt_vs_oracle_and_reference_golden():
+    """R13: `window_multi_prompt_dict` (t2v_sphere_panorama_pipeline.py:561-566, utils/multi_prompt_utils.py:1-7) on the toy
+    dock geometry.  Fake eps, fp32 latents: bit-equal to the oracle on this host and 1e-4 from the reference's panorama
+    (other host's RNG stream); tiny UNet: within tolerance of the reference's panorama; a window whose lower edge wraps
+    (grid4x2) trips the same factor assert as the reference."""
+    from oracle import loops as oloops, ddim as oddim
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    d = dev()
+    z = np.load(os.path.join(G, "loops_multiprompt.npz"))
+    meta = json.load(open(os.path.join(G, "loops_multiprompt.json")))
+    geoms = json.load(open(os.path.join(G, "loops_small_traces.json")))["geoms"]
+    emb = {"a prompt": T(z["emb_a_prompt"]), "": T(z["emb_empty"]), "sky": T(z["emb_sky"]), "ground": T(z["emb_ground"])}
+    mp = {float(k): v for k, v in meta["multi_prompt_dict"].items()}
+    geom = geoms[meta["geom"]]
+    ld = _fake_host(emb["a prompt"], emb[""], d)
+    ld.get_learned_conditioning = lambda p: emb[p[0]]
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": {"in_channels": 4}}}})
+    pipe.to(d, torch.float32)
+    trace = []
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                   window_multi_prompt_dict=mp,
+                                                   step_callback=lambda i, t, wins, p, p0: trace.append(wins), **geom)
+    torch.manual_seed(2333333)
+    ref, _, _ = oloops.t2v_ring_sample(_oracle_fake, oddim.DiffusionTables(), emb["a prompt"], emb[""], guidance_scale=7.5,
+                                       window_multi_prompt_dict=mp, get_learned_conditioning=lambda p: emb[p[0]], **geom)
+    assert torch.equal(den.cpu(), ref)
+    assert relerr(den, T(z["ring_dock_multiprompt_fake"])) < 1e-4
+    assert [[list(w) for w in wins] for wins in trace] == [s["windows"] for s in meta["trace"]]
+    with pytest.raises(AssertionError, match="not legal"):
+        torch.manual_seed(2333333)
+        pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                              window_multi_prompt_dict=mp, **geoms["grid4x2"])
+    # tiny UNet
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    ld2 = _host(params, 5, emb["a prompt"], emb[""], d)
+    ld2.conditioner = lambda p: emb[p[0]]
+    pipe = VC2_Pipeline_T2V_SpherePano(ld2, lvdm_DDIM_Scheduler(ld2), {"params": {"unet_config": {"params": params}}}).to(d, torch.float16)
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                   window_multi_prompt_dict=mp, **geom)
+    e = relerr(den, T(z["ring_dock_multiprompt_tiny"]))
+    print(f"multi-prompt ring, tiny UNet: rel err {e:.3e}")
+    assert e < PIPE_TOL_F16
+
+
 @pytest.mark.parametrize("name", ["cfg2_2048x512", "cfg3_4096x512", "cfg3_overlap_nw10", "cfg5_8192x1024x24"])
 def test_ring_pipeline_baseline_geometries_fake_eps_bit_exact(name):
     """BASELINE.json's full-size geometries (configs 2, 3, 3 with W overlap, 5: up to an 8192x1024x24f panorama, 64 tiles
@@ -427,7 +482,7 @@ def test_grid_pipeline_vs_reference_golden():
                                                    guidance_scale=7.5, output_type="latent", **meta["grid_geoms"]["plain"])
     e = relerr(den, T(z["grid_plain_tiny"]))
     print(f"grid plain tiny fp16: rel err {e:.3e}")
-    assert e < 3e-2
+    assert e < PIPE_TOL
 
 
 def test_grid_pipeline_pre_denoise_and_residual_merge():
@@ -468,7 +523,7 @@ def test_grid_pipeline_pre_denoise_and_residual_merge():
                                                    guidance_scale=7.5, output_type="latent", **meta["grid_pre_geoms"]["pre_sparse"])
     e = relerr(den, T(z["gridpre_pre_sparse_tiny"]))
     print(f"grid pre_sparse tiny fp16: rel err {e:.3e}")
-    assert e < 3e-2
+    assert e < PIPE_TOL
     with pytest.raises(NotImplementedError):
         pipe.basic_sample_shift_multi_windows(prompt="a", height=64, width=128, frames=4, num_windows_w=1, num_windows_h=1,
                                               num_windows_f=2, loop_step=2, num_inference_steps=3, output_type="latent",
@@ -517,7 +572,44 @@ def test_i2v_ring_pipeline_vs_reference_golden():
                                                    pano_image_tensor=pano_img, **meta["i2v_geoms"]["ring"])
     e = relerr(den, T(z["i2v_ring_tiny"]))
     print(f"i2v ring tiny fp16: rel err {e:.3e}")
-    assert e < 3e-2
+    assert e < PIPE_TOL
+
+
+def test_i2v_ring_pipeline_cfg4_geometry_fake_eps_bit_exact():
+    """BASELINE config 4 at full size (i2v ring 4096x512x16f, 8x2 windows, 77 + 16 = 93 context tokens per window, per-window
+    image crops, 5-D mask, merge-prev) through the HIP tile engine with the fake eps-model in fp32: window trace equal to
+    the reference's, final pred-x0 panorama EQUAL to the oracle's on this host (the oracle is pinned to the reference's
+    SHA-256 in the build container, test_oracle_golden.py::test_g20_...)."""
+    import hashlib
+    from helpers import synth_image_embedder
+    from oracle import loops as oloops, ddim as oddim
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano
+    from dynamicscaler_amd.synth import synth_normal
+    d = dev()
+    rec = json.load(open(os.path.join(G, "loop_trace_cfg4_i2v.json")))
+    geom = rec["geom"]
+    cond, uncond = synth_normal((1, 77, 64), 61), synth_normal((1, 77, 64), 62)
+    embed = synth_image_embedder(rec["embedder_dim"])
+    pano_img = synth_normal((3, 512, 4096), rec["pano_img_seed"]).clamp(-1, 1)
+    ld = _fake_host(cond, uncond, d, embed)
+    ld.temporal_length = 16
+    pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": {"in_channels": 4}}}})
+    pipe.to(d, torch.float32)
+    trace = []
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                   pano_image_tensor=pano_img,
+                                                   step_callback=lambda i, t, w, p, p0: trace.append((i, t, w)), **geom)
+    torch.manual_seed(2333333)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 40, 64))], dim=1)
+    oref, _, _ = oloops.i2v_ring_sample(_oracle_fake, embed, oddim.DiffusionTables(), cond, uc, pano_img, guidance_scale=7.5, **geom)
+    assert list(den.shape) == rec["shape"]
+    assert torch.equal(den.cpu(), oref), float((den.cpu() - oref).abs().max())
+    for (i, t, wins), ref in zip(trace, rec["trace"]):
+        assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"], i
+    if hashlib.sha256(oref.numpy().tobytes()).hexdigest() == rec["denoised_sha256"]:
+        print("cfg4: this host's CPU normal stream matches the build container's: panorama SHA-256 == the reference's")
 
 
 # ------------------------------------------------------------------------------------------------ sphere path (S1-S4, P5)
@@ -580,7 +672,9 @@ def test_sphere_pipeline_vs_oracle_and_reference_golden():
         assert torch.equal(final.cpu(), of) and torch.equal(den.cpu(), od), (gname, float((final.cpu() - of).abs().max()))
         # vs the reference's own panorama generated on another CPU: the scalar-path normal stream behind the sphere loop's
         # re_noise (and possibly a floor() flip in an index map) is host dependent, so this is only a loose sanity bound
-        assert relerr(den, T(z[f"sphere_{gname}_fake_denoised"])) < 5e-2
+        e_host = relerr(den, T(z[f"sphere_{gname}_fake_denoised"]))
+        print(f"sphere {gname} fake eps vs the reference's panorama (other host's RNG stream): {e_host:.3e}")
+        assert e_host < 5e-2
         for (i, t, views), ref in zip(trace, meta["traces"][gname]):
             assert i == ref["i"] and t == ref["t"] and [list(v) for v in views] == ref["views"], (gname, i)
     zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
@@ -592,7 +686,7 @@ def test_sphere_pipeline_vs_oracle_and_reference_golden():
                                                          **_sphere_geom(meta["geoms"]["base"]))
     e1, e2 = relerr(final, T(z["sphere_base_tiny_final"])), relerr(den, T(z["sphere_base_tiny_denoised"]))
     print(f"sphere base tiny fp16: final rel err {e1:.3e}, denoised rel err {e2:.3e}")
-    assert e1 < 3e-2 and e2 < 3e-2
+    assert e1 < PIPE_TOL and e2 < PIPE_TOL
 
 
 def test_i2v_sphere_pipeline_vs_oracle_and_reference_golden():
@@ -630,7 +724,9 @@ def test_i2v_sphere_pipeline_vs_oracle_and_reference_golden():
         assert torch.equal(final.cpu(), of) and torch.equal(den.cpu(), od), (gname, float((final.cpu() - of).abs().max()))
         # vs the reference's panoramas generated on another CPU: torch's CPU normal stream and a floor() flip in an index
         # map are host dependent (see the t2v sphere test), so this is only a loose sanity bound
-        assert relerr(final, T(z[f"i2vs_{gname}_fake_final"])) < 5e-2 and relerr(den, T(z[f"i2vs_{gname}_fake_denoised"])) < 5e-2
+        e_hf, e_hd = relerr(final, T(z[f"i2vs_{gname}_fake_final"])), relerr(den, T(z[f"i2vs_{gname}_fake_denoised"]))
+        print(f"i2v sphere {gname} fake eps vs the reference's panoramas (other host's RNG stream): {e_hf:.3e} {e_hd:.3e}")
+        assert e_hf < 5e-2 and e_hd < 5e-2
         for (i, t, views), ref in zip(trace, meta["traces"][gname]):
             assert i == ref["i"] and t == ref["t"] and [list(v) for v in views] == ref["views"], (gname, i)
     zt = np.load(os.path.join(G, "unet_tiny_i2v.npz"))
@@ -644,13 +740,13 @@ def test_i2v_sphere_pipeline_vs_oracle_and_reference_golden():
                                                          pano_image_tensor=pano_img, **geom_of("base"))
     e1, e2 = relerr(final, T(z["i2vs_base_tiny_final"])), relerr(den, T(z["i2vs_base_tiny_denoised"]))
     print(f"i2v sphere base tiny fp16: final rel err {e1:.3e}, denoised rel err {e2:.3e}")
-    assert e1 < 3e-2 and e2 < 3e-2
+    assert e1 < PIPE_TOL and e2 < PIPE_TOL
 
 
 def test_vae_decode_vs_reference_golden():
     """N2 decode side: AutoencoderKLDecoder (HIP) against the reference's AutoencoderKL.decode / decode_first_stage_2DAE:
     toy config (fp32 golden) and the real first-stage config on one 40x64 latent frame (320x512 image, fp16 fixture).
-    fp16 activations vs the reference's fp32: tolerance 1e-2 rel-L2 on the decoded pixels."""
+    fp16 activations vs the reference's fp32: tolerance VAE_TOL (2x measured) rel-L2 on the decoded pixels."""
     from dynamicscaler_amd.vae import AutoencoderKLDecoder
     from dynamicscaler_amd.vae_spec import decoder_param_shapes
     from dynamicscaler_amd.synth import synth_state_dict
@@ -665,7 +761,7 @@ def test_vae_decode_vs_reference_golden():
     vid = m.decode_frames(zz, in_scale=1.0 / 0.18215)
     e2 = relerr(vid, T(z["tiny_video"]))
     print(f"vae tiny: frame rel err {e1:.3e}, video rel err {e2:.3e}")
-    assert frame.shape == (2, 3, 16, 32) and vid.shape == (2, 3, 3, 16, 32) and e1 < 1e-2 and e2 < 1e-2
+    assert frame.shape == (2, 3, 16, 32) and vid.shape == (2, 3, 3, 16, 32) and e1 < VAE_TOL and e2 < VAE_TOL
     zf = np.load(os.path.join(G, "vae_full.npz"))
     ddf = json.loads(bytes(zf["full_dd_json"]).decode())
     mf = AutoencoderKLDecoder(ddf, 4)
@@ -673,7 +769,7 @@ def test_vae_decode_vs_reference_golden():
     out = mf.decode(T(zf["full_z"]).to(d))
     e3 = relerr(out, T(zf["full_frame"]).float())
     print(f"vae full (1 frame 40x64 -> 320x512): rel err {e3:.3e}")
-    assert out.shape == (1, 3, 320, 512) and e3 < 1e-2
+    assert out.shape == (1, 3, 320, 512) and e3 < VAE_TOL
 
 
 def test_decode_tail_seam_safe_with_vae():
@@ -712,7 +808,7 @@ def test_decode_tail_seam_safe_with_vae():
     ref = torch.cat(torch.chunk(ref, 18, dim=4)[1:-1], dim=4)
     e = relerr(videos, ref)
     print(f"seam-safe decode tail: rel err {e:.3e}")
-    assert e < 1e-2
+    assert e < 1.7e-3                       # measured 8.1e-4
 
 
 def test_vae_encode_vs_reference_golden():
@@ -746,7 +842,7 @@ def test_vae_encode_vs_reference_golden():
     til = pipe.tiled_vae_encode_tensor_simple(T(z["tiny8_big"]).to(d), overlap_h=2, overlap_w=2)
     e3 = relerr(til, T(z["tiny8_tiled"]))
     print(f"vae encode tiny8: moments {e1:.3e}, sampled {e2:.3e}, tiled {e3:.3e}")
-    assert e1 < 1e-2 and e2 < 1e-2 and e3 < 1e-2 and til.shape == (1, 4, 1, 16, 32)
+    assert e1 < 1.8e-3 and e2 < 6e-4 and e3 < 7e-4 and til.shape == (1, 4, 1, 16, 32)   # measured 8.8e-4 / 2.7e-4 / 3.2e-4
     zf = np.load(os.path.join(G, "vae_enc_full.npz"))
     ddf = json.loads(bytes(zf["full_dd_json"]).decode())
     mf = AutoencoderKL(ddf, 4)
@@ -754,7 +850,7 @@ def test_vae_encode_vs_reference_golden():
     mom, (h, w) = mf.encode_moments(T(zf["full_img"]).float().to(d).unsqueeze(2))
     e4 = relerr(mom.reshape(1, h, w, 8).permute(0, 3, 1, 2), T(zf["full_moments"]))
     print(f"vae encode full (320x512 -> 40x64): moments rel err {e4:.3e}")
-    assert (h, w) == (40, 64) and e4 < 1e-2
+    assert (h, w) == (40, 64) and e4 < 2.1e-3   # measured 1.04e-3
 
 
 def test_i2v_sphere_paste_on_static_with_vae_encoder():
@@ -799,7 +895,7 @@ def test_i2v_sphere_paste_on_static_with_vae_encoder():
                                  **g)
     e1, e2 = relerr(final, of), relerr(den, od)
     print(f"paste_on_static with the VAE encoder in the loop: final {e1:.3e}, denoised {e2:.3e}")
-    assert e1 < 1e-2 and e2 < 1e-2
+    assert e1 < 2e-5 and e2 < 2e-5         # measured 9.4e-6 / 5.1e-6 (fake eps: only the first-stage encoder differs)
 
 
 def test_i2v_grid_pipeline_vs_reference_golden():
@@ -851,7 +947,7 @@ def test_i2v_grid_pipeline_vs_reference_golden():
                                                    pano_image_tensor=img, **geom_of("plain"))
     e = relerr(den, T(z["i2vgrid_plain_tiny"]))
     print(f"i2v grid tiny fp16: rel err {e:.3e}")
-    assert e < 3e-2
+    assert e < PIPE_TOL
 
 
 def test_gen_pano_360_stage_chain_runs():
@@ -915,4 +1011,4 @@ def test_gen_pano_360_stage_chain_runs():
     ref = torch.cat(torch.chunk(decode_first_stage_2dae(vsd, dd, padded, scale_factor=0.18215), 18, dim=4)[1:-1], dim=4)
     e = relerr(videos, ref)
     print(f"stage chain: final decode rel err vs the oracle decoder {e:.3e}")
-    assert e < 1e-2
+    assert e < 2.3e-3                       # measured 1.13e-3

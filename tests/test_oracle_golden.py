@@ -171,6 +171,33 @@ def test_g9_small_loops_tiny_unet():
         assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4, gname
 
 
+def test_g19_multi_prompt_ring_loop_vs_reference_golden():
+    """R13: per-window prompt selection on the toy dock geometry (fake eps bit-exact, tiny UNet 1e-4), and the reference's
+    own factor assert once a window wraps in H (grid4x2)."""
+    z = npz("loops_multiprompt.npz")
+    meta = json.load(open(os.path.join(G, "loops_multiprompt.json")))
+    geoms = json.load(open(os.path.join(G, "loops_small_traces.json")))["geoms"]
+    emb = {"a prompt": T(z["emb_a_prompt"]), "": T(z["emb_empty"]), "sky": T(z["emb_sky"]), "ground": T(z["emb_ground"])}
+    mp = {float(k): v for k, v in meta["multi_prompt_dict"].items()}
+    tables = oddim.DiffusionTables()
+    kw = dict(guidance_scale=7.5, window_multi_prompt_dict=mp, get_learned_conditioning=lambda p: emb[p[0]])
+    trace = []
+    torch.manual_seed(2333333)
+    den, _, _ = oloops.t2v_ring_sample(_fake_eps, tables, emb["a prompt"], emb[""], trace=trace, **kw, **geoms[meta["geom"]])
+    assert torch.equal(den, T(z["ring_dock_multiprompt_fake"]))
+    assert [[list(w) for w in wins] for _, _, wins in trace] == [s["windows"] for s in meta["trace"]]
+    params, sd = _tiny_setup()
+    torch.manual_seed(2333333)
+    den, _, _ = oloops.t2v_ring_sample(lambda x, ts, ctx: unet_forward(sd, params, x, ts, ctx, fps=8), tables, emb["a prompt"],
+                                       emb[""], **kw, **geoms[meta["geom"]])
+    ref = T(z["ring_dock_multiprompt_tiny"])
+    assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4
+    assert meta["grid4x2_raises"] is not None
+    with pytest.raises(AssertionError, match="not legal"):
+        torch.manual_seed(2333333)
+        oloops.t2v_ring_sample(_fake_eps, tables, emb["a prompt"], emb[""], **kw, **geoms["grid4x2"])
+
+
 def test_g9_baseline_geometry_traces():
     """Window coordinates of BASELINE configs 2/3/5 (bit-exact index sequences) -- arithmetic only."""
     data = json.load(open(os.path.join(G, "loop_traces.json")))
@@ -233,6 +260,27 @@ def test_g11_i2v_ring_loop_fake_eps_bit_exact_and_traces():
         assert torch.equal(den, T(z[f"i2v_{gname}_fake"])), gname
         for (i, t, wins), ref in zip(trace, meta["traces"][f"i2v_{gname}"]):
             assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"], (gname, i)
+
+
+def test_g20_cfg4_i2v_geometry_trace_and_panorama_sha():
+    """BASELINE config 4's geometry (i2v ring 4096x512x16f, 8x2 windows, 93-token contexts) through the oracle's i2v ring
+    loop with the fake eps-model: window trace and SHA-256 of the final pred-x0 panorama equal the reference's."""
+    import hashlib
+    from helpers import synth_image_embedder
+    from dynamicscaler_amd.synth import synth_normal
+    rec = json.load(open(os.path.join(G, "loop_trace_cfg4_i2v.json")))
+    cond, uncond = synth_normal((1, 77, 64), 61), synth_normal((1, 77, 64), 62)
+    embed = synth_image_embedder(rec["embedder_dim"])
+    pano_img = synth_normal((3, 512, 4096), rec["pano_img_seed"]).clamp(-1, 1)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 40, 64))], dim=1)
+    trace = []
+    torch.manual_seed(2333333)
+    den, _, _ = oloops.i2v_ring_sample(_fake_eps, embed, oddim.DiffusionTables(), cond, uc, pano_img, guidance_scale=7.5,
+                                       trace=trace, **rec["geom"])
+    assert list(den.shape) == rec["shape"]
+    for (i, t, wins), ref in zip(trace, rec["trace"]):
+        assert i == ref["i"] and t == ref["t"] and [list(w) for w in wins] == ref["windows"], i
+    assert hashlib.sha256(den.numpy().tobytes()).hexdigest() == rec["denoised_sha256"]
 
 
 def test_g11_grid_and_i2v_tiny_unet():
