@@ -174,7 +174,7 @@ def main():
 
         def image_tokens(batch_imgs):
             seed = 1000 + int(batch_imgs.float().abs().sum().item() * 16) % 100000
-            return synth_normal((batch_imgs.shape[0], 16, params["context_dim"]), seed).to(dev)
+            return synth_normal((batch_imgs.shape[0], 16, params["context_dim"]), seed).to(batch_imgs.device)
 
         ld.embedder = True                                   # marks the host as image-conditioned (uncond image tokens)
         ld.get_image_embeds = image_tokens

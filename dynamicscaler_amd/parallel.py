@@ -2,12 +2,20 @@
 (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 
 The reference is sequential (Gauss-Seidel over tiles).  Tiles whose ring footprints do not overlap are
-independent, so a step is cut into LEVELS of pairwise-disjoint windows (`plan_levels`); each rank takes a
-strided share of a level, and after the level every rank needs the others' updated tiles because the next level
-(and the next step's shifted grid) straddles ownership.  That is the path's one real exchange: an ALL-GATHER of
-the (x_prev, x0) tiles of the level -- identical in result to an all-reduce(sum) of zero-filled panorama-sized
-accumulators with a 0/1 weight map (the "overlap accumulator" reading), at 1/W of the bytes.  Every rank then
-scatters all tiles into its own replica of the panorama, so replicas stay bit-identical.
+independent, so a step is cut into LEVELS of pairwise-disjoint windows (`plan_levels`), and the overlap graph of a
+step falls into connected COMPONENTS (`plan_components`: with no W overlap every panorama column is one -- configs
+2-5).  `run_step` shares the step out in one of two exact ways:
+
+  components  (>= world components): a rank owns whole components, walks their levels locally (its own tiles go
+              straight into its replica) and the step has ONE exchange at its end -- an ALL-GATHER of every rank's
+              (x_prev, x0) tiles, after which each rank scatters the others' tiles.  SURVEY.md 8-e's column ownership.
+  levels      (fewer components than ranks, e.g. W-overlapped rings = one chain): each rank takes a strided share of
+              every level and the level's tiles are all-gathered before the next level starts.
+
+Either exchange is identical in result to an all-reduce(sum) of zero-filled panorama-sized accumulators with a 0/1
+weight map (the "overlap accumulator" reading of north_star) at a fraction of the bytes.  Every rank scatters all
+tiles into its own replica of the panorama in an order that keeps every overlapping pair in reference order, so
+replicas stay bit-identical to the single-process panorama.
 """
 import torch
 import torch.distributed as dist
@@ -43,6 +51,46 @@ def plan_levels(windows, pano_fhw):
     return out
 
 
+def plan_components(windows, pano_fhw):
+    """Connected components of the step's overlap graph (union-find), each a list of window indices in reference
+    order; components ordered by their first window.  Windows of different components never touch the same panorama
+    element within the step, so components can be processed in any order or concurrently."""
+    n = len(windows)
+    parent = list(range(n))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    for j in range(n):
+        for k in range(j):
+            if windows_overlap(windows[k], windows[j], pano_fhw):
+                ra, rb = find(k), find(j)
+                if ra != rb:
+                    parent[max(ra, rb)] = min(ra, rb)
+    comps = {}
+    for j in range(n):
+        comps.setdefault(find(j), []).append(j)
+    return [comps[k] for k in sorted(comps)]
+
+
+def plan_owners(windows, pano_fhw, world):
+    """Owner rank per window when the step has at least `world` components (component c -> rank c % world, so every
+    rank's tile count differs by at most one component), else None (`run_step` then shares every level out)."""
+    if world <= 1:
+        return None
+    comps = plan_components(windows, pano_fhw)
+    if len(comps) < world:
+        return None
+    owner = [0] * len(windows)
+    for c, members in enumerate(comps):
+        for j in members:
+            owner[j] = c % world
+    return owner
+
+
 def rank_share(items, rank, world):
     """Strided share of a level for one rank (items keep their order)."""
     return items[rank::world]
@@ -60,6 +108,68 @@ def host_staged_collectives(on=True):
     all-gather goes through host buffers.  RCCL runs never enable it."""
     global _HOST_STAGED
     _HOST_STAGED = bool(on)
+
+
+def all_gather_tiles(x_prev_local, x0_local, counts, group=None):
+    """All-gather of per-rank tile lists of different lengths.  x_prev_local / x0_local: [counts[rank], C, tf, th, tw].
+    Returns a list over ranks of (x_prev_r, x0_r) with counts[r] tiles each (this rank's own entry is the input)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    cmax = max(counts)
+    tile_shape = tuple(x_prev_local.shape[1:])
+    send = torch.zeros((2, cmax) + tile_shape, dtype=x_prev_local.dtype, device=x_prev_local.device)
+    if counts[rank]:
+        send[0, :counts[rank]] = x_prev_local
+        send[1, :counts[rank]] = x0_local
+    recv = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    if _HOST_STAGED and send.is_cuda:
+        recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(recv_h, send.cpu(), group=group)
+        recv.copy_(recv_h)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view((world,) + tuple(send.shape))
+    return [(x_prev_local, x0_local) if r == rank else (recv[r, 0, :counts[r]], recv[r, 1, :counts[r]]) for r in range(world)]
+
+
+def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, group=None):
+    """One DDIM step over `windows` (reference order), shared over `world` ranks -- the scheduling both the HIP pipelines
+    (pipelines._denoise_windows) and the CPU rehearsal (tests/test_parallel_gloo.py) run.
+      process(ids) -> (x_prev, x0) tiles [len(ids), ...] of the windows `ids` (pairwise disjoint, in the given order)
+      scatter(ids, x_prev, x0)       writes tiles into this rank's panorama replica
+      empty_tiles()                  -> a [0, ...] tile tensor (dtype / device of the tiles)
+    Returns the mode used: "single", "components" or "levels"."""
+    levels = plan_levels(windows, pano_fhw)
+    if world <= 1:
+        for level in levels:
+            xp, x0 = process(level)
+            scatter(level, xp, x0)
+        return "single"
+    owner = plan_owners(windows, pano_fhw, world)
+    if owner is not None:
+        mine_xp, mine_x0 = [], []
+        for level in levels:
+            ids = [j for j in level if owner[j] == rank]
+            if ids:
+                xp, x0 = process(ids)
+                scatter(ids, xp, x0)                     # own tiles: visible to this rank's later levels at once
+                mine_xp.append(xp)
+                mine_x0.append(x0)
+        order = [[j for level in levels for j in level if owner[j] == r] for r in range(world)]
+        counts = [len(o) for o in order]
+        xp_l = torch.cat(mine_xp, 0) if mine_xp else empty_tiles()
+        x0_l = torch.cat(mine_x0, 0) if mine_x0 else empty_tiles()
+        parts = all_gather_tiles(xp_l, x0_l, counts, group)    # the step's ONE exchange
+        for r in range(world):
+            if r != rank and counts[r]:
+                scatter(order[r], parts[r][0], parts[r][1])
+        return "components"
+    for level in levels:
+        ids = rank_share(level, rank, world)
+        xp, x0 = process(ids) if ids else (empty_tiles(), empty_tiles())
+        xp_all, x0_all = exchange_level(xp, x0, len(level), group)
+        scatter(level, xp_all, x0_all)
+    return "levels"
 
 
 def exchange_level(x_prev_local, x0_local, n_items, group=None, force=False):

@@ -6,8 +6,9 @@ Same constructor `(pretrained_t2v, scheduler, model_config)`, same method names 
 the whole loop; a DDIM step is cut into levels of independent windows (parallel.plan_levels) and each level is
   ds_ring_gather (latent + mask, all windows of the level in one launch) -> ds_renoise_mix ->
   ONE batched UNet evaluation for [cond | uncond] x windows -> ds_cfg_ddim -> ds_ring_scatter3
-instead of ~300 tiny torch launches per tile.  With torch.distributed initialised, a level's windows are shared
-out over the ranks and all-gathered back (parallel.exchange_level).
+instead of ~300 tiny torch launches per tile.  With torch.distributed initialised, the step's windows are shared
+out over the ranks -- whole panorama columns per rank with one all-gather per step, or a strided share of every level
+(parallel.run_step).
 """
 import numpy as np
 import torch
@@ -254,41 +255,42 @@ class VC2_Pipeline_T2V:
             c_rn, s_rn = sched.renoise_coefficients(st.total_steps - i - 2, st.total_steps - i - 1)
         self._log(f"i = {i}, t = {t}: {len(wins)} windows")
         mask = st.mask if use_mask else None
-        for level in parallel.plan_levels(wins, st.pano_fhw):
-            mine = parallel.rank_share(level, st.rank, st.world)
-            def run_batch(ids):
-                origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
-                tiles, mtiles = ops.ring_gather(pano, origins, st.tile_fhw, mask)
-                prev = tiles.clone() if merge_prev_ratio is not None else None
-                if renoise:
-                    nz = None
-                    if noises[ids[0]][0] is not None:
-                        nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=pano.dtype)
-                    ops.renoise_mix_(tiles, mtiles, st.total_shape, c_rn, s_rn, st.ratio, noise=nz,
-                                     mask_frame0=mask_frame0, seed=sched.philox_seed,
-                                     offset=sched.tile_philox_offset(i, tiles[0].numel()), tile_ids=ids)
-                n = len(ids)
-                if st.guidance_scale != 1.0:
-                    eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n,
-                                    st.fps, st.frames, cfg_pairs=n, **st.kwargs)
-                    e_c, e_u = eps[:n], eps[n:]
-                else:
-                    e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], st.fps, st.frames, **st.kwargs), None
-                sn = None
-                if coef["sigma"] != 0.0:
-                    sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=pano.dtype)
-                x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, st.total_shape, st.guidance_scale, coef, sn)
-                if merge_prev_ratio is not None:
-                    # merge-prev (i2v_sphere_panorama_pipeline.py:938-943): mix(x_prev, window_before_renoise, mask, r_i)
-                    ops.renoise_mix_(x_prev, mtiles, st.total_shape, 0.0, 1.0, merge_prev_ratio, noise=prev,
-                                     mask_frame0=mask_frame0)
-                return x_prev, x0
 
-            # the tile batches of a level are independent (disjoint windows, the panorama is only read until the
-            # scatter below): with num_streams > 1 they run concurrently on separate HIP streams, so the partial last
-            # round of workgroups of one batch's kernels is filled by the other batch's kernels
+        def run_batch(ids):
+            origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
+            tiles, mtiles = ops.ring_gather(pano, origins, st.tile_fhw, mask)
+            prev = tiles.clone() if merge_prev_ratio is not None else None
+            if renoise:
+                nz = None
+                if noises[ids[0]][0] is not None:
+                    nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=pano.dtype)
+                ops.renoise_mix_(tiles, mtiles, st.total_shape, c_rn, s_rn, st.ratio, noise=nz,
+                                 mask_frame0=mask_frame0, seed=sched.philox_seed,
+                                 offset=sched.tile_philox_offset(i, tiles[0].numel()), tile_ids=ids)
+            n = len(ids)
+            if st.guidance_scale != 1.0:
+                eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n,
+                                st.fps, st.frames, cfg_pairs=n, **st.kwargs)
+                e_c, e_u = eps[:n], eps[n:]
+            else:
+                e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], st.fps, st.frames, **st.kwargs), None
+            sn = None
+            if coef["sigma"] != 0.0:
+                sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=pano.dtype)
+            x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, st.total_shape, st.guidance_scale, coef, sn)
+            if merge_prev_ratio is not None:
+                # merge-prev (i2v_sphere_panorama_pipeline.py:938-943): mix(x_prev, window_before_renoise, mask, r_i)
+                ops.renoise_mix_(x_prev, mtiles, st.total_shape, 0.0, 1.0, merge_prev_ratio, noise=prev,
+                                 mask_frame0=mask_frame0)
+            return x_prev, x0
+
+        def process(mine):
+            """(x_prev, x0) tiles of the pairwise-disjoint windows `mine` (this rank's part of a level), in that order.
+            The tile batches are independent (the panorama is only read until the scatter): with num_streams > 1 they run
+            concurrently on separate HIP streams, so the partial last round of workgroups of one batch's kernels is filled
+            by the other batch's kernels."""
             bsz = self.max_tile_batch
-            if self.num_streams > 1:         # spread this rank's share of the level over the streams
+            if self.num_streams > 1:         # spread the windows over the streams
                 bsz = max(1, min(bsz, -(-len(mine) // self.num_streams)))
             batches = [mine[s:s + bsz] for s in range(0, len(mine), bsz)]
             if self.num_streams > 1 and len(batches) > 1:
@@ -298,20 +300,21 @@ class VC2_Pipeline_T2V:
                                                       on_slot=lambda k: setattr(self, "_slot", k))
             else:
                 parts = [run_batch(ids) for ids in batches]
-            xp_parts, x0_parts = [p[0] for p in parts], [p[1] for p in parts]
-            if st.world > 1:
-                empty = torch.empty((0,) + st.tile_shape[1:], dtype=pano.dtype, device=device)
-                xp_l = torch.cat(xp_parts, 0) if xp_parts else empty
-                x0_l = torch.cat(x0_parts, 0) if x0_parts else empty
-                xp_all, x0_all = parallel.exchange_level(xp_l, x0_l, len(level))
-                order = level
-            else:
-                xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
-            for s in range(0, len(order), ops.DS_MAX_WINDOWS):
-                ids = order[s:s + ops.DS_MAX_WINDOWS]
-                origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
-                ops.ring_scatter3(pano, st.pano_x0, mask, xp_all[s:s + len(ids)].contiguous(),
-                                  x0_all[s:s + len(ids)].contiguous(), origins)
+            return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
+
+        def scatter(ids, xp, x0):
+            for s in range(0, len(ids), ops.DS_MAX_WINDOWS):
+                part = ids[s:s + ops.DS_MAX_WINDOWS]
+                origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in part]
+                ops.ring_scatter3(pano, st.pano_x0, mask, xp[s:s + len(part)].contiguous(), x0[s:s + len(part)].contiguous(),
+                                  origins)
+
+        def empty_tiles():
+            return torch.empty((0,) + st.tile_shape[1:], dtype=pano.dtype, device=device)
+
+        # levels of pairwise-disjoint windows; over several ranks whole components (columns) per rank with one exchange
+        # per step, or a strided share of every level (parallel.run_step)
+        st.share_mode = parallel.run_step(wins, st.pano_fhw, st.rank, st.world, process, scatter, empty_tiles)
 
     def _new_state(self, init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
                    text_emb, uc_emb, ratio, kwargs):

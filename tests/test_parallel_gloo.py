@@ -18,26 +18,27 @@ def _update(tile, j):
 
 
 def _run_step(pano, pano_x0, wins, pano_fhw, rank, world):
+    """parallel.run_step -- the scheduling the HIP pipelines run -- with a CPU stand-in for the tile compute."""
     from dynamicscaler_amd import parallel
     from oracle import ring as oring
-    for level in parallel.plan_levels(wins, pano_fhw):
-        mine = parallel.rank_share(level, rank, world)
+    shape = (0, pano.shape[1], wins[0][5] - wins[0][4], wins[0][3] - wins[0][2], wins[0][1] - wins[0][0])
+
+    def process(ids):
         xp, x0 = [], []
-        for j in mine:
+        for j in ids:
             l, r, t, d, fb, fe = wins[j]
-            tile = oring.ring_gather(pano, l, r, t, d, fb, fe)
-            a, b = _update(tile, j)
+            a, b = _update(oring.ring_gather(pano, l, r, t, d, fb, fe), j)
             xp.append(a)
             x0.append(b)
-        shape = (0, pano.shape[1], wins[0][5] - wins[0][4], wins[0][3] - wins[0][2], wins[0][1] - wins[0][0])
-        xp = torch.cat(xp) if xp else torch.empty(shape)
-        x0 = torch.cat(x0) if x0 else torch.empty(shape)
-        xp_all, x0_all = parallel.exchange_level(xp, x0, len(level))
-        order = level if world > 1 else mine
-        for n, j in enumerate(order):
+        return torch.cat(xp), torch.cat(x0)
+
+    def scatter(ids, xp, x0):
+        for n, j in enumerate(ids):
             l, r, t, d, fb, fe = wins[j]
-            oring.ring_scatter(pano, xp_all[n:n + 1], l, r, t, d, fb, fe)
-            oring.ring_scatter(pano_x0, x0_all[n:n + 1], l, r, t, d, fb, fe)
+            oring.ring_scatter(pano, xp[n:n + 1], l, r, t, d, fb, fe)
+            oring.ring_scatter(pano_x0, x0[n:n + 1], l, r, t, d, fb, fe)
+
+    return parallel.run_step(wins, pano_fhw, rank, world, process, scatter, lambda: torch.empty(shape))
 
 
 def _worker(rank, world, port, steps, geom_name, out):
@@ -50,9 +51,10 @@ def _worker(rank, world, port, steps, geom_name, out):
     torch.manual_seed(0)
     pano = torch.randn((1, 4) + fhw)
     pano_x0 = torch.zeros_like(pano)
+    modes = set()
     for step in rec["trace"][:steps]:
-        _run_step(pano, pano_x0, [tuple(w) for w in step["windows"]], fhw, rank, world)
-    out[rank] = (pano, pano_x0)
+        modes.add(_run_step(pano, pano_x0, [tuple(w) for w in step["windows"]], fhw, rank, world))
+    out[rank] = (pano, pano_x0, sorted(modes))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -66,15 +68,43 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("geom_name,steps", [("cfg3_4096x512", 3), ("cfg3_overlap_nw10", 2)])
-def test_two_ranks_equal_single_process(geom_name, steps):
+@pytest.mark.parametrize("geom_name,steps,world,mode", [
+    ("cfg3_4096x512", 3, 2, "components"),        # 8 columns of 2 dependent tiles: 4 columns per rank, one exchange per step
+    ("cfg2_2048x512", 2, 3, "components"),        # 4 columns over 3 ranks: uneven tile counts (4 / 2 / 2) in the all-gather
+    ("cfg3_overlap_nw10", 2, 2, "levels"),        # W overlap: one chain -> a strided share of every level
+])
+def test_ranks_equal_single_process(geom_name, steps, world, mode):
     mgr = mp.Manager()
     single = mgr.dict()
     _worker(0, 1, 0, steps, geom_name, single)
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), steps, geom_name, out), nprocs=2, join=True)
-    for r in (0, 1):
+    mp.spawn(_worker, args=(world, _free_port(), steps, geom_name, out), nprocs=world, join=True)
+    for r in range(world):
         assert torch.equal(out[r][0], single[0][0]) and torch.equal(out[r][1], single[0][1])
+        assert out[r][2] == [mode]
+
+
+def test_plan_components_and_owners():
+    """Columns of the BASELINE geometries are the connected components of a step's overlap graph; with fewer components
+    than ranks plan_owners declines (levels are shared out instead)."""
+    from dynamicscaler_amd import parallel
+    traces = json.load(open(os.path.join(G, "loop_traces.json")))
+    for name, ncomp, per in (("cfg2_2048x512", 4, 2), ("cfg3_4096x512", 8, 2), ("cfg5_8192x1024x24", 16, 4), ("cfg3_overlap_nw10", 1, 20)):
+        g = traces[name]["geom"]
+        fhw = (g["frames"], g["total_h"] // 8, g["total_w"] // 8)
+        for step in traces[name]["trace"][:3]:
+            wins = [tuple(w) for w in step["windows"]]
+            comps = parallel.plan_components(wins, fhw)
+            assert len(comps) == ncomp and all(len(c) == per for c in comps), (name, [len(c) for c in comps])
+            assert sorted(j for c in comps for j in c) == list(range(len(wins)))
+            for a in range(len(comps)):            # no window of one component touches a window of another
+                for b in range(a + 1, len(comps)):
+                    assert not any(parallel.windows_overlap(wins[i], wins[j], fhw) for i in comps[a] for j in comps[b])
+            owner = parallel.plan_owners(wins, fhw, 8)
+            if ncomp >= 8:
+                assert all(len({owner[j] for j in c}) == 1 for c in comps) and set(owner) == set(range(8))
+            else:
+                assert owner is None
 
 
 def test_sequential_reference_order_equals_levels():

@@ -28,8 +28,8 @@ except Exception as e:
 PY
 done
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_cfg3 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_cfg3.log 2>&1; echo "rocprof cfg3 rc=$?" | tee -a $O/summary.txt
-timeout 1500 rocprofv3 --kernel-trace --stats -d $O/prof_cfg5 -- python3 $R/bench.py --config cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_cfg5.log 2>&1; echo "rocprof cfg5 rc=$?" | tee -a $O/summary.txt
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg3 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_cfg3.log 2>&1; echo "rocprof cfg3 rc=$?" | tee -a $O/summary.txt
+timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg5 -- python3 $R/bench.py --config cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_cfg5.log 2>&1; echo "rocprof cfg5 rc=$?" | tee -a $O/summary.txt
 cd $R
 for c in cfg3 cfg5; do
   f=$(find $O/prof_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$c.csv
