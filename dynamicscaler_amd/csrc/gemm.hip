@@ -488,107 +488,6 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             }
         }
         DS_STAMP(3);
-        // ---- register epilogue (fp16 output, aligned shapes: every launch of the UNet but the fp32-out ones) ----
-        // No LDS round trip.  In the accumulator layout a lane holds, for its row, the 4 columns 8g + 4*(lane>>5) .. +3 of
-        // every register quad g; its partner lane (lane ^ 32) holds the other 4 of each 8.  After rounding to fp16 (2 dwords
-        // per quad) ONE v_permlane32_swap per dword on the quad pair (2k, 2k+1) leaves lanes 0-31 with columns 16k .. 16k+7
-        // and lanes 32-63 with 16k+8 .. 16k+15 of the row: 16 contiguous bytes per lane, two 16-byte stores per 32x32
-        // tile.  A residual is loaded in that same 16-byte form and brought back to the accumulator layout by the same
-        // swap (an involution), so bias (already in the accumulators, or added here), per-item bias, residual and SiLU are
-        // applied in fp32 in the same order as before and the value is rounded once.  The LDS-strip epilogue it replaces
-        // moved 655 KB through the LDS per 256x320 tile and cost 9.1k cycles (profiles/r1_notes.md); this one is ~60
-        // vector instructions per 32x32 tile.
-        if (fast && !out_f32) {
-            auto pack2 = [](float a, float b) -> unsigned {
-                const f16x2 h = {(f16)a, (f16)b};
-                return __builtin_bit_cast(unsigned, h);
-            };
-            const bool add_bias = !GE && bias && !bias_in_acc && !PIB;     // a shared vector passed with bias_rows == M
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const int row = m0 + wm * WM + mi * 32 + fr;
-                const bool row_ok = row < d.M;
-                const int rowi = row_ok ? row : 0;
-                const long rowc = rowi;
-                const float* pib_row = PIB ? bias + (long)(rowi / d.bias_rows) * d.ldbias : nullptr;
-                f16* const out_row = reinterpret_cast<f16*>(out) + rowc * d.ldc;
-                const f16* const res_row = RES ? residual + rowc * d.ldr : nullptr;
-#pragma unroll
-                for (int c = 0; c < TNE; ++c) {
-                    // column of the tile's first element: in the N space (bias, bounds) and in the output
-                    const int ncol = GE ? n0 + wn * WN + 2 * c * 32 : n0 + wn * WN + c * 32;
-                    const long ocol = GE ? (long)tile_n * (BN / 2) + wn * (WN / 2) + c * 32 : (long)ncol;
-                    const f32x16& a = acc[c][mi];
-                    float v[16];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) v[j] = a[j];
-                    // residual: 16 bytes per lane and quad pair, columns 16k + 8*fh .. +7
-                    u32x4 rr[2];
-                    bool ok[2];
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int cc = 16 * k + 8 * fh;
-                        ok[k] = row_ok && (GE ? ncol + cc + 32 < d.N : ncol + cc < d.N);
-                        if constexpr (RES) rr[k] = ok[k] ? *reinterpret_cast<const u32x4*>(res_row + ocol + cc) : u32x4{0, 0, 0, 0};
-                    }
-                    if (add_bias || PIB) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int col = ncol + 8 * g + 4 * fh;
-                            const bool okc = col < d.N;
-                            if (add_bias) {
-                                const f32x4 b = okc ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0, 0, 0, 0};
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[4 * g + j] += b[j];
-                            }
-                            if constexpr (PIB) {
-                                const f32x4 b = okc ? *reinterpret_cast<const f32x4*>(pib_row + col) : f32x4{0, 0, 0, 0};
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[4 * g + j] += b[j];
-                            }
-                        }
-                    }
-                    if constexpr (RES) {
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            // back to the accumulator layout: (d0,d1) -> quad 2k, (d2,d3) -> quad 2k+1
-                            auto s0 = __builtin_amdgcn_permlane32_swap(rr[k][0], rr[k][2], false, false);
-                            auto s1 = __builtin_amdgcn_permlane32_swap(rr[k][1], rr[k][3], false, false);
-                            const unsigned q0[2] = {s0[0], s1[0]}, q1[2] = {s0[1], s1[1]};
-#pragma unroll
-                            for (int w = 0; w < 2; ++w) {
-                                const f16x2 h0 = __builtin_bit_cast(f16x2, q0[w]);
-                                const f16x2 h1 = __builtin_bit_cast(f16x2, q1[w]);
-                                v[8 * k + 2 * w] += (float)h0[0];
-                                v[8 * k + 2 * w + 1] += (float)h0[1];
-                                v[8 * k + 4 + 2 * w] += (float)h1[0];
-                                v[8 * k + 4 + 2 * w + 1] += (float)h1[1];
-                            }
-                        }
-                    }
-                    if constexpr (!GE) {
-                        if (silu) {
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) v[j] = fast_silu(v[j]);
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        unsigned p0 = pack2(v[8 * k], v[8 * k + 1]), p1 = pack2(v[8 * k + 2], v[8 * k + 3]);          // quad 2k
-                        unsigned p2 = pack2(v[8 * k + 4], v[8 * k + 5]), p3 = pack2(v[8 * k + 6], v[8 * k + 7]);      // quad 2k+1
-                        auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);
-                        auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
-                        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-#ifdef DS_EXP_NOSTORE
-                        asm volatile("" ::"v"(o));
-#else
-                        if (ok[k]) *reinterpret_cast<u32x4*>(out_row + ocol + 16 * k + 8 * fh) = o;
-#endif
-                    }
-                }
-            }
-            return;
-        }
         // fp16 strips for launches without bias / residual / per-item bias and fp16 output (QKV and q projections, GEGLU:
         // its bias is added in the stage above): SiLU is applied in the ACCUMULATOR layout and the value rounded to fp16
         // there -- the same fp32 operations and the same single rounding as the fp32-strip path below, so the bits are

@@ -101,6 +101,13 @@ def share_counts(n_items, world):
 
 
 _HOST_STAGED = False
+_FORCE_LEVELS = False      # share_mode("levels"): always share every level out (diagnostics / A-B runs)
+
+
+def share_mode(mode):
+    """'auto' (default): whole components per rank when there are enough of them; 'levels': always share levels."""
+    global _FORCE_LEVELS
+    _FORCE_LEVELS = mode == "levels"
 
 
 def host_staged_collectives(on=True):
@@ -136,7 +143,8 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
     """One DDIM step over `windows` (reference order), shared over `world` ranks -- the scheduling both the HIP pipelines
     (pipelines._denoise_windows) and the CPU rehearsal (tests/test_parallel_gloo.py) run.
       process(ids) -> (x_prev, x0) tiles [len(ids), ...] of the windows `ids` (pairwise disjoint, in the given order)
-      scatter(ids, x_prev, x0)       writes tiles into this rank's panorama replica
+      scatter(ids, x_prev, x0)       writes tiles into this rank's panorama replica; `ids` are pairwise disjoint (a batched
+                                     scatter has no order among its windows)
       empty_tiles()                  -> a [0, ...] tile tensor (dtype / device of the tiles)
     Returns the mode used: "single", "components" or "levels"."""
     levels = plan_levels(windows, pano_fhw)
@@ -145,7 +153,7 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
             xp, x0 = process(level)
             scatter(level, xp, x0)
         return "single"
-    owner = plan_owners(windows, pano_fhw, world)
+    owner = None if _FORCE_LEVELS else plan_owners(windows, pano_fhw, world)
     if owner is not None:
         mine_xp, mine_x0 = [], []
         for level in levels:
@@ -155,14 +163,26 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
                 scatter(ids, xp, x0)                     # own tiles: visible to this rank's later levels at once
                 mine_xp.append(xp)
                 mine_x0.append(x0)
-        order = [[j for level in levels for j in level if owner[j] == r] for r in range(world)]
-        counts = [len(o) for o in order]
+        # what every rank sends: its tiles level by level (the order it produced them in)
+        by_level = [[[j for j in level if owner[j] == r] for level in levels] for r in range(world)]
+        counts = [sum(len(ids) for ids in by_level[r]) for r in range(world)]
         xp_l = torch.cat(mine_xp, 0) if mine_xp else empty_tiles()
         x0_l = torch.cat(mine_x0, 0) if mine_x0 else empty_tiles()
         parts = all_gather_tiles(xp_l, x0_l, counts, group)    # the step's ONE exchange
-        for r in range(world):
-            if r != rank and counts[r]:
-                scatter(order[r], parts[r][0], parts[r][1])
+        # the other ranks' tiles go into this replica LEVEL BY LEVEL: one scatter call only ever holds pairwise-disjoint
+        # windows (a component's later level overwrites part of its earlier one, and a batched scatter has no order)
+        for li in range(len(levels)):
+            ids, xs, x0s = [], [], []
+            for r in range(world):
+                if r == rank or not by_level[r][li]:
+                    continue
+                off = sum(len(b) for b in by_level[r][:li])
+                n = len(by_level[r][li])
+                ids += by_level[r][li]
+                xs.append(parts[r][0][off:off + n])
+                x0s.append(parts[r][1][off:off + n])
+            if ids:
+                scatter(ids, torch.cat(xs, 0), torch.cat(x0s, 0))
         return "components"
     for level in levels:
         ids = rank_share(level, rank, world)

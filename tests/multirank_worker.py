@@ -38,9 +38,20 @@ def main():
     pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode=rng_mode),
                                        {"params": {"unet_config": {"params": params}}}).to(d, torch.float16)
     pipe.use_graph, pipe.num_streams, pipe.max_tile_batch = True, 2, 2
+    if os.environ.get("DS_SHARE_MODE"):
+        parallel.share_mode(os.environ["DS_SHARE_MODE"])
+    if os.environ.get("DS_WORKER_EAGER"):
+        pipe.use_graph, pipe.num_streams = False, 1
+    steps = []
+
+    def on_step(i, t, wins, pano, pano_x0):
+        import hashlib
+        steps.append(hashlib.sha256(pano.float().cpu().numpy().tobytes()).hexdigest()[:10])
+
     torch.manual_seed(2333333)
     _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
-                                                   **meta["geoms"][geom_name])
+                                                   step_callback=on_step, **meta["geoms"][geom_name])
+    print("STEP_HASHES", dist.get_rank() if dist.is_initialized() else 0, getattr(pipe, "_last_share_mode", None), steps, flush=True)
     rank = dist.get_rank() if dist.is_initialized() else 0
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), den=den.float().cpu().numpy(),
              final=pipe.final_latent.float().cpu().numpy())

@@ -33,7 +33,9 @@ def _run_step(pano, pano_x0, wins, pano_fhw, rank, world):
         return torch.cat(xp), torch.cat(x0)
 
     def scatter(ids, xp, x0):
-        for n, j in enumerate(ids):
+        # the HIP scatter writes all windows of a call concurrently: they must be pairwise disjoint
+        assert not any(parallel.windows_overlap(wins[a], wins[b], pano_fhw) for k, a in enumerate(ids) for b in ids[k + 1:])
+        for n, j in reversed(list(enumerate(ids))):          # ... so any order within a call gives the same panorama
             l, r, t, d, fb, fe = wins[j]
             oring.ring_scatter(pano, xp[n:n + 1], l, r, t, d, fb, fe)
             oring.ring_scatter(pano_x0, x0[n:n + 1], l, r, t, d, fb, fe)
