@@ -119,7 +119,7 @@ template <int BM, int BN, int WGM, int WGN, int AMODE, int NS>
 __global__ void __launch_bounds__((TileCfg<BM, BN, WGM, WGN, NS>::NT), (TileCfg<BM, BN, WGM, WGN, NS>::WG_PER_CU))
 gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const float* __restrict__ bias,
                 const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n,
-                unsigned a_bytes, unsigned w_bytes) {
+                unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum) {
     using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
     constexpr int LROWS = Cfg::LROWS, A_ROWS_PER_THREAD = Cfg::AR, B_ROWS_PER_THREAD = Cfg::BR;
@@ -267,7 +267,8 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     // (bias_rows <= M, also when it covers the launch with ONE item) is always added after the K sum.
     // Each lane reads the 4 columns of its register quads straight from global memory (two addresses per wave-instruction,
     // L2-resident) while the first K-steps' loads are in flight.
-    const bool bias_in_acc = bias && d.bias_rows > d.M && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.ldbias % 4 == 0) &&
+    const bool ln_fold = ln_stats != nullptr;   // LayerNorm folded into this GEMM (ds_gemm_f16_ln): see the transform after the K loop
+    const bool bias_in_acc = !ln_fold && bias && d.bias_rows > d.M && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.ldbias % 4 == 0) &&
                              (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && !(d.epilogue & DS_EPI_OUT_F32) &&
                              (!residual || d.ldr % 8 == 0);
     if (bias_in_acc) {
@@ -435,6 +436,34 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         for (; kt < nk; ++kt) kstep(kt, std::false_type{});
     }
 
+    // ---- LayerNorm folded into the GEMM (ds_gemm_f16_ln).  The A operand is the RAW activation x, W holds gamma (.) W
+    //      rounded to fp16, and with the row's (mean, rstd) the LayerNorm'ed product is recovered exactly:
+    //        sum_k ((x_k - mean) rstd gamma_k + beta_k) W_nk = rstd (acc_n - mean cs_n) + cb_n,
+    //      cs_n = sum_k fp16(gamma_k W_nk) (the sum of the operand row actually multiplied), cb_n = sum_k beta_k W_nk (+ bias).
+    //      Applied in the accumulator layout (a lane owns one row: two scalars per 32-row block; cs / cb are 16-byte loads
+    //      per register quad like the accumulator-init bias), after which the epilogue sees a plain bias-free product.
+    //      The normalised activation is never rounded to fp16 and never written to memory. ----
+    if (ln_fold) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int row = m0 + wm * WM + mi * 32 + fr;
+            const float2 st = row < d.M ? reinterpret_cast<const float2*>(ln_stats)[row] : make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + wn * WN + ni * 32 + 8 * g + 4 * fh;
+                    const bool okc = col < d.N;
+                    const f32x4 cs = okc ? *reinterpret_cast<const f32x4*>(ln_colsum + col) : f32x4{0, 0, 0, 0};
+                    const f32x4 cb = okc && bias ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[ni][mi][4 * g + j] = fmaf(st.y, acc[ni][mi][4 * g + j] - st.x * cs[j], cb[j]);
+                }
+        }
+    }
+    const bool bias_done = bias_in_acc || ln_fold;   // nothing left to add in the epilogue
+
     DS_STAMP(2);
     const bool geglu = d.epilogue & DS_EPI_GEGLU;
     const bool silu = d.epilogue & DS_EPI_SILU;
@@ -470,7 +499,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 f32x4 bxq[4], bgq[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const bool okn = nx + 8 * g + 32 < d.N && bias && !bias_in_acc;
+                    const bool okn = nx + 8 * g + 32 < d.N && bias && !bias_done;
                     bxq[g] = okn ? *reinterpret_cast<const f32x4*>(bias + nx + 8 * g) : f32x4{0, 0, 0, 0};
                     bgq[g] = okn ? *reinterpret_cast<const f32x4*>(bias + nx + 8 * g + 32) : f32x4{0, 0, 0, 0};
                 }
@@ -496,7 +525,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         // with nothing in between, so all sweeps of a group are in flight together.  A shared bias is already in the
         // accumulators (bias_in_acc above).
         if constexpr (!RES && !PIB) {
-            if (fast && !out_f32 && (!bias || GE || bias_in_acc)) {
+            if (fast && !out_f32 && (!bias || GE || bias_done)) {
                 constexpr int NGH_ = TNE < 2 * NG ? TNE : 2 * NG;      // tiles per group in the same strip bytes,
                 constexpr int NGH = NGH_ < 4 ? NGH_ : 4;               // at most 4: 16 chunks per row, 8 sweeps of 4 rows
                 constexpr int STRH = 32 * NGH + 8;                     // halfs per strip row (16-byte aligned chunks)
@@ -573,7 +602,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             float bx[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) bx[j] = 0.0f;
-            if (!GE && shared_bias && fast && col_on && !bias_in_acc) {
+            if (!GE && shared_bias && fast && col_on && !bias_done) {
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + ncol);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + ncol + 4);
                 bx[0] = b0[0]; bx[1] = b0[1]; bx[2] = b0[2]; bx[3] = b0[3];
@@ -701,7 +730,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 
 template <int BM, int BN, int WGM, int WGN, int AMODE, int NS = 2>
 int launch(const void* A, const void* W, const float* bias, const void* residual, void* out,
-           const ds_gemm_desc& d, hipStream_t st) {
+           const ds_gemm_desc& d, hipStream_t st, const float* ln_stats, const float* ln_colsum) {
     using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
     constexpr size_t lds = Cfg::LDS;
     static bool attr_set = false;
@@ -724,7 +753,8 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
         return DS_EINVAL;
     }
     gemm_f16_kernel<BM, BN, WGM, WGN, AMODE, NS><<<tiles_m * tiles_n, Cfg::NT, lds, st>>>(
-        (const f16*)A, (const f16*)W, bias, (const f16*)residual, out, d, tiles_m, tiles_n, (unsigned)a_bytes, (unsigned)w_bytes);
+        (const f16*)A, (const f16*)W, bias, (const f16*)residual, out, d, tiles_m, tiles_n, (unsigned)a_bytes, (unsigned)w_bytes,
+        ln_stats, ln_colsum);
     DS_CHECK_LAUNCH("ds_gemm_f16");
     return DS_OK;
 }
@@ -762,14 +792,14 @@ int choose_tile(const ds_gemm_desc& d) {
 
 template <int AMODE>
 int dispatch(int tile, const void* A, const void* W, const float* bias, const void* residual, void* out,
-             const ds_gemm_desc& d, hipStream_t st) {
+             const ds_gemm_desc& d, hipStream_t st, const float* ln_stats = nullptr, const float* ln_colsum = nullptr) {
     switch (tile) {
-        case TILE_256x256: return launch<256, 256, 2, 4, AMODE>(A, W, bias, residual, out, d, st);
-        case TILE_256x320: return launch<256, 320, 4, 2, AMODE>(A, W, bias, residual, out, d, st);
-        case TILE_128x128: return launch<128, 128, 2, 2, AMODE>(A, W, bias, residual, out, d, st);
-        case TILE_128x128_DEEP: return launch<128, 128, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st);
-        case TILE_128x64_DEEP: return launch<128, 64, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st);
-        default:           return launch<128, 64, 2, 2, AMODE>(A, W, bias, residual, out, d, st);
+        case TILE_256x256: return launch<256, 256, 2, 4, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
+        case TILE_256x320: return launch<256, 320, 4, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
+        case TILE_128x128: return launch<128, 128, 2, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
+        case TILE_128x128_DEEP: return launch<128, 128, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
+        case TILE_128x64_DEEP: return launch<128, 64, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
+        default:           return launch<128, 64, 2, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
     }
 }
 
@@ -782,8 +812,8 @@ extern "C" int ds_dbg_set_stamps(void* p) {
 }
 #endif
 
-extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,
-                           const ds_gemm_desc* desc, void* stream) {
+static int gemm_entry(const void* A, const void* W, const float* bias, const void* residual, void* out,
+                      const ds_gemm_desc* desc, void* stream, const float* ln_stats, const float* ln_colsum) {
     DS_CHECK_ARG(A && W && out && desc, "ds_gemm_f16: null argument");
     const ds_gemm_desc& d = *desc;
     DS_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "ds_gemm_f16: M,N,K must be positive (got %d,%d,%d)", d.M, d.N, d.K);
@@ -827,12 +857,27 @@ extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, cons
             const char* a_p = (const char*)A + r0 * d.lda * 2;
             const char* r_p = residual ? (const char*)residual + r0 * d.ldr * 2 : nullptr;
             char* o_p = (char*)out + r0 * d.ldc * out_elt;
-            int rc = dispatch<DS_A_DENSE>(tile, a_p, W, bias, r_p, o_p, c, st);
+            int rc = dispatch<DS_A_DENSE>(tile, a_p, W, bias, r_p, o_p, c, st, ln_stats ? ln_stats + 2 * r0 : nullptr, ln_colsum);
             if (rc) return rc;
         }
         return DS_OK;
     }
     if (d.a_mode == DS_A_CONV3) return dispatch<DS_A_CONV3>(tile, A, W, bias, residual, out, d, st);
     if (d.a_mode == DS_A_TCONV) return dispatch<DS_A_TCONV>(tile, A, W, bias, residual, out, d, st);
-    return dispatch<DS_A_DENSE>(tile, A, W, bias, residual, out, d, st);
+    return dispatch<DS_A_DENSE>(tile, A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
+}
+
+extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,
+                           const ds_gemm_desc* desc, void* stream) {
+    return gemm_entry(A, W, bias, residual, out, desc, stream, nullptr, nullptr);
+}
+
+extern "C" int ds_gemm_f16_ln(const void* x, const void* W_gamma, const float* ln_stats, const float* ln_colsum,
+                              const float* ln_colbias, void* out, const ds_gemm_desc* desc, void* stream) {
+    DS_CHECK_ARG(x && W_gamma && ln_stats && ln_colsum && out && desc, "ds_gemm_f16_ln: null argument");
+    DS_CHECK_ARG(desc->a_mode == DS_A_DENSE, "ds_gemm_f16_ln: dense A operand only (the LayerNorm row is the K dimension)");
+    DS_CHECK_ARG(!(desc->epilogue & DS_EPI_OUT_F32) && desc->N % 8 == 0 && desc->ldc % 8 == 0, "ds_gemm_f16_ln: fp16 output, N and ldc multiples of 8");
+    DS_CHECK_ARG((reinterpret_cast<uintptr_t>(ln_stats) & 7) == 0 && (reinterpret_cast<uintptr_t>(ln_colsum) & 15) == 0 &&
+                 (!ln_colbias || (reinterpret_cast<uintptr_t>(ln_colbias) & 15) == 0), "ds_gemm_f16_ln: stats 8-byte, column vectors 16-byte aligned");
+    return gemm_entry(x, W_gamma, ln_colbias, nullptr, out, desc, stream, ln_stats, ln_colsum);
 }

@@ -273,7 +273,7 @@ gn_small_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, cons
 template <int NV, int RW>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                 f16* __restrict__ y, int rows, int C, float eps) {
+                 f16* __restrict__ y, int rows, int C, float eps, float2* __restrict__ stats) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row0 = ((long)blockIdx.x * 4 + wave) * RW;
     if (row0 >= rows) return;
@@ -288,13 +288,17 @@ layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, con
             t[rw][i] = col < nvec ? *reinterpret_cast<const f16x8*>(x + row * C + col * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
+    // stats != nullptr: only (mean, rstd) per row are written (ds_layernorm_stats: the normalisation itself is folded into
+    // the consumer GEMM, ds_gemm_f16_ln) -- the same two-pass statistics as the full kernel
     f32x4 g0[NV], g1[NV], b0[NV], b1[NV];
+    if (!stats) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int col = lane + 64 * i;
-        const int c = (col < nvec ? col : 0) * 8;
-        g0[i] = *reinterpret_cast<const f32x4*>(gamma + c); g1[i] = *reinterpret_cast<const f32x4*>(gamma + c + 4);
-        b0[i] = *reinterpret_cast<const f32x4*>(beta + c);  b1[i] = *reinterpret_cast<const f32x4*>(beta + c + 4);
+        for (int i = 0; i < NV; ++i) {
+            const int col = lane + 64 * i;
+            const int c = (col < nvec ? col : 0) * 8;
+            g0[i] = *reinterpret_cast<const f32x4*>(gamma + c); g1[i] = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+            b0[i] = *reinterpret_cast<const f32x4*>(beta + c);  b1[i] = *reinterpret_cast<const f32x4*>(beta + c + 4);
+        }
     }
 #pragma unroll
     for (int rw = 0; rw < RW; ++rw) {
@@ -319,6 +323,10 @@ layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, con
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) q += __shfl_xor(q, sh);
         const float rstd = rsqrtf(q / (float)C + eps);
+        if (stats) {
+            if (lane == 0) stats[row0 + rw] = make_float2(mean, rstd);
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = lane + 64 * i;
@@ -399,10 +407,25 @@ extern "C" int ds_layernorm(const void* x, const float* gamma, const float* beta
     hipStream_t st = (hipStream_t)stream;
     DS_CHECK_ARG((reinterpret_cast<uintptr_t>(gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(beta) & 15) == 0, "ds_layernorm: gamma/beta must be 16-byte aligned");
     const int nv = (C / 8 + 63) / 64;
-    if (nv == 1) layernorm_kernel<1, 4><<<(rows + 15) / 16, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps);
-    else if (nv == 2) layernorm_kernel<2, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps);
-    else if (nv == 3) layernorm_kernel<3, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps);
-    else layernorm_kernel<5, 1><<<(rows + 3) / 4, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps);
+    if (nv == 1) layernorm_kernel<1, 4><<<(rows + 15) / 16, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps, nullptr);
+    else if (nv == 2) layernorm_kernel<2, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps, nullptr);
+    else if (nv == 3) layernorm_kernel<3, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps, nullptr);
+    else layernorm_kernel<5, 1><<<(rows + 3) / 4, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps, nullptr);
     DS_CHECK_LAUNCH("ds_layernorm");
+    return DS_OK;
+}
+
+extern "C" int ds_layernorm_stats(const void* x, float* stats, int rows, int C, float eps, void* stream) {
+    DS_CHECK_ARG(x && stats, "ds_layernorm_stats: null argument");
+    DS_CHECK_ARG(rows > 0 && C % 8 == 0 && C <= 2560, "ds_layernorm_stats: rows=%d C=%d unsupported (C %% 8 == 0, C <= 2560)", rows, C);
+    DS_CHECK_ARG((reinterpret_cast<uintptr_t>(stats) & 7) == 0, "ds_layernorm_stats: stats must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    float2* s2 = reinterpret_cast<float2*>(stats);
+    const int nv = (C / 8 + 63) / 64;
+    if (nv == 1) layernorm_kernel<1, 4><<<(rows + 15) / 16, 256, 0, st>>>((const f16*)x, nullptr, nullptr, nullptr, rows, C, eps, s2);
+    else if (nv == 2) layernorm_kernel<2, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, nullptr, nullptr, nullptr, rows, C, eps, s2);
+    else if (nv == 3) layernorm_kernel<3, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, nullptr, nullptr, nullptr, rows, C, eps, s2);
+    else layernorm_kernel<5, 1><<<(rows + 3) / 4, 256, 0, st>>>((const f16*)x, nullptr, nullptr, nullptr, rows, C, eps, s2);
+    DS_CHECK_LAUNCH("ds_layernorm_stats");
     return DS_OK;
 }

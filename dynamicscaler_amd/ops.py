@@ -340,6 +340,42 @@ def layernorm(x, gamma, beta, eps=1e-5, stream=None, out=None):
     return y
 
 
+def layernorm_stats(x, eps=1e-5, stream=None):
+    """(mean, rstd) per row as fp32 [rows, 2] (the statistics half of nn.LayerNorm; see gemm_ln)."""
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    rows, Cch = x.shape
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    check(lib.ds_layernorm_stats(x.data_ptr(), stats.data_ptr(), rows, Cch, float(eps), st), "ds_layernorm_stats")
+    return stats
+
+
+def gemm_ln(x, Wg, stats, colsum, colbias=None, *, M, N, K, out=None, epilogue=0, stream=None):
+    """out = LayerNorm(x) @ W^T (+ b) with the LayerNorm folded into the GEMM (ds_gemm_f16_ln): x raw fp16 [M,K], Wg =
+    fp16(gamma*W) [N,K], stats from layernorm_stats, colsum / colbias fp32 [N].  N' = N/2 for GEGLU."""
+    lib = _lib.load()
+    n_out = N // 2 if (epilogue & DS_EPI_GEGLU) else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float16, device=x.device)
+    d = GemmDesc()
+    d.M, d.N, d.K, d.a_mode = M, N, K, DS_A_DENSE
+    d.cin, d.lda = K, x.stride(0)
+    d.ldc, d.ldr = out.stride(0), 0
+    d.bias_rows, d.ldbias = 0x7FFFFFFF, N
+    d.epilogue = epilogue
+    st = _stream() if stream is None else stream
+
+    def launch():
+        check(lib.ds_gemm_f16_ln(x.data_ptr(), Wg.data_ptr(), stats.data_ptr(), colsum.data_ptr(), _ptr(colbias),
+                                 out.data_ptr(), C.byref(d), st), "ds_gemm_f16_ln")
+
+    if _timing_hook is not None:
+        _timing_hook("gemm", 2.0 * M * N * K, launch, (DS_A_DENSE, M, N, K, epilogue))
+    else:
+        launch()
+    return out
+
+
 def attention(q, k, v, out, *, batch, heads, nq, nk, ldq, ldk, ldv, ldo, kv_batch_div=1, scale, accumulate=False,
               stream=None):
     lib = _lib.load()

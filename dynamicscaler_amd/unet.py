@@ -73,6 +73,8 @@ class UNetModel(nn.Module):
                 node = getattr(node, p)
             node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape), requires_grad=False))
         self._packed = None
+        # LayerNorm folded into the projection it feeds (ds_gemm_f16_ln); False = separate LayerNorm kernel (A/B, tests)
+        self.fold_layernorm = os.environ.get("DS_FOLD_LN", "1") != "0"
         self._tap = None                     # optional callable(name, rows [M,C] fp16, (B,T,H,W)) after every block (tests)
         self._generation = 0                 # bumped by every prepare(): identifies the packed buffers (hipGraph cache keys)
         self._prepare_lock = threading.Lock()
@@ -145,21 +147,40 @@ class UNetModel(nn.Module):
                 p = f"{prefix}.transformer_blocks.{d}"
                 for n in ("norm1", "norm2", "norm3"):
                     norm(f"{p}.{n}")
-                P[f"{p}.attn1.qkv.w"] = w16(torch.cat([sd[f"{p}.attn1.to_q.weight"], sd[f"{p}.attn1.to_k.weight"],
-                                                       sd[f"{p}.attn1.to_v.weight"]], 0))
+
+                def proj(name, w, ln, bias=None, geglu=False):
+                    """A projection fed by LayerNorm `ln`: plain fp16 operand, or (fold_layernorm) the LayerNorm folded into
+                    it (ds_gemm_f16_ln): Wg = fp16(gamma * W), colsum of the ROUNDED operand rows, colbias = W beta (+ b)."""
+                    w = w.detach().to(dev, torch.float32)
+                    if not self.fold_layernorm:
+                        P[name + ".w"] = w16(_interleave_geglu(w) if geglu else w)
+                        if bias is not None:
+                            P[name + ".b"] = f32(_interleave_geglu(bias) if geglu else bias)
+                        return
+                    g, be = P[f"{p}.{ln}.g"], P[f"{p}.{ln}.be"]
+                    wg = (w * g[None, :]).to(torch.float16)
+                    cs = wg.float().sum(1)
+                    cb = w @ be
+                    if bias is not None:
+                        cb = cb + bias.detach().to(dev, torch.float32)
+                    if geglu:
+                        wg, cs, cb = _interleave_geglu(wg), _interleave_geglu(cs), _interleave_geglu(cb)
+                    P[name + ".wg"], P[name + ".cs"], P[name + ".cb"] = wg.contiguous(), cs.contiguous(), cb.contiguous()
+
+                proj(f"{p}.attn1.qkv", torch.cat([sd[f"{p}.attn1.to_q.weight"], sd[f"{p}.attn1.to_k.weight"],
+                                                 sd[f"{p}.attn1.to_v.weight"]], 0), "norm1")
                 lin(f"{p}.attn1.to_out.0")
                 if cross:
-                    lin(f"{p}.attn2.to_q", bias=False)
+                    proj(f"{p}.attn2.to_q", sd[f"{p}.attn2.to_q.weight"], "norm2")
                     P[f"{p}.attn2.kv.w"] = w16(torch.cat([sd[f"{p}.attn2.to_k.weight"], sd[f"{p}.attn2.to_v.weight"]], 0))
                     if img:
                         P[f"{p}.attn2.kv_ip.w"] = w16(torch.cat([sd[f"{p}.attn2.to_k_ip.weight"],
                                                                  sd[f"{p}.attn2.to_v_ip.weight"]], 0))
                 else:
-                    P[f"{p}.attn2.qkv.w"] = w16(torch.cat([sd[f"{p}.attn2.to_q.weight"], sd[f"{p}.attn2.to_k.weight"],
-                                                           sd[f"{p}.attn2.to_v.weight"]], 0))
+                    proj(f"{p}.attn2.qkv", torch.cat([sd[f"{p}.attn2.to_q.weight"], sd[f"{p}.attn2.to_k.weight"],
+                                                     sd[f"{p}.attn2.to_v.weight"]], 0), "norm2")
                 lin(f"{p}.attn2.to_out.0")
-                P[f"{p}.ff1.w"] = w16(_interleave_geglu(sd[f"{p}.ff.net.0.proj.weight"]))
-                P[f"{p}.ff1.b"] = f32(_interleave_geglu(sd[f"{p}.ff.net.0.proj.bias"]))
+                proj(f"{p}.ff1", sd[f"{p}.ff.net.0.proj.weight"], "norm3", bias=sd[f"{p}.ff.net.0.proj.bias"], geglu=True)
                 lin(f"{p}.ff.net.2")
 
         cfg = self.cfg
@@ -264,10 +285,18 @@ class UNetModel(nn.Module):
         M, inner = x.shape
         scale = HEAD_DIM ** -0.5
 
+        def ln_proj(xin, ln, name, N, epilogue=0):
+            """LayerNorm `ln` of xin followed by the projection `name`: the LayerNorm folded into the GEMM (row statistics +
+            ds_gemm_f16_ln on the raw activation), or the two separate kernels."""
+            Mx = xin.shape[0]
+            if self.fold_layernorm:
+                st = ops.layernorm_stats(xin)
+                return ops.gemm_ln(xin, P[name + ".wg"], st, P[name + ".cs"], P[name + ".cb"], M=Mx, N=N, K=inner, epilogue=epilogue)
+            n = ops.layernorm(xin, P[f"{p}.{ln}.g"], P[f"{p}.{ln}.be"])
+            return ops.gemm(n, P[name + ".w"], P.get(name + ".b"), None, M=Mx, N=N, K=inner, epilogue=epilogue)
+
         def self_attn(name, xin):
-            n = ops.layernorm(xin, P[f"{p}.norm{1 if name == 'attn1' else 2}.g"], P[f"{p}.norm{1 if name == 'attn1' else 2}.be"])
-            wq = P[f"{p}.{name}.qkv.w"]
-            qkv = ops.gemm(n, wq, None, None, M=M, N=3 * inner, K=inner)
+            qkv = ln_proj(xin, "norm1" if name == "attn1" else "norm2", f"{p}.{name}.qkv", 3 * inner)
             o = torch.empty((M, inner), dtype=torch.float16, device=x.device)
             ld = 3 * inner
             if spatial:
@@ -283,8 +312,7 @@ class UNetModel(nn.Module):
             x = dup(x)
             B, M = 2 * B, 2 * M
         if spatial:
-            n2 = ops.layernorm(x, P[f"{p}.norm2.g"], P[f"{p}.norm2.be"])
-            q = ops.gemm(n2, P[f"{p}.attn2.to_q.w"], None, None, M=M, N=inner, K=inner)
+            q = ln_proj(x, "norm2", f"{p}.attn2.to_q", inner)
             ctx_text, ctx_img, ltxt, limg = ctx
             wkv = P[f"{p}.attn2.kv.w"]
             kv = ops.gemm(ctx_text, wkv, None, None, M=ctx_text.shape[0], N=2 * inner, K=wkv.shape[1])
@@ -300,9 +328,7 @@ class UNetModel(nn.Module):
             x = self._linear(o, f"{p}.attn2.to_out.0", residual=x)
         else:
             x = self_attn("attn2", x)
-        n3 = ops.layernorm(x, P[f"{p}.norm3.g"], P[f"{p}.norm3.be"])
-        w1 = P[f"{p}.ff1.w"]
-        g = ops.gemm(n3, w1, P[f"{p}.ff1.b"], None, M=M, N=w1.shape[0], K=w1.shape[1], epilogue=DS_EPI_GEGLU)
+        g = ln_proj(x, "norm3", f"{p}.ff1", 8 * inner, epilogue=DS_EPI_GEGLU)      # GEGLU: 2 x (4 x inner) columns
         return self._linear(g, f"{p}.ff.net.2", residual=x)
 
     def _transformer(self, h, prefix, heads, depth, spatial, geo, ctx, dup=None):

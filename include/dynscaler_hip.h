@@ -177,6 +177,15 @@ typedef struct ds_gemm_desc {
  * bias: fp32 [ceil(M/bias_rows)][ldbias] or NULL.  residual: fp16 [M][ldr] or NULL.  out: fp16/fp32 [M][ldc]. */
 int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,
                 const ds_gemm_desc* desc, void* stream);
+/* LayerNorm folded into the projection that consumes it (BasicTransformerBlock: norm1 -> to_q/to_k/to_v, norm2 -> to_q,
+ * norm3 -> GEGLU proj; attention.py:199-220, 376-403):  out = LayerNorm(x) W^T + b  computed as
+ *   rstd[m] * (x[m,:] . Wg[n,:] - mean[m] * colsum[n]) + colbias[n]
+ * with Wg = fp16(gamma (.) W) [N][K], colsum[n] = sum_k Wg[n][k] (fp32), colbias[n] = sum_k beta[k] W[n][k] (+ b[n]),
+ * stats from ds_layernorm_stats.  x is the RAW activation (dense A operand, K = the LayerNorm width); the normalised
+ * activation is never rounded to fp16 nor written to memory.  desc as for ds_gemm_f16 (a_mode DENSE, fp16 output, no
+ * residual); DS_EPI_GEGLU / DS_EPI_SILU apply after the fold.  colbias may be NULL. */
+int ds_gemm_f16_ln(const void* x, const void* W_gamma, const float* ln_stats, const float* ln_colsum,
+                   const float* ln_colbias, void* out, const ds_gemm_desc* desc, void* stream);
 
 /* GroupNorm statistics: x fp16 [ninst*rows_per_inst][C]; instance i = rows [i*rows_per_inst, (i+1)*...).
  * Writes mean/rstd fp32 [ninst][groups]; `workspace` = caller scratch of ds_groupnorm_stats_workspace_floats(...)
@@ -197,6 +206,9 @@ int ds_groupnorm_f16(const void* x, const float* gamma, const float* beta, void*
 /* nn.LayerNorm(C) eps 1e-5 over each row (attention.py:199-201). x,y fp16 [rows][C]. */
 int ds_layernorm(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
                  void* stream);
+/* The statistics half of nn.LayerNorm (attention.py:199-201): stats[row] = (mean, 1/sqrt(var + eps)) fp32 pairs, two-pass
+ * like ds_layernorm.  The normalisation itself is folded into the consumer GEMM by ds_gemm_f16_ln. */
+int ds_layernorm_stats(const void* x, float* stats, int rows, int C, float eps, void* stream);
 
 /* softmax(q k^T * scale) v, head_dim 64 (CrossAttention.forward, attention.py:76-127).
  * q: fp16, element (b, i, h, d) at q[(b*nq + i)*ldq + h*64 + d]; k/v likewise with nk rows per kv batch;

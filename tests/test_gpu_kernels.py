@@ -402,6 +402,42 @@ def test_layernorm(rows, C):
     assert relerr(y, F.layer_norm(x, (C,), g, b, 1e-5)) < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(1000, 960, 320, False), (300, 320, 320, False), (77, 3840, 1280, False),
+                                        (2100, 2560, 320, True), (130, 1024, 128, True), (5, 192, 64, False)])
+def test_gemm_layernorm_folded(M, N, K, geglu):
+    """ds_layernorm_stats + ds_gemm_f16_ln == LayerNorm -> Linear (-> GEGLU) in fp32 (attention.py:199-220, 376-403), with a
+    row mean that is NOT small against the row's spread (the fold subtracts mean * colsum from the raw product)."""
+    from dynamicscaler_amd import ops
+    from dynamicscaler_amd._lib import DS_EPI_GEGLU
+    from dynamicscaler_amd.unet import _interleave_geglu
+    d = dev()
+    x = _h(rnd((M, K), 1) * 2 + 1.5)
+    g, be = 1 + 0.2 * rnd((K,), 2), 0.3 * rnd((K,), 3)
+    w, b = _h(rnd((N, K), 4) * K ** -0.5), 0.1 * rnd((N,), 5)
+    wg = (w * g[None, :]).half()
+    cs, cb = wg.float().sum(1), w @ be + b
+    ref = F.layer_norm(x, (K,), g, be, 1e-5) @ w.t() + b
+    if geglu:
+        a, gate = ref.chunk(2, dim=-1)
+        ref = a * F.gelu(gate)
+        wg, cs, cb = _interleave_geglu(wg), _interleave_geglu(cs), _interleave_geglu(cb)
+    xd = x.half().to(d)
+    st = ops.layernorm_stats(xd)
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    assert relerr(st[:, 0], mean) < 1e-5 and relerr(st[:, 1], (var + 1e-5).rsqrt()) < 1e-5
+    out = ops.gemm_ln(xd, wg.to(d).contiguous(), st, cs.to(d).contiguous(), cb.to(d).contiguous(), M=M, N=N, K=K,
+                      epilogue=DS_EPI_GEGLU if geglu else 0)
+    e = relerr(out, ref)
+    # against the two-kernel path (LayerNorm output rounded to fp16, then the plain GEMM): the fold must not be worse
+    n16 = ops.layernorm(xd, g.to(d), be.to(d))
+    w_plain = (_interleave_geglu(w) if geglu else w).half().to(d).contiguous()
+    b_plain = (_interleave_geglu(b) if geglu else b).to(d).contiguous()
+    two = ops.gemm(n16, w_plain, b_plain, None, M=M, N=N, K=K, epilogue=DS_EPI_GEGLU if geglu else 0)
+    e2 = relerr(two, ref)
+    print(f"gemm_ln {M}x{N}x{K} geglu={geglu}: folded {e:.3e}, LayerNorm kernel + GEMM {e2:.3e}")
+    assert out.shape == ref.shape and e < 1.2e-3 and e < 1.5 * e2 + 1e-4
+
+
 def test_misc_ops():
     from dynamicscaler_amd import ops
     d = dev()

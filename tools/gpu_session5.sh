@@ -3,6 +3,10 @@
 S=${1:-s5}; R=$PWD; O=$R/gpurun_out/$S; mkdir -p $O
 export PYTHONUNBUFFERED=1
 cd /tmp && export TMPDIR=/tmp
+# kernel stats with ONE stream (kernels one at a time: per-launch durations comparable with bench.py's HIP-event figure)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg3_s1 -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline > $O/prof_cfg3_s1.log 2>&1; echo "rocprof cfg3 1 stream rc=$?" | tee -a $O/summary.txt
+f=$(find $O/prof_cfg3_s1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_cfg3_s1.csv
+find $O/prof_cfg3_s1 -name "*kernel_trace.csv" -delete
 rocprofv3 -L > $O/counters_available.txt 2>&1
 pick() { python3 - "$@" <<'PY'
 import re,sys
