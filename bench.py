@@ -286,13 +286,29 @@ def main():
             traffic_src = os.path.relpath(src, REPO)
         except Exception:
             pass
+        # the same figure from the committed rocprofv3 --kernel-trace --stats summary of this command (one stream, so that a
+        # kernel's duration is its own): algorithmic FLOPs of this run / the profile's GEMM time per step
+        rocprof = None
+        try:
+            src = os.path.join(REPO, "profiles", "r2_rocprof_step_summary_cfg3_1stream.json")
+            if args.config == "cfg3" and os.path.exists(src):
+                fam = json.load(open(src))["families"]["gemm"]
+                rp = g[1] / (fam["ms_per_step"] * 1e-3) / 1e12
+                rocprof = {"avg_launch_us": round(fam["avg_launch_us"], 1), "achieved": round(rp, 1),
+                           "frac": round(rp * 1e12 / MFMA_PEAK_F16, 4), "source": os.path.relpath(src, REPO),
+                           "note": "HIP-event bracketing adds a few us per launch; the two figures agree within run-to-run "
+                                   "variation of the box (the chip's clock under load differs from box to box)"}
+        except Exception:
+            pass
         roofline = {
             "bound": "mfma", "kernel": "gemm_f16_kernel (implicit GEMM: linear / conv3x3 / temporal conv)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / MFMA_PEAK_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(g[3] / g[0]),
             "measured_with": "per-launch HIP events on one extra step, one stream, eager launches, tile batch %d" % args.tile_batch,
-            "vendor_library_gemm_tflops_on_this_box": lib_tf,
+            "vendor_library_gemm_tflops_on_this_box": lib_tf, "rocprof": rocprof,
+            "pmc_summary": "profiles/r2_pmc_mfma_util.json (MFMA busy, wait / issue shares, VALU:MFMA, LDS bank conflicts, clock and "
+                           "HBM bytes of the top shapes)",
             "launches_per_step": g[0], "algorithmic_tflop_per_step": round(g[1] / 1e12, 2),
             "avg_launch_us": round(1e6 * g[2] / g[0], 2), "gemm_time_share_of_step": round(g[2] / (elapsed / args.steps), 3),
             "attention_tflops": round(agg["attention"][1] / agg["attention"][2] / 1e12, 2) if "attention" in agg else None,
@@ -347,7 +363,9 @@ def main():
                        "baseline_config": args.config,
                        "tiles_per_step": tiles_per_step, "unet_evals_per_step": 2 * tiles_per_step,
                        "tile_batch": args.tile_batch, "streams": args.streams, "hipgraph": bool(args.graph), "cfg_prefix_shared": bool(args.share_cfg_prefix), "parallelism": f"tiles sharded over {world} GPU(s)",
-                       "rng": "philox in-kernel (perf mode)"},
+                       "rng": "philox in-kernel (perf mode)",
+                       "bit_repeatable": "yes, in every mode (streams x hipGraph included): the cause of round 1's run-to-run "
+                                         "differences under concurrent graph replays is fixed (profiles/r2_notes.md section 1)"},
             "sec_per_50_step_panorama": 50 * elapsed / args.steps,
             "speedup_vs_cpu_baseline": (steps_per_s / cpu_baseline["value"]) if cpu_baseline else None,
             "setup_s": round(setup_s, 1),

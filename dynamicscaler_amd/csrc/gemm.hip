@@ -26,6 +26,7 @@
 
 namespace {
 
+constexpr int A_DENSE_LN = 3;   // internal template value: DS_A_DENSE addressing + the LayerNorm fold after the K loop (ds_gemm_f16_ln)
 constexpr int BK = 64;  // halfs per K-step (128-byte LDS rows, 8 chunks of 16 bytes)
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -240,7 +241,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         if (cb == d.cin) {
             cb = 0;
             ++tap;
-            if constexpr (AMODE != DS_A_DENSE) tap_offsets();
+            if constexpr (AMODE == DS_A_CONV3 || AMODE == DS_A_TCONV) tap_offsets();
         }
     };
     auto store_lds = [&](int buf) {
@@ -267,7 +268,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     // (bias_rows <= M, also when it covers the launch with ONE item) is always added after the K sum.
     // Each lane reads the 4 columns of its register quads straight from global memory (two addresses per wave-instruction,
     // L2-resident) while the first K-steps' loads are in flight.
-    const bool ln_fold = ln_stats != nullptr;   // LayerNorm folded into this GEMM (ds_gemm_f16_ln): see the transform after the K loop
+    constexpr bool ln_fold = AMODE == A_DENSE_LN;   // LayerNorm folded into this GEMM (ds_gemm_f16_ln): see the transform after the K loop
     const bool bias_in_acc = !ln_fold && bias && d.bias_rows > d.M && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.ldbias % 4 == 0) &&
                              (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && !(d.epilogue & DS_EPI_OUT_F32) &&
                              (!residual || d.ldr % 8 == 0);
@@ -345,7 +346,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         if (cb == d.cin) {
             cb = 0;
             ++tap;
-            if constexpr (AMODE != DS_A_DENSE) tap_offsets();
+            if constexpr (AMODE == DS_A_CONV3 || AMODE == DS_A_TCONV) tap_offsets();
         }
     };
 
@@ -443,23 +444,34 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     //      Applied in the accumulator layout (a lane owns one row: two scalars per 32-row block; cs / cb are 16-byte loads
     //      per register quad like the accumulator-init bias), after which the epilogue sees a plain bias-free product.
     //      The normalised activation is never rounded to fp16 and never written to memory. ----
-    if (ln_fold) {
+    if constexpr (ln_fold) {
+        const float* ln_cb = bias ? bias : ln_colsum;      // no column bias: any readable vector, scaled by 0 below
+        const float cb_on = bias ? 1.0f : 0.0f;
+        float2 st[TM];
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
-            const int row = m0 + wm * WM + mi * 32 + fr;
-            const float2 st = row < d.M ? reinterpret_cast<const float2*>(ln_stats)[row] : make_float2(0.0f, 0.0f);
+            st[mi] = reinterpret_cast<const float2*>(ln_stats)[min(m0 + wm * WM + mi * 32 + fr, d.M - 1)];   // tail rows: never stored
+        }
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
+        for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = n0 + wn * WN + ni * 32 + 8 * g + 4 * fh;
-                    const bool okc = col < d.N;
-                    const f32x4 cs = okc ? *reinterpret_cast<const f32x4*>(ln_colsum + col) : f32x4{0, 0, 0, 0};
-                    const f32x4 cb = okc && bias ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0, 0, 0, 0};
+            for (int g = 0; g < 4; ++g) {
+                // branch-free loads (a select around a load becomes a divergent branch): columns beyond N are clamped to the
+                // last quad -- their products are never stored (N % 8 == 0 is checked on the host).  Known cost: the scheduler
+                // hoists all these loads in front of the arithmetic; on the 256x320 tile (already at 248 VGPRs) that spills
+                // ~300 B per lane and makes the folded QKV launches SLOWER than LayerNorm kernel + plain GEMM
+                // (profiles/r2_notes.md section 4) -- why UNetModel.fold_layernorm is off by default.
+                const int col = min(n0 + wn * WN + ni * 32 + 8 * g + 4 * fh, d.N - 4);
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(ln_colsum + col);
+                f32x4 cb = *reinterpret_cast<const f32x4*>(ln_cb + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cb[j] *= cb_on;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[ni][mi][4 * g + j] = fmaf(st.y, acc[ni][mi][4 * g + j] - st.x * cs[j], cb[j]);
-                }
+                        acc[ni][mi][4 * g + j] = fmaf(st[mi].y, acc[ni][mi][4 * g + j] - st[mi].x * cs[j], cb[j]);
+            }
         }
     }
     const bool bias_done = bias_in_acc || ln_fold;   // nothing left to add in the epilogue
@@ -715,7 +727,13 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         if (pib) epilogue(ge_tag, res_tag, std::true_type{});
         else epilogue(ge_tag, res_tag, std::false_type{});
     };
-    if (geglu) {
+    if constexpr (ln_fold) {         // ds_gemm_f16_ln: no residual, no per-item bias (checked on the host)
+        if (geglu) {
+            if constexpr (TN % 2 == 0) epilogue(std::true_type{}, std::false_type{}, std::false_type{});
+        } else {
+            epilogue(std::false_type{}, std::false_type{}, std::false_type{});
+        }
+    } else if (geglu) {
         if constexpr (TN % 2 == 0) {
             if (residual) epilogue(std::true_type{}, std::true_type{}, std::false_type{});
             else epilogue(std::true_type{}, std::false_type{}, std::false_type{});
@@ -857,14 +875,16 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
             const char* a_p = (const char*)A + r0 * d.lda * 2;
             const char* r_p = residual ? (const char*)residual + r0 * d.ldr * 2 : nullptr;
             char* o_p = (char*)out + r0 * d.ldc * out_elt;
-            int rc = dispatch<DS_A_DENSE>(tile, a_p, W, bias, r_p, o_p, c, st, ln_stats ? ln_stats + 2 * r0 : nullptr, ln_colsum);
+            int rc = ln_stats ? dispatch<A_DENSE_LN>(tile, a_p, W, bias, r_p, o_p, c, st, ln_stats + 2 * r0, ln_colsum)
+                              : dispatch<DS_A_DENSE>(tile, a_p, W, bias, r_p, o_p, c, st);
             if (rc) return rc;
         }
         return DS_OK;
     }
     if (d.a_mode == DS_A_CONV3) return dispatch<DS_A_CONV3>(tile, A, W, bias, residual, out, d, st);
     if (d.a_mode == DS_A_TCONV) return dispatch<DS_A_TCONV>(tile, A, W, bias, residual, out, d, st);
-    return dispatch<DS_A_DENSE>(tile, A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
+    if (ln_stats) return dispatch<A_DENSE_LN>(tile, A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
+    return dispatch<DS_A_DENSE>(tile, A, W, bias, residual, out, d, st);
 }
 
 extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,

@@ -44,3 +44,4 @@ def install():
     _mod("utils.multi_prompt_utils",
          select_prompt_from_multi_prompt_dict_by_factor=pipelines.select_prompt_from_multi_prompt_dict_by_factor)
     _mod("utils.utils", instantiate_from_config=host_model.instantiate_from_config)
+    _mod("scripts.evaluation.funcs", load_model_checkpoint=host_model.load_model_checkpoint)

@@ -30,6 +30,30 @@ def instantiate_from_config(config):
     return get_obj_from_str(config["target"])(**config.get("params", dict()))
 
 
+def load_model_checkpoint(model, ckpt):
+    """scripts/evaluation/funcs.py:88-104: the three checkpoint layouts the reference accepts -- a DeepSpeed dump
+    ({'module': {'_forward_module.<key>': ...}}: the first 16 characters of every key are stripped), a Lightning checkpoint
+    ({'state_dict': {...}}) or a bare state dict.  `ckpt` is a path (torch.load, map_location='cpu') or an already loaded
+    mapping.  Loading is strict for everything this build holds parameters for (UNet, first stage, conditioning encoders);
+    the reference model's DDPM schedule buffers and EMA copies, which this build recomputes, are the only keys ignored."""
+    sd = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__") else ckpt
+    if "module" in sd and isinstance(sd["module"], dict):
+        sd = {k[16:]: v for k, v in sd["module"].items()}
+    elif "state_dict" in sd:
+        sd = sd["state_dict"]
+    own = model.state_dict()
+    recomputed = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_", "log_one_minus", "posterior_", "logvar",
+                  "lvlb_weights", "scale_arr", "model_ema.")
+    use = {k: v for k, v in sd.items() if k in own}
+    unexpected = [k for k in sd if k not in own and not k.startswith(recomputed)]
+    missing = [k for k in own if k not in sd and not k.startswith(recomputed)]
+    if unexpected or missing:
+        raise RuntimeError(f"load_model_checkpoint: {len(missing)} missing key(s) {missing[:5]}, "
+                           f"{len(unexpected)} unexpected key(s) {unexpected[:5]}")
+    model.load_state_dict(use, strict=False)
+    return model
+
+
 class SyntheticConditioner:
     """prompt -> seeded N(0,1) embedding [1, L, dim] (fp16-representable), "" -> a different seed."""
 

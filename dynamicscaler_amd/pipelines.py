@@ -314,7 +314,7 @@ class VC2_Pipeline_T2V:
 
         # levels of pairwise-disjoint windows; over several ranks whole components (columns) per rank with one exchange
         # per step, or a strided share of every level (parallel.run_step)
-        st.share_mode = parallel.run_step(wins, st.pano_fhw, st.rank, st.world, process, scatter, empty_tiles)
+        st.share_mode = self.last_share_mode = parallel.run_step(wins, st.pano_fhw, st.rank, st.world, process, scatter, empty_tiles)
 
     def _new_state(self, init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
                    text_emb, uc_emb, ratio, kwargs):
@@ -386,9 +386,6 @@ class VC2_Pipeline_T2V:
             raise NotImplementedError("random_shuffle_init_frame_stride: the reference indexes the H axis with frame "
                                       "indices there (t2v_normal_pipeline.py:337) and fails for panoramas lower than "
                                       "their frame count; no driver uses it")
-        if clear_pre_denoised_video_tensor is not None:
-            raise NotImplementedError("clear_pre_denoised_video_tensor (resize + VAE encode of a clip, :363-368): "
-                                      "encode it with encode_first_stage_2DAE and pass clear_pre_denoised_latent")
         unet_config = self.model_config["params"]["unet_config"]
         frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
         prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
@@ -403,7 +400,7 @@ class VC2_Pipeline_T2V:
         lat_h, lat_w = height // vs, width // vs
         c_lat = unet_config["params"]["in_channels"]
         total_shape = (1, c_lat, frames * num_windows_f, lat_h * num_windows_h, lat_w * num_windows_w)
-        resized = None
+        resized, fm = None, True
         if init_panorama_latent is None:
             init_panorama_latent = torch.randn(total_shape)  # host draw, reference order
             if use_skip_time:
@@ -417,21 +414,31 @@ class VC2_Pipeline_T2V:
                 device = self._execution_device
                 basic_shape = (1, c_lat, frames, lat_h, lat_w)
                 latent = torch.randn(basic_shape)            # drawn in every branch (:358)
-                if clear_pre_denoised_latent is not None:
-                    assert tuple(clear_pre_denoised_latent.shape) == basic_shape, \
-                        f"[basic_sample_shift_multi_windows] clear_pre_denoised_latent shape :{tuple(clear_pre_denoised_latent.shape)}" \
-                        f"not equal to _basic_latent_shape: {basic_shape}"
-                    latent = clear_pre_denoised_latent.clone()
-                latent = latent.to(device=device, dtype=self.latent_dtype).contiguous()
-                if clear_pre_denoised_latent is None:
-                    self._log(f"[basic_sample_shift_multi_windows] Pre Denosing {pre_denoise_steps} Steps...")
-                    for i, t in enumerate(full_timesteps[:pre_denoise_steps]):
-                        latent, _ = self._basic_denoise_one_step(latent, t, i, total_steps, text_emb, uc_emb,
-                                                                 guidance_scale, fps, frames, kwargs)
                 from .tensor_utils import resize_video_latent
-                resized = resize_video_latent(latent, lat_h * num_windows_h, lat_w * num_windows_w, mode="bicubic")
-                # `resized` is a permuted view in the reference: its randn_like draws follow frames-major strides
-                init_panorama_latent = self.scheduler.add_noise(resized, total_steps - 1, frames_major_strides=True)
+                fm = True     # `resized` is a permuted view in the reference: its randn_like draws follow frames-major strides
+                if clear_pre_denoised_video_tensor is not None:
+                    # a clear CLIP in pixel space (:363-368): bicubic resize to the panorama size, first-stage encode (posterior
+                    # noise drawn on the host in the reference's order); the encoder's output is contiguous [B,C,F,H,W]
+                    clip = clear_pre_denoised_video_tensor.to(device=device, dtype=torch.float32).contiguous()
+                    resized_clip = resize_video_latent(clip, height * num_windows_h, width * num_windows_w, mode="bicubic")
+                    resized = self.pretrained_t2v.encode_first_stage_2DAE(resized_clip).to(self.latent_dtype).contiguous()
+                    assert tuple(resized.shape) == total_shape, \
+                        f"[basic_sample_shift_multi_windows] encoded clip {tuple(resized.shape)} != panorama latent {total_shape}"
+                    fm = False
+                else:
+                    if clear_pre_denoised_latent is not None:
+                        assert tuple(clear_pre_denoised_latent.shape) == basic_shape, \
+                            f"[basic_sample_shift_multi_windows] clear_pre_denoised_latent shape :{tuple(clear_pre_denoised_latent.shape)}" \
+                            f"not equal to _basic_latent_shape: {basic_shape}"
+                        latent = clear_pre_denoised_latent.clone()
+                    latent = latent.to(device=device, dtype=self.latent_dtype).contiguous()
+                    if clear_pre_denoised_latent is None:
+                        self._log(f"[basic_sample_shift_multi_windows] Pre Denosing {pre_denoise_steps} Steps...")
+                        for i, t in enumerate(full_timesteps[:pre_denoise_steps]):
+                            latent, _ = self._basic_denoise_one_step(latent, t, i, total_steps, text_emb, uc_emb,
+                                                                     guidance_scale, fps, frames, kwargs)
+                    resized = resize_video_latent(latent, lat_h * num_windows_h, lat_w * num_windows_w, mode="bicubic")
+                init_panorama_latent = self.scheduler.add_noise(resized, total_steps - 1, frames_major_strides=fm)
                 if use_skip_time:
                     if progressive_skip:
                         for frame_idx, progs_skip_idx in enumerate(list(reversed(range(skip_time_step_idx)))):
@@ -439,7 +446,7 @@ class VC2_Pipeline_T2V:
                                                               total_steps - progs_skip_idx - 1)
                             init_panorama_latent[:, :, [frame_idx]] = noised
                     else:
-                        init_panorama_latent = self.scheduler.add_noise(resized, total_steps - 1, frames_major_strides=True)
+                        init_panorama_latent = self.scheduler.add_noise(resized, total_steps - 1, frames_major_strides=fm)
         else:
             assert tuple(init_panorama_latent.shape) == total_shape, \
                 f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_panorama_latent.shape)} " \
@@ -453,7 +460,7 @@ class VC2_Pipeline_T2V:
             if use_pre_denoise and merge_predenoise_ratio_list is not None and resized is not None:       # :445-468
                 assert len(merge_predenoise_ratio_list) == len(timesteps), \
                     f"merge_predenoise_ratio_list ({len(merge_predenoise_ratio_list)}) should have same length as timesteps({len(timesteps)})"
-                noised_resized = self.scheduler.re_noise(resized, 0, total_steps - i - 1, frames_major_strides=True)
+                noised_resized = self.scheduler.re_noise(resized, 0, total_steps - i - 1, frames_major_strides=fm)
                 st.pano = ops.residual_merge(st.pano, noised_resized, merge_predenoise_ratio_list[i], i, sparse_add_residual)
             wins = t2v_grid_windows(i, latent_h=lat_h, latent_w=lat_w, frames=frames, num_windows_w=num_windows_w,
                                     num_windows_h=num_windows_h, num_windows_f=num_windows_f, loop_step=loop_step,

@@ -73,8 +73,11 @@ class UNetModel(nn.Module):
                 node = getattr(node, p)
             node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape), requires_grad=False))
         self._packed = None
-        # LayerNorm folded into the projection it feeds (ds_gemm_f16_ln); False = separate LayerNorm kernel (A/B, tests)
-        self.fold_layernorm = os.environ.get("DS_FOLD_LN", "1") != "0"
+        # LayerNorm folded into the projection it feeds (ds_layernorm_stats + ds_gemm_f16_ln: the normalised activation is never
+        # rounded to fp16 nor written to memory).  OFF by default: measured 505 vs 489 ms per cfg3 step on MI355X (the fold's
+        # column loads spill on the 256x320 tile, profiles/r2_notes.md section 4).  DS_FOLD_LN=1 or set the attribute (and
+        # invalidate()) to use it.
+        self.fold_layernorm = os.environ.get("DS_FOLD_LN", "0") == "1"
         self._tap = None                     # optional callable(name, rows [M,C] fp16, (B,T,H,W)) after every block (tests)
         self._generation = 0                 # bumped by every prepare(): identifies the packed buffers (hipGraph cache keys)
         self._prepare_lock = threading.Lock()

@@ -241,7 +241,8 @@ def t2v_grid_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, *,
                     num_inference_steps=50, init_panorama_latent=None, in_channels=4, trace=None,
                     use_pre_denoise=False, pre_denoise_steps=None, skip_steps_after_pre_denoise=0,
                     clear_pre_denoised_latent=None, merge_predenoise_ratio_list=None, sparse_add_residual=True,
-                    use_skip_time=False, skip_time_step_idx=None, progressive_skip=False, **grid_kw):
+                    use_skip_time=False, skip_time_step_idx=None, progressive_skip=False,
+                    clear_pre_denoised_video_tensor=None, encode_first_stage=None, **grid_kw):
     """Returns (denoised, denoised) for output_type='latent' (t2v_normal_pipeline.py:561-568).  Includes the pre-denoise
     start (:345-412: a single tile denoised for a few steps or given, resized bicubically to the panorama, re-noised,
     optionally with a per-frame progressive noise level) and the per-step sparse / dense residual merge (:445-468)."""
@@ -270,12 +271,18 @@ def t2v_grid_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, *,
             if (num_windows_h != 1 or num_windows_w != 1) and num_windows_f != 1:
                 raise NotImplementedError()
             latent = torch.randn((1, in_channels, frames, lh, lw))                            # drawn in every branch (:358)
-            if clear_pre_denoised_latent is not None:
-                latent = clear_pre_denoised_latent.clone()
+            if clear_pre_denoised_video_tensor is not None:                                   # :363-368, a clear clip in pixel space
+                clip = resize_video_latent(clear_pre_denoised_video_tensor.clone(), height * num_windows_h,
+                                           width * num_windows_w, "bicubic")
+                resized = encode_first_stage(clip).clone()       # pretrained_t2v.encode_first_stage_2DAE (ddpm3d.py:485-490)
+                assert tuple(resized.shape) == total_shape
             else:
-                for i, t in enumerate(full_timesteps[:pre_denoise_steps]):
-                    latent, _ = basic_step(latent, t, i)
-            resized = resize_video_latent(latent.clone(), lh * num_windows_h, lw * num_windows_w, "bicubic")
+                if clear_pre_denoised_latent is not None:
+                    latent = clear_pre_denoised_latent.clone()
+                else:
+                    for i, t in enumerate(full_timesteps[:pre_denoise_steps]):
+                        latent, _ = basic_step(latent, t, i)
+                resized = resize_video_latent(latent.clone(), lh * num_windows_h, lw * num_windows_w, "bicubic")
             pano = _add_noise(sched, resized, total_steps - 1)
             if use_skip_time:
                 if progressive_skip:

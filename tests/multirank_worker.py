@@ -44,14 +44,18 @@ def main():
         pipe.use_graph, pipe.num_streams = False, 1
     steps = []
 
+    share_modes = []
+
     def on_step(i, t, wins, pano, pano_x0):
         import hashlib
+        share_modes.append(getattr(pipe, "last_share_mode", None))
         steps.append(hashlib.sha256(pano.float().cpu().numpy().tobytes()).hexdigest()[:10])
 
     torch.manual_seed(2333333)
     _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
                                                    step_callback=on_step, **meta["geoms"][geom_name])
-    print("STEP_HASHES", dist.get_rank() if dist.is_initialized() else 0, getattr(pipe, "_last_share_mode", None), steps, flush=True)
+    print("STEP_HASHES", dist.get_rank() if dist.is_initialized() else 0, steps, flush=True)
+    print("SHARE_MODE", share_modes[-1] if share_modes else None, flush=True)
     rank = dist.get_rank() if dist.is_initialized() else 0
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), den=den.float().cpu().numpy(),
              final=pipe.final_latent.float().cpu().numpy())

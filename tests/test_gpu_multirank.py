@@ -31,10 +31,13 @@ def _torchrun(nproc, script_and_args, env_extra=None, timeout=900):
     return subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("geom,rng", [("grid4x2", "reference"), ("overlapw", "device")])
-def test_two_ranks_equal_single_process(tmp_path, geom, rng):
+@pytest.mark.parametrize("geom,rng,share", [("grid4x2", "reference", "auto"), ("grid4x2", "reference", "levels"),
+                                            ("overlapw", "device", "auto")])
+def test_two_ranks_equal_single_process(tmp_path, geom, rng, share):
     """Both replicas of a rank-sharded run equal the single-process panorama bit for bit (host RNG with the same seed on
-    every rank, or the in-kernel Philox streams keyed by tile number)."""
+    every rank, or the in-kernel Philox streams keyed by tile number).  grid4x2 has 4 independent columns: `auto` gives each
+    rank whole columns with ONE all-gather per step, `levels` forces a strided share of every level (one all-gather per
+    level); overlapw is one chain (W overlap), so `auto` falls back to levels."""
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
     worker = os.path.join(REPO, "tests", "multirank_worker.py")
@@ -42,27 +45,33 @@ def test_two_ranks_equal_single_process(tmp_path, geom, rng):
     one.mkdir(); two.mkdir()
     r = subprocess.run([sys.executable, worker, str(one), geom, rng], cwd=REPO, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    r = _torchrun(2, [worker, str(two), geom, rng])
+    r = _torchrun(2, [worker, str(two), geom, rng], env_extra={"DS_SHARE_MODE": share})
     assert r.returncode == 0, r.stderr[-2000:]
+    want = "components" if (geom == "grid4x2" and share == "auto") else "levels"
+    assert r.stdout.count(f"SHARE_MODE {want}") == 2, r.stdout[-1500:]
     ref = np.load(one / "rank0.npz")
     for rank in (0, 1):
         got = np.load(two / f"rank{rank}.npz")
         assert np.array_equal(got["den"], ref["den"]) and np.array_equal(got["final"], ref["final"]), (geom, rank)
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py as the driver launches it for N = 2 (torch.distributed.run, RANK / WORLD_SIZE from the env), rehearsed on
-    one GPU: one JSON line from rank 0 with n_gpus 2 and a finite whole-job value."""
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` exactly as a user types it (no launcher, no RANK / WORLD_SIZE): the parent starts the two
+    ranks itself as a child torch.distributed.run before touching the GPU and relays rank 0's JSON line.  Rehearsed on one
+    GPU (both ranks on cuda:0, gloo with host-staged collectives; the driver's real runs use RCCL, one rank per GPU)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
-    r = _torchrun(2, ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline"],
-                  env_extra={"DS_DIST_BACKEND": "gloo", "DS_BENCH_DEVICE": "0"}, timeout=1500)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DS_DIST_BACKEND="gloo", DS_BENCH_DEVICE="0", GLOO_SOCKET_IFNAME="lo")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline"], cwd=REPO,
+                       env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "strong" and j["cpu_baseline"] is None
     assert np.isfinite(j["value"]) and j["value"] > 0 and j["unit"] == "denoising-steps/sec"
+    assert j["config"]["baseline_config"] == "cfg3" and "4096x512x16f" in j["metric"]
 
 
 def test_graph_and_streams_repeatable_across_processes():

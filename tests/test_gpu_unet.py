@@ -64,6 +64,28 @@ def test_unet_tiny_vs_reference_golden(name):
             assert e < EPS_TOL_TINY
 
 
+def test_unet_layernorm_fold_option_vs_reference_golden():
+    """UNetModel.fold_layernorm (opt-in: LayerNorm folded into the projection it feeds, ds_layernorm_stats + ds_gemm_f16_ln):
+    same reference goldens, same tolerance; the normalised activation is never rounded to fp16, so the distance to the fp32
+    reference must not grow."""
+    d = dev()
+    z = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(z["params_json"]).decode())
+    errs = {}
+    for fold in (False, True):
+        m = build_unet(params, 5, d)
+        m.fold_layernorm = fold
+        m.invalidate()
+        e = []
+        for case in range(3):
+            x, t, ctx = T(z[f"x_{case}"]), T(z[f"t_{case}"]), T(z[f"ctx_{case}"])
+            eps = m(x.to(d, torch.float16), t.to(d), context=ctx.to(d), fps=int(z[f"fps_{case}"]))
+            e.append(relerr(eps, T(z[f"eps_{case}"])))
+        errs[fold] = e
+    print(f"toy UNet eps rel err: LayerNorm kernel {errs[False]}, folded {errs[True]}")
+    assert max(errs[True]) < EPS_TOL_TINY and max(errs[True]) < 1.1 * max(errs[False])
+
+
 @pytest.mark.parametrize("name", ["t2v", "i2v"])
 def test_unet_cfg_pair_prefix_sharing_is_bit_identical(name):
     """cfg_pairs=n: the context-free prefix of a [cond | uncond] batch (conv_in, init_attn, first ResBlock, GroupNorm /
@@ -528,6 +550,48 @@ def test_grid_pipeline_pre_denoise_and_residual_merge():
         pipe.basic_sample_shift_multi_windows(prompt="a", height=64, width=128, frames=4, num_windows_w=1, num_windows_h=1,
                                               num_windows_f=2, loop_step=2, num_inference_steps=3, output_type="latent",
                                               random_shuffle_init_frame_stride=2)
+
+
+def test_grid_pipeline_clear_video_tensor_start():
+    """`clear_pre_denoised_video_tensor` (t2v_normal_pipeline.py:363-368): a clear clip in pixel space is resized bicubically
+    to the panorama size, encoded by the first stage (posterior noise in the reference's RNG order), noised to the first
+    step's level and merged back every step.  HIP path (resize kernel, first-stage encoder, fake eps, fp32 latents) against
+    the oracle's composition of the same pinned pieces (resize_video_latent, encode_first_stage_2dae, _add_noise, grid
+    loop); the difference is the fp16 first-stage encoder's (1e-3 on its own, test_vae_encode_vs_reference_golden)."""
+    from oracle import loops as oloops, ddim as oddim
+    from oracle.vae import encode_first_stage_2dae
+    from dynamicscaler_amd.host_model import LatentDiffusionHost
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V
+    from dynamicscaler_amd.vae_spec import vae_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict, synth_normal
+    d = dev()
+    dd = json.loads(bytes(np.load(os.path.join(G, "vae_enc_tiny.npz"))["tiny8_dd_json"]).decode())
+    cond, uncond = synth_normal((1, 77, 64), 61), synth_normal((1, 77, 64), 62)
+    ld = LatentDiffusionHost({"params": {"in_channels": 4, "out_channels": 4, "model_channels": 64, "attention_resolutions": [],
+                                         "num_res_blocks": 1, "channel_mult": [1], "num_head_channels": 64, "context_dim": 64,
+                                         "use_linear": True, "temporal_attention": False, "use_relative_position": False}},
+                             conditioner=lambda p: uncond if p[0] == "" else cond,
+                             first_stage_config={"params": {"ddconfig": dd, "embed_dim": 4}}, scale_factor=0.18215)
+    vsd = synth_state_dict(vae_param_shapes(dd, 4), seed=23)
+    ld.first_stage_model.load_state_dict(vsd)
+    ld.temporal_length = 4
+    ld = ld.to(d).eval()
+    ld.model = _FakeModel()                     # the survey's fake eps-model: only the start differs from the other grid tests
+    clip = synth_normal((1, 3, 4, 48, 96), 91).clamp(-1, 1)
+    kw = dict(num_windows_w=2, num_windows_h=2, num_windows_f=1, loop_step=4, num_inference_steps=4, use_pre_denoise=True,
+              pre_denoise_steps=2, merge_predenoise_ratio_list=[0.5, 0.6, 0.7, 0.8], sparse_add_residual=True)
+    pipe = VC2_Pipeline_T2V(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": {"in_channels": 4}}}}).to(d, torch.float32)
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=64, width=128, frames=4, fps=8, guidance_scale=7.5,
+                                                   output_type="latent", clear_pre_denoised_video_tensor=clip, **kw)
+    torch.manual_seed(2333333)
+    oref, _ = oloops.t2v_grid_sample(_oracle_fake, oddim.DiffusionTables(), cond, uncond, height=64, width=128, frames=4,
+                                     guidance_scale=7.5, clear_pre_denoised_video_tensor=clip,
+                                     encode_first_stage=lambda x: encode_first_stage_2dae(vsd, dd, x, scale_factor=0.18215), **kw)
+    e = relerr(den, oref)
+    print(f"grid loop started from a clear clip (resize + first-stage encode): rel err vs the oracle {e:.3e}")
+    assert den.shape == (1, 4, 4, 16, 32) and e < 2e-3
 
 
 def test_i2v_ring_pipeline_vs_reference_golden():
