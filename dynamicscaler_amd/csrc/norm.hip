@@ -14,6 +14,7 @@ namespace {
 
 constexpr int MAX_C = 4096;
 constexpr int GN_CHUNK_ROWS = 256;
+constexpr int GN_U = 4;   // rows in flight per thread in the streaming loops (2 and 8 measured 1-8 % slower, tools/bench_norms.py)
 constexpr int GN_LDS_FLOATS = 4096;   // per array: rl*C (<= 2048 + C) when C <= 2048, C otherwise
 
 __device__ __forceinline__ float fast_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -36,12 +37,12 @@ gn_partial_kernel(const f16* __restrict__ x, float2* __restrict__ part, int rows
     auto accumulate = [&](int col, int rfirst, int rstep, float* s, float* q) {
         const f16* p = base + col * 8;
         int r = rfirst;
-        for (; r + 3 * rstep < r1; r += 4 * rstep) {
-            f16x8 v[4];
+        for (; r + (GN_U - 1) * rstep < r1; r += GN_U * rstep) {
+            f16x8 v[GN_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(p + (long)(r + u * rstep) * C);
+            for (int u = 0; u < GN_U; ++u) v[u] = *reinterpret_cast<const f16x8*>(p + (long)(r + u * rstep) * C);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < GN_U; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
         }
@@ -168,12 +169,12 @@ gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const
         const f16* px = x + base + col * 8;
         f16* py = y + base + col * 8;
         int r = r0 + rlane;
-        for (; r + 3 * rl < r1; r += 4 * rl) {
-            f16x8 v[4];
+        for (; r + (GN_U - 1) * rl < r1; r += GN_U * rl) {
+            f16x8 v[GN_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(px + (long)(r + u * rl) * C);
+            for (int u = 0; u < GN_U; ++u) v[u] = *reinterpret_cast<const f16x8*>(px + (long)(r + u * rl) * C);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<f16x8*>(py + (long)(r + u * rl) * C) = one(v[u]);
+            for (int u = 0; u < GN_U; ++u) *reinterpret_cast<f16x8*>(py + (long)(r + u * rl) * C) = one(v[u]);
         }
         for (; r < r1; r += rl) *reinterpret_cast<f16x8*>(py + (long)r * C) = one(*reinterpret_cast<const f16x8*>(px + (long)r * C));
     }
