@@ -35,8 +35,19 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
-    const int qt = blockIdx.x % q_tiles;
-    const int bh = blockIdx.x / q_tiles;
+    // XCD-aware block order (bijective for any grid size): workgroup ids go round-robin over the 8 XCDs, each with its own
+    // 4 MB L2.  The q-tiles of one (batch, head) all stream the same K / V (655 KB at 2560 keys); in plain order they are
+    // spread over all 8 L2s, every L2 sees every head in flight (~25 MB) and K / V come from beyond L2 (7.4 GB per launch
+    // measured against 1.26 GB algorithmic, profiles/r2_pmc_mfma_util.json).  Remapped, an XCD works through whole heads.
+    int bid = blockIdx.x;
+#ifndef DS_ATTN_NO_XCD_REMAP
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+        bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+    }
+#endif
+    const int qt = bid % q_tiles;
+    const int bh = bid / q_tiles;
     const int head = bh % heads, b = bh / heads;
     const int kvb = b / kv_batch_div;
     const int q_base = qt * (128 * QB) + wave * (32 * QB);

@@ -325,7 +325,7 @@ class VC2_Pipeline_T2V:
         if unet is not None and hasattr(unet, "prepare") and not _ROUND1_LAZY_PREPARE:
             unet.prepare(device)
         st = _RingState()
-        st.in_device = init_panorama_latent.device
+        st.in_device = init_panorama_latent.device    # overwritten with the execution device when the loop drew the latent itself
         st.pano = init_panorama_latent.to(device=device, dtype=self.latent_dtype).contiguous().clone()
         st.pano_x0 = torch.zeros_like(st.pano)
         st.mask = torch.zeros(total_shape[2:], dtype=torch.uint8, device=device)  # 1 byte per (f,y,x)
@@ -347,12 +347,17 @@ class VC2_Pipeline_T2V:
         return st
 
     def _finish(self, st, output_type, total_frames, seam_safe):
+        """Return tuple of the ring loops.  Like the reference (t2v_sphere_panorama_pipeline.py:636-660) the second element
+        is moved to the device of the `init_panorama_latent` the caller passed (the execution device when the loop drew its
+        own), and in the seam-safe decode branch it is the W-PADDED latent (the reference reassigns `denoised` there)."""
         self.final_latent = st.pano  # x_t panorama after the last step (not returned by the reference's ring variants)
         denoised = st.pano_x0.clone()
+        out_dev = st.in_device
         if output_type == "latent":
+            denoised = denoised.to(out_dev)
             return denoised, denoised
         if not seam_safe:
-            return self.pretrained_t2v.decode_first_stage_2DAE(denoised), denoised
+            return self.pretrained_t2v.decode_first_stage_2DAE(denoised), denoised.to(out_dev)
         # seam-safe decode (t2v_sphere_panorama_pipeline.py:638-655): pad W with wrapped 1/16 chunks, decode per
         # frame, crop (vae.AutoencoderKL behind decode_first_stage_2DAE).
         chunks = list(torch.chunk(denoised, 16, dim=4))
@@ -360,7 +365,7 @@ class VC2_Pipeline_T2V:
         frames_out = [self.pretrained_t2v.decode_first_stage_2DAE(padded[:, :, [f]]) for f in range(total_frames)]
         videos = torch.cat(frames_out, dim=2)
         videos = torch.cat(torch.chunk(videos, 18, dim=4)[1:-1], dim=4)
-        return videos, denoised
+        return videos, padded.to(out_dev)
 
     @torch.no_grad()
     def basic_sample_shift_multi_windows(self, prompt=None, height=320, width=512, frames=16, fps=16, guidance_scale=7.5,
@@ -402,7 +407,7 @@ class VC2_Pipeline_T2V:
         total_shape = (1, c_lat, frames * num_windows_f, lat_h * num_windows_h, lat_w * num_windows_w)
         resized, fm = None, True
         if init_panorama_latent is None:
-            init_panorama_latent = torch.randn(total_shape)  # host draw, reference order
+            init_panorama_latent = torch.randn(total_shape).to(self._execution_device)  # host draw, reference order; lives on the execution device like the reference's
             if use_skip_time:
                 assert use_pre_denoise and pre_denoise_steps > 0, \
                     "[basic_sample_shift_multi_windows] skip ts should be used with pre denoise if init_panorama_latent is not provided "
@@ -524,7 +529,7 @@ class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
         c_lat = unet_config["params"]["in_channels"]
         total_shape = (1, c_lat, frames * num_windows_f, total_h // vs, total_w // vs)
         if init_panorama_latent is None:
-            init_panorama_latent = torch.randn(total_shape)  # host draw (global CPU generator), reference order
+            init_panorama_latent = torch.randn(total_shape).to(self._execution_device)  # host draw (global CPU generator), reference order
             if use_skip_time:
                 raise NotImplementedError  # same as the reference (:420-422)
         else:

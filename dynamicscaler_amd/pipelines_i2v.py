@@ -96,7 +96,7 @@ class VC2_Pipeline_I2V(VC2_Pipeline_T2V):
         total_h, total_w = height * num_windows_h, width * num_windows_w
         total_shape = (1, unet_config["params"]["in_channels"], frames * num_windows_f, total_h // vs, total_w // vs)
         if init_panorama_latent is None:
-            init_panorama_latent = torch.randn(total_shape)  # host draw, reference order
+            init_panorama_latent = torch.randn(total_shape).to(self._execution_device)  # host draw, reference order; lives on the execution device like the reference's
         else:
             assert tuple(init_panorama_latent.shape) == total_shape, \
                 f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_panorama_latent.shape)} " \
@@ -218,7 +218,7 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
         lat_h, lat_w = height // vs, width // vs
         total_shape = (1, unet_config["params"]["in_channels"], total_f, total_h // vs, total_w // vs)
         if init_panorama_latent is None:
-            init_panorama_latent = torch.randn(total_shape)  # host draw, reference order
+            init_panorama_latent = torch.randn(total_shape).to(self._execution_device)  # host draw, reference order; lives on the execution device like the reference's
             if use_skip_time:                                # :704-722: start from the (re-noised) VAE-encoded panorama image
                 frame_0 = self.tiled_vae_encode_image(image_path=pano_image_path, image_size=(total_h, total_w),
                                                       image_tensor=pano_image_tensor)

@@ -58,7 +58,7 @@ def main():
     print("SHARE_MODE", share_modes[-1] if share_modes else None, flush=True)
     rank = dist.get_rank() if dist.is_initialized() else 0
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), den=den.float().cpu().numpy(),
-             final=pipe.final_latent.float().cpu().numpy())
+             final=pipe.final_latent.float().cpu().numpy(), share_mode=np.array(str(share_modes[-1] if share_modes else None)))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -864,10 +864,12 @@ def test_decode_tail_seam_safe_with_vae():
     torch.manual_seed(2333333)
     videos, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="tensor",
                                                         **meta["geoms"]["grid4x2"])
-    assert videos.shape[:3] == (1, 3, den.shape[2]) and videos.shape[3] == den.shape[3] * 2 and videos.shape[4] == den.shape[4] * 2
-    lat = den.float().cpu()
-    chunks = list(torch.chunk(lat, 16, dim=4))
-    padded = torch.cat([chunks[-1]] + chunks + [chunks[0]], dim=4)
+    # like the reference (t2v_sphere_panorama_pipeline.py:640-642) the second return value is the W-PADDED latent here
+    wlat = den.shape[4] * 16 // 18
+    assert videos.shape[:3] == (1, 3, den.shape[2]) and videos.shape[3] == den.shape[3] * 2 and videos.shape[4] == wlat * 2
+    padded = den.float().cpu()
+    inner = padded[..., wlat // 16:-(wlat // 16)]
+    assert torch.equal(padded[..., :wlat // 16], inner[..., -(wlat // 16):]) and torch.equal(padded[..., -(wlat // 16):], inner[..., :wlat // 16])
     ref = decode_first_stage_2dae(vsd, dd, padded, scale_factor=0.18215)
     ref = torch.cat(torch.chunk(ref, 18, dim=4)[1:-1], dim=4)
     e = relerr(videos, ref)
@@ -1068,10 +1070,8 @@ def test_gen_pano_360_stage_chain_runs():
     big_img = synth_normal((3, 512, 1024), 90).clamp(-1, 1)
     videos, lat3 = pipe.basic_sample_shift_multi_windows(init_panorama_latent=mixed, total_h=512, total_w=1024, num_windows_h=9,
                                                          num_windows_w=9, pano_image_tensor=big_img, output_type="tensor", **ring_args)
-    assert lat3.shape == (1, 4, 4, 64, 128) and videos.shape == (1, 3, 4, 512, 1024) and bool(torch.isfinite(videos).all())
-    lat = lat3.float().cpu()
-    chunks = list(torch.chunk(lat, 16, dim=4))
-    padded = torch.cat([chunks[-1]] + chunks + [chunks[0]], dim=4)
+    assert lat3.shape == (1, 4, 4, 64, 144) and videos.shape == (1, 3, 4, 512, 1024) and bool(torch.isfinite(videos).all())
+    padded = lat3.float().cpu()                # the decode branch returns the W-padded latent, like the reference
     ref = torch.cat(torch.chunk(decode_first_stage_2dae(vsd, dd, padded, scale_factor=0.18215), 18, dim=4)[1:-1], dim=4)
     e = relerr(videos, ref)
     print(f"stage chain: final decode rel err vs the oracle decoder {e:.3e}")
