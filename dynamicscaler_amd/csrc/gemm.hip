@@ -26,6 +26,7 @@
 
 namespace {
 
+constexpr int A_CONV3_TI = 4;   // internal: DS_A_CONV3, stride 1, no upsample, K walked channel-chunk-major with the 9 TAPS INNERMOST
 constexpr int A_DENSE_LN = 3;   // internal template value: DS_A_DENSE addressing + the LayerNorm fold after the K loop (ds_gemm_f16_ln)
 constexpr int BK = 64;  // halfs per K-step (128-byte LDS rows, 8 chunks of 16 bytes)
 
@@ -158,8 +159,35 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(A), 0, (int)a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W), 0, (int)w_bytes, 0x00020000);
     RowInfo ri[A_ROWS_PER_THREAD];
+    // A_CONV3_TI (3x3, stride 1, no upsample): the K loop walks the 64-channel chunks in the OUTER loop and the 9 taps in the
+    // inner one.  Tap-major order re-reads a workgroup's rows once per tap with a whole channel sweep (164 KB) in between:
+    // with 32 workgroups per XCD that is > 4 MB between reuses, so 8 of 9 tap passes came from beyond L2 (3.6-3.8 GB per
+    // level-1 launch against 0.84 GB algorithmic, profiles/r2_pmc_hbm_traffic_v9.json).  Taps innermost, the reuse distance is
+    // one K-step.  Per row: the byte offset of the CENTRE pixel and a 9-bit mask of the taps that fall inside the image;
+    // the tap's displacement is wave-uniform (scalar), so a K-step costs an add, a bit test and a select per staged row.
+    unsigned ctr[A_ROWS_PER_THREAD], vmask[A_ROWS_PER_THREAD];
+    if constexpr (AMODE == A_CONV3_TI) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
+            const int m = m0 + ld_row + LROWS * i;
+            const bool valid = m < d.M;
+            const int mm = valid ? m : 0;
+            const int hw = d.hout * d.wout;
+            const int img = mm / hw, rem = mm - img * hw;
+            const int oy = rem / d.wout, ox = rem - oy * d.wout;
+            ctr[i] = (unsigned)(img * d.hin * d.win + oy * d.win + ox) * (unsigned)d.lda * 2u + src_chunk_bytes;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                mk |= (valid && iy >= 0 && iy < d.hin && ix >= 0 && ix < d.win) ? (1u << t) : 0u;
+            }
+            vmask[i] = mk;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
+        if constexpr (AMODE == A_CONV3_TI) break;
         const int m = m0 + ld_row + LROWS * i;
         ri[i].valid = m < d.M;
         const int mm = ri[i].valid ? m : 0;
@@ -197,6 +225,13 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     // has to issue the MFMAs; profiles/r1_notes.md), so instructions removed here are MFMA slots won.
     unsigned voff_a[A_ROWS_PER_THREAD];
     auto tap_offsets = [&]() {
+        if constexpr (AMODE == A_CONV3_TI) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const unsigned delta = (unsigned)(((ky - 1) * d.win + (kx - 1)) * d.lda * 2);   // wave-uniform, may be "negative"
+#pragma unroll
+            for (int i = 0; i < A_ROWS_PER_THREAD; ++i) voff_a[i] = ((vmask[i] >> tap) & 1u) ? ctr[i] + delta : OOB;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
             bool ok = ri[i].valid;
@@ -218,6 +253,22 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     };
     tap_offsets();
 
+    // cursor of the next K-step: (tap, channel chunk) -> soffset of the A load (cb), byte offset inside a W row (kbytes)
+    auto next_k = [&]() {
+        if constexpr (AMODE == A_CONV3_TI) {
+            if (++tap == 9) { tap = 0; cb += BK; }
+            kbytes = (unsigned)(tap * d.cin + cb) * 2u;
+            tap_offsets();
+        } else {
+            kbytes += BK * 2;
+            cb += BK;
+            if (cb == d.cin) {
+                cb = 0;
+                ++tap;
+                if constexpr (AMODE == DS_A_CONV3 || AMODE == DS_A_TCONV) tap_offsets();
+            }
+        }
+    };
     // issue the global loads of the NEXT K-step (no waits, no branches, no vector address math); DMA: straight into
     // LDS buffer `buf` (an out-of-range lane zero-fills its 16 bytes)
     auto load_global = [&](int buf) {
@@ -236,13 +287,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             else
                 rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_off[i], kbytes, 0);
         }
-        kbytes += BK * 2;
-        cb += BK;
-        if (cb == d.cin) {
-            cb = 0;
-            ++tap;
-            if constexpr (AMODE == DS_A_CONV3 || AMODE == DS_A_TCONV) tap_offsets();
-        }
+        next_k();
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
@@ -340,15 +385,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         if (j < A_ROWS_PER_THREAD) dma16(rsA, sA + (buf * BM + LROWS * j + 8 * wave) * BK, voff_a[j], (unsigned)cb * 2u);
         else dma16(rsW, sB + (buf * BN + LROWS * (j - A_ROWS_PER_THREAD) + 8 * wave) * BK, b_off[j - A_ROWS_PER_THREAD], kbytes);
     };
-    auto advance_k = [&]() {
-        kbytes += BK * 2;
-        cb += BK;
-        if (cb == d.cin) {
-            cb = 0;
-            ++tap;
-            if constexpr (AMODE == DS_A_CONV3 || AMODE == DS_A_TCONV) tap_offsets();
-        }
-    };
+    auto advance_k = [&]() { next_k(); };
 
     auto kstep = [&](int kt, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;   // K-step kt+NS-1 exists: stage it while computing this one
@@ -763,7 +800,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
     }
     const int tiles_m = ds_cdiv(d.M, BM), tiles_n = ds_cdiv(d.N, BN);
     // buffer-load addressing is 32-bit and offset 2^31 marks 'out of range': the A operand and W must each stay below 2 GiB
-    const long a_rows = AMODE == DS_A_CONV3 ? (long)d.nimg * d.hin * d.win : (long)d.M;
+    const long a_rows = (AMODE == DS_A_CONV3 || AMODE == A_CONV3_TI) ? (long)d.nimg * d.hin * d.win : (long)d.M;
     const long a_bytes = ((a_rows - 1) * d.lda + d.cin) * 2;
     const long w_bytes = (long)d.N * d.K * 2;
     if (a_bytes >= 0x7FFF0000L || w_bytes >= 0x7FFF0000L) {
@@ -881,7 +918,15 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
         }
         return DS_OK;
     }
-    if (d.a_mode == DS_A_CONV3) return dispatch<DS_A_CONV3>(tile, A, W, bias, residual, out, d, st);
+    if (d.a_mode == DS_A_CONV3) {
+        // taps innermost where the tap-major order thrashes the L2 (large images: a workgroup's rows x all channels no longer
+        // fit next to its 31 neighbours'): level-1 tiles 40x64 fetch 0.57 GB instead of 3.8 GB per launch and run 2.5 % faster;
+        // on the 20x32 / 10x16 levels L2 already caught the reuse and the per-K-step select costs 1-3 % (gpurun_out/conv)
+        static const int ti_mode = getenv("DS_CONV_TAPS_INNER") ? atoi(getenv("DS_CONV_TAPS_INNER")) : -1;   // A/B: 0 never, 1 always
+        const bool taps_inner = ti_mode < 0 ? (long)d.hin * d.win >= 2048 : ti_mode > 0;
+        if (taps_inner && d.stride == 1 && !d.upsample && !d.asym_pad) return dispatch<A_CONV3_TI>(tile, A, W, bias, residual, out, d, st);
+        return dispatch<DS_A_CONV3>(tile, A, W, bias, residual, out, d, st);
+    }
     if (d.a_mode == DS_A_TCONV) return dispatch<DS_A_TCONV>(tile, A, W, bias, residual, out, d, st);
     if (ln_stats) return dispatch<A_DENSE_LN>(tile, A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
     return dispatch<DS_A_DENSE>(tile, A, W, bias, residual, out, d, st);
