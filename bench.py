@@ -281,7 +281,9 @@ def main():
         traffic, traffic_src = None, None
         try:
             import glob
-            src = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic_v*.json")))[-1]
+            import re
+            src = max(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic_v*.json")),
+                      key=lambda f: tuple(int(x) for x in re.findall(r"r(\d+)_pmc_hbm_traffic_v(\d+)", f)[0]))
             traffic = json.load(open(src))["gemm_f16_kernel(all)"]["hbm_bytes_per_launch"]
             traffic_src = os.path.relpath(src, REPO)
         except Exception:

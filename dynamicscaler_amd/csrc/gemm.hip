@@ -162,7 +162,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     // A_CONV3_TI (3x3, stride 1, no upsample): the K loop walks the 64-channel chunks in the OUTER loop and the 9 taps in the
     // inner one.  Tap-major order re-reads a workgroup's rows once per tap with a whole channel sweep (164 KB) in between:
     // with 32 workgroups per XCD that is > 4 MB between reuses, so 8 of 9 tap passes came from beyond L2 (3.6-3.8 GB per
-    // level-1 launch against 0.84 GB algorithmic, profiles/r2_pmc_hbm_traffic_v9.json).  Taps innermost, the reuse distance is
+    // level-1 launch against 0.84 GB algorithmic, profiles/r2_pmc_hbm_traffic_v10.json).  Taps innermost, the reuse distance is
     // one K-step.  Per row: the byte offset of the CENTRE pixel and a 9-bit mask of the taps that fall inside the image;
     // the tap's displacement is wave-uniform (scalar), so a K-step costs an add, a bit test and a select per staged row.
     unsigned ctr[A_ROWS_PER_THREAD], vmask[A_ROWS_PER_THREAD];
