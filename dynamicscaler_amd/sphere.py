@@ -96,6 +96,18 @@ class SplatMaps:
         self.wgt = torch.from_numpy(w_all[order]).to(dev)
 
 
+class _SubsampledGather:
+    """Gather map of a view taken at g x the tile size and resized back with 'nearest' (F.interpolate: source index =
+    g * destination index): rows and columns 0, g, 2g, ... of the big view's map."""
+
+    def __init__(self, big, g, height, width, HW):
+        sub = big.gather_np.reshape(height * g, width * g)[::g, ::g].reshape(-1).copy()
+        self.gather_np = sub
+        self.gather = big.gather.view(height * g, width * g)[::g, ::g].reshape(-1).contiguous()
+        self.read_set = np.zeros(HW, dtype=bool)
+        self.read_set[sub[sub >= 0]] = True
+
+
 class ViewMapCache:
     def __init__(self, device):
         self.device = device
@@ -183,11 +195,15 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
         """[sic] name kept from the reference.  Views are perspective crops of the 2:1 equirect latent; they are
         processed with the reference's sequential semantics (levels of views with disjoint footprints are batched).
         Returns (final_latents, denoised) for output_type='latent' (:307-312)."""
-        if view_get_scale_factor != 1 or view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
-            raise NotImplementedError("view / decode scale factors other than 1 (gen_pano_360.py uses 1) need the "
-                                      "resize_video_latent hand-off (SURVEY.md 8-f N1)")
+        if view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
+            raise NotImplementedError("view_set_scale_factor / downsample_factor_before_vae_decode other than 1 (gen_pano_360.py "
+                                      "uses 1).  With view_set_scale_factor > 1 the reference itself is not repeatable: its "
+                                      "scatter then has several sources per target and torch's CPU index_put_ resolves "
+                                      "duplicates that straddle a thread's chunk by timing (tests/golden/make_golden.py g21)")
         if use_skip_time:
             raise NotImplementedError  # like the reference (:146-148)
+        gsf = int(view_get_scale_factor)
+        assert gsf >= 1 and gsf == view_get_scale_factor, "view_get_scale_factor must be a positive integer"
         unet_config = self.model_config["params"]["unet_config"]
         frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
         prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
@@ -233,15 +249,21 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
                         ctxs.append(prompt_cache[cur])
                     else:
                         ctxs.append(st.text_emb)
-            lat_maps = [cache.get(view_fov, th, ph, lat_w, lat_h, W, H) for (ph, th, fv) in views]   # latent gather: view_fov (:196)
+            # latent gather: view_fov (:196).  view_get_scale_factor g: the reference gathers a (g h) x (g w) view and resizes
+            # it back with 'nearest' (:194-203), i.e. it keeps every g-th pixel of every g-th row: the same gather with a
+            # sub-sampled index map, no extra kernel
+            lat_maps = [cache.get(view_fov, th, ph, lat_w, lat_h, W, H) if gsf == 1 else
+                        _SubsampledGather(cache.get(view_fov, th, ph, lat_w * gsf, lat_h * gsf, W, H), gsf, lat_h, lat_w, H * W)
+                        for (ph, th, fv) in views]
             set_maps = [cache.get(fv, th, ph, lat_w, lat_h, W, H) for (ph, th, fv) in views]          # mask gather + scatters: curr_fov
             renoise = st.ratio is not None and i < total_steps - 1
             coef = sched.step_coefficients(total_steps - i - 1)
             # host noise in reference order; see scheduler.draw_renoise_noise(sphere_view=...) for the layout quirk
             noises = []
             for j in range(len(views)):
+                # (with a get scale factor the view handed to re_noise is resize_video_latent's permuted output: always strided)
                 nz = sched.draw_renoise_noise(st.tile_shape, "cpu", torch.float32,
-                                              sphere_view="first" if scattered + j == 0 else "later") if renoise else None
+                                              sphere_view="first" if (scattered + j == 0 and gsf == 1) else "later") if renoise else None
                 sn = sched.draw_step_noise(st.tile_shape, "cpu", torch.float32, coef["sigma"])
                 noises.append((nz, sn))
             if renoise:

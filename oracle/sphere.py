@@ -138,9 +138,13 @@ def sphere_renoise_noise(shape, first_view):
 def t2v_sphere_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, *, height=320, width=512, frames=16,
                       guidance_scale=7.5, equirect_width, equirect_height, phi_theta_dict, view_fov, loop_step_theta,
                       merge_renoised_overlap_latent_ratio=None, phi_fov_dict=None, denoise_to_step=None,
-                      num_inference_steps=4, init_sphere_latent=None, in_channels=4, trace=None):
-    """basic_sample_shift_shpere_panorama with view scale factors 1 and output_type='latent'
-    (t2v_sphere_panorama_pipeline.py:23-312).  Returns (final_latents, denoised) (:307-312)."""
+                      num_inference_steps=4, init_sphere_latent=None, in_channels=4, trace=None,
+                      view_get_scale_factor=1, view_set_scale_factor=1):
+    """basic_sample_shift_shpere_panorama, output_type='latent' (t2v_sphere_panorama_pipeline.py:23-312).  Returns
+    (final_latents, denoised) (:307-312).  view_get_scale_factor g: the view is gathered at g x the tile size and resized
+    back with 'nearest' (:194-203); view_set_scale_factor s: x_prev / pred_x0 are resized up by s with 'nearest' before the
+    scatter (:268-275), and so is the ones-tensor that marks the mask."""
+    from .loops import resize_video_latent
     sched = DDIMSchedule(tables, num_inference_steps)
     timesteps = np.flip(sched.ddim_timesteps)
     if denoise_to_step is not None:
@@ -161,7 +165,12 @@ def t2v_sphere_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, 
                 cfov = phi_fov_dict.get(cphi, view_fov) if phi_fov_dict is not None else view_fov
                 views.append((cphi, cth, cfov))
                 first_view = scattered == 0
-                view, _ = sphere_gather(pano, view_fov, cth, cphi, lw, lh)
+                view, _ = sphere_gather(pano, view_fov, cth, cphi, lw * view_get_scale_factor, lh * view_get_scale_factor)
+                if view_get_scale_factor != 1:
+                    # the resize returns a permuted view of [B,N,C,h,w] storage: randn_like then ALWAYS takes the strided
+                    # path, also for the first view of a run (see sphere_renoise_noise)
+                    view = resize_video_latent(view, lh, lw, "nearest")
+                    first_view = False
                 vmask, _ = sphere_gather(mask, cfov, cth, cphi, lw, lh)
                 vmask = vmask[0, 0]  # [1,h,w]
                 if merge_renoised_overlap_latent_ratio is not None and i < total_steps - 1:
@@ -172,10 +181,15 @@ def t2v_sphere_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, 
                 e_c = eps_model(view, ts, cond_ctx)
                 e = cfg_combine(e_c, eps_model(view, ts, uncond_ctx), guidance_scale) if guidance_scale != 1.0 else e_c
                 x_prev, x0 = ddim_step(sched, view, e, [total_steps - i - 1] * view.shape[2])
+                ones = torch.ones((1, 1, 1, lh, lw))
+                if view_set_scale_factor != 1:
+                    sh, sw = lh * view_set_scale_factor, lw * view_set_scale_factor
+                    x_prev, x0 = resize_video_latent(x_prev, sh, sw, "nearest"), resize_video_latent(x0, sh, sw, "nearest")
+                    ones = torch.ones((1, 1, 1, sh, sw))
                 sphere_scatter_fast(pano, x_prev, cfov, cth, cphi)
                 scattered += 1
                 sphere_scatter_fast(pano_x0, x0, cfov, cth, cphi)
-                sphere_scatter_fast(mask, torch.ones((1, 1, 1, lh, lw)), cfov, cth, cphi)
+                sphere_scatter_fast(mask, ones, cfov, cth, cphi)
         if trace is not None:
             trace.append((i, int(t), views))
     return pano.clone(), pano_x0.clone()

@@ -21,6 +21,7 @@ so parity is pinned by what this script captures from the imported reference cod
   G18 unet_t24.npz           (--full) the UNet at T = 24 (config 5): toy config and the real t2v UNet, one forward each
   G19 loops_multiprompt.npz  per-window prompt selection (window_multi_prompt_dict) on the toy dock geometry
   G20 loop_trace_cfg4_i2v.json  BASELINE config 4 geometry through the reference's i2v ring loop (fake eps): trace + SHA-256
+  G21 sphere_scale.npz       t2v sphere loop with view_get_scale_factor 2 / 3 (fake eps)
   G17 cfg1_full_t2v.npz      (--full) BASELINE config 1: basic_sample, real t2v UNet, 512x320x16f, 4 steps, CFG 7.5;
                              per-step x_t / e_t / x_prev / pred_x0 (8 forwards, ~8 min)
 
@@ -505,6 +506,42 @@ def g20_cfg4_geometry():
     with open(os.path.join(HERE, "loop_trace_cfg4_i2v.json"), "w") as f:
         json.dump(out, f)
     print("cfg4 i2v ring: tiles/step", sorted({len(s["windows"]) for s in out["trace"]}), out["denoised_sha256"][:12])
+
+
+
+SPHERE_SCALE_GEOMS = {
+    # view_SET_scale_factor != 1 is deliberately absent: the reference's scatter `pano_flat[:, idx] = view` then has several
+    # sources per target NEXT to each other, torch's CPU index_put_ splits the index range over threads, and which duplicate
+    # wins at a chunk boundary depends on thread timing -- the reference itself is not repeatable there (a couple of elements
+    # per scatter differ from "last source wins" with 8 threads, none with torch.set_num_threads(1)).
+    "get2": dict(height=64, width=128, frames=4, equirect_width=512, equirect_height=256, view_fov=120, loop_step_theta=4,
+                 phi_theta_dict={"60": [0, 180], "0": [0, 120, 240], "-60": [90, 270]}, merge_renoised_overlap_latent_ratio=1,
+                 num_inference_steps=4, view_get_scale_factor=2),
+    "get3_fov": dict(height=64, width=128, frames=4, equirect_width=512, equirect_height=256, view_fov=120, loop_step_theta=3,
+                     phi_theta_dict={"45": [0, 120, 240], "-45": [60, 180, 300]}, phi_fov_dict={"45": 100},
+                     merge_renoised_overlap_latent_ratio=0.6, num_inference_steps=3, view_get_scale_factor=3),
+}
+
+
+def g21_sphere_view_scale():
+    """view_get_scale_factor of the t2v sphere loop (t2v_sphere_panorama_pipeline.py:45,194-203): the view gathered at 2x / 3x
+    the tile size and resized back with 'nearest'.  Fake eps, fp32."""
+    cond, uncond = synth_normal((1, 77, 64), 61), synth_normal((1, 77, 64), 62)
+    arrays = {"cond": cond, "uncond": uncond}
+    ld = FakeLatentDiffusion(FakeEps(), cond, uncond, temporal_length=4)
+    for gname, geom in SPHERE_SCALE_GEOMS.items():
+        g = dict(geom)
+        g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+        if "phi_fov_dict" in g:
+            g["phi_fov_dict"] = {int(k): v for k, v in g["phi_fov_dict"].items()}
+        pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": dict(TINY)}}})
+        torch.manual_seed(2333333)
+        with contextlib.redirect_stdout(io.StringIO()):
+            final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent", **g)
+        arrays[f"sphere_{gname}_final"], arrays[f"sphere_{gname}_denoised"] = final, den
+    save_npz("sphere_scale.npz", **arrays)
+    with open(os.path.join(HERE, "sphere_scale.json"), "w") as f:
+        json.dump({"geoms": SPHERE_SCALE_GEOMS}, f)
 
 
 GRID_GEOMS = {
@@ -1069,7 +1106,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale}
     if args.full:
         steps["g10"] = g10_unet_full
         steps["g10i"] = g10_unet_full_i2v

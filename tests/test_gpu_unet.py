@@ -591,7 +591,7 @@ def test_grid_pipeline_clear_video_tensor_start():
                                      encode_first_stage=lambda x: encode_first_stage_2dae(vsd, dd, x, scale_factor=0.18215), **kw)
     e = relerr(den, oref)
     print(f"grid loop started from a clear clip (resize + first-stage encode): rel err vs the oracle {e:.3e}")
-    assert den.shape == (1, 4, 4, 16, 32) and e < 2e-3
+    assert den.shape == (1, 4, 4, 16, 32) and e < 3e-5          # measured 1.3e-5 (the fp16 first-stage encoder, diluted by the merge ratios)
 
 
 def test_i2v_ring_pipeline_vs_reference_golden():
@@ -710,6 +710,36 @@ def test_sphere_gather_scatter_bit_exact(dtype):
             assert torch.equal(view.cpu(), T(z[f"rt_view_{n}"])) and torch.equal(proxy.get_equirect_tensor().cpu(), T(z[f"rt_after_{n}"]))
         n += 1
     assert n == 6
+
+
+def test_sphere_pipeline_view_get_scale_factor():
+    """view_get_scale_factor 2 / 3 (t2v_sphere_panorama_pipeline.py:45,194-203): the reference gathers the view at g x the tile
+    size and resizes it back with 'nearest'; here the same pixels come from a sub-sampled gather map.  fp32 + fake eps:
+    bit-equal to the oracle on this host (which is bit-equal to the reference's panoramas in the build container,
+    test_g21_...).  view_set_scale_factor > 1 is refused: the reference is not repeatable there."""
+    from oracle import sphere as S, ddim as oddim
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.sphere import VC2_Pipeline_T2V_SpherePano
+    d = dev()
+    z = np.load(os.path.join(G, "sphere_scale.npz"))
+    meta = json.load(open(os.path.join(G, "sphere_scale.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    ld = _fake_host(cond, uncond, d)
+    for gname, geom in meta["geoms"].items():
+        g = _sphere_geom(geom)
+        pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": {"in_channels": 4}}}})
+        pipe.to(d, torch.float32)
+        torch.manual_seed(2333333)
+        final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent", **g)
+        torch.manual_seed(2333333)
+        of, od = S.t2v_sphere_sample(_oracle_fake, oddim.DiffusionTables(), cond, uncond, guidance_scale=7.5, **g)
+        assert torch.equal(final.cpu(), of) and torch.equal(den.cpu(), od), (gname, float((final.cpu() - of).abs().max()))
+        e_host = relerr(den, T(z[f"sphere_{gname}_denoised"]))
+        print(f"sphere {gname} (get scale factor) vs the reference's panorama (other host's RNG stream): {e_host:.3e}")
+        assert e_host < 5e-2
+    with pytest.raises(NotImplementedError, match="not repeatable"):
+        pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                **dict(g, view_set_scale_factor=2))
 
 
 def test_sphere_pipeline_vs_oracle_and_reference_golden():

@@ -364,6 +364,19 @@ def test_g12_sphere_loop_fake_eps_bit_exact():
             assert i == ref["i"] and t == ref["t"] and [list(v) for v in views] == ref["views"], (gname, i)
 
 
+def test_g21_sphere_loop_view_get_scale_factor_bit_exact():
+    """view_get_scale_factor 2 / 3 of the t2v sphere loop (the view gathered at g x the tile size, resized back with 'nearest';
+    its re_noise noise always takes the strided randn_like path) -- bit-exact against the reference's panoramas."""
+    from oracle import sphere as S
+    z = npz("sphere_scale.npz")
+    meta = json.load(open(os.path.join(G, "sphere_scale.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    for gname, geom in meta["geoms"].items():
+        torch.manual_seed(2333333)
+        final, den = S.t2v_sphere_sample(_fake_eps, oddim.DiffusionTables(), cond, uncond, guidance_scale=7.5, **_sphere_geom(geom))
+        assert torch.equal(final, T(z[f"sphere_{gname}_final"])) and torch.equal(den, T(z[f"sphere_{gname}_denoised"])), gname
+
+
 def test_g12_sphere_loop_tiny_unet():
     from oracle import sphere as S
     z = npz("sphere.npz")
