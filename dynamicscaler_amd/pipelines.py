@@ -14,7 +14,6 @@ import numpy as np
 import torch
 
 from . import ops, parallel
-from .unet import _ROUND1_LAZY_PREPARE
 from .ring import RingLatent, VAE_SCALE_FACTOR, ring_axis_steps, t2v_ring_windows, t2v_grid_windows
 
 
@@ -132,7 +131,7 @@ class VC2_Pipeline_T2V:
         # the captured graphs hold the packed-weight pointers of ONE prepare(): a reload / .to() / invalidate() of the UNet
         # repacks into new buffers (generation + 1) and every older graph is dropped
         unet = getattr(model, "diffusion_model", None)
-        if unet is not None and hasattr(unet, "prepare") and not _ROUND1_LAZY_PREPARE:
+        if unet is not None and hasattr(unet, "prepare"):
             unet.prepare(x.device)           # no-op when packed; never inside a capture (the eager warm call comes first)
         gen = getattr(unet, "_generation", 0)
         if gen != self._graph_generation:
@@ -322,7 +321,7 @@ class VC2_Pipeline_T2V:
         # weights are repacked here, on the caller's stream and followed by a device synchronisation, never lazily by
         # whichever side stream happens to run the first evaluation
         unet = getattr(getattr(self.pretrained_t2v, "model", None), "diffusion_model", None)
-        if unet is not None and hasattr(unet, "prepare") and not _ROUND1_LAZY_PREPARE:
+        if unet is not None and hasattr(unet, "prepare"):
             unet.prepare(device)
         st = _RingState()
         st.in_device = init_panorama_latent.device    # overwritten with the execution device when the loop drew the latent itself

@@ -23,9 +23,6 @@ from ._lib import DS_A_CONV3, DS_A_TCONV, DS_EPI_GEGLU, DS_EPI_SILU, DS_EPI_OUT_
 from .unet_spec import build_program, param_shapes
 
 HEAD_DIM = 64
-# DIAGNOSTIC ONLY (tests/test_gpu_multirank.py): DS_EXP_ROUND1_LAZY_PREPARE=1 restores round 1's behaviour -- the repack runs
-# lazily on whichever stream evaluates first and nothing orders the other streams after it -- to demonstrate the hazard.
-_ROUND1_LAZY_PREPARE = os.environ.get("DS_EXP_ROUND1_LAZY_PREPARE") == "1"
 
 
 class _Container(nn.Module):
@@ -246,8 +243,7 @@ class UNetModel(nn.Module):
         P["emb_all.w"] = w16(torch.cat(emb_w, 0))
         P["emb_all.b"] = f32(torch.cat(emb_b, 0))
         self._emb_total = off
-        if not _ROUND1_LAZY_PREPARE:
-            torch.cuda.synchronize(dev)      # the packed buffers are complete before any other stream can see them
+        torch.cuda.synchronize(dev)          # the packed buffers are complete before any other stream can see them
         self._device = dev
         self._generation += 1
         self._packed = P

@@ -17,7 +17,7 @@ run_guard() {  # $1 label
 }
 export DS_HIP_LIBRARY=$PWD/dynamicscaler_amd/libdynscaler_hip_accinit.so
 unset DS_EXP_ROUND1_LAZY_PREPARE; run_guard "accinit fixed-prepare"
-export DS_EXP_ROUND1_LAZY_PREPARE=1; run_guard "accinit lazy-prepare(r1)"
+# (the lazy-prepare switch of that session was removed afterwards) run_guard "accinit lazy-prepare(r1)"
 unset DS_HIP_LIBRARY
 run_guard "product lazy-prepare(r1)"
 unset DS_EXP_ROUND1_LAZY_PREPARE; run_guard "product fixed-prepare"

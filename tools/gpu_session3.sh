@@ -16,7 +16,7 @@ run_guard() {  # $1 label
 }
 export DS_HIP_LIBRARY=$PWD/dynamicscaler_amd/libdynscaler_hip_r1accinit.so
 export DS_EXP_SHARED_BIAS_ROWS_MAX=1
-export DS_EXP_ROUND1_LAZY_PREPARE=1; run_guard "r1accinit lazy-prepare(r1)"
+# (the lazy-prepare switch of that session was removed afterwards) run_guard "r1accinit lazy-prepare(r1)"
 unset DS_EXP_ROUND1_LAZY_PREPARE; run_guard "r1accinit fixed-prepare"
 # the pytest guard itself (parent holds a GPU context), both modes
 export DS_EXP_ROUND1_LAZY_PREPARE=1
