@@ -34,4 +34,21 @@ typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// cache hints of the norm kernels (read-once / write-once streams next to GEMMs that want their operands to stay in L2):
+// DS_EXP_STREAM_NT bit 0 = output stores, bit 1 = last-use input loads are non-temporal.  -0.35 % of the cfg3 step
+// (profiles/r2_notes.md section 10).  NOT for the attention / concat outputs: non-temporal 8-byte stores there cost +2.6 %.
+#ifndef DS_EXP_STREAM_NT
+#define DS_EXP_STREAM_NT 3
+#endif
+#if DS_EXP_STREAM_NT & 1
+#define DS_SSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define DS_SSTORE(ptr, val) (*(ptr) = (val))
+#endif
+#if DS_EXP_STREAM_NT & 2
+#define DS_SLOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define DS_SLOAD(ptr) (*(ptr))
+#endif
+
 static inline int ds_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -24,6 +24,31 @@
 #include <stdlib.h>
 #include "common.h"
 
+// cache hints of the epilogue's global accesses: DS_EXP_NT bit 0 = fp16-strip output stores, bit 1 = fp32-strip output
+// stores, bit 2 = residual loads are non-temporal.  Outputs are never re-read by the launch that writes them; marking
+// their stores non-temporal keeps them from displacing A rows / W panels in L2: -1 % of the cfg3 step (mostly in the
+// two-stream mode; A/B builds via tools/gpu_ab.sh, profiles/r2_notes.md section 10).  Residual loads: no effect.
+#ifndef DS_EXP_NT
+#define DS_EXP_NT 3
+#endif
+#define DS_STORE_NT(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define DS_STORE_PLAIN(ptr, val) (*(ptr) = (val))
+#if DS_EXP_NT & 1
+#define DS_OUT_STORE_H DS_STORE_NT
+#else
+#define DS_OUT_STORE_H DS_STORE_PLAIN
+#endif
+#if DS_EXP_NT & 2
+#define DS_OUT_STORE_F DS_STORE_NT
+#else
+#define DS_OUT_STORE_F DS_STORE_PLAIN
+#endif
+#if DS_EXP_NT & 4
+#define DS_RES_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define DS_RES_LOAD(ptr) (*(ptr))
+#endif
+
 namespace {
 
 constexpr int A_CONV3_TI = 4;   // internal: DS_A_CONV3, stride 1, no upsample, K walked channel-chunk-major with the 9 TAPS INNERMOST
@@ -626,7 +651,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #ifdef DS_EXP_NOSTORE
                                 asm volatile("" ::"v"(hv[sw]));
 #else
-                                if (col_on && row < 32 && mrow0 + row < d.M) *reinterpret_cast<u32x4*>(out_base + sw * out_step) = hv[sw];
+                                if (col_on && row < 32 && mrow0 + row < d.M) DS_OUT_STORE_H(reinterpret_cast<u32x4*>(out_base + sw * out_step), hv[sw]);
 #endif
                             }
                         }
@@ -692,7 +717,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                             for (int u = 0; u < SB; ++u) {
                                 const int row = (sb + u) * rps + r0;
                                 ok[u] = col_on && row < 32 && mrow0 + row < d.M;
-                                if constexpr (RES) res[u] = *reinterpret_cast<const f16x8*>(ok[u] ? res_base + (sb + u) * res_step : residual);
+                                if constexpr (RES) res[u] = DS_RES_LOAD(reinterpret_cast<const f16x8*>(ok[u] ? res_base + (sb + u) * res_step : residual));
                                 if constexpr (PIB) {
                                     const int mm = ok[u] ? mrow0 + row : 0;
                                     const float* bp = bias + (long)(mm / d.bias_rows) * d.ldbias + (ok[u] ? ncol : 0);
@@ -734,7 +759,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                                         *reinterpret_cast<f32x4*>(o32) = f32x4{v[0], v[1], v[2], v[3]};
                                         *reinterpret_cast<f32x4*>(o32 + 4) = f32x4{v[4], v[5], v[6], v[7]};
                                     } else {
-                                        *reinterpret_cast<f16x8*>(out_base + (sb + u) * out_step) = o;
+                                        DS_OUT_STORE_F(reinterpret_cast<f16x8*>(out_base + (sb + u) * out_step), o);
                                     }
                                 }
 #endif

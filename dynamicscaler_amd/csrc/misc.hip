@@ -10,10 +10,10 @@ concat_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restr
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long r = idx / vt;
         const int c = (int)(idx - r * vt);
-        uint4 val;
-        if (c < v1) val = *reinterpret_cast<const uint4*>(a + r * c1 + c * 8);
-        else val = *reinterpret_cast<const uint4*>(b + r * c2 + (c - v1) * 8);
-        *reinterpret_cast<uint4*>(dst + r * (c1 + c2) + c * 8) = val;
+        f16x8 val;
+        if (c < v1) val = *reinterpret_cast<const f16x8*>(a + r * c1 + c * 8);
+        else val = *reinterpret_cast<const f16x8*>(b + r * c2 + (c - v1) * 8);
+        *reinterpret_cast<f16x8*>(dst + r * (c1 + c2) + c * 8) = val;
     }
 }
 

@@ -172,11 +172,11 @@ gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const
         for (; r + (GN_U - 1) * rl < r1; r += GN_U * rl) {
             f16x8 v[GN_U];
 #pragma unroll
-            for (int u = 0; u < GN_U; ++u) v[u] = *reinterpret_cast<const f16x8*>(px + (long)(r + u * rl) * C);
+            for (int u = 0; u < GN_U; ++u) v[u] = DS_SLOAD(reinterpret_cast<const f16x8*>(px + (long)(r + u * rl) * C));
 #pragma unroll
-            for (int u = 0; u < GN_U; ++u) *reinterpret_cast<f16x8*>(py + (long)(r + u * rl) * C) = one(v[u]);
+            for (int u = 0; u < GN_U; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)(r + u * rl) * C), one(v[u]));
         }
-        for (; r < r1; r += rl) *reinterpret_cast<f16x8*>(py + (long)r * C) = one(*reinterpret_cast<const f16x8*>(px + (long)r * C));
+        for (; r < r1; r += rl) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(DS_SLOAD(reinterpret_cast<const f16x8*>(px + (long)r * C))));
     }
 }
 
@@ -264,9 +264,9 @@ gn_small_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, cons
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(px + (long)(r + u * rlu) * C);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<f16x8*>(py + (long)(r + u * rlu) * C) = one(v[u]);
+        for (int u = 0; u < 4; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)(r + u * rlu) * C), one(v[u]));
     }
-    for (; r < rows_per_inst; r += rlu) *reinterpret_cast<f16x8*>(py + (long)r * C) = one(*reinterpret_cast<const f16x8*>(px + (long)r * C));
+    for (; r < rows_per_inst; r += rlu) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(*reinterpret_cast<const f16x8*>(px + (long)r * C)));
 }
 
 // LayerNorm: one wave per row, NV 8-channel vectors per lane (C <= 512*NV), RW rows per wave with all their loads issued
@@ -286,7 +286,7 @@ layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, con
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = lane + 64 * i;
-            t[rw][i] = col < nvec ? *reinterpret_cast<const f16x8*>(x + row * C + col * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            t[rw][i] = col < nvec ? DS_SLOAD(reinterpret_cast<const f16x8*>(x + row * C + col * 8)) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
     // stats != nullptr: only (mean, rstd) per row are written (ds_layernorm_stats: the normalisation itself is folded into
@@ -338,7 +338,7 @@ layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, con
                     const float gm = j < 4 ? g0[i][j & 3] : g1[i][j & 3], bt = j < 4 ? b0[i][j & 3] : b1[i][j & 3];
                     o[j] = (f16)((v[i][j] - mean) * rstd * gm + bt);
                 }
-                *reinterpret_cast<f16x8*>(y + (row0 + rw) * C + col * 8) = o;
+                DS_SSTORE(reinterpret_cast<f16x8*>(y + (row0 + rw) * C + col * 8), o);
             }
         }
     }
