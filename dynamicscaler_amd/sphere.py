@@ -357,8 +357,13 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
         `static_frame_latent` [1,C,1,H,W] = a VAE-encoded panorama image to reuse for paste_on_static; without it the tiled
         VAE encode runs every step like the reference's (:247, fresh posterior noise each time).
         Returns (final_latents, denoised) for output_type='latent' (:476-495)."""
-        if view_get_scale_factor != 1 or view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
-            raise NotImplementedError("view / decode scale factors other than 1 (gen_pano_360.py uses 1)")
+        if view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
+            raise NotImplementedError("view_set_scale_factor / downsample_factor_before_vae_decode other than 1 (gen_pano_360.py "
+                                      "uses 1).  With view_set_scale_factor > 1 the reference itself is not repeatable: its "
+                                      "scatter then has adjacent duplicate targets, which torch's CPU index_put_ resolves by "
+                                      "thread timing (tests/golden/make_golden.py, g21)")
+        gsf = int(view_get_scale_factor)
+        assert gsf >= 1 and gsf == view_get_scale_factor, "view_get_scale_factor must be a positive integer"
         has_vae = getattr(self.pretrained_t2v, "first_stage_model", None) is not None
         if (use_skip_time and init_sphere_latent is None) or (paste_on_static and static_frame_latent is None):
             if not has_vae:
@@ -421,15 +426,27 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
             static = static_frame_latent.to(device=device, dtype=st.pano.dtype)
             assert tuple(static.shape) == (1, shape[1], 1, H, W)
         cache, img_cache = ViewMapCache(device), ViewMapCache(device)
-        emb_cache, prompt_cache, conflict_cache = {}, {}, {}
+        emb_cache, prompt_cache, conflict_cache, sub_cache = {}, {}, {}, {}
         P = lat_h * lat_w
+
+        def lat_map(ph, th):
+            """latent gather map of a view.  view_get_scale_factor g (:330-341): the reference gathers a (g h) x (g w) view and
+            resizes it back with 'nearest', i.e. keeps every g-th pixel of every g-th row -- the same gather with a
+            sub-sampled index map (the mask view and the scatters stay at the tile size, :345-352)."""
+            if gsf == 1:
+                return cache.get(view_fov, th, ph, lat_w, lat_h, W, H)
+            r = sub_cache.get((ph, th))
+            if r is None:
+                r = sub_cache[(ph, th)] = _SubsampledGather(cache.get(view_fov, th, ph, lat_w * gsf, lat_h * gsf, W, H), gsf,
+                                                            lat_h, lat_w, H * W)
+            return r
 
         def pix_conflict(ka, kb):
             r = conflict_cache.get((ka, kb))
             if r is None:
                 a, b = cache.get(view_fov, ka[1], ka[0], lat_w, lat_h, W, H), cache.get(view_fov, kb[1], kb[0], lat_w, lat_h, W, H)
-                r = conflict_cache[(ka, kb)] = bool((a.write_set & (b.read_set | b.write_set)).any() or
-                                                    (a.read_set & b.write_set).any())
+                ra, rb = a.read_set | lat_map(ka[0], ka[1]).read_set, b.read_set | lat_map(kb[0], kb[1]).read_set
+                r = conflict_cache[(ka, kb)] = bool((a.write_set & (rb | b.write_set)).any() or (ra & b.write_set).any())
             return r
 
         for i in range(len(timesteps)):
@@ -461,12 +478,16 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                                 batch_imgs=crop.to(self.pretrained_t2v.device)).to(device)
                         ctxs.append(torch.cat([cur_text, emb_cache[(cphi, cth)].to(cur_text.dtype)], dim=1))
             maps = [cache.get(view_fov, th, ph, lat_w, lat_h, W, H) for (_, _, ph, th) in items]
+            lat_maps = [lat_map(ph, th) for (_, _, ph, th) in items]
             renoise = st.ratio is not None and live
             merge_prev = merge_prev_denoised_ratio_list[i] if (merge_prev_denoised_ratio_list is not None and live) else None
             coef = sched.step_coefficients(total_steps - i - 1)
             noises = []                                            # host noise in the reference's item order
             for _ in items:
-                nz = sched.draw_renoise_noise(st.tile_shape, "cpu", torch.float32) if renoise else None
+                # (with a get scale factor the view handed to re_noise is resize_video_latent's permuted output: strided, so
+                # randn_like takes torch's scalar normal path, scheduler.draw_renoise_noise)
+                nz = sched.draw_renoise_noise(st.tile_shape, "cpu", torch.float32,
+                                              sphere_view=None if gsf == 1 else "later") if renoise else None
                 sn = sched.draw_step_noise(st.tile_shape, "cpu", torch.float32, coef["sigma"])
                 noises.append((nz, sn))
             if renoise:
@@ -479,8 +500,9 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                     ids = mine[s0:s0 + self.max_tile_batch]
                     n = len(ids)
                     g_idx = torch.stack([maps[j].gather for j in ids])
+                    l_idx = g_idx if gsf == 1 else torch.stack([lat_maps[j].gather for j in ids])
                     f0 = torch.tensor([items[j][0] for j in ids], dtype=torch.int32, device=device)
-                    tiles = ops.map_gather_frames(st.pano, g_idx, f0, frames).reshape((n,) + st.tile_shape[1:])
+                    tiles = ops.map_gather_frames(st.pano, l_idx, f0, frames).reshape((n,) + st.tile_shape[1:])
                     prev = tiles.clone() if merge_prev is not None else None
                     mt = ops.map_gather_frames(mask, g_idx, f0, frames).reshape(n, frames, lat_h, lat_w)
                     if renoise:

@@ -201,19 +201,21 @@ def i2v_sphere_sample(eps_model, image_embedder, tables: DiffusionTables, text_c
                       loop_step_frame=None, equirect_width, equirect_height, phi_theta_dict, view_fov, loop_step_theta,
                       merge_renoised_overlap_latent_ratio=None, merge_prev_denoised_ratio_list=None,
                       denoise_to_step=None, paste_on_static=None, static_frame_latent=None, num_inference_steps=4,
-                      init_sphere_latent=None, in_channels=4, trace=None):
-    """basic_sample_shift_shpere_panorama of the i2v pipeline (i2v_sphere_panorama_pipeline.py:31-495), view scale
-    factors 1, output_type='latent'; returns (final_latents, denoised) (:476-495).
+                      init_sphere_latent=None, in_channels=4, trace=None, view_get_scale_factor=1):
+    """basic_sample_shift_shpere_panorama of the i2v pipeline (i2v_sphere_panorama_pipeline.py:31-495), set scale factor 1,
+    output_type='latent'; returns (final_latents, denoised) (:476-495).  view_get_scale_factor g: the latent view is
+    gathered at g x the tile size and resized back with 'nearest' (:330-341; the mask view is not, :345-352).
     `image_embedder(crop [1,3,height,width]) -> [1,L,D]` stands for get_image_embeds, `pano_image` [3,H_img,W_img] for
     the loaded panorama image, `static_frame_latent` [1,C,1,H,W] for tiled_vae_encode_image's result (VAE: SURVEY 8-f N2);
     uncond_ctx must already contain the image-token part (:123-129)."""
-    from .loops import i2v_frame_windows
+    from .loops import i2v_frame_windows, resize_video_latent
     sched = DDIMSchedule(tables, num_inference_steps)
     timesteps = np.flip(sched.ddim_timesteps)
     if denoise_to_step is not None:
         timesteps = timesteps[:denoise_to_step]
     total_steps = sched.ddim_timesteps.shape[0]
     lh, lw = height // VAE_SCALE, width // VAE_SCALE
+    gsf = view_get_scale_factor
     if total_f is None:
         total_f = frames
     shape = (1, in_channels, total_f, equirect_height // VAE_SCALE, equirect_width // VAE_SCALE)
@@ -236,7 +238,11 @@ def i2v_sphere_sample(eps_model, image_embedder, tables: DiffusionTables, text_c
                 for theta_angle in phi_theta_dict[phi_angle]:
                     cphi, cth = phi_angle, theta_angle + theta_offset
                     views.append((fb, fe, cphi, cth))
-                    view, _ = sphere_gather(pano[:, :, fidx], view_fov, cth, cphi, lw, lh)
+                    view, _ = sphere_gather(pano[:, :, fidx], view_fov, cth, cphi, lw * gsf, lh * gsf)
+                    if gsf != 1:
+                        # the resize hands back a permuted view of [B,N,C,h,w] storage (diffusion_utils.py:27-31): clone() keeps
+                        # those strides and re_noise's randn_like then takes torch's strided (scalar) normal path
+                        view = resize_video_latent(view, lh, lw, "nearest")
                     prev = view.clone()
                     vmask, _ = sphere_gather(mask[:, :, fidx], view_fov, cth, cphi, lw, lh)
                     if merge_renoised_overlap_latent_ratio is not None and i < total_steps - 1:

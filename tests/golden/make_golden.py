@@ -22,6 +22,7 @@ so parity is pinned by what this script captures from the imported reference cod
   G19 loops_multiprompt.npz  per-window prompt selection (window_multi_prompt_dict) on the toy dock geometry
   G20 loop_trace_cfg4_i2v.json  BASELINE config 4 geometry through the reference's i2v ring loop (fake eps): trace + SHA-256
   G21 sphere_scale.npz       t2v sphere loop with view_get_scale_factor 2 / 3 (fake eps)
+  G22 sphere_i2v_scale.npz   i2v sphere loop with view_get_scale_factor 2 / 3 (fake eps; inputs = sphere_i2v.npz)
   G17 cfg1_full_t2v.npz      (--full) BASELINE config 1: basic_sample, real t2v UNet, 512x320x16f, 4 steps, CFG 7.5;
                              per-step x_t / e_t / x_prev / pred_x0 (8 forwards, ~8 min)
 
@@ -884,6 +885,50 @@ def g13_i2v_sphere():
     print("wrote sphere_i2v_traces.json")
 
 
+def g22_i2v_sphere_view_scale():
+    """view_get_scale_factor of the i2v sphere loop (i2v_sphere_panorama_pipeline.py:58,330-341): the latent view gathered at
+    2x / 3x the tile size and resized back with 'nearest'.  Same inputs, stubs and seeds as g13 (sphere_i2v.npz holds them);
+    only the outputs are stored here.  Fake eps-model."""
+    import pipeline.i2v_sphere_panorama_pipeline as mod
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    cond = synth_normal((1, 77, 64), 61)
+    uncond = synth_normal((1, 77, 64), 62)
+    pano_img = synth_normal((3, 256, 512), 89).clamp(-1, 1)
+    static_latent = synth_normal((1, 4, 1, 32, 64), 90)
+    p_i2v = dict(TINY)
+    p_i2v["use_image_attention"] = True
+    embed = synth_image_embedder(64)
+    cases = {"base_g2": dict(I2V_SPHERE_GEOMS["base"], view_get_scale_factor=2),
+             "long_g3": dict(I2V_SPHERE_GEOMS["long"], view_get_scale_factor=3),
+             "static_g2": dict(I2V_SPHERE_GEOMS["static"], view_get_scale_factor=2)}
+    arrays = {}
+    orig_loader = mod.load_image_tensor_from_path
+    mod.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: pano_img   # I/O stub (cv2 absent)
+    try:
+        ld = FakeLatentDiffusion(FakeEps(), cond, uncond, temporal_length=4)
+        ld.get_image_embeds = embed
+        ld.embedder = object()
+        for name, geom in cases.items():
+            g = dict(geom)
+            g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+            pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": p_i2v}}})
+            pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+            pipe.tiled_vae_encode_image = lambda image_path, image_size: static_latent.clone()      # VAE stub (N2)
+            torch.manual_seed(2333333)
+            with contextlib.redirect_stdout(io.StringIO()):
+                final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", img_cond_path="unused.png", fps=8,
+                                                                     guidance_scale=7.5, pano_image_path="unused.png",
+                                                                     output_type="latent", **g)
+            arrays[f"{name}_final"] = final
+            arrays[f"{name}_denoised"] = den
+    finally:
+        mod.load_image_tensor_from_path = orig_loader
+    save_npz("sphere_i2v_scale.npz", **arrays)
+    with open(os.path.join(HERE, "sphere_i2v_scale.json"), "w") as f:
+        json.dump({"cases": cases}, f)
+    print("wrote sphere_i2v_scale.json")
+
+
 VAE_TINY = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2], num_res_blocks=1,
                 attn_resolutions=[], dropout=0.0)
 VAE_FULL = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
@@ -1106,7 +1151,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale, "g22": g22_i2v_sphere_view_scale}
     if args.full:
         steps["g10"] = g10_unet_full
         steps["g10i"] = g10_unet_full_i2v

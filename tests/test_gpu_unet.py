@@ -837,6 +837,44 @@ def test_i2v_sphere_pipeline_vs_oracle_and_reference_golden():
     assert e1 < PIPE_TOL and e2 < PIPE_TOL
 
 
+def test_i2v_sphere_pipeline_view_get_scale_factor():
+    """view_get_scale_factor 2 / 3 of the i2v sphere loop (i2v_sphere_panorama_pipeline.py:58,330-341): a sub-sampled latent
+    gather map (the mask view and the scatters stay at the tile size) and the strided-tensor re-noise stream.  fp32 + fake
+    eps: bit-exact vs the oracle re-run on this host (the oracle itself equals the reference's goldens bit for bit,
+    test_g22_...), loosely vs the reference's panoramas from another host.  view_set_scale_factor > 1 is refused."""
+    from helpers import synth_image_embedder
+    from oracle import sphere as S, ddim as oddim
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.sphere import VC2_Pipeline_I2V_SpherePano
+    d = dev()
+    z = np.load(os.path.join(G, "sphere_i2v.npz"))
+    zs = np.load(os.path.join(G, "sphere_i2v_scale.npz"))
+    cases = json.load(open(os.path.join(G, "sphere_i2v_scale.json")))["cases"]
+    cond, uncond, pano_img, static = T(z["cond"]), T(z["uncond"]), T(z["pano_img"]), T(z["static_latent"])
+    embed = synth_image_embedder(64)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
+    ld = _fake_host(cond, uncond, d, embed)
+    for name, geom in cases.items():
+        g = dict(geom)
+        g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+        pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": {"in_channels": 4}}}})
+        pipe.to(d, torch.float32)
+        torch.manual_seed(2333333)
+        final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                             pano_image_tensor=pano_img, static_frame_latent=static, **g)
+        torch.manual_seed(2333333)
+        of, od = S.i2v_sphere_sample(_oracle_fake, embed, oddim.DiffusionTables(), cond, uc, pano_img, guidance_scale=7.5,
+                                     static_frame_latent=static, **g)
+        assert torch.equal(final.cpu(), of) and torch.equal(den.cpu(), od), (name, float((final.cpu() - of).abs().max()))
+        e_hf, e_hd = relerr(final, T(zs[f"{name}_final"])), relerr(den, T(zs[f"{name}_denoised"]))
+        print(f"i2v sphere get scale factor {name} vs the reference's panoramas (other host's RNG stream): {e_hf:.3e} {e_hd:.3e}")
+        assert e_hf < 5e-2 and e_hd < 5e-2
+    with pytest.raises(NotImplementedError, match="not repeatable"):
+        pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                pano_image_tensor=pano_img, static_frame_latent=static,
+                                                **dict(g, view_get_scale_factor=1, view_set_scale_factor=2))
+
+
 def test_vae_decode_vs_reference_golden():
     """N2 decode side: AutoencoderKLDecoder (HIP) against the reference's AutoencoderKL.decode / decode_first_stage_2DAE:
     toy config (fp32 golden) and the real first-stage config on one 40x64 latent frame (320x512 image, fp16 fixture).

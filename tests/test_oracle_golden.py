@@ -432,6 +432,33 @@ def test_g13_i2v_sphere_loop_vs_reference_golden():
             assert i == ref["i"] and t == ref["t"] and [list(v) for v in views] == ref["views"], (gname, i)
 
 
+def test_g22_i2v_sphere_loop_view_get_scale_factor_bit_exact():
+    """view_get_scale_factor 2 / 3 of the i2v sphere loop (i2v_sphere_panorama_pipeline.py:58,330-341): the latent view is
+    gathered at g x the tile size and resized back with 'nearest' (a strided tensor: the re-noise draw takes torch's scalar
+    normal path).  Fake eps: bit-exact against the reference's own final latents, incl. frame windows + docking and
+    paste_on_static.  Inputs are those of g13 (sphere_i2v.npz)."""
+    from oracle.sphere import i2v_sphere_sample
+    from oracle.ddim import DiffusionTables
+    from helpers import synth_image_embedder
+    z = np.load(os.path.join(G, "sphere_i2v.npz"))
+    zs = np.load(os.path.join(G, "sphere_i2v_scale.npz"))
+    cases = json.load(open(os.path.join(G, "sphere_i2v_scale.json")))["cases"]
+    cond, uncond, pano_img = T(z["cond"]), T(z["uncond"]), T(z["pano_img"])
+    embed = synth_image_embedder(64)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
+    fake = lambda x, ts, ctx: 0.1 * x + 0.01 * ctx.mean()
+    assert len(cases) == 3
+    for name, geom in cases.items():
+        g = dict(geom)
+        g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+        dock = g.pop("dock_at_f", None)
+        torch.manual_seed(2333333)
+        final, den = i2v_sphere_sample(fake, embed, DiffusionTables(), cond, uc, pano_img, guidance_scale=7.5, dock_at_f=dock,
+                                       static_frame_latent=T(z["static_latent"]), **g)
+        assert torch.equal(final, T(zs[f"{name}_final"])), name
+        assert torch.equal(den, T(zs[f"{name}_denoised"])), name
+
+
 def test_g13_i2v_sphere_loop_tiny_unet():
     from oracle.sphere import i2v_sphere_sample
     from helpers import synth_image_embedder
