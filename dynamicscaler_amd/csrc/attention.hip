@@ -224,6 +224,40 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
     }
 
     // ---- normalise and store: lane owns query fr, d = 32*db + (j&3) + 8*(j>>2) + 4*fh ----
+    // Wide form (no accumulate, 16-byte aligned rows): the wave transposes its 32 x 64 block through a private LDS strip (the
+    // K / V tiles are dead after the loop's last barrier) so that a lane stores 16 bytes and 8 lanes cover the 128-byte head
+    // slice of a row -- whole lines instead of 32 rows x 16 B per store instruction.
+#ifndef DS_ATTN_NARROW_STORES
+    constexpr int OSW = 72;   // halfs per strip row (64 + 8 pad)
+    const bool wide = !accumulate && (ldo % 8 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (wide) {
+        f16* so = wave < 2 ? &sK2[0][0] + wave * 32 * OSW : &sVT2[0][0] + (wave - 2) * 32 * OSW;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float l = lrun[qb] + __shfl_xor(lrun[qb], 32);
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = (f16)(o[qb][db][4 * g + j] * inv);
+                    *reinterpret_cast<f16x4*>(so + fr * OSW + db * 32 + 8 * g + 4 * fh) = w;
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (lane >> 3) + 8 * i, ch = lane & 7;
+                const int qi = q_base + qb * 32 + row;
+                const u32x4 w = *reinterpret_cast<const u32x4*>(so + row * OSW + ch * 8);
+                if (qi < nq) *reinterpret_cast<u32x4*>(out + ((long)b * nq + qi) * ldo + head * HD + ch * 8) = w;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const float l = lrun[qb] + __shfl_xor(lrun[qb], 32);
