@@ -57,6 +57,7 @@ SIGNATURES = {
     "ds_groupnorm_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ds_groupnorm_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ds_groupnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "ds_groupnorm_f16_strided": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "ds_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ds_layernorm_stats": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "ds_gemm_f16_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),

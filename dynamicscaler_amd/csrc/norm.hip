@@ -24,7 +24,7 @@ __device__ __forceinline__ float fast_silu(float v) { return v * __builtin_amdgc
 // accumulated (one accumulation chain per channel, in row order: the sums do not depend on the unrolling), so a
 // workgroup keeps ~15 KB in flight instead of one 16-byte load per thread.
 __global__ void __launch_bounds__(256)
-gn_partial_kernel(const f16* __restrict__ x, float2* __restrict__ part, int rows_per_inst, int C, int groups) {
+gn_partial_kernel(const f16* __restrict__ x, float2* __restrict__ part, int rows_per_inst, int C, int groups, int ldx) {
     __shared__ float csum[GN_LDS_FLOATS];
     __shared__ float csq[GN_LDS_FLOATS];
     const int tid = threadIdx.x;
@@ -32,7 +32,7 @@ gn_partial_kernel(const f16* __restrict__ x, float2* __restrict__ part, int rows
     const int r0 = chunk * GN_CHUNK_ROWS;
     const int r1 = min(rows_per_inst, r0 + GN_CHUNK_ROWS);
     const int nvec = C / 8;
-    const f16* base = x + (long)inst * rows_per_inst * C;
+    const f16* base = x + (long)inst * rows_per_inst * ldx;   // input rows may sit in a wider buffer (row stride ldx >= C)
     const int rl = nvec <= 256 ? 256 / nvec : 1;  // row lanes; rl*C <= 2048 + C when rl > 1
     auto accumulate = [&](int col, int rfirst, int rstep, float* s, float* q) {
         const f16* p = base + col * 8;
@@ -40,14 +40,14 @@ gn_partial_kernel(const f16* __restrict__ x, float2* __restrict__ part, int rows
         for (; r + (GN_U - 1) * rstep < r1; r += GN_U * rstep) {
             f16x8 v[GN_U];
 #pragma unroll
-            for (int u = 0; u < GN_U; ++u) v[u] = *reinterpret_cast<const f16x8*>(p + (long)(r + u * rstep) * C);
+            for (int u = 0; u < GN_U; ++u) v[u] = *reinterpret_cast<const f16x8*>(p + (long)(r + u * rstep) * ldx);
 #pragma unroll
             for (int u = 0; u < GN_U; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
         }
         for (; r < r1; r += rstep) {
-            const f16x8 v = *reinterpret_cast<const f16x8*>(p + (long)r * C);
+            const f16x8 v = *reinterpret_cast<const f16x8*>(p + (long)r * ldx);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
         }
@@ -106,7 +106,7 @@ __global__ void gn_finalize_kernel(const float2* __restrict__ part, float* __res
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                 const float2* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
-                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps) {
+                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps, int ldx) {
     __shared__ double sred[2][8][32];
     __shared__ float smean[256], srstd[256];
     const int tid = threadIdx.x;
@@ -140,7 +140,7 @@ gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const
     const int r0 = chunk * GN_CHUNK_ROWS;
     const int r1 = min(rows_per_inst, r0 + GN_CHUNK_ROWS);
     const int nvec = C / 8;
-    const long base = (long)inst * rows_per_inst * C;
+    const long base = (long)inst * rows_per_inst * C, xbase = (long)inst * rows_per_inst * ldx;
     const int rl = nvec <= 256 ? 256 / nvec : 1;
     const int ncolpass = nvec <= 256 ? 1 : (nvec + 255) / 256;
     for (int cp = 0; cp < ncolpass; ++cp) {
@@ -166,17 +166,17 @@ gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const
             }
             return o;
         };
-        const f16* px = x + base + col * 8;
+        const f16* px = x + xbase + col * 8;
         f16* py = y + base + col * 8;
         int r = r0 + rlane;
         for (; r + (GN_U - 1) * rl < r1; r += GN_U * rl) {
             f16x8 v[GN_U];
 #pragma unroll
-            for (int u = 0; u < GN_U; ++u) v[u] = DS_SLOAD(reinterpret_cast<const f16x8*>(px + (long)(r + u * rl) * C));
+            for (int u = 0; u < GN_U; ++u) v[u] = DS_SLOAD(reinterpret_cast<const f16x8*>(px + (long)(r + u * rl) * ldx));
 #pragma unroll
             for (int u = 0; u < GN_U; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)(r + u * rl) * C), one(v[u]));
         }
-        for (; r < r1; r += rl) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(DS_SLOAD(reinterpret_cast<const f16x8*>(px + (long)r * C))));
+        for (; r < r1; r += rl) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(DS_SLOAD(reinterpret_cast<const f16x8*>(px + (long)r * ldx))));
     }
 }
 
@@ -189,13 +189,13 @@ constexpr int GN_SMALL_NT = 1024;
 
 __global__ void __launch_bounds__(GN_SMALL_NT)
 gn_small_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps) {
+                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps, int ldx) {
     __shared__ float csum[GN_LDS_FLOATS + MAX_C];
     __shared__ float csq[GN_LDS_FLOATS + MAX_C];
     __shared__ float smean[256], srstd[256];
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int nvec = C / 8, cpg = C / groups;
-    const f16* base = x + (long)inst * rows_per_inst * C;
+    const f16* base = x + (long)inst * rows_per_inst * ldx;
     f16* ybase = y + (long)inst * rows_per_inst * C;
     const int rl = nvec <= GN_SMALL_NT ? GN_SMALL_NT / nvec : 1;      // row lanes (nvec <= 512 -> rl >= 2)
     const int cap = (GN_LDS_FLOATS + MAX_C) / C;                       // rlu*C floats must fit the LDS arrays
@@ -211,14 +211,14 @@ gn_small_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, cons
         for (; r + 3 * rlu < rows_per_inst; r += 4 * rlu) {
             f16x8 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(p + (long)(r + u * rlu) * C);
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(p + (long)(r + u * rlu) * ldx);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
         }
         for (; r < rows_per_inst; r += rlu) {
-            const f16x8 v = *reinterpret_cast<const f16x8*>(p + (long)r * C);
+            const f16x8 v = *reinterpret_cast<const f16x8*>(p + (long)r * ldx);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
         }
@@ -262,11 +262,11 @@ gn_small_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, cons
     for (; r + 3 * rlu < rows_per_inst; r += 4 * rlu) {
         f16x8 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(px + (long)(r + u * rlu) * C);
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(px + (long)(r + u * rlu) * ldx);
 #pragma unroll
         for (int u = 0; u < 4; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)(r + u * rlu) * C), one(v[u]));
     }
-    for (; r < rows_per_inst; r += rlu) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(*reinterpret_cast<const f16x8*>(px + (long)r * C)));
+    for (; r < rows_per_inst; r += rlu) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(*reinterpret_cast<const f16x8*>(px + (long)r * ldx)));
 }
 
 // LayerNorm: one wave per row, NV 8-channel vectors per lane (C <= 512*NV), RW rows per wave with all their loads issued
@@ -359,7 +359,7 @@ extern "C" int ds_groupnorm_stats(const void* x, float* mean, float* rstd, float
     DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_stats: C=%d groups=%d unsupported", C, groups);
     hipStream_t st = (hipStream_t)stream;
     const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
-    gn_partial_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups);
+    gn_partial_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups, C);
     DS_CHECK_LAUNCH("ds_groupnorm_stats(partial)");
     const int n = ninst * groups;
     gn_finalize_kernel<<<(n + 255) / 256, 256, 0, st>>>((const float2*)workspace, mean, rstd, ninst, nchunks, groups,
@@ -376,29 +376,37 @@ extern "C" int ds_groupnorm_apply(const void* x, const float* mean, const float*
     DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && C % groups == 0, "ds_groupnorm_apply: C=%d groups=%d unsupported", C, groups);
     hipStream_t st = (hipStream_t)stream;
     const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
-    gn_apply_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, mean, rstd, nullptr, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, 0.0f);
+    gn_apply_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, mean, rstd, nullptr, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, 0.0f, C);
     DS_CHECK_LAUNCH("ds_groupnorm_apply");
+    return DS_OK;
+}
+
+// ldx: row stride of x in elements (>= C, multiple of 8): the input may be a column slice of a wider row-major buffer (the UNet
+// writes skip tensors straight into the buffer the decoder side concatenates in, unet.py).  y is dense [rows][C].
+extern "C" int ds_groupnorm_f16_strided(const void* x, int ldx, const float* gamma, const float* beta, void* y, float* workspace,
+                                        int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream) {
+    DS_CHECK_ARG(x && gamma && beta && y && workspace, "ds_groupnorm_f16: null argument");
+    DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0, "ds_groupnorm_f16: ninst/rows_per_inst must be positive");
+    DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_f16: C=%d groups=%d unsupported", C, groups);
+    DS_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "ds_groupnorm_f16: ldx=%d (>= C, multiple of 8, x 16-byte aligned)", ldx);
+    hipStream_t st = (hipStream_t)stream;
+    if (rows_per_inst <= GN_SMALL_ROWS && C / 8 <= 512 && ninst >= 64) {   // enough instances to fill the chip
+        gn_small_kernel<<<ninst, GN_SMALL_NT, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, eps, ldx);
+        DS_CHECK_LAUNCH("ds_groupnorm_f16(small)");
+        return DS_OK;
+    }
+    const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
+    gn_partial_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups, ldx);
+    DS_CHECK_LAUNCH("ds_groupnorm_f16(stats)");
+    gn_apply_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, nullptr, nullptr, (const float2*)workspace, gamma, beta,
+                                                          (f16*)y, rows_per_inst, C, groups, silu, eps, ldx);
+    DS_CHECK_LAUNCH("ds_groupnorm_f16(apply)");
     return DS_OK;
 }
 
 extern "C" int ds_groupnorm_f16(const void* x, const float* gamma, const float* beta, void* y, float* workspace, int ninst,
                                 int rows_per_inst, int C, int groups, float eps, int silu, void* stream) {
-    DS_CHECK_ARG(x && gamma && beta && y && workspace, "ds_groupnorm_f16: null argument");
-    DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0, "ds_groupnorm_f16: ninst/rows_per_inst must be positive");
-    DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_f16: C=%d groups=%d unsupported", C, groups);
-    hipStream_t st = (hipStream_t)stream;
-    if (rows_per_inst <= GN_SMALL_ROWS && C / 8 <= 512 && ninst >= 64) {   // enough instances to fill the chip
-        gn_small_kernel<<<ninst, GN_SMALL_NT, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, eps);
-        DS_CHECK_LAUNCH("ds_groupnorm_f16(small)");
-        return DS_OK;
-    }
-    const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
-    gn_partial_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups);
-    DS_CHECK_LAUNCH("ds_groupnorm_f16(stats)");
-    gn_apply_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, nullptr, nullptr, (const float2*)workspace, gamma, beta,
-                                                          (f16*)y, rows_per_inst, C, groups, silu, eps);
-    DS_CHECK_LAUNCH("ds_groupnorm_f16(apply)");
-    return DS_OK;
+    return ds_groupnorm_f16_strided(x, C, gamma, beta, y, workspace, ninst, rows_per_inst, C, groups, eps, silu, stream);
 }
 
 extern "C" int ds_layernorm(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,

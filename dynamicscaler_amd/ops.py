@@ -299,13 +299,16 @@ def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE
 
 
 def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None):
+    """x [ninst*rows_per_inst, Cch] fp16, rows contiguous or a column slice of a wider row-major buffer (row stride x.stride(0));
+    returns a dense [rows, Cch] tensor."""
     lib = _lib.load()
     st = _stream() if stream is None else stream
+    assert x.dim() == 2 and x.shape[1] == Cch and x.stride(1) == 1, "groupnorm: x must be [rows, C] with unit column stride"
     ws = torch.empty((lib.ds_groupnorm_stats_workspace_floats(ninst, rows_per_inst, groups),), dtype=torch.float32,
                      device=x.device)
-    y = torch.empty_like(x)
-    check(lib.ds_groupnorm_f16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), ws.data_ptr(), ninst,
-                               rows_per_inst, Cch, groups, float(eps), int(bool(silu)), st), "ds_groupnorm_f16")
+    y = torch.empty((x.shape[0], Cch), dtype=x.dtype, device=x.device)
+    check(lib.ds_groupnorm_f16_strided(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                       ninst, rows_per_inst, Cch, groups, float(eps), int(bool(silu)), st), "ds_groupnorm_f16")
     return y
 
 

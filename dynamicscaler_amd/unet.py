@@ -44,6 +44,15 @@ class UNetModel(nn.Module):
     def __init__(self, **params):
         super().__init__()
         self.cfg, self._inputs, self._middle, self._outputs = build_program(params)
+        # per decoder group: (channels of h, channels of the skip tensor) of its torch.cat([h, skip], dim=1)
+        skip_ch, ch = [], 0
+        for group in self._inputs:
+            for b in group:
+                if b.kind in ("conv_in", "res", "down", "up"):
+                    ch = b.cout
+            skip_ch.append(ch)
+        self._cat_ch = [(group[0].cin - c, c) for group, c in zip(self._outputs, reversed(skip_ch))]
+        self.inplace_concat = os.environ.get("DS_INPLACE_CONCAT", "1") == "1"   # skip tensors produced inside the concat buffers
         cfg = self.cfg
         self.in_channels = cfg["in_channels"]
         self.model_channels = cfg["model_channels"]
@@ -254,14 +263,14 @@ class UNetModel(nn.Module):
         P = self._packed
         return ops.groupnorm(h, P[prefix + ".g"], P[prefix + ".be"], ninst, rows, C, eps, silu)
 
-    def _linear(self, a, prefix, residual=None, epilogue=0, bias=True):
+    def _linear(self, a, prefix, residual=None, epilogue=0, bias=True, out=None):
         P = self._packed
         w = P[prefix + ".w"]
         return ops.gemm(a, w, P[prefix + ".b"] if bias else None, residual, M=a.shape[0], N=w.shape[0], K=w.shape[1],
-                        epilogue=epilogue)
+                        lda=a.stride(0), epilogue=epilogue, out=out)
 
     def _conv3(self, a, prefix, dims, cin, stride=1, upsample=0, residual=None, bias=None, bias_rows=None, ldbias=None,
-               epilogue=0):
+               epilogue=0, out=None):
         """dims = (nimg, hin, win) physical input; returns (out, (hout, wout))."""
         P = self._packed
         w = P[prefix + ".w"]
@@ -272,7 +281,7 @@ class UNetModel(nn.Module):
         M = nimg * hout * wout
         out = ops.gemm(a, w, P[prefix + ".b"] if bias is None else bias, residual, M=M, N=w.shape[0], K=w.shape[1],
                        a_mode=DS_A_CONV3, cin=cin, lda=a.stride(0), conv=(nimg, hin, win, hout, wout, stride, upsample),
-                       bias_rows=bias_rows, ldbias=ldbias, epilogue=epilogue)
+                       bias_rows=bias_rows, ldbias=ldbias, epilogue=epilogue, out=out)
         return out, (hout, wout)
 
     def _transformer_block(self, x, p, heads, spatial, geo, ctx, dup=None):
@@ -330,7 +339,7 @@ class UNetModel(nn.Module):
         g = ln_proj(x, "norm3", f"{p}.ff1", 8 * inner, epilogue=DS_EPI_GEGLU)      # GEGLU: 2 x (4 x inner) columns
         return self._linear(g, f"{p}.ff.net.2", residual=x)
 
-    def _transformer(self, h, prefix, heads, depth, spatial, geo, ctx, dup=None):
+    def _transformer(self, h, prefix, heads, depth, spatial, geo, ctx, dup=None, out=None):
         B, T, H, W = geo
         C = h.shape[1]
         if spatial:
@@ -343,9 +352,9 @@ class UNetModel(nn.Module):
                                         dup=dup if d == 0 else None)
             if dup is not None and d == 0:
                 h, geo = dup(h), (2 * B, T, H, W)
-        return self._linear(x, prefix + ".proj_out", residual=h)
+        return self._linear(x, prefix + ".proj_out", residual=h, out=out)
 
-    def _resblock(self, h, b, geo, emb_all):
+    def _resblock(self, h, b, geo, emb_all, out=None):
         P = self._packed
         B, T, H, W = geo
         p = b.prefix
@@ -355,7 +364,7 @@ class UNetModel(nn.Module):
                             ldbias=self._emb_total)
         a2 = self._gn(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5, True)
         skip = h if b.cin == b.cout else self._linear(h, p + ".skip_connection")
-        h2, _ = self._conv3(a2, p + ".out_layers.3", (B * T, H, W), b.cout, residual=skip)
+        h2, _ = self._conv3(a2, p + ".out_layers.3", (B * T, H, W), b.cout, residual=skip, out=None if b.tconv else out)
         if b.tconv:
             x = h2
             M = x.shape[0]
@@ -365,7 +374,7 @@ class UNetModel(nn.Module):
                 an = self._gn(x, q + ".0", B, T * H * W, b.cout, 1e-5, True)
                 w = P[f"{q}.{ci}.w"]
                 x = ops.gemm(an, w, P[f"{q}.{ci}.b"], h2 if i == 4 else None, M=M, N=w.shape[0], K=w.shape[1],
-                             a_mode=DS_A_TCONV, cin=b.cout, lda=an.stride(0), tconv=(T, H * W))
+                             a_mode=DS_A_TCONV, cin=b.cout, lda=an.stride(0), tconv=(T, H * W), out=out if i == 4 else None)
             h2 = x
         return h2
 
@@ -430,48 +439,88 @@ class UNetModel(nn.Module):
         def dup(t):
             return torch.cat([t, t], 0)
 
-        def run(group, h, geo):
+        def run(group, h, geo, out=None):
+            """`out`: where the group's LAST block writes its result ([rows, C] view, e.g. a column slice of a concat buffer)."""
             nonlocal shared
-            for b in group:
+            for bi, b in enumerate(group):
+                o = out if bi == len(group) - 1 else None
                 Bq, Tq, Hq, Wq = geo
                 if b.kind == "conv_in":
                     patches = ops.im2col_in(x[:pairs] if shared else x, self._kpad_in)
                     w = P[b.prefix + ".w"]
-                    h = ops.gemm(patches, w, P[b.prefix + ".b"], None, M=patches.shape[0], N=w.shape[0], K=w.shape[1])
+                    h = ops.gemm(patches, w, P[b.prefix + ".b"], None, M=patches.shape[0], N=w.shape[0], K=w.shape[1], out=o)
                 elif b.kind == "res":
-                    h = self._resblock(h, b, geo, emb_all)
+                    h = self._resblock(h, b, geo, emb_all, out=o)
                 elif b.kind == "st":
-                    h = self._transformer(h, b.prefix, b.heads, b.depth, True, geo, ctx, dup=dup if shared else None)
+                    h = self._transformer(h, b.prefix, b.heads, b.depth, True, geo, ctx, dup=dup if shared else None, out=o)
                     if shared:
                         shared, geo = False, (2 * Bq, Tq, Hq, Wq)
                 elif b.kind == "tt":
-                    h = self._transformer(h, b.prefix, b.heads, b.depth, False, geo, ctx)
+                    h = self._transformer(h, b.prefix, b.heads, b.depth, False, geo, ctx, out=o)
                 elif b.kind == "down":
-                    h, (ho, wo) = self._conv3(h, b.prefix + ".op", (Bq * Tq, Hq, Wq), b.cin, stride=2)
+                    h, (ho, wo) = self._conv3(h, b.prefix + ".op", (Bq * Tq, Hq, Wq), b.cin, stride=2, out=o)
                     geo = (Bq, Tq, ho, wo)
                 elif b.kind == "up":
-                    h, (ho, wo) = self._conv3(h, b.prefix + ".conv", (Bq * Tq, Hq, Wq), b.cin, upsample=1)
+                    h, (ho, wo) = self._conv3(h, b.prefix + ".conv", (Bq * Tq, Hq, Wq), b.cin, upsample=1, out=o)
                     geo = (Bq, Tq, ho, wo)
                 if self._tap is not None:
                     self._tap(b.prefix, h, geo)
             return h, geo
 
+        def geo_after(group, geo):
+            Bq, Tq, Hq, Wq = geo
+            for b in group:
+                if b.kind == "down":
+                    Hq, Wq = (Hq - 1) // 2 + 1, (Wq - 1) // 2 + 1
+                elif b.kind == "up":
+                    Hq, Wq = 2 * Hq, 2 * Wq
+            return (Bq, Tq, Hq, Wq)
+
+        # torch.cat([h, hs.pop()], dim=1) (openaimodel3d.py:700-703) without the copy: every skip tensor is produced straight
+        # into the right-hand columns of the buffer its decoder block reads ([rows, C_h + C_skip]; the encoder side keeps
+        # reading it there through row strides), and the decoder-side h into the left-hand columns by whatever block ends the
+        # previous group.  Same kernels on the same numbers; only where the rows live changes.
         geo = (pairs if shared else B, T, H, W)
         h = None
-        hs = []
+        hs = []                                  # (concat buffer | skip tensor, C_h, geometry)
+        n_in = len(self._inputs)
+        inplace = self.inplace_concat
         for gi, group in enumerate(self._inputs):
-            h, geo = run(group, h, geo)
-            if gi == 0 and cfg["addition_attention"]:
-                h = self._transformer(h, "init_attn.0", 8, cfg["transformer_depth"], False, geo, ctx)
+            c_h, c_skip = self._cat_ch[n_in - 1 - gi]
+            g_out = geo_after(group, geo)
+            init_attn = gi == 0 and cfg["addition_attention"]
+            shared_after = shared and not any(b.kind == "st" for b in group)
+            full = (B,) + g_out[1:]
+            cat = dst = None
+            if inplace:
+                cat = torch.empty((full[0] * full[1] * full[2] * full[3], c_h + c_skip), dtype=torch.float16, device=dev)
+                dst = None if shared_after else cat[:, c_h:]
+            h, geo = run(group, h, geo, out=None if init_attn else dst)
+            if init_attn:
+                h = self._transformer(h, "init_attn.0", 8, cfg["transformer_depth"], False, geo, ctx, out=dst)
                 if self._tap is not None:
                     self._tap("init_attn.0", h, geo)
-            hs.append((dup(h), (B,) + geo[1:]) if shared else (h, geo))
-        h, geo = run(self._middle, h, geo)
+            assert h.shape[1] == c_skip
+            if not inplace:
+                hs.append((dup(h) if shared_after else h, c_h, full))
+                continue
+            if shared_after:                     # one copy of the pair batch so far: both halves of the skip rows get it
+                half = h.shape[0]
+                cat[:half, c_h:].copy_(h)
+                cat[half:, c_h:].copy_(h)
+            hs.append((cat, c_h, full))
+        assert geo_after(self._middle, geo) == hs[-1][2], \
+            f"skip connection geometry {hs[-1][2]} != {geo_after(self._middle, geo)} (tile h/w must be divisible by 8)"
+        h, geo = run(self._middle, h, geo, out=hs[-1][0][:, :hs[-1][1]] if inplace else None)
         for group in self._outputs:
-            skip, sgeo = hs.pop()
-            assert sgeo == geo, f"skip connection geometry {sgeo} != {geo} (tile h/w must be divisible by 8)"
-            h = ops.concat_channels(h, skip)
-            h, geo = run(group, h, geo)
+            cat, c_h, sgeo = hs.pop()
+            assert sgeo == geo and h.shape[1] == c_h
+            if hs:
+                assert geo_after(group, geo) == hs[-1][2], \
+                    f"skip connection geometry {hs[-1][2]} != {geo_after(group, geo)} (tile h/w must be divisible by 8)"
+            if not inplace:
+                cat = ops.concat_channels(h, cat)        # the copy (DS_INPLACE_CONCAT=0: A/B and diagnostics)
+            h, geo = run(group, cat, geo, out=hs[-1][0][:, :hs[-1][1]] if (hs and inplace) else None)
         a = self._gn(h, "out.0", B * T, H * W, mc, 1e-5, True)
         y, _ = self._conv3(a, "out.2", (B * T, H, W), mc, epilogue=DS_EPI_OUT_F32)
         return ops.rows_to_ncthw(y, (B, cfg["out_channels"], T, H, W), torch.float32)

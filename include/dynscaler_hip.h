@@ -203,6 +203,11 @@ int ds_groupnorm_apply(const void* x, const float* mean, const float* rstd, cons
    y = GroupNorm(x) (+ SiLU).  workspace: ds_groupnorm_stats_workspace_floats(...) floats.                            */
 int ds_groupnorm_f16(const void* x, const float* gamma, const float* beta, void* y, float* workspace, int ninst,
                      int rows_per_inst, int C, int groups, float eps, int silu, void* stream);
+/* the same with a row stride on the input: x row r starts at x + r*ldx elements (ldx >= C, multiple of 8) -- a column slice of
+   a wider row-major buffer; y stays dense [rows][C].  (The UNet's skip tensors live in the buffer the decoder side
+   concatenates in, torch.cat([h, hs.pop()], dim=1) of openaimodel3d.py:700-703 without the copy.)                   */
+int ds_groupnorm_f16_strided(const void* x, int ldx, const float* gamma, const float* beta, void* y, float* workspace,
+                             int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream);
 /* nn.LayerNorm(C) eps 1e-5 over each row (attention.py:199-201). x,y fp16 [rows][C]. */
 int ds_layernorm(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
                  void* stream);

@@ -390,6 +390,11 @@ def test_groupnorm(ninst, rows, C, silu):
     assert relerr(y2, ref) < 1e-3 and relerr(y2, y.float().cpu()) < 2e-3
     mref = x.reshape(ninst, rows, 32, C // 32).permute(0, 2, 1, 3).reshape(ninst * 32, -1).mean(1)
     assert torch.allclose(mean.cpu(), mref, atol=1e-4)
+    # input as a column slice of a wider row-major buffer (ds_groupnorm_f16_strided: the UNet's skip tensors): same bits
+    wide = torch.full((ninst * rows, C + 64), 7.0, dtype=torch.float16, device=d)
+    wide[:, 24:24 + C] = x.half().to(d)
+    y3 = ops.groupnorm(wide[:, 24:24 + C], g.to(d), b.to(d), ninst, rows, C, 1e-5, silu)
+    assert y3.is_contiguous() and torch.equal(y3, y)
 
 
 @pytest.mark.parametrize("rows,C", [(1000, 320), (77, 1280), (5, 64), (333, 512)])

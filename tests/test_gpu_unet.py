@@ -112,6 +112,34 @@ def test_unet_cfg_pair_prefix_sharing_is_bit_identical(name):
         m(x2, t, context=ctx, fps=8, cfg_pairs=2)
 
 
+@pytest.mark.parametrize("name", ["t2v", "i2v"])
+def test_unet_skip_tensors_in_place_equal_the_concat_copy(name):
+    """torch.cat([h, hs.pop()], dim=1) (openaimodel3d.py:700-703): by default every skip tensor is produced straight into the
+    columns of the buffer its decoder block reads (strided GEMM outputs, GroupNorm / GEMM operands read through row strides)
+    and there is no concat kernel; inplace_concat=False runs the copy.  Same kernels on the same numbers: bit-identical,
+    with and without the shared CFG prefix."""
+    d = dev()
+    z = np.load(os.path.join(G, f"unet_tiny_{name}.npz"))
+    params = json.loads(bytes(z["params_json"]).decode())
+    m = build_unet(params, 5, d)
+    from dynamicscaler_amd.synth import synth_normal
+    x0, c0 = T(z["x_0"]), T(z["ctx_0"])
+    x = torch.cat([x0, synth_normal(x0.shape, 101)], 0).to(d, torch.float16)
+    x2 = torch.cat([x, x], 0)
+    t = T(z["t_0"]).to(d).reshape(-1)[:1].expand(4).contiguous()
+    ctx = torch.cat([c0, synth_normal(c0.shape, 201), synth_normal(c0.shape, 301), synth_normal(c0.shape, 302)], 0).to(d)
+    assert m.inplace_concat
+    a = m(x2, t, context=ctx, fps=int(z["fps_0"]))
+    a_pairs = m(x2, t, context=ctx, fps=int(z["fps_0"]), cfg_pairs=2)
+    m.inplace_concat = False
+    try:
+        b = m(x2, t, context=ctx, fps=int(z["fps_0"]))
+        b_pairs = m(x2, t, context=ctx, fps=int(z["fps_0"]), cfg_pairs=2)
+    finally:
+        m.inplace_concat = True
+    assert torch.equal(a, b) and torch.equal(a_pairs, b_pairs) and torch.equal(a, a_pairs)
+
+
 def test_ring_pipeline_cfg_prefix_sharing_same_panorama():
     from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
     from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
