@@ -61,6 +61,7 @@ SIGNATURES = {
     "ds_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ds_layernorm_stats": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "ds_gemm_f16_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),
+    "ds_gemm_f16_lnk": (_i, [_vp, _vp, _f, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),
     "ds_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "ds_temporal_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ds_concat_channels": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -51,6 +51,7 @@
 
 namespace {
 
+constexpr int A_DENSE_LNK = 5;  // internal: as A_DENSE_LN, with the rows' (mean, rstd) computed IN the kernel from the A fragments (ds_gemm_f16_lnk)
 constexpr int A_CONV3_TI = 4;   // internal: DS_A_CONV3, stride 1, no upsample, K walked channel-chunk-major with the 9 TAPS INNERMOST
 constexpr int A_DENSE_LN = 3;   // internal template value: DS_A_DENSE addressing + the LayerNorm fold after the K loop (ds_gemm_f16_ln)
 constexpr int BK = 64;  // halfs per K-step (128-byte LDS rows, 8 chunks of 16 bytes)
@@ -146,7 +147,8 @@ template <int BM, int BN, int WGM, int WGN, int AMODE, int NS>
 __global__ void __launch_bounds__((TileCfg<BM, BN, WGM, WGN, NS>::NT), (TileCfg<BM, BN, WGM, WGN, NS>::WG_PER_CU))
 gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const float* __restrict__ bias,
                 const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n,
-                unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum) {
+                unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum,
+                float ln_eps) {
     using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
     constexpr int LROWS = Cfg::LROWS, A_ROWS_PER_THREAD = Cfg::AR, B_ROWS_PER_THREAD = Cfg::BR;
@@ -330,6 +332,15 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const int nk = d.K / BK;
     const int fr = lane & 31, fh = lane >> 5;
 
+    if constexpr (AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK) {   // column sums / column bias of this tile's BN columns -> LDS (read after the K loop)
+        float* sLNw = reinterpret_cast<float*>(smem + Cfg::LDS);
+        for (int c = threadIdx.x; c < BN; c += Cfg::NT) {
+            const int col = min(n0 + c, d.N - 1);
+            sLNw[c] = ln_colsum[col];
+            sLNw[BN + c] = bias ? bias[col] : 0.0f;
+        }
+    }
+
     f32x16 acc[TN][TM];
     // A bias vector DECLARED shared (bias_rows > M, e.g. INT32_MAX: one vector for every row) starts in the accumulators:
     // the epilogue then has no bias work, and launches without residual / per-item bias transpose fp16 strips (below).
@@ -338,7 +349,8 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     // (bias_rows <= M, also when it covers the launch with ONE item) is always added after the K sum.
     // Each lane reads the 4 columns of its register quads straight from global memory (two addresses per wave-instruction,
     // L2-resident) while the first K-steps' loads are in flight.
-    constexpr bool ln_fold = AMODE == A_DENSE_LN;   // LayerNorm folded into this GEMM (ds_gemm_f16_ln): see the transform after the K loop
+    constexpr bool ln_fold = AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK;   // LayerNorm folded into this GEMM (ds_gemm_f16_ln / _lnk): see the transform after the K loop
+    constexpr bool ln_kstats = AMODE == A_DENSE_LNK;   // row statistics from the A fragments of the K loop (no statistics launch)
     const bool bias_in_acc = !ln_fold && bias && d.bias_rows > d.M && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.ldbias % 4 == 0) &&
                              (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && !(d.epilogue & DS_EPI_OUT_F32) &&
                              (!residual || d.ldr % 8 == 0);
@@ -362,6 +374,24 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[ni][mi][j] = 0.0f;
     }
+
+    // ln_kstats: per lane the partial sum / sum of squares of ITS row's k-chunks (lane = (row fr, k half fh)); every A fragment of
+    // the K loop passes through two v_dot2 chains (8 vector ops per fragment, in the shadow of the matrix pipe).  One-pass
+    // variance in fp32 -- E[x^2] - mean^2 over the fp16 values the matrix cores multiply.
+    float ks1[TM], ks2[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) { ks1[mi] = 0.0f; ks2[mi] = 0.0f; }
+    auto kstats = [&](const f16x8& a, int mi) {
+        if constexpr (ln_kstats) {
+            const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const f16x2 v = {a[2 * h], a[2 * h + 1]};
+                ks1[mi] = __builtin_amdgcn_fdot2(v, one2, ks1[mi], false);
+                ks2[mi] = __builtin_amdgcn_fdot2(v, v, ks2[mi], false);
+            }
+        }
+    };
 
     // K-step synchronisation.  Register staging: store the staged operands, one barrier.  DMA: wait for this wave's
     // LDS-DMA of the next K-step, one barrier (then every wave's part has landed and the current buffer is free).
@@ -448,8 +478,10 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
+                    for (int mi = 0; mi < TM; ++mi) {
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][ni], af[kk][mi], acc[ni][mi], 0, 0, 0);
+                        if (ni == 0) kstats(af[kk][mi], mi);
+                    }
         } else {
             // big wave tiles: the fragments of k-slice kk+1 are read while the MFMAs of kk run (two register sets), and
             // the LDS-DMA pieces of the next K-step are issued one at a time BETWEEN the MFMAs of the first two k-slices:
@@ -471,6 +503,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 for (int idx = 0; idx < NMF; ++idx) {
                     const int ni = idx / TM, mi = idx % TM;
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk & 1][ni], af[kk & 1][mi], acc[ni][mi], 0, 0, 0);
+                    if (ni == 0) kstats(af[kk & 1][mi], mi);
                     // the fragments of the next k-slice are read one per MFMA (not as a burst in front of the slice):
                     // right after the barrier only the first slice's reads of the eight waves queue up at the LDS
                     if (kk + 1 < 4 && idx < TM + TN) {
@@ -507,33 +540,39 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     //      per register quad like the accumulator-init bias), after which the epilogue sees a plain bias-free product.
     //      The normalised activation is never rounded to fp16 and never written to memory. ----
     if constexpr (ln_fold) {
-        const float* ln_cb = bias ? bias : ln_colsum;      // no column bias: any readable vector, scaled by 0 below
-        const float cb_on = bias ? 1.0f : 0.0f;
         float2 st[TM];
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
-            st[mi] = reinterpret_cast<const float2*>(ln_stats)[min(m0 + wm * WM + mi * 32 + fr, d.M - 1)];   // tail rows: never stored
+            if constexpr (ln_kstats) {
+                const float s1 = ks1[mi] + __shfl_xor(ks1[mi], 32), s2 = ks2[mi] + __shfl_xor(ks2[mi], 32);   // the two k halves of the row
+                const float mean = s1 / (float)d.K;
+                st[mi] = make_float2(mean, rsqrtf(fmaxf(s2 / (float)d.K - mean * mean, 0.0f) + ln_eps));
+            } else {
+                st[mi] = reinterpret_cast<const float2*>(ln_stats)[min(m0 + wm * WM + mi * 32 + fr, d.M - 1)];   // tail rows: never stored
+            }
         }
+        // cs / cb of this tile's BN columns were staged in LDS behind the operand stages at kernel start (sLN, visible after the
+        // K loop's first barrier).  One 32-column tile at a time: with all 4*TN quads' vectors loaded in front of the
+        // arithmetic (what the compiler does by itself) the 256x320 tile spilled ~300 B per lane.
+        const float* sLN = reinterpret_cast<const float*>(smem + Cfg::LDS);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // branch-free loads (a select around a load becomes a divergent branch): columns beyond N are clamped to the
-                // last quad -- their products are never stored (N % 8 == 0 is checked on the host).  Known cost: the scheduler
-                // hoists all these loads in front of the arithmetic; on the 256x320 tile (already at 248 VGPRs) that spills
-                // ~300 B per lane and makes the folded QKV launches SLOWER than LayerNorm kernel + plain GEMM
-                // (profiles/r2_notes.md section 4) -- why UNetModel.fold_layernorm is off by default.
-                const int col = min(n0 + wn * WN + ni * 32 + 8 * g + 4 * fh, d.N - 4);
-                const f32x4 cs = *reinterpret_cast<const f32x4*>(ln_colsum + col);
-                f32x4 cb = *reinterpret_cast<const f32x4*>(ln_cb + col);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cb[j] *= cb_on;
+                const int cl = wn * WN + ni * 32 + 8 * g + 4 * fh;
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(sLN + cl);
+                const f32x4 cb = *reinterpret_cast<const f32x4*>(sLN + BN + cl);
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[ni][mi][4 * g + j] = fmaf(st[mi].y, acc[ni][mi][4 * g + j] - st[mi].x * cs[j], cb[j]);
             }
+            // the tile's values are pinned here: left alone, the arithmetic sinks down to its uses in the epilogue and the
+            // 8*TN column vectors stay live across it
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) asm volatile("" : "+v"(acc[ni][mi]));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     const bool bias_done = bias_in_acc || ln_fold;   // nothing left to add in the epilogue
@@ -810,9 +849,10 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 
 template <int BM, int BN, int WGM, int WGN, int AMODE, int NS = 2>
 int launch(const void* A, const void* W, const float* bias, const void* residual, void* out,
-           const ds_gemm_desc& d, hipStream_t st, const float* ln_stats, const float* ln_colsum) {
+           const ds_gemm_desc& d, hipStream_t st, const float* ln_stats, const float* ln_colsum, float ln_eps) {
     using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
-    constexpr size_t lds = Cfg::LDS;
+    constexpr size_t lds = Cfg::LDS + ((AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK) ? 2 * BN * sizeof(float) : 0);   // + staged column sums / bias
+    static_assert(lds <= 163840, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WGM, WGN, AMODE, NS>),
@@ -834,7 +874,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
     }
     gemm_f16_kernel<BM, BN, WGM, WGN, AMODE, NS><<<tiles_m * tiles_n, Cfg::NT, lds, st>>>(
         (const f16*)A, (const f16*)W, bias, (const f16*)residual, out, d, tiles_m, tiles_n, (unsigned)a_bytes, (unsigned)w_bytes,
-        ln_stats, ln_colsum);
+        ln_stats, ln_colsum, ln_eps);
     DS_CHECK_LAUNCH("ds_gemm_f16");
     return DS_OK;
 }
@@ -872,14 +912,14 @@ int choose_tile(const ds_gemm_desc& d) {
 
 template <int AMODE>
 int dispatch(int tile, const void* A, const void* W, const float* bias, const void* residual, void* out,
-             const ds_gemm_desc& d, hipStream_t st, const float* ln_stats = nullptr, const float* ln_colsum = nullptr) {
+             const ds_gemm_desc& d, hipStream_t st, const float* ln_stats = nullptr, const float* ln_colsum = nullptr, float ln_eps = 0.0f) {
     switch (tile) {
-        case TILE_256x256: return launch<256, 256, 2, 4, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
-        case TILE_256x320: return launch<256, 320, 4, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
-        case TILE_128x128: return launch<128, 128, 2, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
-        case TILE_128x128_DEEP: return launch<128, 128, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
-        case TILE_128x64_DEEP: return launch<128, 64, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
-        default:           return launch<128, 64, 2, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
+        case TILE_256x256: return launch<256, 256, 2, 4, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
+        case TILE_256x320: return launch<256, 320, 4, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
+        case TILE_128x128: return launch<128, 128, 2, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
+        case TILE_128x128_DEEP: return launch<128, 128, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
+        case TILE_128x64_DEEP: return launch<128, 64, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
+        default:           return launch<128, 64, 2, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
     }
 }
 
@@ -892,8 +932,9 @@ extern "C" int ds_dbg_set_stamps(void* p) {
 }
 #endif
 
+// ln_colsum != nullptr: LayerNorm folded in; ln_stats == nullptr then selects the in-kernel statistics (ln_eps)
 static int gemm_entry(const void* A, const void* W, const float* bias, const void* residual, void* out,
-                      const ds_gemm_desc* desc, void* stream, const float* ln_stats, const float* ln_colsum) {
+                      const ds_gemm_desc* desc, void* stream, const float* ln_stats, const float* ln_colsum, float ln_eps = 0.0f) {
     DS_CHECK_ARG(A && W && out && desc, "ds_gemm_f16: null argument");
     const ds_gemm_desc& d = *desc;
     DS_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "ds_gemm_f16: M,N,K must be positive (got %d,%d,%d)", d.M, d.N, d.K);
@@ -938,6 +979,7 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
             const char* r_p = residual ? (const char*)residual + r0 * d.ldr * 2 : nullptr;
             char* o_p = (char*)out + r0 * d.ldc * out_elt;
             int rc = ln_stats ? dispatch<A_DENSE_LN>(tile, a_p, W, bias, r_p, o_p, c, st, ln_stats + 2 * r0, ln_colsum)
+                     : ln_colsum ? dispatch<A_DENSE_LNK>(tile, a_p, W, bias, r_p, o_p, c, st, nullptr, ln_colsum, ln_eps)
                               : dispatch<DS_A_DENSE>(tile, a_p, W, bias, r_p, o_p, c, st);
             if (rc) return rc;
         }
@@ -954,6 +996,7 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
     }
     if (d.a_mode == DS_A_TCONV) return dispatch<DS_A_TCONV>(tile, A, W, bias, residual, out, d, st);
     if (ln_stats) return dispatch<A_DENSE_LN>(tile, A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
+    if (ln_colsum) return dispatch<A_DENSE_LNK>(tile, A, W, bias, residual, out, d, st, nullptr, ln_colsum, ln_eps);
     return dispatch<DS_A_DENSE>(tile, A, W, bias, residual, out, d, st);
 }
 
@@ -970,4 +1013,17 @@ extern "C" int ds_gemm_f16_ln(const void* x, const void* W_gamma, const float* l
     DS_CHECK_ARG((reinterpret_cast<uintptr_t>(ln_stats) & 7) == 0 && (reinterpret_cast<uintptr_t>(ln_colsum) & 15) == 0 &&
                  (!ln_colbias || (reinterpret_cast<uintptr_t>(ln_colbias) & 15) == 0), "ds_gemm_f16_ln: stats 8-byte, column vectors 16-byte aligned");
     return gemm_entry(x, W_gamma, ln_colbias, nullptr, out, desc, stream, ln_stats, ln_colsum);
+}
+
+// The same with the rows' statistics computed inside the kernel (every tile walks its rows' whole K = C extent, so each
+// A fragment also feeds a sum / sum-of-squares chain): no statistics launch, x is read once in all.
+extern "C" int ds_gemm_f16_lnk(const void* x, const void* W_gamma, float ln_eps, const float* ln_colsum,
+                               const float* ln_colbias, void* out, const ds_gemm_desc* desc, void* stream) {
+    DS_CHECK_ARG(x && W_gamma && ln_colsum && out && desc, "ds_gemm_f16_lnk: null argument");
+    DS_CHECK_ARG(desc->a_mode == DS_A_DENSE && desc->cin == desc->K, "ds_gemm_f16_lnk: dense A operand only (the LayerNorm row is the K dimension)");
+    DS_CHECK_ARG(!(desc->epilogue & DS_EPI_OUT_F32) && desc->N % 8 == 0 && desc->ldc % 8 == 0, "ds_gemm_f16_lnk: fp16 output, N and ldc multiples of 8");
+    DS_CHECK_ARG((reinterpret_cast<uintptr_t>(ln_colsum) & 15) == 0 && (!ln_colbias || (reinterpret_cast<uintptr_t>(ln_colbias) & 15) == 0),
+                 "ds_gemm_f16_lnk: colsum / colbias 16-byte aligned");
+    DS_CHECK_ARG(ln_eps > 0.0f, "ds_gemm_f16_lnk: eps must be positive");
+    return gemm_entry(x, W_gamma, ln_colbias, nullptr, out, desc, stream, nullptr, ln_colsum, ln_eps);
 }

@@ -353,9 +353,10 @@ def layernorm_stats(x, eps=1e-5, stream=None):
     return stats
 
 
-def gemm_ln(x, Wg, stats, colsum, colbias=None, *, M, N, K, out=None, epilogue=0, stream=None):
-    """out = LayerNorm(x) @ W^T (+ b) with the LayerNorm folded into the GEMM (ds_gemm_f16_ln): x raw fp16 [M,K], Wg =
-    fp16(gamma*W) [N,K], stats from layernorm_stats, colsum / colbias fp32 [N].  N' = N/2 for GEGLU."""
+def gemm_ln(x, Wg, stats, colsum, colbias=None, *, M, N, K, out=None, epilogue=0, stream=None, eps=1e-5):
+    """out = LayerNorm(x) @ W^T (+ b) with the LayerNorm folded into the GEMM: x raw fp16 [M,K], Wg = fp16(gamma*W) [N,K],
+    colsum / colbias fp32 [N].  stats from layernorm_stats (ds_gemm_f16_ln), or None: the kernel takes the rows' statistics
+    from its own operand fragments (ds_gemm_f16_lnk, `eps`) and no statistics launch exists.  N' = N/2 for GEGLU."""
     lib = _lib.load()
     n_out = N // 2 if (epilogue & DS_EPI_GEGLU) else N
     if out is None:
@@ -369,8 +370,12 @@ def gemm_ln(x, Wg, stats, colsum, colbias=None, *, M, N, K, out=None, epilogue=0
     st = _stream() if stream is None else stream
 
     def launch():
-        check(lib.ds_gemm_f16_ln(x.data_ptr(), Wg.data_ptr(), stats.data_ptr(), colsum.data_ptr(), _ptr(colbias),
-                                 out.data_ptr(), C.byref(d), st), "ds_gemm_f16_ln")
+        if stats is None:
+            check(lib.ds_gemm_f16_lnk(x.data_ptr(), Wg.data_ptr(), float(eps), colsum.data_ptr(), _ptr(colbias),
+                                      out.data_ptr(), C.byref(d), st), "ds_gemm_f16_lnk")
+        else:
+            check(lib.ds_gemm_f16_ln(x.data_ptr(), Wg.data_ptr(), stats.data_ptr(), colsum.data_ptr(), _ptr(colbias),
+                                     out.data_ptr(), C.byref(d), st), "ds_gemm_f16_ln")
 
     if _timing_hook is not None:
         _timing_hook("gemm", 2.0 * M * N * K, launch, (DS_A_DENSE, M, N, K, epilogue))

@@ -79,11 +79,12 @@ class UNetModel(nn.Module):
                 node = getattr(node, p)
             node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape), requires_grad=False))
         self._packed = None
-        # LayerNorm folded into the projection it feeds (ds_layernorm_stats + ds_gemm_f16_ln: the normalised activation is never
-        # rounded to fp16 nor written to memory).  OFF by default: measured 505 vs 489 ms per cfg3 step on MI355X (the fold's
-        # column loads spill on the 256x320 tile, profiles/r2_notes.md section 4).  DS_FOLD_LN=1 or set the attribute (and
-        # invalidate()) to use it.
-        self.fold_layernorm = os.environ.get("DS_FOLD_LN", "0") == "1"
+        # LayerNorm folded into the projection it feeds (the normalised activation is never rounded to fp16 nor written to
+        # memory): False = LayerNorm kernel + plain GEMM; "stats" = ds_layernorm_stats + ds_gemm_f16_ln; "kernel" = ds_gemm_f16_lnk,
+        # the GEMM takes the rows' statistics from its own operand fragments (no other launch; measured slower at the bench's
+        # batch sizes).  DS_FOLD_LN = 0 | 1 (default) | 2; after changing the attribute call invalidate() (the packed projection
+        # weights differ).  profiles/r2_notes.md section 4.
+        self.fold_layernorm = {"0": False, "1": "stats", "2": "kernel"}[os.environ.get("DS_FOLD_LN", "1")]
         self._tap = None                     # optional callable(name, rows [M,C] fp16, (B,T,H,W)) after every block (tests)
         self._generation = 0                 # bumped by every prepare(): identifies the packed buffers (hipGraph cache keys)
         self._prepare_lock = threading.Lock()
@@ -298,7 +299,7 @@ class UNetModel(nn.Module):
             ds_gemm_f16_ln on the raw activation), or the two separate kernels."""
             Mx = xin.shape[0]
             if self.fold_layernorm:
-                st = ops.layernorm_stats(xin)
+                st = ops.layernorm_stats(xin) if self.fold_layernorm != "kernel" else None
                 return ops.gemm_ln(xin, P[name + ".wg"], st, P[name + ".cs"], P[name + ".cb"], M=Mx, N=N, K=inner, epilogue=epilogue)
             n = ops.layernorm(xin, P[f"{p}.{ln}.g"], P[f"{p}.{ln}.be"])
             return ops.gemm(n, P[name + ".w"], P.get(name + ".b"), None, M=Mx, N=N, K=inner, epilogue=epilogue)

@@ -186,6 +186,12 @@ int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* res
  * residual); DS_EPI_GEGLU / DS_EPI_SILU apply after the fold.  colbias may be NULL. */
 int ds_gemm_f16_ln(const void* x, const void* W_gamma, const float* ln_stats, const float* ln_colsum,
                    const float* ln_colbias, void* out, const ds_gemm_desc* desc, void* stream);
+/* The same without a statistics launch: every tile walks its rows' whole K = C extent, so the kernel takes each row's sum and
+ * sum of squares from the operand fragments it feeds to the matrix cores (one-pass variance in fp32 over the fp16 values)
+ * and forms (mean, 1/sqrt(var + ln_eps)) itself.  LayerNorm -> Linear (-> GEGLU) then reads x once and writes only the
+ * projection (attention.py:199-220, 376-403). */
+int ds_gemm_f16_lnk(const void* x, const void* W_gamma, float ln_eps, const float* ln_colsum, const float* ln_colbias,
+                    void* out, const ds_gemm_desc* desc, void* stream);
 
 /* GroupNorm statistics: x fp16 [ninst*rows_per_inst][C]; instance i = rows [i*rows_per_inst, (i+1)*...).
  * Writes mean/rstd fp32 [ninst][groups]; `workspace` = caller scratch of ds_groupnorm_stats_workspace_floats(...)

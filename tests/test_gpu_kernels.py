@@ -433,14 +433,19 @@ def test_gemm_layernorm_folded(M, N, K, geglu):
     out = ops.gemm_ln(xd, wg.to(d).contiguous(), st, cs.to(d).contiguous(), cb.to(d).contiguous(), M=M, N=N, K=K,
                       epilogue=DS_EPI_GEGLU if geglu else 0)
     e = relerr(out, ref)
+    # the rows' statistics taken inside the GEMM from the operand fragments (ds_gemm_f16_lnk; one-pass variance)
+    outk = ops.gemm_ln(xd, wg.to(d).contiguous(), None, cs.to(d).contiguous(), cb.to(d).contiguous(), M=M, N=N, K=K,
+                       epilogue=DS_EPI_GEGLU if geglu else 0, eps=1e-5)
+    ek = relerr(outk, ref)
     # against the two-kernel path (LayerNorm output rounded to fp16, then the plain GEMM): the fold must not be worse
     n16 = ops.layernorm(xd, g.to(d), be.to(d))
     w_plain = (_interleave_geglu(w) if geglu else w).half().to(d).contiguous()
     b_plain = (_interleave_geglu(b) if geglu else b).to(d).contiguous()
     two = ops.gemm(n16, w_plain, b_plain, None, M=M, N=N, K=K, epilogue=DS_EPI_GEGLU if geglu else 0)
     e2 = relerr(two, ref)
-    print(f"gemm_ln {M}x{N}x{K} geglu={geglu}: folded {e:.3e}, LayerNorm kernel + GEMM {e2:.3e}")
+    print(f"gemm_ln {M}x{N}x{K} geglu={geglu}: folded {e:.3e}, in-kernel statistics {ek:.3e}, LayerNorm kernel + GEMM {e2:.3e}")
     assert out.shape == ref.shape and e < 1.2e-3 and e < 1.5 * e2 + 1e-4
+    assert outk.shape == ref.shape and ek < 1.2e-3 and ek < 1.5 * e2 + 1e-4
 
 
 def test_misc_ops():
