@@ -381,6 +381,14 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     float ks1[TM], ks2[TM];
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) { ks1[mi] = 0.0f; ks2[mi] = 0.0f; }
+    auto kstat_op = [&](const f16x8& a, int mi, int h, int kind) {   // one op: pair h of the fragment into the sum / sum-of-squares chain
+        if constexpr (ln_kstats) {
+            const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
+            const f16x2 v = {a[2 * h], a[2 * h + 1]};
+            if (kind == 0) ks1[mi] = __builtin_amdgcn_fdot2(v, one2, ks1[mi], false);
+            else ks2[mi] = __builtin_amdgcn_fdot2(v, v, ks2[mi], false);
+        }
+    };
     auto kstats = [&](const f16x8& a, int mi) {
         if constexpr (ln_kstats) {
             const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
@@ -503,7 +511,6 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                 for (int idx = 0; idx < NMF; ++idx) {
                     const int ni = idx / TM, mi = idx % TM;
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk & 1][ni], af[kk & 1][mi], acc[ni][mi], 0, 0, 0);
-                    if (ni == 0) kstats(af[kk & 1][mi], mi);
                     // the fragments of the next k-slice are read one per MFMA (not as a burst in front of the slice):
                     // right after the barrier only the first slice's reads of the eight waves queue up at the LDS
                     if (kk + 1 < 4 && idx < TM + TN) {
@@ -516,6 +523,16 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                         __builtin_amdgcn_sched_barrier(0);
                         dma_piece((kk == 0 ? 0 : P0) + idx / stride, nbuf);
                         __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (ln_kstats) {
+                        // the k-slice's 8*TM statistic ops, a few per MFMA slot BEHIND the slot's reads / DMA piece, consecutive
+                        // ops on different chains (a burst of 8 dependent v_dot2 in front of the fragment reads cost 20 %)
+                        constexpr int PER = (8 * TM + NMF - 1) / NMF;
+#pragma unroll
+                        for (int q = 0; q < PER; ++q) {
+                            const int o = idx * PER + q;
+                            if (o < 8 * TM) kstat_op(af[kk & 1][o % TM], o % TM, (o / TM) >> 1, (o / TM) & 1);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
