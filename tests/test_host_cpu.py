@@ -189,6 +189,33 @@ def test_unet_state_dict_keys_and_geglu_interleave():
     assert iw[64:96].tolist() == list(range(32, 64)) and iw[224:].tolist() == list(range(224, 256))
 
 
+def test_unet_concat_buffer_channels_match_the_reference_skip_bookkeeping():
+    """UNetModel._cat_ch: per decoder group (channels of h, channels of the skip tensor) of its torch.cat([h, hs.pop()], dim=1)
+    (openaimodel3d.py:700-703; `input_block_chans` bookkeeping :441-649).  The skip tensors are produced straight into these
+    buffers, so the table must match both the first decoder ResBlock's in_layers width and the encoder outputs, for the toy
+    configs and the two real yaml configs."""
+    import yaml
+    from dynamicscaler_amd.unet import UNetModel
+    from dynamicscaler_amd.unet_spec import param_shapes
+    cfgs = [json.loads(bytes(np.load(os.path.join(G, f"unet_tiny_{n}.npz"))["params_json"]).decode()) for n in ("t2v", "i2v")]
+    for n in ("t2v_512_v2_unet.yaml", "i2v_512_v1_unet.yaml"):
+        cfgs.append(yaml.safe_load(open(os.path.join(REPO, "dynamicscaler_amd", "configs", n))))
+    for params in cfgs:
+        m = UNetModel(**params)
+        shapes = param_shapes(params)
+        assert len(m._cat_ch) == len(m._outputs) == len(m._inputs)
+        enc_out = []
+        for group in m._inputs:                    # output channels of every encoder group, from the state-dict shapes
+            last = [b for b in group if b.kind in ("conv_in", "res", "down")][-1]
+            key = {"conv_in": ".weight", "res": ".out_layers.3.weight", "down": ".op.weight"}[last.kind]
+            enc_out.append(shapes[last.prefix + key][0])
+        for k, (group, (c_h, c_skip)) in enumerate(zip(m._outputs, m._cat_ch)):
+            assert shapes[group[0].prefix + ".in_layers.0.weight"][0] == c_h + c_skip        # GroupNorm over the concatenation
+            assert c_skip == enc_out[len(enc_out) - 1 - k]
+        mc = params["model_channels"]
+        assert m._cat_ch[-1] == (mc, mc)            # the last decoder group concatenates conv_in's output
+
+
 def test_sphere_index_maps_equal_reference_golden_and_winner_rule():
     from dynamicscaler_amd.sphere import ViewMaps, plan_levels_sets
     z = np.load(os.path.join(G, "sphere.npz"))
