@@ -52,6 +52,12 @@ CONFIGS = {
                  "ring windows (16 tiles/step), 77 text + 16 image tokens per window", size="4096x512x16f",
                  geom=dict(height=320, width=512, frames=16, total_w=4096, total_h=512, num_windows_w=8, num_windows_h=2,
                            num_windows_f=1, loop_step=8, num_inference_steps=50)),
+    # diagnostic, not a BASELINE configuration: TWO columns of cfg3 (2 x 2 tiles per step); with --tile-batch 1 --streams 1 a step
+    # is twice what a rank of an 8-GPU cfg3 run executes, exchange aside (profiles/r2_notes.md section 5)
+    "col2": dict(model="t2v", f_unet=12580.6e9, ctx_len=77, label="diagnostic: two columns of cfg3 (1024x512x16f, 2x2 ring windows, 4 tiles/step)",
+                 size="1024x512x16f",
+                 geom=dict(height=320, width=512, frames=16, total_w=1024, total_h=512, num_windows_w=2, num_windows_h=2,
+                           num_windows_f=1, loop_step=8, num_inference_steps=50)),
     "cfg5": dict(model="t2v", f_unet=18884.0e9, ctx_len=77, label="t2v_sphere_panorama 8192x1024x24f, 16x4 shifted ring windows (64 tiles/step), "
                  "UNet at T=24", size="8192x1024x24f",
                  geom=dict(height=320, width=512, frames=24, total_w=8192, total_h=1024, num_windows_w=16, num_windows_h=4,

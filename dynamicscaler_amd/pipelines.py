@@ -10,6 +10,8 @@ instead of ~300 tiny torch launches per tile.  With torch.distributed initialise
 out over the ranks -- whole panorama columns per rank with one all-gather per step, or a strided share of every level
 (parallel.run_step).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -63,6 +65,9 @@ class VC2_Pipeline_T2V:
         self._graphs = {}
         self._graph_generation = None        # UNetModel._generation the cached graphs were captured with
         self._slot = 0                       # stream slot of the tile batch being enqueued (one graph set per slot)
+        # a level with a single tile batch: cond and uncond evaluations on two streams instead of one [cond | uncond] batch
+        # ("2": every batch, batches one after the other -- emulates a rank's single-batch levels on a larger panorama)
+        self.split_cfg_over_streams = int(os.environ.get("DS_SPLIT_CFG", "0"))
         self.verbose = False
 
     # -- the bits of DiffusionPipeline the reference relies on --
@@ -255,6 +260,8 @@ class VC2_Pipeline_T2V:
         self._log(f"i = {i}, t = {t}: {len(wins)} windows")
         mask = st.mask if use_mask else None
 
+        split_cfg = [False]
+
         def run_batch(ids):
             origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
             tiles, mtiles = ops.ring_gather(pano, origins, st.tile_fhw, mask)
@@ -267,7 +274,15 @@ class VC2_Pipeline_T2V:
                                  mask_frame0=mask_frame0, seed=sched.philox_seed,
                                  offset=sched.tile_philox_offset(i, tiles[0].numel()), tile_ids=ids)
             n = len(ids)
-            if st.guidance_scale != 1.0:
+            if st.guidance_scale != 1.0 and split_cfg[0]:
+                # a level with ONE tile batch (a rank's share on many GPUs, single-tile panoramas): nothing else to overlap it
+                # with, so the cond and the uncond evaluations go to two streams instead of one [cond | uncond] batch --
+                # the same kernels on the same numbers (a batch equals its separate forwards), without the shared prefix
+                def one(cl):
+                    return self._eps(tiles, t, cl, st.fps, st.frames, **st.kwargs)
+                e_c, e_u = self._stream_pool(device).map(one, [[ctxs[j] for j in ids], [st.uc_emb] * n], inline=self.use_graph,
+                                                         on_slot=lambda k: setattr(self, "_slot", k))
+            elif st.guidance_scale != 1.0:
                 eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n,
                                 st.fps, st.frames, cfg_pairs=n, **st.kwargs)
                 e_c, e_u = eps[:n], eps[n:]
@@ -292,7 +307,8 @@ class VC2_Pipeline_T2V:
             if self.num_streams > 1:         # spread the windows over the streams
                 bsz = max(1, min(bsz, -(-len(mine) // self.num_streams)))
             batches = [mine[s:s + bsz] for s in range(0, len(mine), bsz)]
-            if self.num_streams > 1 and len(batches) > 1:
+            split_cfg[0] = self.num_streams > 1 and (self.split_cfg_over_streams == 2 or (self.split_cfg_over_streams == 1 and len(batches) == 1))
+            if self.num_streams > 1 and len(batches) > 1 and not split_cfg[0]:
                 # graph replays are enqueued by this thread (one call per evaluation); eager launches need a host
                 # thread per stream to keep both streams fed
                 parts = self._stream_pool(device).map(run_batch, batches, inline=self.use_graph,

@@ -160,6 +160,14 @@ def test_ring_pipeline_cfg_prefix_sharing_same_panorama():
                                                        **meta["geoms"]["grid4x2"])
         outs.append((den.float().cpu(), pipe.final_latent.float().cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # split_cfg_over_streams (the option for levels with a single tile batch, DS_SPLIT_CFG): cond and uncond evaluations as two
+    # batches on two streams (graph replays), instead of one [cond | uncond] batch -- same panorama, bit for bit
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}}).to(d, torch.float16)
+    pipe.num_streams, pipe.use_graph, pipe.split_cfg_over_streams = 2, True, 2
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                   **meta["geoms"]["grid4x2"])
+    assert torch.equal(den.float().cpu(), outs[0][0]) and torch.equal(pipe.final_latent.float().cpu(), outs[0][1])
 
 
 def test_unet_batch_equals_separate_forwards():
