@@ -148,7 +148,7 @@ __global__ void __launch_bounds__((TileCfg<BM, BN, WGM, WGN, NS>::NT), (TileCfg<
 gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const float* __restrict__ bias,
                 const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n,
                 unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum,
-                float ln_eps) {
+                float ln_eps, int group_m) {
     using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
     constexpr int LROWS = Cfg::LROWS, A_ROWS_PER_THREAD = Cfg::AR, B_ROWS_PER_THREAD = Cfg::BR;
@@ -165,8 +165,22 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tile_n = bid % tiles_n;
-    const int tile_m = bid / tiles_n;
+    // Within an XCD consecutive ids run concurrently (one workgroup per CU, 32 CUs): walking N fastest, a wide launch has
+    // ~1 A panel against all tiles_n W panels in flight, and a W that exceeds the 4 MB L2 (GEGLU 5120x640: 6.5 MB, 10240x1280:
+    // 26 MB) is streamed from beyond L2 once per A panel (3.3 GB read per launch of the level-2 GEGLU against 0.22 GB
+    // algorithmic).  group_m > 1: ids walk group_m A panels x tiles_n W panels with M fastest, so the concurrent set is about
+    // group_m x (32 / group_m) panels.  +3-4 % on the two wide GEGLU projections (tools/bench_wide_gemm.py), pure scheduling.
+    int tile_m, tile_n;
+    if (group_m > 1) {
+        const int per_group = group_m * tiles_n;
+        const int first_m = (bid / per_group) * group_m, in_group = bid % per_group;
+        const int gsz = min(tiles_m - first_m, group_m);
+        tile_m = first_m + in_group % gsz;
+        tile_n = in_group / gsz;
+    } else {
+        tile_n = bid % tiles_n;
+        tile_m = bid / tiles_n;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x;
@@ -881,6 +895,9 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
         attr_set = true;
     }
     const int tiles_m = ds_cdiv(d.M, BM), tiles_n = ds_cdiv(d.N, BN);
+    // grouped walk for wide one-workgroup-per-CU launches (see the kernel); DS_GEMM_GROUP_M: 0 = never (A/B runs)
+    static const int group_env = getenv("DS_GEMM_GROUP_M") ? atoi(getenv("DS_GEMM_GROUP_M")) : 6;
+    const int group_m = (Cfg::WG_PER_CU == 1 && tiles_n >= 16 && group_env > 1) ? group_env : 1;   // 10 N tiles (2560 x 320): no gain, -2 % at M = 327680
     // buffer-load addressing is 32-bit and offset 2^31 marks 'out of range': the A operand and W must each stay below 2 GiB
     const long a_rows = (AMODE == DS_A_CONV3 || AMODE == A_CONV3_TI) ? (long)d.nimg * d.hin * d.win : (long)d.M;
     const long a_bytes = ((a_rows - 1) * d.lda + d.cin) * 2;
@@ -891,7 +908,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
     }
     gemm_f16_kernel<BM, BN, WGM, WGN, AMODE, NS><<<tiles_m * tiles_n, Cfg::NT, lds, st>>>(
         (const f16*)A, (const f16*)W, bias, (const f16*)residual, out, d, tiles_m, tiles_n, (unsigned)a_bytes, (unsigned)w_bytes,
-        ln_stats, ln_colsum, ln_eps);
+        ln_stats, ln_colsum, ln_eps, group_m);
     DS_CHECK_LAUNCH("ds_gemm_f16");
     return DS_OK;
 }
