@@ -7,12 +7,14 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# DS_HIP_LIBRARY: a diagnostic build of the same ABI (tests/hazard_probe.py); the product always loads the in-tree library
-LIB_PATH = os.environ.get("DS_HIP_LIBRARY") or os.path.join(HERE, "libdynscaler_hip.so")
+# The product loads the in-tree library.  DS_HIP_LIBRARY names a diagnostic build of the same ABI instead (tests/hazard_probe.py,
+# A/B runs); load() says so on stderr, so a leftover variable cannot silently swap the kernels under a test or a bench.
+IN_TREE_LIB = os.path.join(HERE, "libdynscaler_hip.so")
+LIB_PATH = os.environ.get("DS_HIP_LIBRARY") or IN_TREE_LIB
 
 DS_F16, DS_F32 = 0, 1
 DS_A_DENSE, DS_A_CONV3, DS_A_TCONV = 0, 1, 2
-DS_EPI_GEGLU, DS_EPI_SILU, DS_EPI_OUT_F32 = 1, 2, 4
+DS_EPI_GEGLU, DS_EPI_SILU, DS_EPI_OUT_F32, DS_EPI_RES_F32 = 1, 2, 4, 8
 DS_MAX_WINDOWS = 64
 ABI_VERSION = 1
 
@@ -35,7 +37,17 @@ class GemmDesc(C.Structure):
         "t_len", "hw", "ldc", "ldr", "bias_rows", "ldbias", "epilogue", "asym_pad")]
 
 
+class UNetConfig(C.Structure):
+    """ds_unet_config (include/dynscaler_hip.h)."""
+    _fields_ = ([(n, C.c_int32) for n in ("in_channels", "out_channels", "model_channels", "num_res_blocks", "n_channel_mult")]
+                + [("channel_mult", C.c_int32 * 8), ("n_attention_resolutions", C.c_int32), ("attention_resolutions", C.c_int32 * 8)]
+                + [(n, C.c_int32) for n in ("num_head_channels", "transformer_depth", "temporal_transformer_depth", "context_dim",
+                                            "use_linear", "temporal_conv", "temporal_attention", "addition_attention",
+                                            "use_image_attention", "fps_cond", "residual_f32", "fold_layernorm")])
+
+
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+_pp = C.POINTER
 
 # name -> (restype, argtypes); mirrors include/dynscaler_hip.h one to one
 SIGNATURES = {
@@ -58,6 +70,9 @@ SIGNATURES = {
     "ds_groupnorm_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ds_groupnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "ds_groupnorm_f16_strided": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "ds_groupnorm_rows": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "ds_layernorm_rows": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "ds_cast_rows_f32_f16": (_i, [_vp, _i, _vp, _i, C.c_long, _i, _vp]),
     "ds_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ds_layernorm_stats": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "ds_gemm_f16_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),
@@ -79,6 +94,20 @@ SIGNATURES = {
     "ds_clip_preprocess": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ds_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ds_dbg_poison_cu_state": (_i, [_vp]),
+    "ds_cast_to_f16": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "ds_unet_create": (_i, [_pp(UNetConfig), _pp(_vp)]),
+    "ds_unet_destroy": (_i, [_vp]),
+    "ds_unet_num_weights": (_i, [_vp]),
+    "ds_unet_weight_info": (_i, [_vp, _i, _pp(C.c_char_p), _pp(_i), _pp(C.c_int64)]),
+    "ds_unet_load_weight": (_i, [_vp, C.c_char_p, _vp, _i, _pp(C.c_int64), _i]),
+    "ds_unet_packed_bytes": (_sz, [_vp]),
+    "ds_unet_pack": (_i, [_vp, _vp, _sz, _vp]),
+    "ds_unet_num_packed": (_i, [_vp]),
+    "ds_unet_packed_info": (_i, [_vp, _i, _pp(C.c_char_p), _pp(_sz), _pp(_sz), _pp(C.c_long), _pp(_i)]),
+    "ds_unet_emb_offset": (_i, [_vp, C.c_char_p]),
+    "ds_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
+    "ds_unet_forward": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "ds_unet_trace": (C.c_long, [_vp, _i, _i, _i, _i, _i, _i, C.c_char_p, _sz]),
 }
 
 _lib = None
@@ -93,6 +122,9 @@ def load():
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -m dynamicscaler_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback for the DynamicScaler hot path.")
+    if os.path.abspath(LIB_PATH) != os.path.abspath(IN_TREE_LIB):
+        import sys
+        sys.stderr.write(f"[dynamicscaler_amd] DS_HIP_LIBRARY is set: loading {LIB_PATH} instead of the in-tree library\n")
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

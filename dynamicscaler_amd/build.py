@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libdynscaler_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["error.cpp", "tile_ops.hip", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "encoders.hip"]
+SOURCES = ["error.cpp", "tile_ops.hip", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "encoders.hip", "unet_program.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=on"]
 
@@ -34,19 +34,18 @@ VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"], "attnplain": ["-DDS_ATTN_N
 
 
 def build(force=False, verbose=True, variant=None):
-    global OBJ, LIB
-    extra = []
+    extra, obj_dir, lib = [], OBJ, LIB          # the product; a variant builds into its own directory / library
     if variant is not None:
         extra = VARIANTS[variant]
-        OBJ = os.path.join(HERE, "_build_" + variant)
-        LIB = os.path.join(HERE, f"libdynscaler_hip_{variant}.so")
-    os.makedirs(OBJ, exist_ok=True)
+        obj_dir = os.path.join(HERE, "_build_" + variant)
+        lib = os.path.join(HERE, f"libdynscaler_hip_{variant}.so")
+    os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "dynscaler_hip.h")]
     jobs = []
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
+        obj = os.path.join(obj_dir, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _newer([src] + headers, obj):
             cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
@@ -62,13 +61,13 @@ def build(force=False, verbose=True, variant=None):
                 sys.stderr.write(r.stdout + r.stderr)
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    if force or jobs or _newer(objs, LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or jobs or _newer(objs, lib):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("link failed")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

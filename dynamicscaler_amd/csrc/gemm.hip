@@ -365,6 +365,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     // L2-resident) while the first K-steps' loads are in flight.
     constexpr bool ln_fold = AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK;   // LayerNorm folded into this GEMM (ds_gemm_f16_ln / _lnk): see the transform after the K loop
     constexpr bool ln_kstats = AMODE == A_DENSE_LNK;   // row statistics from the A fragments of the K loop (no statistics launch)
+    const bool res_f32 = residual && (d.epilogue & DS_EPI_RES_F32);   // fp32 residual rows (strict-precision residual stream)
     const bool bias_in_acc = !ln_fold && bias && d.bias_rows > d.M && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.ldbias % 4 == 0) &&
                              (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && !(d.epilogue & DS_EPI_OUT_F32) &&
                              (!residual || d.ldr % 8 == 0);
@@ -613,9 +614,10 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const bool silu = d.epilogue & DS_EPI_SILU;
     const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;
     // fp32 output on the fast path: plain accumulator dump (+ shared bias), e.g. attention scores that go through memory
-    const bool fast32 = out_f32 && !residual && !geglu && !silu && (d.N % 8 == 0) && (d.ldc % 4 == 0) &&
+    const bool fast32 = out_f32 && (!residual || res_f32) && !geglu && !silu && (d.N % 8 == 0) && (d.ldc % 4 == 0) &&
                         (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    const bool fast = (!out_f32 || fast32) && (d.N % 8 == 0) && (d.ldc % 8 == 0 || fast32) && (!residual || d.ldr % 8 == 0) &&
+    const bool fast = (!out_f32 || fast32) && (d.N % 8 == 0) && (d.ldc % 8 == 0 || fast32) &&
+                      (!residual || (res_f32 ? (d.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0) : d.ldr % 8 == 0)) &&
                       (!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0));
     const bool shared_bias = bias && d.bias_rows >= d.M;   // (bias_rows == M: a per-item table covering the launch with one item)
 
@@ -630,7 +632,8 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     };
     auto epilogue = [&](auto ge_tag, auto res_tag, auto pib_tag) {
         constexpr bool GE = decltype(ge_tag)::value;
-        constexpr bool RES = decltype(res_tag)::value;   // residual add
+        constexpr int RMODE = decltype(res_tag)::value;  // residual add: 0 none, 1 fp16 rows, 2 fp32 rows (DS_EPI_RES_F32)
+        constexpr bool RES = RMODE != 0, RES32 = RMODE == 2;
         constexpr bool PIB = !GE && decltype(pib_tag)::value;   // per-item bias (time-embedding add), never with GEGLU
         constexpr int TNE = GE ? TN / 2 : TN;          // output tiles per wave row (GEGLU halves the columns)
         constexpr int NG = Cfg::NG, STR = Cfg::STR;
@@ -776,18 +779,26 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                     const int nsw = (32 + rps - 1) / rps;
                     const long out_step = (long)rps * d.ldc, res_step = (long)rps * d.ldr;
                     f16* const out_base = reinterpret_cast<f16*>(out) + (long)(mrow0 + r0) * d.ldc + ocol;
-                    const f16* const res_base = RES ? residual + (long)(mrow0 + r0) * d.ldr + ocol : nullptr;
+                    const f16* const res_base = (RES && !RES32) ? residual + (long)(mrow0 + r0) * d.ldr + ocol : nullptr;
+                    const float* const res32_base = RES32 ? reinterpret_cast<const float*>(residual) + (long)(mrow0 + r0) * d.ldr + ocol : nullptr;
 #pragma unroll
                     for (int sb = 0; sb < 8; sb += SB) {
                         if (sb < nsw) {
                             f16x8 res[SB];
+                            f32x4 rs0[SB], rs1[SB];
                             f32x4 pb0[SB], pb1[SB], p0[SB], p1[SB];
                             bool ok[SB];
 #pragma unroll
                             for (int u = 0; u < SB; ++u) {
                                 const int row = (sb + u) * rps + r0;
                                 ok[u] = col_on && row < 32 && mrow0 + row < d.M;
-                                if constexpr (RES) res[u] = DS_RES_LOAD(reinterpret_cast<const f16x8*>(ok[u] ? res_base + (sb + u) * res_step : residual));
+                                if constexpr (RES32) {
+                                    const float* rp = ok[u] ? res32_base + (sb + u) * res_step : reinterpret_cast<const float*>(residual);
+                                    rs0[u] = DS_RES_LOAD(reinterpret_cast<const f32x4*>(rp));
+                                    rs1[u] = DS_RES_LOAD(reinterpret_cast<const f32x4*>(rp + 4));
+                                } else if constexpr (RES) {
+                                    res[u] = DS_RES_LOAD(reinterpret_cast<const f16x8*>(ok[u] ? res_base + (sb + u) * res_step : residual));
+                                }
                                 if constexpr (PIB) {
                                     const int mm = ok[u] ? mrow0 + row : 0;
                                     const float* bp = bias + (long)(mm / d.bias_rows) * d.ldbias + (ok[u] ? ncol : 0);
@@ -809,7 +820,10 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                                     v[0] += pb0[u][0]; v[1] += pb0[u][1]; v[2] += pb0[u][2]; v[3] += pb0[u][3];
                                     v[4] += pb1[u][0]; v[5] += pb1[u][1]; v[6] += pb1[u][2]; v[7] += pb1[u][3];
                                 }
-                                if constexpr (RES) {
+                                if constexpr (RES32) {
+                                    v[0] += rs0[u][0]; v[1] += rs0[u][1]; v[2] += rs0[u][2]; v[3] += rs0[u][3];
+                                    v[4] += rs1[u][0]; v[5] += rs1[u][1]; v[6] += rs1[u][2]; v[7] += rs1[u][3];
+                                } else if constexpr (RES) {
 #pragma unroll
                                     for (int j = 0; j < 8; ++j) v[j] += (float)res[u][j];
                                 }
@@ -843,8 +857,8 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                         const int m = mrow0 + row, n = n0 + wn * WN + c0 * 32 + col;
                         if (m >= d.M || n >= d.N) continue;
                         float v = sW[row * STR + col];
-                        if (bias) v += bias[(long)(m / d.bias_rows) * d.ldbias + n];
-                        if (residual) v += (float)residual[(long)m * d.ldr + n];
+                        if (bias && !bias_done) v += bias[(long)(m / d.bias_rows) * d.ldbias + n];
+                        if (residual) v += res_f32 ? reinterpret_cast<const float*>(residual)[(long)m * d.ldr + n] : (float)residual[(long)m * d.ldr + n];
                         if (silu) v = fast_silu(v);
                         if (out_f32) reinterpret_cast<float*>(out)[(long)m * d.ldc + n] = v;
                         else reinterpret_cast<f16*>(out)[(long)m * d.ldc + n] = (f16)v;
@@ -859,21 +873,26 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         if (pib) epilogue(ge_tag, res_tag, std::true_type{});
         else epilogue(ge_tag, res_tag, std::false_type{});
     };
+    using R0 = std::integral_constant<int, 0>;
+    using R16 = std::integral_constant<int, 1>;
+    using R32 = std::integral_constant<int, 2>;
     if constexpr (ln_fold) {         // ds_gemm_f16_ln: no residual, no per-item bias (checked on the host)
         if (geglu) {
-            if constexpr (TN % 2 == 0) epilogue(std::true_type{}, std::false_type{}, std::false_type{});
+            if constexpr (TN % 2 == 0) epilogue(std::true_type{}, R0{}, std::false_type{});
         } else {
-            epilogue(std::false_type{}, std::false_type{}, std::false_type{});
+            epilogue(std::false_type{}, R0{}, std::false_type{});
         }
     } else if (geglu) {
         if constexpr (TN % 2 == 0) {
-            if (residual) epilogue(std::true_type{}, std::true_type{}, std::false_type{});
-            else epilogue(std::true_type{}, std::false_type{}, std::false_type{});
+            if (residual) epilogue(std::true_type{}, R16{}, std::false_type{});     // fp16 residual only (checked on the host)
+            else epilogue(std::true_type{}, R0{}, std::false_type{});
         }
+    } else if (res_f32) {
+        epilogue(std::false_type{}, R32{}, std::false_type{});                      // shared bias only (checked on the host)
     } else if (residual) {
-        with_bias_mode(std::false_type{}, std::true_type{});
+        with_bias_mode(std::false_type{}, R16{});
     } else {
-        with_bias_mode(std::false_type{}, std::false_type{});
+        with_bias_mode(std::false_type{}, R0{});
     }
     DS_STAMP(4);
 }
@@ -996,6 +1015,11 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
         DS_CHECK_ARG(d.N % 64 == 0, "ds_gemm_f16: GEGLU needs N %% 64 == 0");
         DS_CHECK_ARG(!(d.epilogue & DS_EPI_OUT_F32) && d.ldc % 8 == 0, "ds_gemm_f16: GEGLU needs fp16 out, ldc %% 8 == 0");
     }
+    if (d.epilogue & DS_EPI_RES_F32) {
+        DS_CHECK_ARG(residual, "ds_gemm_f16: DS_EPI_RES_F32 without a residual");
+        DS_CHECK_ARG(!(d.epilogue & DS_EPI_GEGLU), "ds_gemm_f16: DS_EPI_RES_F32 is not available with GEGLU");
+        DS_CHECK_ARG(!bias || d.bias_rows >= d.M, "ds_gemm_f16: DS_EPI_RES_F32 takes a shared bias vector only");
+    }
     hipStream_t st = (hipStream_t)stream;
     const int tile = choose_tile(d);
     // 32-bit buffer addressing with offset 2^31 as the 'out of range' marker: an A operand of 2 GiB or more (dense
@@ -1010,7 +1034,7 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
             c.M = (int)((d.M - r0) < rows_max ? (d.M - r0) : rows_max);
             c.bias_rows = d.bias_rows;   // shared bias: any value >= c.M
             const char* a_p = (const char*)A + r0 * d.lda * 2;
-            const char* r_p = residual ? (const char*)residual + r0 * d.ldr * 2 : nullptr;
+            const char* r_p = residual ? (const char*)residual + r0 * d.ldr * ((d.epilogue & DS_EPI_RES_F32) ? 4 : 2) : nullptr;
             char* o_p = (char*)out + r0 * d.ldc * out_elt;
             int rc = ln_stats ? dispatch<A_DENSE_LN>(tile, a_p, W, bias, r_p, o_p, c, st, ln_stats + 2 * r0, ln_colsum)
                      : ln_colsum ? dispatch<A_DENSE_LNK>(tile, a_p, W, bias, r_p, o_p, c, st, nullptr, ln_colsum, ln_eps)

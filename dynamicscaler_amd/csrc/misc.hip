@@ -17,6 +17,21 @@ concat_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restr
     }
 }
 
+// y[r][0:C] = fp16(x[r][0:C]) for fp32 rows with strides ldx / ldy (8 channels per thread: two 16-byte loads, one 16-byte store)
+__global__ void __launch_bounds__(256)
+cast_rows_kernel(const float* __restrict__ x, f16* __restrict__ y, long rows, int C, int ldx, int ldy) {
+    const int nv = C / 8;
+    const long total = rows * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / nv;
+        const int c = (int)(idx - r * nv) * 8;
+        const f32x4 a = DS_SLOAD(reinterpret_cast<const f32x4*>(x + r * ldx + c));
+        const f32x4 b = DS_SLOAD(reinterpret_cast<const f32x4*>(x + r * ldx + c + 4));
+        const f16x8 o = {(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)b[0], (f16)b[1], (f16)b[2], (f16)b[3]};
+        *reinterpret_cast<f16x8*>(y + r * ldy + c) = o;
+    }
+}
+
 // patches[m][(ky*3+kx)*C + c] = x[b][c][t][y+ky-1][x+kx-1] (zero outside), m = ((b*T+t)*H+y)*W+x; columns >= 9C are 0
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -229,6 +244,16 @@ extern "C" int ds_concat_channels(const void* a, const void* b, void* dst, int r
     const long work = (long)rows * ((c1 + c2) / 8);
     concat_kernel<<<grid_for(work), 256, 0, (hipStream_t)stream>>>((const f16*)a, (const f16*)b, (f16*)dst, rows, c1, c2);
     DS_CHECK_LAUNCH("ds_concat_channels");
+    return DS_OK;
+}
+
+extern "C" int ds_cast_rows_f32_f16(const float* x, int ldx, void* y, int ldy, long rows, int C, void* stream) {
+    DS_CHECK_ARG(x && y, "ds_cast_rows_f32_f16: null argument");
+    DS_CHECK_ARG(rows > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 4 == 0 && ldy >= C && ldy % 8 == 0,
+                 "ds_cast_rows_f32_f16: rows=%ld C=%d ldx=%d ldy=%d (C %% 8, ldx %% 4, ldy %% 8)", rows, C, ldx, ldy);
+    DS_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "ds_cast_rows_f32_f16: 16-byte aligned pointers");
+    cast_rows_kernel<<<grid_for(rows * (C / 8)), 256, 0, (hipStream_t)stream>>>(x, (f16*)y, rows, C, ldx, ldy);
+    DS_CHECK_LAUNCH("ds_cast_rows_f32_f16");
     return DS_OK;
 }
 

@@ -19,12 +19,37 @@ constexpr int GN_LDS_FLOATS = 4096;   // per array: rl*C (<= 2048 + C) when C <=
 
 __device__ __forceinline__ float fast_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
+// 8 consecutive channels of one row as they sit in memory: fp16 (16 bytes) or fp32 (32 bytes: the strict-precision mode
+// keeps the UNet's residual stream in fp32, unet.py `residual_dtype`; the norms read it and write the fp16 GEMM operand).
+struct f32x8 { f32x4 lo, hi; };
+template <typename XT> struct Row8;
+template <> struct Row8<f16> {
+    typedef f16x8 raw;
+    static __device__ __forceinline__ raw load(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
+    static __device__ __forceinline__ raw load_stream(const f16* p) { return DS_SLOAD(reinterpret_cast<const f16x8*>(p)); }
+    static __device__ __forceinline__ float get(const raw& v, int j) { return (float)v[j]; }
+    static __device__ __forceinline__ raw zero() { return f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+};
+template <> struct Row8<float> {
+    typedef f32x8 raw;
+    static __device__ __forceinline__ raw load(const float* p) {
+        return f32x8{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
+    }
+    static __device__ __forceinline__ raw load_stream(const float* p) {
+        return f32x8{DS_SLOAD(reinterpret_cast<const f32x4*>(p)), DS_SLOAD(reinterpret_cast<const f32x4*>(p + 4))};
+    }
+    static __device__ __forceinline__ float get(const raw& v, int j) { return j < 4 ? v.lo[j & 3] : v.hi[j & 3]; }
+    static __device__ __forceinline__ raw zero() { return f32x8{f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}; }
+};
+
 // partial sums: grid (nchunks, ninst), 256 threads. part[(inst*nchunks + chunk)*groups + g] = (sum, sumsq).
 // A thread owns one 8-channel vector column and every rl-th row of the chunk; four rows are loaded before they are
 // accumulated (one accumulation chain per channel, in row order: the sums do not depend on the unrolling), so a
 // workgroup keeps ~15 KB in flight instead of one 16-byte load per thread.
+template <typename XT>
 __global__ void __launch_bounds__(256)
-gn_partial_kernel(const f16* __restrict__ x, float2* __restrict__ part, int rows_per_inst, int C, int groups, int ldx) {
+gn_partial_kernel(const XT* __restrict__ x, float2* __restrict__ part, int rows_per_inst, int C, int groups, int ldx) {
+    typedef Row8<XT> R8;
     __shared__ float csum[GN_LDS_FLOATS];
     __shared__ float csq[GN_LDS_FLOATS];
     const int tid = threadIdx.x;
@@ -32,24 +57,24 @@ gn_partial_kernel(const f16* __restrict__ x, float2* __restrict__ part, int rows
     const int r0 = chunk * GN_CHUNK_ROWS;
     const int r1 = min(rows_per_inst, r0 + GN_CHUNK_ROWS);
     const int nvec = C / 8;
-    const f16* base = x + (long)inst * rows_per_inst * ldx;   // input rows may sit in a wider buffer (row stride ldx >= C)
+    const XT* base = x + (long)inst * rows_per_inst * ldx;   // input rows may sit in a wider buffer (row stride ldx >= C)
     const int rl = nvec <= 256 ? 256 / nvec : 1;  // row lanes; rl*C <= 2048 + C when rl > 1
     auto accumulate = [&](int col, int rfirst, int rstep, float* s, float* q) {
-        const f16* p = base + col * 8;
+        const XT* p = base + col * 8;
         int r = rfirst;
         for (; r + (GN_U - 1) * rstep < r1; r += GN_U * rstep) {
-            f16x8 v[GN_U];
+            typename R8::raw v[GN_U];
 #pragma unroll
-            for (int u = 0; u < GN_U; ++u) v[u] = *reinterpret_cast<const f16x8*>(p + (long)(r + u * rstep) * ldx);
+            for (int u = 0; u < GN_U; ++u) v[u] = R8::load(p + (long)(r + u * rstep) * ldx);
 #pragma unroll
             for (int u = 0; u < GN_U; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
+                for (int j = 0; j < 8; ++j) { const float f = R8::get(v[u], j); s[j] += f; q[j] += f * f; }
         }
         for (; r < r1; r += rstep) {
-            const f16x8 v = *reinterpret_cast<const f16x8*>(p + (long)r * ldx);
+            const typename R8::raw v = R8::load(p + (long)r * ldx);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+            for (int j = 0; j < 8; ++j) { const float f = R8::get(v, j); s[j] += f; q[j] += f * f; }
         }
     };
     if (nvec <= 256) {
@@ -103,10 +128,14 @@ __global__ void gn_finalize_kernel(const float2* __restrict__ part, float* __res
 // thread's 8 channels live in registers, four rows are in flight per thread.  With `part` != nullptr the workgroup first
 // reduces the instance's per-chunk partial sums itself (fp64, fixed order: 8 interleaved slices, then the slices in
 // order) instead of reading mean / rstd -- the separate finalize launch (1300 per DDIM step, each latency-bound) is gone.
+// `xraw` != nullptr (fp32 input only): the raw x rounded to fp16 is written next to y (dense [rows][C]) -- the fp16 A operand of
+// a projection that reads the un-normalised tensor (ResBlock skip_connection, openaimodel3d.py:186-193), for free in this pass.
+template <typename XT>
 __global__ void __launch_bounds__(256)
-gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+gn_apply_kernel(const XT* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                 const float2* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
-                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps, int ldx) {
+                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps, int ldx, f16* __restrict__ xraw) {
+    typedef Row8<XT> R8;
     __shared__ double sred[2][8][32];
     __shared__ float smean[256], srstd[256];
     const int tid = threadIdx.x;
@@ -156,27 +185,42 @@ gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const
             a[j] = r * gamma[c];
             b[j] = beta[c] - m * a[j];
         }
-        auto one = [&](const f16x8 v) {
+        auto one = [&](const typename R8::raw& v) {
             f16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float f = (float)v[j] * a[j] + b[j];
+                float f = R8::get(v, j) * a[j] + b[j];
                 if (silu) f = fast_silu(f);
                 o[j] = (f16)f;
             }
             return o;
         };
-        const f16* px = x + xbase + col * 8;
+        auto rawh = [&](const typename R8::raw& v) {
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)R8::get(v, j);
+            return o;
+        };
+        const XT* px = x + xbase + col * 8;
         f16* py = y + base + col * 8;
+        f16* pr = xraw ? xraw + base + col * 8 : nullptr;
         int r = r0 + rlane;
         for (; r + (GN_U - 1) * rl < r1; r += GN_U * rl) {
-            f16x8 v[GN_U];
+            typename R8::raw v[GN_U];
 #pragma unroll
-            for (int u = 0; u < GN_U; ++u) v[u] = DS_SLOAD(reinterpret_cast<const f16x8*>(px + (long)(r + u * rl) * ldx));
+            for (int u = 0; u < GN_U; ++u) v[u] = R8::load_stream(px + (long)(r + u * rl) * ldx);
 #pragma unroll
             for (int u = 0; u < GN_U; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)(r + u * rl) * C), one(v[u]));
+            if (pr) {
+#pragma unroll
+                for (int u = 0; u < GN_U; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(pr + (long)(r + u * rl) * C), rawh(v[u]));
+            }
         }
-        for (; r < r1; r += rl) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(DS_SLOAD(reinterpret_cast<const f16x8*>(px + (long)r * ldx))));
+        for (; r < r1; r += rl) {
+            const typename R8::raw v = R8::load_stream(px + (long)r * ldx);
+            DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(v));
+            if (pr) DS_SSTORE(reinterpret_cast<f16x8*>(pr + (long)r * C), rawh(v));
+        }
     }
 }
 
@@ -187,15 +231,17 @@ gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean, const
 constexpr int GN_SMALL_ROWS = 256;
 constexpr int GN_SMALL_NT = 1024;
 
+template <typename XT>
 __global__ void __launch_bounds__(GN_SMALL_NT)
-gn_small_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps, int ldx) {
+gn_small_kernel(const XT* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps, int ldx, f16* __restrict__ xraw) {
+    typedef Row8<XT> R8;
     __shared__ float csum[GN_LDS_FLOATS + MAX_C];
     __shared__ float csq[GN_LDS_FLOATS + MAX_C];
     __shared__ float smean[256], srstd[256];
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int nvec = C / 8, cpg = C / groups;
-    const f16* base = x + (long)inst * rows_per_inst * ldx;
+    const XT* base = x + (long)inst * rows_per_inst * ldx;
     f16* ybase = y + (long)inst * rows_per_inst * C;
     const int rl = nvec <= GN_SMALL_NT ? GN_SMALL_NT / nvec : 1;      // row lanes (nvec <= 512 -> rl >= 2)
     const int cap = (GN_LDS_FLOATS + MAX_C) / C;                       // rlu*C floats must fit the LDS arrays
@@ -206,21 +252,21 @@ gn_small_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, cons
         float s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
-        const f16* p = base + col * 8;
+        const XT* p = base + col * 8;
         int r = rlane;
         for (; r + 3 * rlu < rows_per_inst; r += 4 * rlu) {
-            f16x8 v[4];
+            typename R8::raw v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(p + (long)(r + u * rlu) * ldx);
+            for (int u = 0; u < 4; ++u) v[u] = R8::load(p + (long)(r + u * rlu) * ldx);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
+                for (int j = 0; j < 8; ++j) { const float f = R8::get(v[u], j); s[j] += f; q[j] += f * f; }
         }
         for (; r < rows_per_inst; r += rlu) {
-            const f16x8 v = *reinterpret_cast<const f16x8*>(p + (long)r * ldx);
+            const typename R8::raw v = R8::load(p + (long)r * ldx);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+            for (int j = 0; j < 8; ++j) { const float f = R8::get(v, j); s[j] += f; q[j] += f * f; }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) { csum[rlane * C + col * 8 + j] = s[j]; csq[rlane * C + col * 8 + j] = q[j]; }
@@ -246,47 +292,63 @@ gn_small_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, cons
         a[j] = srstd[g] * gamma[c];
         b[j] = beta[c] - smean[g] * a[j];
     }
-    auto one = [&](const f16x8 v) {
+    auto one = [&](const typename R8::raw& v) {
         f16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j] * a[j] + b[j];
+            float f = R8::get(v, j) * a[j] + b[j];
             if (silu) f = fast_silu(f);
             o[j] = (f16)f;
         }
         return o;
     };
-    const f16* px = base + col * 8;
+    auto rawh = [&](const typename R8::raw& v) {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)R8::get(v, j);
+        return o;
+    };
+    const XT* px = base + col * 8;
     f16* py = ybase + col * 8;
+    f16* pr = xraw ? xraw + (long)inst * rows_per_inst * C + col * 8 : nullptr;
     int r = rlane;
     for (; r + 3 * rlu < rows_per_inst; r += 4 * rlu) {
-        f16x8 v[4];
+        typename R8::raw v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(px + (long)(r + u * rlu) * ldx);
+        for (int u = 0; u < 4; ++u) v[u] = R8::load(px + (long)(r + u * rlu) * ldx);
 #pragma unroll
         for (int u = 0; u < 4; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)(r + u * rlu) * C), one(v[u]));
+        if (pr) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(pr + (long)(r + u * rlu) * C), rawh(v[u]));
+        }
     }
-    for (; r < rows_per_inst; r += rlu) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(*reinterpret_cast<const f16x8*>(px + (long)r * ldx)));
+    for (; r < rows_per_inst; r += rlu) {
+        const typename R8::raw v = R8::load(px + (long)r * ldx);
+        DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(v));
+        if (pr) DS_SSTORE(reinterpret_cast<f16x8*>(pr + (long)r * C), rawh(v));
+    }
 }
 
 // LayerNorm: one wave per row, NV 8-channel vectors per lane (C <= 512*NV), RW rows per wave with all their loads issued
 // before the first reduction (bytes in flight: the 320-channel rows of the first UNet level are only 640 B each).
-template <int NV, int RW>
+template <int NV, int RW, typename XT>
 __global__ void __launch_bounds__(256)
-layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+layernorm_kernel(const XT* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                  f16* __restrict__ y, int rows, int C, float eps, float2* __restrict__ stats) {
+    typedef Row8<XT> R8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row0 = ((long)blockIdx.x * 4 + wave) * RW;
     if (row0 >= rows) return;
     const int nvec = C / 8;
-    f16x8 t[RW][NV];
+    typename R8::raw t[RW][NV];
 #pragma unroll
     for (int rw = 0; rw < RW; ++rw) {
         const long row = row0 + rw < rows ? row0 + rw : rows - 1;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = lane + 64 * i;
-            t[rw][i] = col < nvec ? DS_SLOAD(reinterpret_cast<const f16x8*>(x + row * C + col * 8)) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            t[rw][i] = col < nvec ? R8::load_stream(x + row * C + col * 8) : R8::zero();
         }
     }
     // stats != nullptr: only (mean, rstd) per row are written (ds_layernorm_stats: the normalisation itself is folded into
@@ -309,7 +371,7 @@ layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma, con
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[rw][i][j]; s += v[i][j]; }
+            for (int j = 0; j < 8; ++j) { v[i][j] = R8::get(t[rw][i], j); s += v[i][j]; }
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) s += __shfl_xor(s, sh);
         const float mean = s / (float)C;
@@ -359,7 +421,7 @@ extern "C" int ds_groupnorm_stats(const void* x, float* mean, float* rstd, float
     DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_stats: C=%d groups=%d unsupported", C, groups);
     hipStream_t st = (hipStream_t)stream;
     const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
-    gn_partial_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups, C);
+    gn_partial_kernel<f16><<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups, C);
     DS_CHECK_LAUNCH("ds_groupnorm_stats(partial)");
     const int n = ninst * groups;
     gn_finalize_kernel<<<(n + 255) / 256, 256, 0, st>>>((const float2*)workspace, mean, rstd, ninst, nchunks, groups,
@@ -376,52 +438,85 @@ extern "C" int ds_groupnorm_apply(const void* x, const float* mean, const float*
     DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && C % groups == 0, "ds_groupnorm_apply: C=%d groups=%d unsupported", C, groups);
     hipStream_t st = (hipStream_t)stream;
     const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
-    gn_apply_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, mean, rstd, nullptr, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, 0.0f, C);
+    gn_apply_kernel<f16><<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, mean, rstd, nullptr, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, 0.0f, C, nullptr);
     DS_CHECK_LAUNCH("ds_groupnorm_apply");
     return DS_OK;
 }
 
-// ldx: row stride of x in elements (>= C, multiple of 8): the input may be a column slice of a wider row-major buffer (the UNet
-// writes skip tensors straight into the buffer the decoder side concatenates in, unet.py).  y is dense [rows][C].
-extern "C" int ds_groupnorm_f16_strided(const void* x, int ldx, const float* gamma, const float* beta, void* y, float* workspace,
-                                        int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream) {
-    DS_CHECK_ARG(x && gamma && beta && y && workspace, "ds_groupnorm_f16: null argument");
-    DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0, "ds_groupnorm_f16: ninst/rows_per_inst must be positive");
-    DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_f16: C=%d groups=%d unsupported", C, groups);
-    DS_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "ds_groupnorm_f16: ldx=%d (>= C, multiple of 8, x 16-byte aligned)", ldx);
-    hipStream_t st = (hipStream_t)stream;
+namespace {
+template <typename XT>
+int groupnorm_rows(const XT* x, int ldx, const float* gamma, const float* beta, f16* y, f16* x_f16, float* workspace, int ninst,
+                   int rows_per_inst, int C, int groups, float eps, int silu, hipStream_t st) {
     if (rows_per_inst <= GN_SMALL_ROWS && C / 8 <= 512 && ninst >= 64) {   // enough instances to fill the chip
-        gn_small_kernel<<<ninst, GN_SMALL_NT, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, eps, ldx);
-        DS_CHECK_LAUNCH("ds_groupnorm_f16(small)");
+        gn_small_kernel<XT><<<ninst, GN_SMALL_NT, 0, st>>>(x, gamma, beta, y, rows_per_inst, C, groups, silu, eps, ldx, x_f16);
+        DS_CHECK_LAUNCH("ds_groupnorm(small)");
         return DS_OK;
     }
     const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
-    gn_partial_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups, ldx);
-    DS_CHECK_LAUNCH("ds_groupnorm_f16(stats)");
-    gn_apply_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, nullptr, nullptr, (const float2*)workspace, gamma, beta,
-                                                          (f16*)y, rows_per_inst, C, groups, silu, eps, ldx);
-    DS_CHECK_LAUNCH("ds_groupnorm_f16(apply)");
+    gn_partial_kernel<XT><<<dim3(nchunks, ninst), 256, 0, st>>>(x, (float2*)workspace, rows_per_inst, C, groups, ldx);
+    DS_CHECK_LAUNCH("ds_groupnorm(stats)");
+    gn_apply_kernel<XT><<<dim3(nchunks, ninst), 256, 0, st>>>(x, nullptr, nullptr, (const float2*)workspace, gamma, beta, y,
+                                                              rows_per_inst, C, groups, silu, eps, ldx, x_f16);
+    DS_CHECK_LAUNCH("ds_groupnorm(apply)");
     return DS_OK;
+}
+}  // namespace
+
+// x_dtype DS_F16 / DS_F32; ldx: row stride of x in elements (>= C, multiple of 8): the input may be a column slice of a wider
+// row-major buffer (the UNet writes skip tensors straight into the buffer the decoder side concatenates in, unet.py).
+// y is dense fp16 [rows][C]; x_f16 (fp32 input only, may be NULL): fp16(x), dense [rows][C].
+extern "C" int ds_groupnorm_rows(const void* x, int x_dtype, int ldx, const float* gamma, const float* beta, void* y, void* x_f16,
+                                 float* workspace, int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream) {
+    DS_CHECK_ARG(x && gamma && beta && y && workspace, "ds_groupnorm_rows: null argument");
+    DS_CHECK_ARG(x_dtype == DS_F16 || x_dtype == DS_F32, "ds_groupnorm_rows: x_dtype must be DS_F16 or DS_F32");
+    DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0, "ds_groupnorm_rows: ninst/rows_per_inst must be positive");
+    DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_rows: C=%d groups=%d unsupported", C, groups);
+    DS_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "ds_groupnorm_rows: ldx=%d (>= C, multiple of 8, x 16-byte aligned)", ldx);
+    DS_CHECK_ARG(!x_f16 || x_dtype == DS_F32, "ds_groupnorm_rows: the fp16 copy of x is only produced from fp32 input");
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == DS_F32)
+        return groupnorm_rows<float>((const float*)x, ldx, gamma, beta, (f16*)y, (f16*)x_f16, workspace, ninst, rows_per_inst, C, groups, eps, silu, st);
+    return groupnorm_rows<f16>((const f16*)x, ldx, gamma, beta, (f16*)y, nullptr, workspace, ninst, rows_per_inst, C, groups, eps, silu, st);
+}
+
+extern "C" int ds_groupnorm_f16_strided(const void* x, int ldx, const float* gamma, const float* beta, void* y, float* workspace,
+                                        int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream) {
+    return ds_groupnorm_rows(x, DS_F16, ldx, gamma, beta, y, nullptr, workspace, ninst, rows_per_inst, C, groups, eps, silu, stream);
 }
 
 extern "C" int ds_groupnorm_f16(const void* x, const float* gamma, const float* beta, void* y, float* workspace, int ninst,
                                 int rows_per_inst, int C, int groups, float eps, int silu, void* stream) {
-    return ds_groupnorm_f16_strided(x, C, gamma, beta, y, workspace, ninst, rows_per_inst, C, groups, eps, silu, stream);
+    return ds_groupnorm_rows(x, DS_F16, C, gamma, beta, y, nullptr, workspace, ninst, rows_per_inst, C, groups, eps, silu, stream);
+}
+
+namespace {
+template <typename XT>
+void layernorm_launch(const XT* x, const float* gamma, const float* beta, f16* y, int rows, int C, float eps, float2* stats, hipStream_t st) {
+    const int nv = (C / 8 + 63) / 64;
+    if (nv == 1) layernorm_kernel<1, 4, XT><<<(rows + 15) / 16, 256, 0, st>>>(x, gamma, beta, y, rows, C, eps, stats);
+    else if (nv == 2) layernorm_kernel<2, 2, XT><<<(rows + 7) / 8, 256, 0, st>>>(x, gamma, beta, y, rows, C, eps, stats);
+    else if (nv == 3) layernorm_kernel<3, 2, XT><<<(rows + 7) / 8, 256, 0, st>>>(x, gamma, beta, y, rows, C, eps, stats);
+    else layernorm_kernel<5, 1, XT><<<(rows + 3) / 4, 256, 0, st>>>(x, gamma, beta, y, rows, C, eps, stats);
+}
+}  // namespace
+
+// x fp16 or fp32 [rows][C] (x_dtype), y fp16.
+extern "C" int ds_layernorm_rows(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int rows, int C,
+                                 float eps, void* stream) {
+    DS_CHECK_ARG(x && gamma && beta && y, "ds_layernorm: null argument");
+    DS_CHECK_ARG(x_dtype == DS_F16 || x_dtype == DS_F32, "ds_layernorm: x_dtype must be DS_F16 or DS_F32");
+    DS_CHECK_ARG(rows > 0 && C % 8 == 0 && C <= 2560, "ds_layernorm: rows=%d C=%d unsupported (C %% 8 == 0, C <= 2560)", rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    DS_CHECK_ARG((reinterpret_cast<uintptr_t>(gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(beta) & 15) == 0, "ds_layernorm: gamma/beta must be 16-byte aligned");
+    if (x_dtype == DS_F32) layernorm_launch<float>((const float*)x, gamma, beta, (f16*)y, rows, C, eps, nullptr, st);
+    else layernorm_launch<f16>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps, nullptr, st);
+    DS_CHECK_LAUNCH("ds_layernorm");
+    return DS_OK;
 }
 
 extern "C" int ds_layernorm(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
                             void* stream) {
-    DS_CHECK_ARG(x && gamma && beta && y, "ds_layernorm: null argument");
-    DS_CHECK_ARG(rows > 0 && C % 8 == 0 && C <= 2560, "ds_layernorm: rows=%d C=%d unsupported (C %% 8 == 0, C <= 2560)", rows, C);
-    hipStream_t st = (hipStream_t)stream;
-    DS_CHECK_ARG((reinterpret_cast<uintptr_t>(gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(beta) & 15) == 0, "ds_layernorm: gamma/beta must be 16-byte aligned");
-    const int nv = (C / 8 + 63) / 64;
-    if (nv == 1) layernorm_kernel<1, 4><<<(rows + 15) / 16, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps, nullptr);
-    else if (nv == 2) layernorm_kernel<2, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps, nullptr);
-    else if (nv == 3) layernorm_kernel<3, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps, nullptr);
-    else layernorm_kernel<5, 1><<<(rows + 3) / 4, 256, 0, st>>>((const f16*)x, gamma, beta, (f16*)y, rows, C, eps, nullptr);
-    DS_CHECK_LAUNCH("ds_layernorm");
-    return DS_OK;
+    return ds_layernorm_rows(x, DS_F16, gamma, beta, y, rows, C, eps, stream);
 }
 
 extern "C" int ds_layernorm_stats(const void* x, float* stats, int rows, int C, float eps, void* stream) {
@@ -429,12 +524,7 @@ extern "C" int ds_layernorm_stats(const void* x, float* stats, int rows, int C, 
     DS_CHECK_ARG(rows > 0 && C % 8 == 0 && C <= 2560, "ds_layernorm_stats: rows=%d C=%d unsupported (C %% 8 == 0, C <= 2560)", rows, C);
     DS_CHECK_ARG((reinterpret_cast<uintptr_t>(stats) & 7) == 0, "ds_layernorm_stats: stats must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    float2* s2 = reinterpret_cast<float2*>(stats);
-    const int nv = (C / 8 + 63) / 64;
-    if (nv == 1) layernorm_kernel<1, 4><<<(rows + 15) / 16, 256, 0, st>>>((const f16*)x, nullptr, nullptr, nullptr, rows, C, eps, s2);
-    else if (nv == 2) layernorm_kernel<2, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, nullptr, nullptr, nullptr, rows, C, eps, s2);
-    else if (nv == 3) layernorm_kernel<3, 2><<<(rows + 7) / 8, 256, 0, st>>>((const f16*)x, nullptr, nullptr, nullptr, rows, C, eps, s2);
-    else layernorm_kernel<5, 1><<<(rows + 3) / 4, 256, 0, st>>>((const f16*)x, nullptr, nullptr, nullptr, rows, C, eps, s2);
+    layernorm_launch<f16>((const f16*)x, nullptr, nullptr, nullptr, rows, C, eps, reinterpret_cast<float2*>(stats), st);
     DS_CHECK_LAUNCH("ds_layernorm_stats");
     return DS_OK;
 }

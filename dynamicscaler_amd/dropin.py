@@ -24,6 +24,7 @@ def _mod(name, **attrs):
 
 def install():
     from . import unet, scheduler, pipelines, pipelines_i2v, ring, tensor_utils, host_model, sphere, vae, encoders
+    from . import panorama_tensors as pt
     _mod("lvdm.modules.networks.openaimodel3d", UNetModel=unet.UNetModel)
     _mod("lvdm.models.ddpm3d", DiffusionWrapper=unet.DiffusionWrapper, LatentDiffusion=host_model.LatentDiffusionHost,
          LatentVisualDiffusion=host_model.LatentDiffusionHost)
@@ -34,7 +35,9 @@ def install():
     _mod("pipeline.scheduler", lvdm_DDIM_Scheduler=scheduler.lvdm_DDIM_Scheduler)
     _mod("pipeline.t2v_normal_pipeline", VC2_Pipeline_T2V=pipelines.VC2_Pipeline_T2V)
     _mod("pipeline.t2v_sphere_panorama_pipeline", VC2_Pipeline_T2V_SpherePano=sphere.VC2_Pipeline_T2V_SpherePano)
-    _mod("utils.panorama_tensor_utils", PanoramaLatentProxy=sphere.PanoramaLatentProxy)
+    _mod("utils.panorama_tensor_utils", PanoramaLatentProxy=sphere.PanoramaLatentProxy, PanoramaTensor=pt.PanoramaTensor)
+    _mod("utils.ring_panorama_tensor_utils", RingPanoramaTensor=pt.RingPanoramaTensor, RingLatentProxy=pt.RingLatentProxy,
+         RingPanoramaLatentProxy=pt.RingPanoramaLatentProxy)
     _mod("pipeline.i2v_normal_pipeline", VC2_Pipeline_I2V=pipelines_i2v.VC2_Pipeline_I2V)
     _mod("pipeline.i2v_sphere_panorama_pipeline", VC2_Pipeline_I2V_SpherePano=sphere.VC2_Pipeline_I2V_SpherePano)
     _mod("utils.shift_window_utils", RingLatent=ring.RingLatent, RingImageTensor=pipelines_i2v.RingImageTensor,

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import (DS_F16, DS_F32, DS_A_DENSE, DS_A_CONV3, DS_A_TCONV, DS_EPI_GEGLU, DS_EPI_SILU,
-                   DS_EPI_OUT_F32, DS_MAX_WINDOWS, RingGeom, GemmDesc, check)
+                   DS_EPI_OUT_F32, DS_EPI_RES_F32, DS_MAX_WINDOWS, RingGeom, GemmDesc, check)
 
 _DT = {torch.float16: DS_F16, torch.float32: DS_F32}
 
@@ -265,9 +265,14 @@ def residual_merge(curr, noised, ratio, step, sparse=True):
 def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE, lda=None, cin=None,
          conv=None, tconv=None, bias_rows=None, ldbias=None, epilogue=0, stream=None):
     """out[M, N'] = gatherA[M,K] @ W[N,K]^T with fused epilogue.  conv=(nimg,hin,win,hout,wout,stride,upsample),
-    tconv=(t_len,hw).  N' = N/2 for GEGLU."""
+    tconv=(t_len,hw).  N' = N/2 for GEGLU.  An fp32 `residual` (strict-precision residual stream) sets DS_EPI_RES_F32, an fp32
+    `out` tensor DS_EPI_OUT_F32."""
     lib = _lib.load()
     n_out = N // 2 if (epilogue & DS_EPI_GEGLU) else N
+    if residual is not None and residual.dtype == torch.float32:
+        epilogue |= DS_EPI_RES_F32
+    if out is not None and out.dtype == torch.float32:
+        epilogue |= DS_EPI_OUT_F32
     if out is None:
         out = torch.empty((M, n_out), dtype=torch.float32 if (epilogue & DS_EPI_OUT_F32) else torch.float16,
                           device=A.device)
@@ -298,18 +303,20 @@ def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE
     return out
 
 
-def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None):
-    """x [ninst*rows_per_inst, Cch] fp16, rows contiguous or a column slice of a wider row-major buffer (row stride x.stride(0));
-    returns a dense [rows, Cch] tensor."""
+def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None, raw_f16=False):
+    """x [ninst*rows_per_inst, Cch] fp16 or fp32, rows contiguous or a column slice of a wider row-major buffer (row stride
+    x.stride(0)); returns a dense fp16 [rows, Cch] tensor.  raw_f16 (fp32 x only): also returns fp16(x) as a dense tensor,
+    written in the same pass -> (y, x16)."""
     lib = _lib.load()
     st = _stream() if stream is None else stream
     assert x.dim() == 2 and x.shape[1] == Cch and x.stride(1) == 1, "groupnorm: x must be [rows, C] with unit column stride"
     ws = torch.empty((lib.ds_groupnorm_stats_workspace_floats(ninst, rows_per_inst, groups),), dtype=torch.float32,
                      device=x.device)
-    y = torch.empty((x.shape[0], Cch), dtype=x.dtype, device=x.device)
-    check(lib.ds_groupnorm_f16_strided(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), ws.data_ptr(),
-                                       ninst, rows_per_inst, Cch, groups, float(eps), int(bool(silu)), st), "ds_groupnorm_f16")
-    return y
+    y = torch.empty((x.shape[0], Cch), dtype=torch.float16, device=x.device)
+    x16 = torch.empty((x.shape[0], Cch), dtype=torch.float16, device=x.device) if raw_f16 else None
+    check(lib.ds_groupnorm_rows(x.data_ptr(), _DT[x.dtype], x.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(x16),
+                                ws.data_ptr(), ninst, rows_per_inst, Cch, groups, float(eps), int(bool(silu)), st), "ds_groupnorm_rows")
+    return (y, x16) if raw_f16 else y
 
 
 def groupnorm_stats(x, ninst, rows_per_inst, Cch, eps, groups=32, stream=None):
@@ -337,9 +344,20 @@ def layernorm(x, gamma, beta, eps=1e-5, stream=None, out=None):
     lib = _lib.load()
     st = _stream() if stream is None else stream
     rows, Cch = x.shape
-    y = torch.empty_like(x) if out is None else out
-    check(lib.ds_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, Cch, float(eps), st),
-          "ds_layernorm")
+    y = torch.empty((rows, Cch), dtype=torch.float16, device=x.device) if out is None else out
+    check(lib.ds_layernorm_rows(x.data_ptr(), _DT[x.dtype], gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, Cch, float(eps),
+                                st), "ds_layernorm_rows")
+    return y
+
+
+def cast_rows_f16(x, stream=None):
+    """fp32 rows [M, C] (unit column stride, any row stride) -> dense fp16 [M, C]."""
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    check(lib.ds_cast_rows_f32_f16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), x.shape[0], x.shape[1], st),
+          "ds_cast_rows_f32_f16")
     return y
 
 

@@ -11,6 +11,11 @@ step falls into connected COMPONENTS (`plan_components`: with no W overlap every
               (x_prev, x0) tiles, after which each rank scatters the others' tiles.  SURVEY.md 8-e's column ownership.
   levels      (fewer components than ranks, e.g. W-overlapped rings = one chain): each rank takes a strided share of
               every level and the level's tiles are all-gathered before the next level starts.
+  units       (a level with fewer tiles than ranks, e.g. config 2 -- 4 columns -- on 8 GPUs): the unit of work is one
+              UNet EVALUATION, (tile, cond | uncond): the two forwards of a tile are independent
+              (pipeline/t2v_sphere_panorama_pipeline.py:588-599), so they go to different ranks; every rank does the
+              level's cheap tile ops (gather, re-noise) itself, evaluates its share of the units, the eps tensors are
+              all-gathered and every rank finishes CFG + DDIM + scatter for all tiles of the level.
 
 Either exchange is identical in result to an all-reduce(sum) of zero-filled panorama-sized accumulators with a 0/1
 weight map (the "overlap accumulator" reading of north_star) at a fraction of the bytes.  Every rank scatters all
@@ -139,14 +144,58 @@ def all_gather_tiles(x_prev_local, x0_local, counts, group=None):
     return [(x_prev_local, x0_local) if r == rank else (recv[r, 0, :counts[r]], recv[r, 1, :counts[r]]) for r in range(world)]
 
 
-def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, group=None):
+class EvalUnits:
+    """The three stages of `process` taken apart, for sharing a level out by UNet evaluation instead of by tile
+    (run_step's "units" mode).  branches = 2 with classifier-free guidance ([cond, uncond]), else 1.
+      prepare(ids)          -> ctx: the level's tiles gathered and re-noised (every rank, all tiles: HBM-bound tile ops)
+      eps(ctx, units)       -> eps [len(units), C, tf, th, tw] of the units (k, b) = (position in ids, branch); a unit's
+                               values must not depend on which other units share the call (a batch equals its separate forwards)
+      finish(ctx, eps_all)  -> (x_prev, x0) tiles [len(ids), ...] from eps_all [len(ids), branches, C, tf, th, tw]"""
+
+    def __init__(self, branches, prepare, eps, finish):
+        self.branches, self.prepare, self.eps, self.finish = branches, prepare, eps, finish
+
+
+def unit_share(n_tiles, branches, rank, world):
+    """Units (k, b) of a level in unit order u = k * branches + b; rank r takes u = r, r + world, ..."""
+    units = [(k, b) for k in range(n_tiles) for b in range(branches)]
+    return units[rank::world]
+
+
+def exchange_units(local, n_units, group=None):
+    """All-gather of one tensor per unit: local [n_local, ...] holds this rank's strided share (units rank, rank + world, ...);
+    returns [n_units, ...] in unit order on every rank."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = share_counts(n_units, world)
+    cmax = max(counts)
+    shape = tuple(local.shape[1:])
+    send = torch.zeros((cmax,) + shape, dtype=local.dtype, device=local.device)
+    if counts[rank]:
+        send[:counts[rank]] = local
+    recv = torch.empty((world * cmax,) + shape, dtype=send.dtype, device=send.device)
+    if _HOST_STAGED and send.is_cuda:
+        recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(recv_h, send.cpu(), group=group)
+        recv.copy_(recv_h)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view((world, cmax) + shape)
+    out = torch.empty((n_units,) + shape, dtype=send.dtype, device=send.device)
+    for r in range(world):
+        if counts[r]:
+            out[r::world] = recv[r, :counts[r]]
+    return out
+
+
+def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, group=None, units=None):
     """One DDIM step over `windows` (reference order), shared over `world` ranks -- the scheduling both the HIP pipelines
     (pipelines._denoise_windows) and the CPU rehearsal (tests/test_parallel_gloo.py) run.
       process(ids) -> (x_prev, x0) tiles [len(ids), ...] of the windows `ids` (pairwise disjoint, in the given order)
       scatter(ids, x_prev, x0)       writes tiles into this rank's panorama replica; `ids` are pairwise disjoint (a batched
                                      scatter has no order among its windows)
       empty_tiles()                  -> a [0, ...] tile tensor (dtype / device of the tiles)
-    Returns the mode used: "single", "components" or "levels"."""
+      units                          EvalUnits or None: lets a level with fewer tiles than ranks be shared out by evaluation
+    Returns the mode used: "single", "components", "levels" or "units" (at least one level shared out by evaluation)."""
     levels = plan_levels(windows, pano_fhw)
     if world <= 1:
         for level in levels:
@@ -184,12 +233,24 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
             if ids:
                 scatter(ids, torch.cat(xs, 0), torch.cat(x0s, 0))
         return "components"
+    mode = "levels"
     for level in levels:
+        if units is not None and len(level) < world and units.branches > 1:
+            # fewer tiles than ranks: share the level out by (tile, branch) evaluation -- the cross-rank CFG split
+            mode = "units"
+            n, nb = len(level), units.branches
+            ctx = units.prepare(level)
+            mine = unit_share(n, nb, rank, world)
+            e_local = units.eps(ctx, mine)
+            e_all = exchange_units(e_local, n * nb, group)
+            xp_all, x0_all = units.finish(ctx, e_all.view((n, nb) + tuple(e_all.shape[1:])))
+            scatter(level, xp_all, x0_all)
+            continue
         ids = rank_share(level, rank, world)
         xp, x0 = process(ids) if ids else (empty_tiles(), empty_tiles())
         xp_all, x0_all = exchange_level(xp, x0, len(level), group)
         scatter(level, xp_all, x0_all)
-    return "levels"
+    return mode
 
 
 def exchange_level(x_prev_local, x0_local, n_items, group=None, force=False):

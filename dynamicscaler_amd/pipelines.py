@@ -262,7 +262,8 @@ class VC2_Pipeline_T2V:
 
         split_cfg = [False]
 
-        def run_batch(ids):
+        def prepare(ids):
+            """Gather + re-noise of the windows `ids` -> (tiles, mask tiles, the windows before the re-noise | None)."""
             origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
             tiles, mtiles = ops.ring_gather(pano, origins, st.tile_fhw, mask)
             prev = tiles.clone() if merge_prev_ratio is not None else None
@@ -273,6 +274,24 @@ class VC2_Pipeline_T2V:
                 ops.renoise_mix_(tiles, mtiles, st.total_shape, c_rn, s_rn, st.ratio, noise=nz,
                                  mask_frame0=mask_frame0, seed=sched.philox_seed,
                                  offset=sched.tile_philox_offset(i, tiles[0].numel()), tile_ids=ids)
+            return ids, tiles, mtiles, prev
+
+        def finish(ctx, e_c, e_u):
+            """CFG + DDIM update (+ merge-prev) of prepared tiles from their eps tensors."""
+            ids, tiles, mtiles, prev = ctx
+            sn = None
+            if coef["sigma"] != 0.0:
+                sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=pano.dtype)
+            x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, st.total_shape, st.guidance_scale, coef, sn)
+            if merge_prev_ratio is not None:
+                # merge-prev (i2v_sphere_panorama_pipeline.py:938-943): mix(x_prev, window_before_renoise, mask, r_i)
+                ops.renoise_mix_(x_prev, mtiles, st.total_shape, 0.0, 1.0, merge_prev_ratio, noise=prev,
+                                 mask_frame0=mask_frame0)
+            return x_prev, x0
+
+        def run_batch(ids):
+            ctx = prepare(ids)
+            tiles = ctx[1]
             n = len(ids)
             if st.guidance_scale != 1.0 and split_cfg[0]:
                 # a level with ONE tile batch (a rank's share on many GPUs, single-tile panoramas): nothing else to overlap it
@@ -288,15 +307,24 @@ class VC2_Pipeline_T2V:
                 e_c, e_u = eps[:n], eps[n:]
             else:
                 e_c, e_u = self._eps(tiles, t, [ctxs[j] for j in ids], st.fps, st.frames, **st.kwargs), None
-            sn = None
-            if coef["sigma"] != 0.0:
-                sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=pano.dtype)
-            x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, st.total_shape, st.guidance_scale, coef, sn)
-            if merge_prev_ratio is not None:
-                # merge-prev (i2v_sphere_panorama_pipeline.py:938-943): mix(x_prev, window_before_renoise, mask, r_i)
-                ops.renoise_mix_(x_prev, mtiles, st.total_shape, 0.0, 1.0, merge_prev_ratio, noise=prev,
-                                 mask_frame0=mask_frame0)
-            return x_prev, x0
+            return finish(ctx, e_c, e_u)
+
+        # a level with fewer tiles than ranks is shared out by EVALUATION (parallel.run_step "units": cond and uncond of one
+        # tile on two ranks).  A unit's eps does not depend on what else is in the batch (a batch equals its separate
+        # forwards, tests/test_gpu_unet.py), so the panorama stays bit-identical to the single-process one.
+        def unit_eps(ctx, units_mine):
+            ids, tiles = ctx[0], ctx[1]
+            if not units_mine:
+                return torch.empty((0,) + tuple(tiles.shape[1:]), dtype=torch.float32, device=device)
+            ks = [k for k, _ in units_mine]
+            x = tiles[ks].contiguous() if ks != list(range(len(ids))) else tiles
+            cl = [ctxs[ids[k]] if b == 0 else st.uc_emb for k, b in units_mine]
+            return self._eps(x, t, cl, st.fps, st.frames, **st.kwargs).float()
+
+        def unit_finish(ctx, e_all):
+            return finish(ctx, e_all[:, 0].contiguous(), e_all[:, 1].contiguous())
+
+        units = parallel.EvalUnits(2, prepare, unit_eps, unit_finish) if (st.guidance_scale != 1.0 and st.world > 1) else None
 
         def process(mine):
             """(x_prev, x0) tiles of the pairwise-disjoint windows `mine` (this rank's part of a level), in that order.
@@ -329,7 +357,8 @@ class VC2_Pipeline_T2V:
 
         # levels of pairwise-disjoint windows; over several ranks whole components (columns) per rank with one exchange
         # per step, or a strided share of every level (parallel.run_step)
-        st.share_mode = self.last_share_mode = parallel.run_step(wins, st.pano_fhw, st.rank, st.world, process, scatter, empty_tiles)
+        st.share_mode = self.last_share_mode = parallel.run_step(wins, st.pano_fhw, st.rank, st.world, process, scatter, empty_tiles,
+                                                                      units=units)
 
     def _new_state(self, init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
                    text_emb, uc_emb, ratio, kwargs):

@@ -18,7 +18,7 @@ import threading
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, _lib
 from ._lib import DS_A_CONV3, DS_A_TCONV, DS_EPI_GEGLU, DS_EPI_SILU, DS_EPI_OUT_F32
 from .unet_spec import build_program, param_shapes
 
@@ -84,7 +84,28 @@ class UNetModel(nn.Module):
         # the GEMM takes the rows' statistics from its own operand fragments (no other launch; measured slower at the bench's
         # batch sizes).  DS_FOLD_LN = 0 | 1 (default) | 2; after changing the attribute call invalidate() (the packed projection
         # weights differ).  profiles/r2_notes.md section 4.
-        self.fold_layernorm = {"0": False, "1": "stats", "2": "kernel"}[os.environ.get("DS_FOLD_LN", "1")]
+        fold = os.environ.get("DS_FOLD_LN", "1")
+        if fold not in ("0", "1", "2"):
+            raise ValueError(f"DS_FOLD_LN={fold!r}: expected 0 (LayerNorm kernels), 1 (folded, statistics launch) or 2 (folded, in-kernel statistics)")
+        self.fold_layernorm = {"0": False, "1": "stats", "2": "kernel"}[fold]
+        # Storage type of the RESIDUAL STREAM (every "+ x" / "skip + h" output, conv_in, down / up-sample, proj_in; the skip
+        # tensors).  The reference computes in fp32 throughout (openaimodel3d.py:657-708); the matrix-core operands are fp16 in
+        # both modes.  torch.float16: everything fp16 (fastest).  torch.float32 ("strict"): the stream is stored, added and
+        # normalised in fp32 -- the error budget's largest term (profiles/r2_notes.md section 2: 1.31e-3 of 1.66e-3 on eps) goes
+        # away; norms read fp32 and write the fp16 operand, residual epilogues add fp32 rows (DS_EPI_RES_F32 | DS_EPI_OUT_F32).
+        # DS_RESIDUAL_DTYPE = f16 | f32; after changing the attribute call invalidate().
+        rd = os.environ.get("DS_RESIDUAL_DTYPE", "f16")
+        if rd not in ("f16", "f32"):
+            raise ValueError(f"DS_RESIDUAL_DTYPE={rd!r}: expected f16 or f32")
+        self.residual_dtype = torch.float32 if rd == "f32" else torch.float16
+        # Which launch program runs the forward: "c" = ds_unet_forward (csrc/unet_program.hip: one call, the launch loop in C++),
+        # "python" = the restatement below (one ctypes call per kernel: per-launch timing hooks, taps, DS_FOLD_LN=2).  The two
+        # issue the same launches on the same packed operands and are bit-identical (tests/test_gpu_unet_c.py).  DS_UNET_PROGRAM.
+        prog = os.environ.get("DS_UNET_PROGRAM", "c")
+        if prog not in ("c", "python"):
+            raise ValueError(f"DS_UNET_PROGRAM={prog!r}: expected c or python")
+        self.program = prog
+        self._handle = None
         self._tap = None                     # optional callable(name, rows [M,C] fp16, (B,T,H,W)) after every block (tests)
         self._generation = 0                 # bumped by every prepare(): identifies the packed buffers (hipGraph cache keys)
         self._prepare_lock = threading.Lock()
@@ -103,166 +124,139 @@ class UNetModel(nn.Module):
         self._packed = None
 
     @torch.no_grad()
-    def prepare(self, device=None):
+    def prepare(self, device=None, force=False):
         """Repack parameters for the kernels (fp16 GEMM operands, fp32 biases / norm affine).
         The repack kernels run on the caller's current stream; the call returns after a device synchronisation, so any
         stream (the pipelines' side streams, hipGraph captures) may read the packed buffers afterwards.  Serialised by a
-        lock: two threads racing into the first forward repack once."""
+        lock: two threads racing into the first forward repack once.  force=True repacks even when packed buffers for the
+        device exist (after in-place parameter edits; invalidate() + the next forward does the same)."""
         with self._prepare_lock:
             dev = torch.device(device) if device is not None else next(self.parameters()).device
             if dev.type == "cuda" and dev.index is None:
                 dev = torch.device("cuda", torch.cuda.current_device())
-            if self._packed is not None and self._device == dev:
+            if not force and self._packed is not None and self._device == dev and self._packed_mode == self._mode():
                 return self
             return self._prepare_locked(dev)
 
+    def _strict(self):
+        return self.residual_dtype == torch.float32
+
+    def _fold(self):
+        """LayerNorm fold in effect: the fold multiplies the RAW activation on the matrix cores, which needs it in fp16 -- with an
+        fp32 residual stream the LayerNorm kernel (fp32 in, fp16 operand out) runs instead."""
+        return False if self._strict() else self.fold_layernorm
+
+    def _mode(self):
+        return (self._fold(), self.residual_dtype)
+
+    def _c_config(self):
+        """ds_unet_config of this model in the current mode."""
+        cfg = self.cfg
+        c = _lib.UNetConfig()
+        for k in ("in_channels", "out_channels", "model_channels", "num_res_blocks", "transformer_depth",
+                  "temporal_transformer_depth", "context_dim"):
+            setattr(c, k, int(cfg[k]))
+        c.num_head_channels = HEAD_DIM
+        cm, ar = list(cfg["channel_mult"]), list(cfg["attention_resolutions"])
+        if len(cm) > 8 or len(ar) > 8:
+            raise NotImplementedError("more than 8 channel_mult / attention_resolutions entries")
+        c.n_channel_mult, c.n_attention_resolutions = len(cm), len(ar)
+        for i, v in enumerate(cm):
+            c.channel_mult[i] = int(v)
+        for i, v in enumerate(ar):
+            c.attention_resolutions[i] = int(v)
+        for k in ("use_linear", "temporal_conv", "temporal_attention", "addition_attention", "use_image_attention", "fps_cond"):
+            setattr(c, k, int(bool(cfg[k])))
+        c.residual_f32 = int(self._strict())
+        c.fold_layernorm = int(bool(self._fold()))
+        return c
+
+    def _release_handle(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            _lib.load().ds_unet_destroy(h)
+
+    def __del__(self):
+        try:
+            self._release_handle()
+        except Exception:
+            pass
+
     def _prepare_locked(self, device):
-        sd = dict(self.named_parameters())
+        """The packing itself is ds_unet_pack (csrc/unet_program.hip): fp16 [N][K] GEMM operands (K = tap*Cin + c for convs),
+        fused QKV / KV / image-KV matrices, the GEGLU projection interleaved in 32-row groups [x_g | gate_g], the
+        time-embedding projections of all ResBlocks in one matrix (conv-1 bias folded in), LayerNorm folded into the projection
+        it feeds (fp16(gamma*W), column sums, beta.W + b).  Both launch programs -- the C one behind ds_unet_forward and the
+        Python one below -- read the same packed buffer; self._packed maps operand names to views of it."""
+        import ctypes as C
         dev = device
         if dev.type != "cuda":
             raise RuntimeError("UNetModel runs on an MI355X only (no CPU path): move the model / inputs to a HIP device")
+        lib = _lib.load()
+        self._release_handle()
+        cc = self._c_config()
+        h = C.c_void_p()
+        _lib.check(lib.ds_unet_create(C.byref(cc), C.byref(h)), "ds_unet_create")
+        self._handle = h
+        sd = dict(self.named_parameters())
+        n = lib.ds_unet_num_weights(h)
+        key, nd, shp = C.c_char_p(), C.c_int(), (C.c_int64 * 5)()
+        keep = []                      # device copies of the raw tensors: alive until the packing has run
+        with torch.cuda.device(dev):
+            for i in range(n):
+                _lib.check(lib.ds_unet_weight_info(h, i, C.byref(key), C.byref(nd), shp), "ds_unet_weight_info")
+                name = key.value.decode()
+                if name not in sd:
+                    raise KeyError(f"parameter {name} expected by the UNet program is missing from the module")
+                t = sd[name].detach()
+                if tuple(t.shape) != tuple(shp[:nd.value]):
+                    raise ValueError(f"parameter {name}: shape {tuple(t.shape)} != {tuple(shp[:nd.value])}")
+                if t.dtype not in (torch.float32, torch.float16):
+                    t = t.float()
+                t = t.to(dev).contiguous()
+                keep.append(t)
+                sh = (C.c_int64 * 5)(*list(t.shape))
+                _lib.check(lib.ds_unet_load_weight(h, name.encode(), t.data_ptr(), ops._DT[t.dtype], sh, t.dim()), "ds_unet_load_weight")
+            if n != len(sd):
+                raise KeyError(f"the module has {len(sd)} parameters, the UNet program expects {n}")
+            nbytes = lib.ds_unet_packed_bytes(h)
+            buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            _lib.check(lib.ds_unet_pack(h, buf.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream), "ds_unet_pack")
+            torch.cuda.synchronize(dev)      # the packed buffer is complete before any other stream can see it
+        del keep
         P = {}
-
-        def w16(t):
-            return t.detach().to(dev, torch.float16).contiguous()
-
-        def f32(t):
-            return t.detach().to(dev, torch.float32).contiguous()
-
-        def lin(prefix, bias=True):
-            w = sd[prefix + ".weight"]
-            P[prefix + ".w"] = w16(w.reshape(w.shape[0], -1))
-            if bias:
-                P[prefix + ".b"] = f32(sd[prefix + ".bias"])
-
-        def conv3(prefix):
-            w = sd[prefix + ".weight"]  # [Cout, Cin, 3, 3] -> [Cout, (ky,kx,c)]
-            P[prefix + ".w"] = w16(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
-            P[prefix + ".b"] = f32(sd[prefix + ".bias"])
-
-        def tconv(prefix):
-            w = sd[prefix + ".weight"]  # [Cout, Cin, 3, 1, 1] -> [Cout, (kt, c)]
-            P[prefix + ".w"] = w16(w[:, :, :, 0, 0].permute(0, 2, 1).reshape(w.shape[0], -1))
-            P[prefix + ".b"] = f32(sd[prefix + ".bias"])
-
-        def norm(prefix):
-            P[prefix + ".g"] = f32(sd[prefix + ".weight"])
-            P[prefix + ".be"] = f32(sd[prefix + ".bias"])
-
-        def transformer(prefix, depth, cross, img):
-            norm(prefix + ".norm")
-            lin(prefix + ".proj_in")
-            lin(prefix + ".proj_out")
-            for d in range(depth):
-                p = f"{prefix}.transformer_blocks.{d}"
-                for n in ("norm1", "norm2", "norm3"):
-                    norm(f"{p}.{n}")
-
-                def proj(name, w, ln, bias=None, geglu=False):
-                    """A projection fed by LayerNorm `ln`: plain fp16 operand, or (fold_layernorm) the LayerNorm folded into
-                    it (ds_gemm_f16_ln): Wg = fp16(gamma * W), colsum of the ROUNDED operand rows, colbias = W beta (+ b)."""
-                    w = w.detach().to(dev, torch.float32)
-                    if not self.fold_layernorm:
-                        P[name + ".w"] = w16(_interleave_geglu(w) if geglu else w)
-                        if bias is not None:
-                            P[name + ".b"] = f32(_interleave_geglu(bias) if geglu else bias)
-                        return
-                    g, be = P[f"{p}.{ln}.g"], P[f"{p}.{ln}.be"]
-                    wg = (w * g[None, :]).to(torch.float16)
-                    cs = wg.float().sum(1)
-                    cb = w @ be
-                    if bias is not None:
-                        cb = cb + bias.detach().to(dev, torch.float32)
-                    if geglu:
-                        wg, cs, cb = _interleave_geglu(wg), _interleave_geglu(cs), _interleave_geglu(cb)
-                    P[name + ".wg"], P[name + ".cs"], P[name + ".cb"] = wg.contiguous(), cs.contiguous(), cb.contiguous()
-
-                proj(f"{p}.attn1.qkv", torch.cat([sd[f"{p}.attn1.to_q.weight"], sd[f"{p}.attn1.to_k.weight"],
-                                                 sd[f"{p}.attn1.to_v.weight"]], 0), "norm1")
-                lin(f"{p}.attn1.to_out.0")
-                if cross:
-                    proj(f"{p}.attn2.to_q", sd[f"{p}.attn2.to_q.weight"], "norm2")
-                    P[f"{p}.attn2.kv.w"] = w16(torch.cat([sd[f"{p}.attn2.to_k.weight"], sd[f"{p}.attn2.to_v.weight"]], 0))
-                    if img:
-                        P[f"{p}.attn2.kv_ip.w"] = w16(torch.cat([sd[f"{p}.attn2.to_k_ip.weight"],
-                                                                 sd[f"{p}.attn2.to_v_ip.weight"]], 0))
-                else:
-                    proj(f"{p}.attn2.qkv", torch.cat([sd[f"{p}.attn2.to_q.weight"], sd[f"{p}.attn2.to_k.weight"],
-                                                     sd[f"{p}.attn2.to_v.weight"]], 0), "norm2")
-                lin(f"{p}.attn2.to_out.0")
-                proj(f"{p}.ff1", sd[f"{p}.ff.net.0.proj.weight"], "norm3", bias=sd[f"{p}.ff.net.0.proj.bias"], geglu=True)
-                lin(f"{p}.ff.net.2")
-
-        cfg = self.cfg
-        for name in ("time_embed",) + (("fps_embedding",) if cfg["fps_cond"] else ()):
-            lin(name + ".0")
-            lin(name + ".2")
-        emb_w, emb_b, self._emb_off = [], [], {}
-        off = 0
-
-        def block(b):
-            nonlocal off
-            p = b.prefix
-            if b.kind == "conv_in":
-                w = sd[p + ".weight"]
-                k = 9 * w.shape[1]
-                kpad = ((k + 63) // 64) * 64
-                wp = torch.zeros((w.shape[0], kpad), dtype=torch.float32, device=w.device)
-                wp[:, :k] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
-                P[p + ".w"] = w16(wp)
-                P[p + ".b"] = f32(sd[p + ".bias"])
-                self._kpad_in = kpad
-            elif b.kind == "res":
-                norm(p + ".in_layers.0")
-                conv3(p + ".in_layers.2")
-                norm(p + ".out_layers.0")
-                conv3(p + ".out_layers.3")
-                if b.cin != b.cout:
-                    lin(p + ".skip_connection")
-                # time-embedding projection of every ResBlock goes into ONE matrix; the conv-1 bias is folded in
-                emb_w.append(sd[p + ".emb_layers.1.weight"])
-                emb_b.append(sd[p + ".emb_layers.1.bias"] + sd[p + ".in_layers.2.bias"])
-                self._emb_off[p] = off
-                off += b.cout
-                if b.tconv:
-                    for i in (1, 2, 3, 4):
-                        ci = 2 if i == 1 else 3
-                        norm(f"{p}.temopral_conv.conv{i}.0")
-                        tconv(f"{p}.temopral_conv.conv{i}.{ci}")
-            elif b.kind == "st":
-                transformer(p, b.depth, True, cfg["use_image_attention"])
-            elif b.kind == "tt":
-                transformer(p, b.depth, False, False)
-            elif b.kind == "down":
-                conv3(p + ".op")
-            elif b.kind == "up":
-                conv3(p + ".conv")
-
-        for gi, group in enumerate(self._inputs):
-            for b in group:
-                block(b)
-            if gi == 0 and cfg["addition_attention"]:
-                transformer("init_attn.0", cfg["transformer_depth"], False, False)
-        for b in self._middle:
-            block(b)
-        for group in self._outputs:
-            for b in group:
-                block(b)
-        norm("out.0")
-        conv3("out.2")
-        P["emb_all.w"] = w16(torch.cat(emb_w, 0))
-        P["emb_all.b"] = f32(torch.cat(emb_b, 0))
-        self._emb_total = off
-        torch.cuda.synchronize(dev)          # the packed buffers are complete before any other stream can see them
+        off, nb, rows, dt = C.c_size_t(), C.c_size_t(), C.c_long(), C.c_int()
+        for i in range(lib.ds_unet_num_packed(h)):
+            _lib.check(lib.ds_unet_packed_info(h, i, C.byref(key), C.byref(off), C.byref(nb), C.byref(rows), C.byref(dt)), "ds_unet_packed_info")
+            raw = buf[off.value:off.value + nb.value]
+            if dt.value == _lib.DS_F16:
+                P[key.value.decode()] = raw.view(torch.float16).view(rows.value, -1)
+            else:
+                P[key.value.decode()] = raw.view(torch.float32)
+        self._packed_buf = buf
+        self._emb_total = P["emb_all.w"].shape[0]
+        self._emb_off = {b.prefix: lib.ds_unet_emb_offset(h, b.prefix.encode())
+                         for g in list(self._inputs) + [self._middle] + list(self._outputs) for b in g if b.kind == "res"}
+        self._kpad_in = P["input_blocks.0.0.w"].shape[1]
+        self._ws_bytes = {}
         self._device = dev
         self._generation += 1
+        self._packed_mode = self._mode()
         self._packed = P
         return self
 
     # ------------------------------------------------------------------ forward program
-    def _gn(self, h, prefix, ninst, rows, C, eps, silu):
+    def _gn(self, h, prefix, ninst, rows, C, eps, silu, raw_f16=False):
         P = self._packed
-        return ops.groupnorm(h, P[prefix + ".g"], P[prefix + ".be"], ninst, rows, C, eps, silu)
+        return ops.groupnorm(h, P[prefix + ".g"], P[prefix + ".be"], ninst, rows, C, eps, silu, raw_f16=raw_f16)
+
+    def _res_epi(self, epilogue=0):
+        """Epilogue flags of a launch whose output belongs to the residual stream."""
+        return epilogue | (DS_EPI_OUT_F32 if self._strict() else 0)
+
+    def _operand(self, h):
+        """The fp16 matrix-core operand of a projection / convolution that reads the residual stream un-normalised."""
+        return ops.cast_rows_f16(h) if h.dtype == torch.float32 else h
 
     def _linear(self, a, prefix, residual=None, epilogue=0, bias=True, out=None):
         P = self._packed
@@ -285,21 +279,25 @@ class UNetModel(nn.Module):
                        bias_rows=bias_rows, ldbias=ldbias, epilogue=epilogue, out=out)
         return out, (hout, wout)
 
-    def _transformer_block(self, x, p, heads, spatial, geo, ctx, dup=None):
+    def _transformer_block(self, x, p, heads, spatial, geo, ctx, dup=None, last=False):
         """x [M, inner].  spatial: attention over H*W per frame (+ cross-attention to ctx); else over T per pixel.
         dup (spatial only): x holds ONE copy of a [cond | uncond] pair batch; attn1 (which does not see the context) runs
-        on it, then dup(x) doubles the batch for the cross-attention and everything after (see forward, cfg_pairs)."""
+        on it, then dup(x) doubles the batch for the cross-attention and everything after (see forward, cfg_pairs).
+        last: the block's output is only read by proj_out as a matrix-core operand, so it is stored in fp16 whatever the
+        residual-stream type (the one rounding the operand needs anyway)."""
         P = self._packed
         B, T, H, W = geo
         M, inner = x.shape
         scale = HEAD_DIM ** -0.5
+        fold = self._fold()
+        rs = self._res_epi()
 
         def ln_proj(xin, ln, name, N, epilogue=0):
             """LayerNorm `ln` of xin followed by the projection `name`: the LayerNorm folded into the GEMM (row statistics +
             ds_gemm_f16_ln on the raw activation), or the two separate kernels."""
             Mx = xin.shape[0]
-            if self.fold_layernorm:
-                st = ops.layernorm_stats(xin) if self.fold_layernorm != "kernel" else None
+            if fold:
+                st = ops.layernorm_stats(xin) if fold != "kernel" else None
                 return ops.gemm_ln(xin, P[name + ".wg"], st, P[name + ".cs"], P[name + ".cb"], M=Mx, N=N, K=inner, epilogue=epilogue)
             n = ops.layernorm(xin, P[f"{p}.{ln}.g"], P[f"{p}.{ln}.be"])
             return ops.gemm(n, P[name + ".w"], P.get(name + ".b"), None, M=Mx, N=N, K=inner, epilogue=epilogue)
@@ -314,7 +312,7 @@ class UNetModel(nn.Module):
             else:
                 ops.temporal_attention(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, nseq_batches=B, T=T, hw=H * W,
                                        heads=heads, ldq=ld, ldk=ld, ldv=ld, ldo=inner, scale=scale)
-            return self._linear(o, f"{p}.{name}.to_out.0", residual=xin)
+            return self._linear(o, f"{p}.{name}.to_out.0", residual=xin, epilogue=rs)
 
         x = self_attn("attn1", x)
         if dup is not None:
@@ -334,11 +332,11 @@ class UNetModel(nn.Module):
                 # out = out + 1.0 * out_ip (attention.py:117-124): second softmax over the image tokens, accumulated
                 ops.attention(q, kvi, kvi[:, inner:], o, batch=B * T, heads=heads, nq=H * W, nk=limg, ldq=inner,
                               ldk=2 * inner, ldv=2 * inner, ldo=inner, kv_batch_div=T, scale=scale, accumulate=True)
-            x = self._linear(o, f"{p}.attn2.to_out.0", residual=x)
+            x = self._linear(o, f"{p}.attn2.to_out.0", residual=x, epilogue=rs)
         else:
             x = self_attn("attn2", x)
         g = ln_proj(x, "norm3", f"{p}.ff1", 8 * inner, epilogue=DS_EPI_GEGLU)      # GEGLU: 2 x (4 x inner) columns
-        return self._linear(g, f"{p}.ff.net.2", residual=x)
+        return self._linear(g, f"{p}.ff.net.2", residual=x, epilogue=0 if last else rs)
 
     def _transformer(self, h, prefix, heads, depth, spatial, geo, ctx, dup=None, out=None):
         B, T, H, W = geo
@@ -347,25 +345,31 @@ class UNetModel(nn.Module):
             a = self._gn(h, prefix + ".norm", B * T, H * W, C, 1e-6, False)
         else:
             a = self._gn(h, prefix + ".norm", B, T * H * W, C, 1e-6, False)
-        x = self._linear(a, prefix + ".proj_in")
+        x = self._linear(a, prefix + ".proj_in", epilogue=self._res_epi())
         for d in range(depth):
             x = self._transformer_block(x, f"{prefix}.transformer_blocks.{d}", heads, spatial, geo, ctx,
-                                        dup=dup if d == 0 else None)
+                                        dup=dup if d == 0 else None, last=d == depth - 1)
             if dup is not None and d == 0:
                 h, geo = dup(h), (2 * B, T, H, W)
-        return self._linear(x, prefix + ".proj_out", residual=h, out=out)
+        return self._linear(x, prefix + ".proj_out", residual=h, epilogue=self._res_epi(), out=out)
 
     def _resblock(self, h, b, geo, emb_all, out=None):
         P = self._packed
         B, T, H, W = geo
         p = b.prefix
-        a = self._gn(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5, True)
+        rs = self._res_epi()
+        need_skip = b.cin != b.cout
+        h16 = h
+        if need_skip and h.dtype == torch.float32:     # the skip projection's fp16 operand comes out of the GroupNorm pass
+            a, h16 = self._gn(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5, True, raw_f16=True)
+        else:
+            a = self._gn(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5, True)
         off = self._emb_off[p]
         h1, _ = self._conv3(a, p + ".in_layers.2", (B * T, H, W), b.cin, bias=emb_all[:, off:], bias_rows=T * H * W,
                             ldbias=self._emb_total)
         a2 = self._gn(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5, True)
-        skip = h if b.cin == b.cout else self._linear(h, p + ".skip_connection")
-        h2, _ = self._conv3(a2, p + ".out_layers.3", (B * T, H, W), b.cout, residual=skip, out=None if b.tconv else out)
+        skip = h if not need_skip else self._linear(h16, p + ".skip_connection", epilogue=rs)
+        h2, _ = self._conv3(a2, p + ".out_layers.3", (B * T, H, W), b.cout, residual=skip, epilogue=rs, out=None if b.tconv else out)
         if b.tconv:
             x = h2
             M = x.shape[0]
@@ -375,7 +379,8 @@ class UNetModel(nn.Module):
                 an = self._gn(x, q + ".0", B, T * H * W, b.cout, 1e-5, True)
                 w = P[f"{q}.{ci}.w"]
                 x = ops.gemm(an, w, P[f"{q}.{ci}.b"], h2 if i == 4 else None, M=M, N=w.shape[0], K=w.shape[1],
-                             a_mode=DS_A_TCONV, cin=b.cout, lda=an.stride(0), tconv=(T, H * W), out=out if i == 4 else None)
+                             a_mode=DS_A_TCONV, cin=b.cout, lda=an.stride(0), tconv=(T, H * W), epilogue=rs if i == 4 else 0,
+                             out=out if i == 4 else None)
             h2 = x
         return h2
 
@@ -392,9 +397,10 @@ class UNetModel(nn.Module):
         pairs = kwargs.pop("cfg_pairs", None)
         if features_adapter is not None or timestep_cond is not None:
             raise NotImplementedError("features_adapter / timestep_cond are not used by the DynamicScaler pipelines")
-        if not x.is_cuda:
+        tracing = x.device.type == "meta"          # python_program_trace: shapes only, ops replaced by recorders
+        if not x.is_cuda and not tracing:
             raise RuntimeError("UNetModel.forward: input is on the CPU; this build has no CPU path (the HIP kernels are the product)")
-        if self._packed is None or self._device != x.device:
+        if not tracing and (self._packed is None or self._device != x.device or self._packed_mode != self._mode()):
             self.prepare(x.device)
         P = self._packed
         cfg = self.cfg
@@ -405,6 +411,9 @@ class UNetModel(nn.Module):
         timesteps = timesteps.to(dev, torch.int64).reshape(-1)
         if timesteps.numel() == 1 and B > 1:
             timesteps = timesteps.expand(B).contiguous()
+        if (self.program == "c" and not tracing and self._tap is None and ops._timing_hook is None and isinstance(fps, int)
+                and self.fold_layernorm != "kernel" and x.dtype in ops._DT):
+            return self._forward_c(x, timesteps.contiguous(), context, fps, int(pairs or 0))
         # ---- time (+fps) embedding -> per-ResBlock projections in one GEMM ----
         t_emb = ops.timestep_embedding(timesteps, mc)
         e1 = self._linear(t_emb, "time_embed.0", epilogue=DS_EPI_SILU)
@@ -449,7 +458,8 @@ class UNetModel(nn.Module):
                 if b.kind == "conv_in":
                     patches = ops.im2col_in(x[:pairs] if shared else x, self._kpad_in)
                     w = P[b.prefix + ".w"]
-                    h = ops.gemm(patches, w, P[b.prefix + ".b"], None, M=patches.shape[0], N=w.shape[0], K=w.shape[1], out=o)
+                    h = ops.gemm(patches, w, P[b.prefix + ".b"], None, M=patches.shape[0], N=w.shape[0], K=w.shape[1],
+                                 epilogue=self._res_epi(), out=o)
                 elif b.kind == "res":
                     h = self._resblock(h, b, geo, emb_all, out=o)
                 elif b.kind == "st":
@@ -459,10 +469,12 @@ class UNetModel(nn.Module):
                 elif b.kind == "tt":
                     h = self._transformer(h, b.prefix, b.heads, b.depth, False, geo, ctx, out=o)
                 elif b.kind == "down":
-                    h, (ho, wo) = self._conv3(h, b.prefix + ".op", (Bq * Tq, Hq, Wq), b.cin, stride=2, out=o)
+                    h, (ho, wo) = self._conv3(self._operand(h), b.prefix + ".op", (Bq * Tq, Hq, Wq), b.cin, stride=2,
+                                              epilogue=self._res_epi(), out=o)
                     geo = (Bq, Tq, ho, wo)
                 elif b.kind == "up":
-                    h, (ho, wo) = self._conv3(h, b.prefix + ".conv", (Bq * Tq, Hq, Wq), b.cin, upsample=1, out=o)
+                    h, (ho, wo) = self._conv3(self._operand(h), b.prefix + ".conv", (Bq * Tq, Hq, Wq), b.cin, upsample=1,
+                                              epilogue=self._res_epi(), out=o)
                     geo = (Bq, Tq, ho, wo)
                 if self._tap is not None:
                     self._tap(b.prefix, h, geo)
@@ -494,7 +506,7 @@ class UNetModel(nn.Module):
             full = (B,) + g_out[1:]
             cat = dst = None
             if inplace:
-                cat = torch.empty((full[0] * full[1] * full[2] * full[3], c_h + c_skip), dtype=torch.float16, device=dev)
+                cat = torch.empty((full[0] * full[1] * full[2] * full[3], c_h + c_skip), dtype=self.residual_dtype, device=dev)
                 dst = None if shared_after else cat[:, c_h:]
             h, geo = run(group, h, geo, out=None if init_attn else dst)
             if init_attn:
@@ -520,11 +532,66 @@ class UNetModel(nn.Module):
                 assert geo_after(group, geo) == hs[-1][2], \
                     f"skip connection geometry {hs[-1][2]} != {geo_after(group, geo)} (tile h/w must be divisible by 8)"
             if not inplace:
-                cat = ops.concat_channels(h, cat)        # the copy (DS_INPLACE_CONCAT=0: A/B and diagnostics)
+                # the copy (DS_INPLACE_CONCAT=0: A/B and diagnostics)
+                cat = ops.concat_channels(h, cat) if h.dtype == torch.float16 else torch.cat([h, cat], 1)
             h, geo = run(group, cat, geo, out=hs[-1][0][:, :hs[-1][1]] if (hs and inplace) else None)
         a = self._gn(h, "out.0", B * T, H * W, mc, 1e-5, True)
         y, _ = self._conv3(a, "out.2", (B * T, H, W), mc, epilogue=DS_EPI_OUT_F32)
         return ops.rows_to_ncthw(y, (B, cfg["out_channels"], T, H, W), torch.float32)
+
+
+
+    def _forward_c(self, x, timesteps, context, fps, pairs):
+        """One ds_unet_forward call: the launch loop runs in C++ (csrc/unet_program.hip) on the caller's current stream, all scratch
+        from one workspace tensor sized by ds_unet_workspace_bytes (under hipGraph capture it lives in the graph's pool)."""
+        lib = _lib.load()
+        dev = x.device
+        B, Cin, T, H, W = x.shape
+        context = context.to(dev)
+        if context.dtype not in ops._DT:
+            context = context.float()
+        context = context.contiguous()
+        L = context.shape[1]
+        key = (B, T, H, W, L, pairs)
+        nbytes = self._ws_bytes.get(key)
+        if nbytes is None:
+            nbytes = self._ws_bytes[key] = lib.ds_unet_workspace_bytes(self._handle, B, T, H, W, L, pairs)
+            if nbytes == 0:
+                _lib.check(-1, "ds_unet_workspace_bytes")
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        eps = torch.empty((B, self.cfg["out_channels"], T, H, W), dtype=torch.float32, device=dev)
+        _lib.check(lib.ds_unet_forward(self._handle, x.data_ptr(), ops._DT[x.dtype], timesteps.data_ptr(), context.data_ptr(),
+                                       ops._DT[context.dtype], L, int(fps), B, T, H, W, pairs, ws.data_ptr(), nbytes, eps.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream), "ds_unet_forward")
+        return eps
+
+    def python_program_trace(self, B, T, H, W, ctx_tokens, cfg_pairs=0):
+        """The launch sequence of the Python restatement for this geometry, in ds_unet_trace's line format (no GPU needed: the
+        forward runs on shape-only "meta" tensors with every op replaced by a recorder, trace.py)."""
+        from . import trace
+        return trace.python_program_trace(self, B, T, H, W, ctx_tokens, cfg_pairs)
+
+    def c_program_trace(self, B, T, H, W, ctx_tokens, cfg_pairs=0):
+        """The C program's launch sequence for this geometry as a list of text lines (ds_unet_trace; no GPU needed)."""
+        import ctypes as C
+        lib = _lib.load()
+        own = None
+        h = self._handle
+        if h is None:                       # not prepared (e.g. on a machine without a GPU): a handle just for the trace
+            own = C.c_void_p()
+            cc = self._c_config()
+            _lib.check(lib.ds_unet_create(C.byref(cc), C.byref(own)), "ds_unet_create")
+            h = own
+        try:
+            n = lib.ds_unet_trace(h, B, T, H, W, ctx_tokens, cfg_pairs, None, 0)
+            if n < 0:
+                _lib.check(int(n), "ds_unet_trace")
+            buf = C.create_string_buffer(n + 1)
+            lib.ds_unet_trace(h, B, T, H, W, ctx_tokens, cfg_pairs, buf, n + 1)
+            return buf.value.decode().splitlines()
+        finally:
+            if own is not None:
+                lib.ds_unet_destroy(own)
 
 
 class DiffusionWrapper(nn.Module):

@@ -145,6 +145,9 @@ int ds_resize_latent(const void* in, void* out, int dtype, long planes, int hin,
                             x32..63 | gate32..63 | ...] and N counts x+gate columns; out has N/2 columns    */
 #define DS_EPI_SILU 2    /* out = silu(acc + bias)                                                          */
 #define DS_EPI_OUT_F32 4 /* store fp32 instead of fp16                                                     */
+#define DS_EPI_RES_F32 8 /* `residual` holds fp32 rows (ldr in fp32 elements): the strict-precision residual stream
+                            (ResBlock `skip + h`, openaimodel3d.py:237-254; transformer `+ x`, attention.py:216-220) added
+                            and -- with DS_EPI_OUT_F32 -- stored without an fp16 rounding.  Shared bias only, no GEGLU.  */
 
 typedef struct ds_gemm_desc {
     int32_t M, N, K;        /* C[M,N] = A'[M,K] * W[N,K]^T ; K = taps*Cin for conv modes; K % 64 == 0       */
@@ -174,7 +177,8 @@ typedef struct ds_gemm_desc {
  * SiLU epilogues.  Replaces nn.Linear, Conv2d 3x3, Conv2d 1x1, Conv1d 1x1 and Conv3d (3,1,1) call sites:
  * attention.py:54-57,63-64,242,258,379,399; openaimodel3d.py:155-159,174-184,186-193,65-72,98-111,275-300.
  * W: [N][K] fp16, K index = tap*Cin + c (conv weights pre-permuted by the host from [Cout,Cin,kh,kw]).
- * bias: fp32 [ceil(M/bias_rows)][ldbias] or NULL.  residual: fp16 [M][ldr] or NULL.  out: fp16/fp32 [M][ldc]. */
+ * bias: fp32 [ceil(M/bias_rows)][ldbias] or NULL.  residual: fp16 (fp32 with DS_EPI_RES_F32) [M][ldr] or NULL.
+ * out: fp16/fp32 [M][ldc]. */
 int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,
                 const ds_gemm_desc* desc, void* stream);
 /* LayerNorm folded into the projection that consumes it (BasicTransformerBlock: norm1 -> to_q/to_k/to_v, norm2 -> to_q,
@@ -214,9 +218,18 @@ int ds_groupnorm_f16(const void* x, const float* gamma, const float* beta, void*
    concatenates in, torch.cat([h, hs.pop()], dim=1) of openaimodel3d.py:700-703 without the copy.)                   */
 int ds_groupnorm_f16_strided(const void* x, int ldx, const float* gamma, const float* beta, void* y, float* workspace,
                              int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream);
+/* The general form: x fp16 or fp32 (x_dtype = DS_F16 / DS_F32) with row stride ldx, y fp16 dense [rows][C].  x_f16 (fp32 input
+   only, may be NULL): the raw x rounded to fp16, dense [rows][C], written in the same pass -- the matrix-core operand of a
+   projection that reads the un-normalised tensor (ResBlock skip_connection, openaimodel3d.py:186-193).  fp32 input is the
+   strict-precision mode's residual stream (UNetModel.residual_dtype).                                                  */
+int ds_groupnorm_rows(const void* x, int x_dtype, int ldx, const float* gamma, const float* beta, void* y, void* x_f16,
+                      float* workspace, int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream);
 /* nn.LayerNorm(C) eps 1e-5 over each row (attention.py:199-201). x,y fp16 [rows][C]. */
 int ds_layernorm(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
                  void* stream);
+/* the same for x fp16 or fp32 (x_dtype); y fp16. */
+int ds_layernorm_rows(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
+                      void* stream);
 /* The statistics half of nn.LayerNorm (attention.py:199-201): stats[row] = (mean, 1/sqrt(var + eps)) fp32 pairs, two-pass
  * like ds_layernorm.  The normalisation itself is folded into the consumer GEMM by ds_gemm_f16_ln. */
 int ds_layernorm_stats(const void* x, float* stats, int rows, int C, float eps, void* stream);
@@ -237,6 +250,10 @@ int ds_temporal_attention_f16(const void* q, const void* k, const void* v, void*
 
 /* dst[m][0:c1] = a[m][:], dst[m][c1:c1+c2] = b[m][:]  (torch.cat([h, hs.pop()], dim=1), openaimodel3d.py:701). */
 int ds_concat_channels(const void* a, const void* b, void* dst, int rows, int c1, int c2, void* stream);
+
+/* y[r][0:C] = fp16(x[r][0:C]): fp32 rows (stride ldx) -> fp16 rows (stride ldy).  Strict-precision mode: the fp16 matrix-core
+ * operand of a convolution that reads the fp32 residual stream directly (Downsample / Upsample, openaimodel3d.py:65-111). */
+int ds_cast_rows_f32_f16(const float* x, int ldx, void* y, int ldy, long rows, int C, void* stream);
 
 /* conv-in im2col: x [B][C][T][H][W] (geom dtype) -> patches fp16 [B*T*H*W][kpad], column (ky*3+kx)*C + c,
  * zero padded borders and columns >= 9*C (openaimodel3d.py:421, 682). */
@@ -293,6 +310,72 @@ int ds_clip_preprocess(const void* img, int dtype, float* out, int nimg, int C, 
 /* conv1 (patch embedding, kernel = stride = P, no bias; condition.py:342) as a GEMM: rows fp16 [nimg*(S/P)^2][kpad],
  * column c*P*P + py*P + px (the flattened conv weight's order), columns >= C*P*P zero. */
 int ds_patchify(const float* img, void* rows, int nimg, int C, int S, int P, int kpad, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * The UNet as ONE call: DiffusionWrapper.forward (lvdm/models/ddpm3d.py:702-712, crossattn branch) ->
+ * UNetModel.forward (lvdm/modules/networks/openaimodel3d.py:657-708).  The handle owns the block program (built from the
+ * yaml `unet_config.params`, openaimodel3d.py:340-655), the weight packing and the launch sequence over the kernels
+ * above; a host in any language with a C FFI can run the UNet.  dynamicscaler_amd.unet.UNetModel binds it (and keeps a
+ * Python restatement of the same launch program for per-launch instrumentation; the two are bit-identical).
+ * Lifecycle:  create -> load_weight x (every state-dict key) -> packed_bytes / pack -> [workspace_bytes -> forward]* -> destroy.
+ * The handle itself lives in host memory (create / destroy); every DEVICE buffer is the caller's.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ds_unet ds_unet;
+
+typedef struct ds_unet_config {          /* the yaml keys of unet_config.params that the VideoCrafter configs set            */
+    int32_t in_channels, out_channels, model_channels;
+    int32_t num_res_blocks;
+    int32_t n_channel_mult, channel_mult[8];
+    int32_t n_attention_resolutions, attention_resolutions[8];
+    int32_t num_head_channels;           /* 64 (the attention kernels' head width)                                          */
+    int32_t transformer_depth, temporal_transformer_depth;
+    int32_t context_dim;
+    int32_t use_linear;                  /* proj_in / proj_out as nn.Linear (1) or 1x1 conv (0): same arithmetic            */
+    int32_t temporal_conv, temporal_attention, addition_attention, use_image_attention, fps_cond;
+    int32_t residual_f32;                /* 0: fp16 residual stream; 1: strict mode, the stream in fp32 (DS_EPI_RES_F32)     */
+    int32_t fold_layernorm;              /* 1: LayerNorm folded into the projections (ds_gemm_f16_ln); forced off by residual_f32 */
+} ds_unet_config;
+
+/* Builds the block program; *out receives the handle.  Unsupported option combinations return DS_EINVAL. */
+int ds_unet_create(const ds_unet_config* cfg, ds_unet** out);
+int ds_unet_destroy(ds_unet* u);
+/* Number of state-dict tensors the model expects, and the i-th key / shape (the reference's names, incl. `temopral_conv`). */
+int ds_unet_num_weights(const ds_unet* u);
+int ds_unet_weight_info(const ds_unet* u, int i, const char** key, int* ndim, int64_t shape[5]);
+/* Registers one raw tensor of the reference's state dict: DEVICE pointer, contiguous, DS_F32 or DS_F16, in the reference's
+ * layout ([Cout,Cin,3,3] conv weights etc.).  The pointer must stay valid until ds_unet_pack returns. */
+int ds_unet_load_weight(ds_unet* u, const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
+/* Bytes of the packed-weight buffer, and the packing itself (async on `stream`): fp16 [N][K] GEMM operands (K = tap*Cin + c for
+ * convolutions), fused QKV / KV matrices, GEGLU rows interleaved, the time-embedding projections of all ResBlocks in one
+ * matrix, LayerNorm folded into the projection it feeds (fp16(gamma*W), column sums, beta.W + b).  `packed` must outlive
+ * every forward.  Fails if a key is missing. */
+size_t ds_unet_packed_bytes(const ds_unet* u);
+int ds_unet_pack(ds_unet* u, void* packed, size_t packed_bytes, void* stream);
+/* Layout of the packed buffer, for hosts that want to address single operands (the Python launch program does): item i is
+ * `name` at byte `offset`, `bytes` long, dtype DS_F16 (a [rows][bytes/rows/2] matrix) or DS_F32 (a vector of `rows` floats).
+ * ds_unet_emb_offset: first column of a ResBlock's slice in the fused time-embedding projection "emb_all" (its total width
+ * is the row count of "emb_all.w"). */
+int ds_unet_num_packed(const ds_unet* u);
+int ds_unet_packed_info(const ds_unet* u, int i, const char** name, size_t* offset, size_t* bytes, long* rows, int* dtype);
+int ds_unet_emb_offset(const ds_unet* u, const char* resblock_prefix);
+/* Scratch bytes one forward of this geometry needs (peak of the program's own arena: activations, concat buffers, norms'
+ * partial sums).  B = batch of independent evaluations, ctx_tokens = 77 (+ image tokens). */
+size_t ds_unet_workspace_bytes(ds_unet* u, int B, int T, int H, int W, int ctx_tokens, int cfg_pairs);
+/* eps[B][C_out][T][H][W] (fp32) = UNet(x[B][C][T][H][W] (x_dtype), timesteps int64 DEVICE [B], context [B][ctx_tokens][context_dim]
+ * (ctx_dtype), fps).  cfg_pairs = n > 0: the batch is [x_1..x_n | x_1..x_n] with only the context differing (classifier-free
+ * guidance); the context-free prefix is evaluated once per pair (bit-identical to cfg_pairs = 0).  Async on `stream`,
+ * capturable; nothing is allocated: all scratch comes from `workspace`. */
+int ds_unet_forward(ds_unet* u, const void* x, int x_dtype, const int64_t* timesteps, const void* context, int ctx_dtype,
+                    int ctx_tokens, int fps, int B, int T, int H, int W, int cfg_pairs, void* workspace, size_t workspace_bytes,
+                    float* eps, void* stream);
+/* The launch sequence of such a forward as text, one line per kernel call ("gemm M N K a_mode epilogue lda ldc ldr ..."), without
+ * launching anything (no GPU needed): what tests compare with the Python restatement of the program.  Returns the number of
+ * bytes written (excluding the terminator), or a negative DS_E* code; buf may be NULL to query the size. */
+long ds_unet_trace(ds_unet* u, int B, int T, int H, int W, int ctx_tokens, int cfg_pairs, char* buf, size_t buf_bytes);
+/* fp16 <- fp32/fp16 helpers the forward needs on its inputs (exported because a host needs them for its own staging):
+ * y[i] = fp16(x[i]). */
+int ds_cast_to_f16(const void* x, int x_dtype, void* y, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

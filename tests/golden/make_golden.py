@@ -408,6 +408,135 @@ def g17_cfg1_full():
     save_npz("cfg1_full_t2v.npz", **arrays)
 
 
+def g23_cfg1_50step():
+    """The schedule the metric runs on (50 DDIM steps), one 512x320x16f tile, real t2v UNet, CFG 7.5, through the reference's
+    own VC2_Pipeline_T2V.basic_sample (pipeline/t2v_normal_pipeline.py:69-210) and lvdm_DDIM_Scheduler.ddim_step
+    (pipeline/scheduler.py:60-96): ONE free-running 50-step run (100 forwards of the reference on CPU) storing x_prev every
+    5 steps + the final pred_x0, and -- at schedule indices TF_INDICES -- one teacher-forced update of the reference from the
+    run's own x_t rounded to fp16 (so that an fp16-latent build starts from identical numbers; 2 forwards each): x_t, the
+    guided e_t, x_prev; pred_x0 by SHA-256 (the oracle's ddim_step reproduces it from x_t and e_t bit for bit, G4).
+    ~2 h on 8 cores.  Partial results are flushed to cfg1_50step_t2v.partial.npz as the run goes."""
+    TF_INDICES = (49, 48, 47, 45, 40, 30, 25, 10, 1, 0)
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"          # plumbing check of this function on the toy UNet (seconds)
+    out_name = "cfg1_50step_dry.npz" if dry else "cfg1_50step_t2v.npz"
+    if dry:
+        params = TINY
+    unet = build_reference_unet(params, seed=0)
+    ctx_dim = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, ctx_dim), 1), synth_normal((1, 77, ctx_dim), 2)
+    guidance, fps, frames = 7.5, 8, (4 if dry else 16)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=frames)
+    sched = lvdm_DDIM_Scheduler(ld)
+    pipe = VC2_Pipeline_T2V(ld, sched, {"params": {"unet_config": {"params": params}}})
+    x_init = synth_normal((1, 4, frames, 8, 8) if dry else (1, 4, 16, 40, 64), 2333333)
+    arrays = {"x_init": x_init, "fps": np.int64(fps), "guidance": np.float32(guidance),
+              "tf_indices": np.asarray(TF_INDICES, np.int64)}
+    stats = []
+    orig_step = sched.ddim_step
+    n_calls = [0]
+
+    def recording_step(sample, noise_pred, indices):
+        import time
+        idx = int(indices[0])
+        x_prev, pred_x0 = orig_step(sample=sample, noise_pred=noise_pred, indices=indices)
+        stats.append((idx, float(sample.std()), float(noise_pred.std()), float(x_prev.std()), float(pred_x0.std())))
+        if idx % 5 == 0:
+            arrays[f"free_x_prev_{idx}"] = x_prev.clone()
+        if idx == 0:
+            arrays["free_pred_x0_0"] = pred_x0.clone()
+        if idx in TF_INDICES:
+            # teacher-forced update of the reference from the fp16-rounded x_t (same calls as basic_sample:171-201)
+            x_h = sample.to(torch.float16).to(torch.float32)
+            t = int(np.flip(sched.ddim_timesteps)[sched.ddim_timesteps.shape[0] - 1 - idx])
+            ts = torch.full((1,), t, dtype=torch.long)
+            kw = dict(fps=fps, curr_time_steps=ts, temporal_length=frames, clean_cond=True)
+            e_c = ld.model(x_h, ts, c_crossattn=[cond], **kw)
+            e_u = ld.model(x_h, ts, c_crossattn=[uncond], **kw)
+            e_t = e_u + guidance * (e_c - e_u)
+            xp, x0 = orig_step(sample=x_h, noise_pred=e_t, indices=indices)
+            arrays.update({f"tf_x_t_{idx}": x_h.to(torch.float16), f"tf_e_t_{idx}": e_t, f"tf_x_prev_{idx}": xp,
+                           f"tf_pred_x0_sha_{idx}": np.asarray(sha(x0)), f"tf_t_{idx}": np.int64(t),
+                           f"tf_e_cond_{idx}": e_c.to(torch.float16)})
+        n_calls[0] += 1
+        print(f"[{time.strftime('%H:%M:%S')}] step {n_calls[0]}: index {idx} |x_t| {stats[-1][1]:.4f} |e_t| {stats[-1][2]:.4f} "
+              f"|x_prev| {stats[-1][3]:.4f} |x0| {stats[-1][4]:.4f}", flush=True, file=sys.stderr)
+        if idx % 5 == 0 or idx in TF_INDICES:
+            save_npz(out_name.replace(".npz", ".partial.npz"), stats=np.asarray(stats, np.float64), **arrays)
+        return x_prev, pred_x0
+
+    sched.ddim_step = recording_step
+    torch.manual_seed(2333333)
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, den = pipe.basic_sample(prompt="a prompt", height=x_init.shape[3] * 8, width=x_init.shape[4] * 8, frames=frames,
+                                   fps=fps, guidance_scale=guidance, num_inference_steps=50, output_type="latent", latents=x_init.clone())
+    assert torch.equal(den, arrays["free_pred_x0_0"])
+    arrays["timesteps"] = np.flip(sched.ddim_timesteps).copy()
+    arrays["stats"] = np.asarray(stats, np.float64)          # (index, |x_t|, |e_t|, |x_prev|, |pred_x0|) per step
+    save_npz(out_name, **arrays)
+    os.remove(os.path.join(HERE, out_name.replace(".npz", ".partial.npz")))
+
+
+def g24_panorama_handlers():
+    """The four handler classes by name: PanoramaTensor (utils/panorama_tensor_utils.py:5-247), RingLatentProxy,
+    RingPanoramaTensor, RingPanoramaLatentProxy (utils/ring_panorama_tensor_utils.py:8-337): seeded tensors through a fixed
+    sequence of gets / sets (wrapping frame windows, duplicate scatter targets, the 4-tap splat); inputs and every result."""
+    from utils.panorama_tensor_utils import PanoramaTensor
+    from utils.ring_panorama_tensor_utils import RingLatentProxy, RingPanoramaTensor, RingPanoramaLatentProxy
+    A = {}
+    views = [(90.0, 30.0, 20.0), (120.0, -170.0, -60.0), (60.0, 0.0, 90.0)]
+    A["views"] = np.asarray(views, np.float64)
+    # PanoramaTensor with leading dims, without, and 2-D
+    for tag, shape in (("p4", (2, 3, 16, 32)), ("p3", (3, 16, 32)), ("p2", (16, 32))):
+        x = synth_normal(shape, 500 + len(shape))
+        h = PanoramaTensor(x)
+        A[f"{tag}_x"] = x
+        for vi, (fov, th, ph) in enumerate(views):
+            v, m = h.get_view_tensor_no_interpolate(fov, th, ph, 12, 10)
+            A[f"{tag}_get{vi}"], A[f"{tag}_mask{vi}"] = v, m
+        lead = shape[:-3] if len(shape) > 3 else (1,)
+        C = shape[-3] if len(shape) >= 3 else 1
+        for vi, (fov, th, ph) in enumerate(views):
+            src = synth_normal((*lead, C, 10, 12), 520 + vi)
+            A[f"{tag}_src{vi}"] = src
+            h.set_view_tensor_no_interpolation(src, fov, th, ph)
+            A[f"{tag}_after_set{vi}"] = h.equirect_tensor.clone()
+        src = synth_normal((*lead, C, 10, 12), 530)
+        A[f"{tag}_splat_src"] = src
+        h.set_view_tensor_bilinear(src, 90.0, 45.0, -30.0)
+        A[f"{tag}_after_splat"] = h.equirect_tensor.clone()
+    # RingLatentProxy: windows over dim 1
+    x = synth_normal((1, 5, 3, 16, 32), 540)
+    r = RingLatentProxy(x)
+    A["rl_x"] = x
+    A["rl_win_3_8"] = r.get_window_latent(3, 8)
+    A["rl_win_none"] = r.get_window_latent(None, None)
+    A["rl_win_1_10"] = r.get_window_latent(1, 10)
+    A["rl_shape_3_8"] = np.asarray(tuple(r.get_operating_shape(3, 8)), np.int64)
+    src = synth_normal((1, 3, 3, 16, 32), 541)
+    A["rl_src"] = src
+    r.set_window_latent(src, 4, 7)
+    A["rl_after_set"] = r.get_torch_latent().clone()
+    # RingPanoramaTensor [1, N, C, H, W] and RingPanoramaLatentProxy [1, C, N, H, W]
+    for tag, cls, shape, vshape in (("rp", RingPanoramaTensor, (1, 5, 3, 16, 32), lambda nf: (1, nf, 3, 10, 12)),
+                                    ("rpl", RingPanoramaLatentProxy, (1, 3, 5, 16, 32), lambda nf: (1, 3, nf, 10, 12))):
+        x = synth_normal(shape, 550)
+        h = cls(x)
+        A[f"{tag}_x"] = x
+        for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views, ((3, 7), (None, None), (4, 9)))):
+            v, m = h.get_view_tensor_no_interpolate(fov, th, ph, 12, 10, frame_begin=fb, frame_end=fe)
+            A[f"{tag}_get{vi}"], A[f"{tag}_mask{vi}"] = v.clone(), m
+        for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views, ((3, 7), (None, None), (4, 9)))):
+            nf = 5 if fb is None else fe - fb
+            src = synth_normal(vshape(nf), 560 + vi)
+            A[f"{tag}_src{vi}"] = src
+            h.set_view_tensor_no_interpolation(src, fov, th, ph, frame_begin=fb, frame_end=fe)
+            full = h.get_equirect_tensor() if tag == "rpl" else h.equirect_tensor_handler.get_torch_latent()
+            A[f"{tag}_after_set{vi}"] = full.clone()
+    save_npz("panorama_handlers.npz", **A)
+
 
 def g18_unet_t24(full=False):
     """BASELINE config 5 runs the UNet at T = 24 (`frames=24`, t2v_sphere_panorama_pipeline.py:411 -> UNetModel.forward with
@@ -1151,12 +1280,13 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale, "g22": g22_i2v_sphere_view_scale}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale, "g22": g22_i2v_sphere_view_scale, "g24": g24_panorama_handlers}
     if args.full:
         steps["g10"] = g10_unet_full
         steps["g10i"] = g10_unet_full_i2v
         steps["g17"] = g17_cfg1_full
         steps["g18"] = lambda: g18_unet_t24(full=True)
+        steps["g23"] = g23_cfg1_50step
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)

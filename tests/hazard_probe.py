@@ -30,8 +30,8 @@ from dynamicscaler_amd.unet import UNetModel  # noqa: E402
 from dynamicscaler_amd.unet_spec import param_shapes  # noqa: E402
 
 d = torch.device("cuda:0")
-OPS = ["gemm", "groupnorm", "layernorm", "attention", "temporal_attention", "concat_channels", "im2col_in",
-       "rows_to_ncthw", "timestep_embedding", "silu"]
+OPS = ["gemm", "gemm_ln", "groupnorm", "layernorm", "layernorm_stats", "cast_rows_f16", "attention", "temporal_attention",
+       "concat_channels", "im2col_in", "rows_to_ncthw", "timestep_embedding", "silu"]
 
 
 def toy_unet():

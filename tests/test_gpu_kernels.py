@@ -407,6 +407,94 @@ def test_layernorm(rows, C):
     assert relerr(y, F.layer_norm(x, (C,), g, b, 1e-5)) < 1e-3
 
 
+# ------------------------------------------------------------------------------------------------ strict-precision (fp32 residual stream) forms
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (257, 256, 128), (161 * 256 - 219, 320, 320), (160 * 256 + 3, 256, 64), (5, 192, 64)])
+@pytest.mark.parametrize("out_f32", [True, False])
+def test_gemm_fp32_residual(M, N, K, out_f32):
+    """DS_EPI_RES_F32: the residual rows are fp32 and are added without an fp16 rounding (ResBlock `skip + h`,
+    openaimodel3d.py:237-254; `+ x` of attention.py:216-220); with DS_EPI_OUT_F32 the sum is stored in fp32 too.  The residual
+    carries a component below fp16 resolution that has to survive."""
+    from dynamicscaler_amd import ops, _lib
+    d = dev()
+    A, W = _h(rnd((M, K), 1)), _h(rnd((N, K), 2, 0.1))
+    b = rnd((N,), 3)
+    R = rnd((M, N), 4) * 8 + 1e-4 * rnd((M, N), 5)                  # not fp16-representable
+    wide = torch.full((M, N + 12), 3.0, dtype=torch.float32, device=d)    # residual as a column slice of a wider fp32 buffer
+    wide[:, 8:8 + N] = R.to(d)
+    out = ops.gemm(A.half().to(d), W.half().to(d), b.to(d), wide[:, 8:8 + N], M=M, N=N, K=K,
+                   epilogue=_lib.DS_EPI_OUT_F32 if out_f32 else 0)
+    ref = (A.double() @ W.double().t() + b.double() + R.double()).float()
+    if out_f32:
+        assert out.dtype == torch.float32
+        assert relerr(out, ref) < 2e-6, relerr(out, ref)
+        assert float((out.cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    else:
+        assert out.dtype == torch.float16
+        assert torch.equal(out.cpu(), ref.half()) or relerr(out, ref.half().float()) < 2e-5   # one rounding of the fp32 sum
+    # into a column slice of a wider fp32 output buffer (the decoder's concat buffers), no bias
+    if out_f32:
+        obuf = torch.zeros((M, N + 24), dtype=torch.float32, device=d)
+        ops.gemm(A.half().to(d), W.half().to(d), None, wide[:, 8:8 + N], M=M, N=N, K=K, out=obuf[:, 16:16 + N])
+        ref2 = (A.double() @ W.double().t() + R.double()).float()
+        assert relerr(obuf[:, 16:16 + N], ref2) < 2e-6 and float(obuf[:, :16].abs().max()) == 0 and float(obuf[:, 16 + N:].abs().max()) == 0
+
+
+def test_gemm_fp32_residual_rejects_unsupported():
+    from dynamicscaler_amd import ops, _lib
+    d = dev()
+    A, W = torch.zeros((64, 64), dtype=torch.float16, device=d), torch.zeros((128, 64), dtype=torch.float16, device=d)
+    R = torch.zeros((64, 64), dtype=torch.float32, device=d)
+    with pytest.raises(_lib.DsError):      # GEGLU + fp32 residual
+        ops.gemm(A, W, None, R, M=64, N=128, K=64, epilogue=_lib.DS_EPI_GEGLU)
+    with pytest.raises(_lib.DsError):      # per-item bias + fp32 residual
+        ops.gemm(A, W[:64].contiguous(), torch.zeros((2, 64), device=d), R, M=64, N=64, K=64, bias_rows=32, ldbias=64)
+
+
+@pytest.mark.parametrize("ninst,rows,C", [(6, 80, 320), (2, 4 * 80, 64), (3, 40, 2560), (2, 700, 1920), (70, 33, 128), (64, 160, 1280)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm_fp32_input(ninst, rows, C, silu):
+    """ds_groupnorm_rows with DS_F32 rows (the fp32 residual stream): statistics and normalisation from the unrounded values,
+    fp16 operand out; optional fp16 copy of the raw rows in the same pass; input as a column slice of a wider buffer."""
+    from dynamicscaler_amd import ops
+    d = dev()
+    x = rnd((ninst * rows, C), 1) * 2 + 0.5 + 1e-4 * rnd((ninst * rows, C), 9)
+    g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    y, x16 = ops.groupnorm(x.to(d), g.to(d), b.to(d), ninst, rows, C, 1e-5, silu, raw_f16=True)
+    xr = x.double().reshape(ninst, rows, C).permute(0, 2, 1)
+    ref = F.group_norm(xr, 32, g.double(), b.double(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(ninst * rows, C).float()
+    assert y.dtype == torch.float16 and relerr(y, ref) < 4e-4          # one fp16 rounding of the output: 2^-11 / sqrt(3) ~ 2.8e-4
+    assert float((y.float().cpu() - ref.half().float()).abs().max()) <= 2 * float(torch.finfo(torch.float16).eps) * float(ref.abs().max())
+    assert torch.equal(x16.cpu(), x.half())
+    y1 = ops.groupnorm(x.to(d), g.to(d), b.to(d), ninst, rows, C, 1e-5, silu)
+    assert torch.equal(y1, y)
+    wide = torch.full((ninst * rows, C + 64), 7.0, dtype=torch.float32, device=d)
+    wide[:, 24:24 + C] = x.to(d)
+    y3 = ops.groupnorm(wide[:, 24:24 + C], g.to(d), b.to(d), ninst, rows, C, 1e-5, silu)
+    assert y3.is_contiguous() and torch.equal(y3, y)
+    # fp16 input through the same entry point stays what it was
+    yh = ops.groupnorm(x.half().to(d), g.to(d), b.to(d), ninst, rows, C, 1e-5, silu)
+    assert relerr(yh, ref) < 1.5e-3
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (77, 1280), (5, 64), (333, 512), (130, 2048)])
+def test_layernorm_fp32_input_and_cast(rows, C):
+    from dynamicscaler_amd import ops
+    d = dev()
+    x = rnd((rows, C), 1) * 3 + 1 + 1e-4 * rnd((rows, C), 7)
+    g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    y = ops.layernorm(x.to(d), g.to(d), b.to(d))
+    ref = F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-5).float()
+    assert y.dtype == torch.float16 and relerr(y, ref) < 4e-4
+    # ds_cast_rows_f32_f16: dense and strided input
+    assert torch.equal(ops.cast_rows_f16(x.to(d)).cpu(), x.half())
+    wide = torch.zeros((rows, C + 16), dtype=torch.float32, device=d)
+    wide[:, 8:8 + C] = x.to(d)
+    assert torch.equal(ops.cast_rows_f16(wide[:, 8:8 + C]).cpu(), x.half())
+
+
 @pytest.mark.parametrize("M,N,K,geglu", [(1000, 960, 320, False), (300, 320, 320, False), (77, 3840, 1280, False),
                                         (2100, 2560, 320, True), (130, 1024, 128, True), (5, 192, 64, False)])
 def test_gemm_layernorm_folded(M, N, K, geglu):

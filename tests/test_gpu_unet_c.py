@@ -1,0 +1,157 @@
+"""-m gpu: ds_unet_* -- the UNet as one C call (include/dynscaler_hip.h; DiffusionWrapper.forward -> UNetModel.forward,
+lvdm/models/ddpm3d.py:702-712, lvdm/modules/networks/openaimodel3d.py:657-708).
+
+  * the C launch program == the Python restatement of it, bit for bit (same packed operands, same kernels);
+  * the raw C-ABI flow a non-Python host would use (create -> load_weight -> pack -> workspace_bytes -> forward), driven
+    through ctypes without dynamicscaler_amd.unet, against the reference's golden eps;
+  * the full-size model through the C program against the reference's fp32 CPU forward.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(REPO, "tests", "golden")
+
+from test_gpu_fullsize import dev, T, relerr, t2v_params      # noqa: E402
+from test_gpu_unet import EPS_TOL, EPS_TOL_TINY               # noqa: E402
+
+
+def build_unet(params, seed, device, residual_dtype=torch.float16, program="c"):
+    from dynamicscaler_amd.unet import UNetModel
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    m = UNetModel(**params)
+    m.load_state_dict(synth_state_dict(param_shapes(params), seed), strict=True)
+    m.residual_dtype = residual_dtype
+    m.program = program
+    return m.to(device).eval()
+
+
+@pytest.mark.parametrize("name", ["t2v", "i2v"])
+@pytest.mark.parametrize("residual_dtype", [torch.float16, torch.float32])
+def test_c_program_equals_python_program_bitwise(name, residual_dtype):
+    d = dev()
+    from dynamicscaler_amd.synth import synth_normal
+    z = np.load(os.path.join(G, f"unet_tiny_{name}.npz"))
+    params = json.loads(bytes(z["params_json"]).decode())
+    m = build_unet(params, 5, d, residual_dtype)
+    x0, c0 = T(z["x_0"]), T(z["ctx_0"])
+    for n in (1, 3):
+        x = torch.cat([x0] + [synth_normal(x0.shape, 100 + k) for k in range(1, n)], 0)
+        ctx = torch.cat([synth_normal(c0.shape, 200 + k) for k in range(2 * n)], 0).to(d)
+        t = torch.tensor([500] * (2 * n), device=d)
+        for xdt in (torch.float16, torch.float32):
+            x2 = torch.cat([x, x], 0).to(d, xdt)
+            for pairs in (None, n):
+                kw = {"cfg_pairs": pairs} if pairs else {}
+                m.program = "c"
+                a = m(x2, t, context=ctx, fps=8, **kw)
+                m.program = "python"
+                b = m(x2, t, context=ctx, fps=8, **kw)
+                assert a.dtype == torch.float32 and torch.equal(a, b), (name, residual_dtype, n, xdt, pairs)
+        # the shared prefix is bit-identical in the C program too, and a batch equals its separate forwards
+        m.program = "c"
+        x2 = torch.cat([x, x], 0).to(d, torch.float16)
+        plain, shared = m(x2, t, context=ctx, fps=8), m(x2, t, context=ctx, fps=8, cfg_pairs=n)
+        assert torch.equal(plain, shared)
+        assert torch.equal(m(x2[:1], t[:1], context=ctx[:1], fps=8), plain[:1])
+    with pytest.raises(Exception):
+        m(x2, t, context=ctx, fps=8, cfg_pairs=2 * n)
+
+
+@pytest.mark.parametrize("name", ["t2v", "i2v"])
+def test_raw_c_abi_flow_vs_reference_golden(name):
+    """What a C / Go / Java host does: no dynamicscaler_amd.unet -- only the shared library and device pointers (torch here is
+    the allocator).  eps against the reference's own forward (tests/golden/unet_tiny_*.npz)."""
+    from dynamicscaler_amd import _lib
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    d = dev()
+    lib = _lib.load()
+    z = np.load(os.path.join(G, f"unet_tiny_{name}.npz"))
+    params = json.loads(bytes(z["params_json"]).decode())
+    cfg = _lib.UNetConfig()
+    for k in ("in_channels", "out_channels", "model_channels", "num_res_blocks", "transformer_depth", "context_dim"):
+        setattr(cfg, k, int(params[k]))
+    cfg.temporal_transformer_depth = int(params.get("temporal_transformer_depth", 1))
+    cfg.num_head_channels = int(params["num_head_channels"])
+    cfg.n_channel_mult = len(params["channel_mult"])
+    cfg.n_attention_resolutions = len(params["attention_resolutions"])
+    for i, v in enumerate(params["channel_mult"]):
+        cfg.channel_mult[i] = v
+    for i, v in enumerate(params["attention_resolutions"]):
+        cfg.attention_resolutions[i] = v
+    for k in ("use_linear", "temporal_conv", "temporal_attention", "addition_attention", "use_image_attention", "fps_cond"):
+        setattr(cfg, k, int(bool(params.get(k, False))))
+    cfg.fold_layernorm = 1
+    h = C.c_void_p()
+    _lib.check(lib.ds_unet_create(C.byref(cfg), C.byref(h)), "ds_unet_create")
+    try:
+        sd = {k: v.to(d) for k, v in synth_state_dict(param_shapes(params), 5).items()}
+        assert lib.ds_unet_num_weights(h) == len(sd)
+        for k, v in sd.items():
+            sh = (C.c_int64 * 5)(*list(v.shape))
+            _lib.check(lib.ds_unet_load_weight(h, k.encode(), v.data_ptr(), _lib.DS_F32, sh, v.dim()), "ds_unet_load_weight")
+        packed = torch.empty((lib.ds_unet_packed_bytes(h),), dtype=torch.uint8, device=d)
+        _lib.check(lib.ds_unet_pack(h, packed.data_ptr(), packed.numel(), None), "ds_unet_pack")
+        torch.cuda.synchronize()
+        del sd                                            # the raw tensors are not needed after the packing
+        for case in range(3):
+            x, t, ctx = T(z[f"x_{case}"]).to(d), T(z[f"t_{case}"]).to(d, torch.int64).reshape(-1), T(z[f"ctx_{case}"]).to(d)
+            B, _, Tn, H, W = x.shape
+            L = ctx.shape[1]
+            nws = lib.ds_unet_workspace_bytes(h, B, Tn, H, W, L, 0)
+            assert nws > 0
+            ws = torch.empty((nws,), dtype=torch.uint8, device=d)
+            eps = torch.empty((B, params["out_channels"], Tn, H, W), dtype=torch.float32, device=d)
+            _lib.check(lib.ds_unet_forward(h, x.data_ptr(), _lib.DS_F32, t.data_ptr(), ctx.data_ptr(), _lib.DS_F32, L, int(z[f"fps_{case}"]),
+                                           B, Tn, H, W, 0, ws.data_ptr(), nws, eps.data_ptr(), None), "ds_unet_forward")
+            torch.cuda.synchronize()
+            e = relerr(eps, T(z[f"eps_{case}"]))
+            print(f"raw C ABI, toy {name} case {case}: eps rel err {e:.3e}")
+            assert e < EPS_TOL_TINY
+            # a workspace one byte class too small is refused, not overrun
+            rc = lib.ds_unet_forward(h, x.data_ptr(), _lib.DS_F32, t.data_ptr(), ctx.data_ptr(), _lib.DS_F32, L, 8, B, Tn, H, W, 0,
+                                     ws.data_ptr(), nws // 2, eps.data_ptr(), None)
+            torch.cuda.synchronize()
+            assert rc != 0 and b"workspace" in lib.ds_last_error()
+    finally:
+        lib.ds_unet_destroy(h)
+
+
+def test_c_program_full_size_vs_reference_golden_and_python_program():
+    """The real t2v UNet through ds_unet_forward: eps against the reference's fp32 CPU forward, bit-equal to the Python program,
+    and the host time of an eager forward (the launch loop in C++ instead of ~800 ctypes calls)."""
+    import time
+    from dynamicscaler_amd.synth import synth_normal
+    d = dev()
+    z = np.load(os.path.join(G, "unet_full_t2v.npz"))
+    m = build_unet(t2v_params(), 0, d)
+    x = T(z["x"])
+    ctx = torch.cat([synth_normal((1, 77, 1024), 1), synth_normal((1, 77, 1024), 2)]).to(d)
+    x2 = torch.cat([x, x]).to(d, torch.float16)
+    t = torch.tensor([int(z["t"])] * 2, device=d)
+    out = {}
+    for prog in ("c", "python"):
+        m.program = prog
+        eps = m(x2, t, context=ctx, fps=int(z["fps"]), cfg_pairs=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eps = m(x2, t, context=ctx, fps=int(z["fps"]), cfg_pairs=1)
+        host = (time.perf_counter() - t0) / 3
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / 3
+        out[prog] = (eps, host, wall)
+    e1, e2 = relerr(out["c"][0][:1], T(z["eps_cond"])), relerr(out["c"][0][1:], T(z["eps_uncond"]))
+    print(f"C program, full UNet eps rel err: cond {e1:.3e} uncond {e2:.3e}; eager forward of one CFG pair: host {out['c'][1] * 1e3:.1f} ms "
+          f"(python program {out['python'][1] * 1e3:.1f} ms), wall {out['c'][2] * 1e3:.1f} ms (python program {out['python'][2] * 1e3:.1f} ms)")
+    assert e1 < EPS_TOL and e2 < EPS_TOL
+    assert torch.equal(out["c"][0], out["python"][0])

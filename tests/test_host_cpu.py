@@ -42,6 +42,85 @@ def test_struct_layouts_match_header():
         assert C.sizeof(cls) == 4 * len(names)
 
 
+def test_unet_config_struct_matches_header():
+    """ds_unet_config (the yaml keys the C program takes) field for field, arrays included."""
+    import ctypes as C
+    from dynamicscaler_amd import _lib
+    header = open(os.path.join(REPO, "include", "dynscaler_hip.h")).read()
+    body = re.search(r"typedef struct ds_unet_config \{(.*?)\} ds_unet_config;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names, words = [], 0
+    for decl in re.findall(r"int32_t\s+([^;]+);", body):
+        for n in decl.split(","):
+            m = re.match(r"\s*(\w+)(?:\[(\d+)\])?\s*$", n)
+            names.append(m.group(1))
+            words += int(m.group(2) or 1)
+    assert names == [f[0] for f in _lib.UNetConfig._fields_]
+    assert C.sizeof(_lib.UNetConfig) == 4 * words
+
+
+def _unet_configs():
+    import json
+    import yaml
+    import numpy as np
+    G = os.path.join(REPO, "tests", "golden")
+    out = {"tiny_t2v": json.loads(bytes(np.load(os.path.join(G, "unet_tiny_t2v.npz"))["params_json"]).decode()),
+           "tiny_i2v": json.loads(bytes(np.load(os.path.join(G, "unet_tiny_i2v.npz"))["params_json"]).decode())}
+    for name in ("t2v_512_v2_unet", "i2v_512_v1_unet"):
+        out[name] = yaml.safe_load(open(os.path.join(REPO, "dynamicscaler_amd", "configs", name + ".yaml")))
+    return out
+
+
+def test_c_unet_program_parameter_table_equals_the_reference_state_dict_keys():
+    """ds_unet_weight_info enumerates exactly unet_spec.param_shapes (= the reference's UNetModel.state_dict(), checked against
+    the imported reference by make_golden.py's build_reference_unet) in the same order."""
+    import ctypes as C
+    from dynamicscaler_amd import _lib
+    from dynamicscaler_amd.unet import UNetModel
+    from dynamicscaler_amd.unet_spec import param_shapes
+    lib = _lib.load()
+    for name, params in _unet_configs().items():
+        m = UNetModel(**params)
+        h, cc = C.c_void_p(), m._c_config()
+        assert lib.ds_unet_create(C.byref(cc), C.byref(h)) == 0
+        key, nd, shp = C.c_char_p(), C.c_int(), (C.c_int64 * 5)()
+        got = []
+        for i in range(lib.ds_unet_num_weights(h)):
+            assert lib.ds_unet_weight_info(h, i, C.byref(key), C.byref(nd), shp) == 0
+            got.append((key.value.decode(), tuple(shp[:nd.value])))
+        assert got == [(k, tuple(v)) for k, v in param_shapes(params).items()], name
+        assert lib.ds_unet_packed_bytes(h) > 0 and lib.ds_unet_workspace_bytes(h, 2, 4, 8, 8, 77, 1) > 0
+        assert lib.ds_unet_load_weight(h, b"no.such.key", 16, 1, shp, 1) != 0 and b"unexpected key" in lib.ds_last_error()
+        assert lib.ds_unet_pack(h, 256, 1 << 40, None) != 0 and b"missing weight" in lib.ds_last_error()
+        assert lib.ds_unet_destroy(h) == 0
+    bad = _lib.UNetConfig()
+    h = C.c_void_p()
+    assert lib.ds_unet_create(C.byref(bad), C.byref(h)) != 0
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_c_unet_program_issues_the_same_launches_as_the_python_program(strict):
+    """The C launch program (ds_unet_trace: csrc/unet_program.hip run dry) and the Python restatement (UNetModel.forward on
+    shape-only tensors with recording ops, dynamicscaler_amd/trace.py) issue the same kernel calls with the same descriptors
+    -- toy and both real configs, plain and shared-CFG-prefix batches, T = 16 and 24, fp16 and fp32 residual stream."""
+    import torch
+    from dynamicscaler_amd import trace
+    from dynamicscaler_amd.unet import UNetModel
+    for name, params in _unet_configs().items():
+        m = UNetModel(**params)
+        m.residual_dtype = torch.float32 if strict else torch.float16
+        L = 93 if params.get("use_image_attention") else 77
+        geoms = [(2, 4, 8, 8, 0), (2, 4, 8, 8, 1), (6, 4, 16, 8, 3)] if name.startswith("tiny") else [(2, 16, 40, 64, 1), (2, 24, 40, 64, 0)]
+        for (B, T, H, W, pairs) in geoms:
+            c_lines = m.c_program_trace(B, T, H, W, L, pairs)
+            a, b = trace.kernel_lines(c_lines), trace.kernel_lines(m.python_program_trace(B, T, H, W, L, pairs))
+            assert len(a) > 100 and a == b, (name, (B, T, H, W, pairs), next((x, y) for x, y in zip(a, b) if x != y))
+            assert any(ln.startswith("gemm_ln ") for ln in a) == (not strict)
+            assert any(ln.startswith("cast_rows ") for ln in a) == strict
+            if pairs:
+                assert sum(ln.startswith("copy ") for ln in c_lines) >= 4       # the duplicated prefix: x, h and the skip halves
+
+
 def test_product_never_imports_oracle_or_reference():
     pkg = os.path.join(REPO, "dynamicscaler_amd")
     for root, _, files in os.walk(pkg):
@@ -311,7 +390,8 @@ from pipeline.i2v_normal_pipeline import VC2_Pipeline_I2V
 from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
 from pipeline.scheduler import lvdm_DDIM_Scheduler
 from utils.shift_window_utils import RingLatent, RingImageTensor, get_dimension_slices_and_sizes
-from utils.panorama_tensor_utils import PanoramaLatentProxy
+from utils.panorama_tensor_utils import PanoramaLatentProxy, PanoramaTensor
+from utils.ring_panorama_tensor_utils import RingPanoramaLatentProxy, RingPanoramaTensor, RingLatentProxy
 from utils.tensor_utils import mix_latents_with_mask
 from utils.diffusion_utils import resize_video_latent
 from utils.multi_prompt_utils import select_prompt_from_multi_prompt_dict_by_factor

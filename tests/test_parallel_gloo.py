@@ -17,11 +17,27 @@ def _update(tile, j):
     return tile * 0.5 + (j + 1), tile * 0.25 - (j + 1)
 
 
-def _run_step(pano, pano_x0, wins, pano_fhw, rank, world):
-    """parallel.run_step -- the scheduling the HIP pipelines run -- with a CPU stand-in for the tile compute."""
+def _run_step(pano, pano_x0, wins, pano_fhw, rank, world, with_units=False):
+    """parallel.run_step -- the scheduling the HIP pipelines run -- with a CPU stand-in for the tile compute.
+    with_units: also hand over the per-evaluation stages (parallel.EvalUnits), the stand-in's two "branches" being the two
+    halves of _update -- what lets a level with fewer tiles than ranks be shared out by evaluation (the CFG split)."""
     from dynamicscaler_amd import parallel
     from oracle import ring as oring
     shape = (0, pano.shape[1], wins[0][5] - wins[0][4], wins[0][3] - wins[0][2], wins[0][1] - wins[0][0])
+
+    def u_prepare(ids):
+        return ids, torch.cat([oring.ring_gather(pano, *wins[j]) for j in ids])
+
+    def u_eps(ctx, units):
+        ids, tiles = ctx
+        if not units:
+            return torch.empty(shape)
+        return torch.cat([_update(tiles[k:k + 1], ids[k])[b] for k, b in units])
+
+    def u_finish(ctx, e_all):
+        return e_all[:, 0].contiguous(), e_all[:, 1].contiguous()
+
+    units = parallel.EvalUnits(2, u_prepare, u_eps, u_finish) if with_units else None
 
     def process(ids):
         xp, x0 = [], []
@@ -40,10 +56,10 @@ def _run_step(pano, pano_x0, wins, pano_fhw, rank, world):
             oring.ring_scatter(pano, xp[n:n + 1], l, r, t, d, fb, fe)
             oring.ring_scatter(pano_x0, x0[n:n + 1], l, r, t, d, fb, fe)
 
-    return parallel.run_step(wins, pano_fhw, rank, world, process, scatter, lambda: torch.empty(shape))
+    return parallel.run_step(wins, pano_fhw, rank, world, process, scatter, lambda: torch.empty(shape), units=units)
 
 
-def _worker(rank, world, port, steps, geom_name, out):
+def _worker(rank, world, port, steps, geom_name, out, with_units=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,7 +71,7 @@ def _worker(rank, world, port, steps, geom_name, out):
     pano_x0 = torch.zeros_like(pano)
     modes = set()
     for step in rec["trace"][:steps]:
-        modes.add(_run_step(pano, pano_x0, [tuple(w) for w in step["windows"]], fhw, rank, world))
+        modes.add(_run_step(pano, pano_x0, [tuple(w) for w in step["windows"]], fhw, rank, world, with_units))
     out[rank] = (pano, pano_x0, sorted(modes))
     if world > 1:
         dist.barrier()
@@ -70,17 +86,19 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("geom_name,steps,world,mode", [
-    ("cfg3_4096x512", 3, 2, "components"),        # 8 columns of 2 dependent tiles: 4 columns per rank, one exchange per step
-    ("cfg2_2048x512", 2, 3, "components"),        # 4 columns over 3 ranks: uneven tile counts (4 / 2 / 2) in the all-gather
-    ("cfg3_overlap_nw10", 2, 2, "levels"),        # W overlap: one chain -> a strided share of every level
+@pytest.mark.parametrize("geom_name,steps,world,mode,with_units", [
+    ("cfg3_4096x512", 3, 2, "components", False),     # 8 columns of 2 dependent tiles: 4 columns per rank, one exchange per step
+    ("cfg2_2048x512", 2, 3, "components", True),      # 4 columns over 3 ranks: uneven tile counts (4 / 2 / 2) in the all-gather
+    ("cfg3_overlap_nw10", 2, 2, "levels", False),     # W overlap: one chain -> a strided share of every level
+    ("cfg2_2048x512", 2, 5, "units", True),           # 4 columns < 5 ranks: levels of 4 tiles shared out as 8 evaluations (2/2/2/1/1)
+    ("cfg3_overlap_nw10", 1, 3, "units", True),       # one chain: levels of 1-2 tiles over 3 ranks, by evaluation
 ])
-def test_ranks_equal_single_process(geom_name, steps, world, mode):
+def test_ranks_equal_single_process(geom_name, steps, world, mode, with_units):
     mgr = mp.Manager()
     single = mgr.dict()
     _worker(0, 1, 0, steps, geom_name, single)
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), steps, geom_name, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, geom_name, out, with_units), nprocs=world, join=True)
     for r in range(world):
         assert torch.equal(out[r][0], single[0][0]) and torch.equal(out[r][1], single[0][1])
         assert out[r][2] == [mode]
