@@ -176,17 +176,20 @@ def main():
     extra = {}
     if cfg["model"] == "i2v":
         # config 4: input/pano_surfing_1.png is absent from the reference tree, so the panorama image is
-        # synthetic; every window takes the 16 image tokens of the crop under it.  The image tower + Resampler are the
-        # next-row components (N3); here a seeded stand-in maps a crop to [1,16,1024] tokens so that the measured path is
-        # the denoising loop with its 93-token contexts, cached per crop position like the product pipeline does.
+        # synthetic; every window takes the 16 image tokens of the crop under it through the REAL conditioning path
+        # (LatentVisualDiffusion.get_image_embeds, ddpm3d.py:689-693): the HIP OpenCLIP ViT-H/14 image tower
+        # (encoders.FrozenOpenCLIPImageEmbedderV2: preprocess + 32 blocks, all 257 tokens) and the Resampler, synthetic
+        # weights, cached per crop position by the pipeline like the product does.
         from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano as Pipe
+        from dynamicscaler_amd.encoders import FrozenOpenCLIPImageEmbedderV2, Resampler
+        from dynamicscaler_amd.encoder_spec import CLIP_VIT_H_14, RESAMPLER_I2V, clip_vision_param_shapes, resampler_param_shapes
+        from dynamicscaler_amd.synth import synth_encoder_state_dict
 
-        def image_tokens(batch_imgs):
-            seed = 1000 + int(batch_imgs.float().abs().sum().item() * 16) % 100000
-            return synth_normal((batch_imgs.shape[0], 16, params["context_dim"]), seed).to(batch_imgs.device)
-
-        ld.embedder = True                                   # marks the host as image-conditioned (uncond image tokens)
-        ld.get_image_embeds = image_tokens
+        ld.embedder = FrozenOpenCLIPImageEmbedderV2()
+        ld.embedder.load_state_dict(synth_encoder_state_dict(clip_vision_param_shapes(CLIP_VIT_H_14["vision"]), 71))
+        ld.image_proj_model = Resampler(**RESAMPLER_I2V)
+        ld.image_proj_model.load_state_dict(synth_encoder_state_dict(resampler_param_shapes(**RESAMPLER_I2V), 72))
+        ld.to(dev)
         extra = dict(pano_image_tensor=synth_normal((3, GEOM["total_h"], GEOM["total_w"]), 77).clamp(-1, 1),
                      overlap_ratio_list_f=[0.0] * GEOM["num_inference_steps"])
     else:
@@ -308,26 +311,36 @@ def main():
             pass
         # HBM bytes per GEMM launch: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_summary.py) cannot
         # run inside this process; the committed summary of the same workload is quoted, with its source
-        traffic, traffic_src = None, None
+        # `traffic` is only reported when that summary was captured on THIS kernel source (it records the SHA-256 of
+        # csrc/gemm.hip); a summary of an older build is named under quoted_from_profile, marked stale, and traffic is null.
+        import glob
+        import hashlib
+        import re
+        cur = hashlib.sha256(open(os.path.join(REPO, "dynamicscaler_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
+        traffic, traffic_src, traffic_stale = None, None, None
         try:
-            import glob
-            import re
             src = max(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic_v*.json")),
                       key=lambda f: tuple(int(x) for x in re.findall(r"r(\d+)_pmc_hbm_traffic_v(\d+)", f)[0]))
-            traffic = json.load(open(src))["gemm_f16_kernel(all)"]["hbm_bytes_per_launch"]
+            summ = json.load(open(src))
             traffic_src = os.path.relpath(src, REPO)
+            traffic_stale = summ.get("gemm_hip_sha256") != cur
+            if not traffic_stale:
+                traffic = summ["gemm_f16_kernel(all)"]["hbm_bytes_per_launch"]
         except Exception:
             pass
         # the same figure from the committed rocprofv3 --kernel-trace --stats summary of this command (one stream, so that a
         # kernel's duration is its own): algorithmic FLOPs of this run / the profile's GEMM time per step
         rocprof = None
         try:
-            src = os.path.join(REPO, "profiles", "r2_rocprof_step_summary_cfg3_1stream.json")
-            if args.config == "cfg3" and os.path.exists(src):
-                fam = json.load(open(src))["families"]["gemm"]
+            cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_rocprof_step_summary_cfg3_1stream.json")))
+            src = cands[-1] if cands else ""
+            if args.config == "cfg3" and os.path.exists(src) and unet.residual_dtype == torch.float16:
+                summ = json.load(open(src))
+                fam = summ["families"]["gemm"]
                 rp = g[1] / (fam["ms_per_step"] * 1e-3) / 1e12
                 rocprof = {"avg_launch_us": round(fam["avg_launch_us"], 1), "achieved": round(rp, 1),
                            "frac": round(rp * 1e12 / MFMA_PEAK_F16, 4), "source": os.path.relpath(src, REPO),
+                           "stale": summ.get("gemm_hip_sha256") != cur,
                            "note": "HIP-event bracketing adds a few us per launch; the two figures agree within run-to-run "
                                    "variation of the box (the chip's clock under load differs from box to box)"}
         except Exception:
@@ -336,11 +349,14 @@ def main():
             "bound": "mfma", "kernel": "gemm_f16_kernel (implicit GEMM: linear / conv3x3 / temporal conv)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / MFMA_PEAK_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(g[3] / g[0]),
+            "algorithmic_bytes_per_launch": round(g[3] / g[0]),
             "measured_with": "per-launch HIP events on one extra step, one stream, eager launches, tile batch %d" % args.tile_batch,
-            "vendor_library_gemm_tflops_on_this_box": lib_tf, "rocprof": rocprof,
-            "pmc_summary": "profiles/r2_pmc_mfma_util.json (MFMA busy, wait / issue shares, VALU:MFMA, LDS bank conflicts, clock and "
-                           "HBM bytes of the top shapes)",
+            "vendor_library_gemm_tflops_on_this_box": lib_tf,
+            # figures that do NOT come from this run: committed rocprofv3 / PMC summaries of the same command (PMC passes cannot run
+            # inside this process); "stale" = captured on a different csrc/gemm.hip than the one that just ran
+            "quoted_from_profile": {"traffic_source": traffic_src, "traffic_stale": traffic_stale, "rocprof": rocprof,
+                                    "pmc_summary": "profiles/*_pmc_mfma_util.json (MFMA busy, wait / issue shares, VALU:MFMA, LDS bank "
+                                                   "conflicts, clock and HBM bytes of the top shapes)"},
             "launches_per_step": g[0], "algorithmic_tflop_per_step": round(g[1] / 1e12, 2),
             "avg_launch_us": round(1e6 * g[2] / g[0], 2), "gemm_time_share_of_step": round(g[2] / (elapsed / args.steps), 3),
             "attention_tflops": round(agg["attention"][1] / agg["attention"][2] / 1e12, 2) if "attention" in agg else None,
@@ -396,6 +412,9 @@ def main():
                        "tiles_per_step": tiles_per_step, "unet_evals_per_step": 2 * tiles_per_step,
                        "tile_batch": args.tile_batch, "streams": args.streams, "hipgraph": bool(args.graph), "cfg_prefix_shared": bool(args.share_cfg_prefix), "parallelism": f"tiles sharded over {world} GPU(s)",
                        "rng": "philox in-kernel (perf mode)",
+                       "residual_stream": "fp32 (strict precision mode, DS_RESIDUAL_DTYPE=f32)" if unet.residual_dtype == torch.float32
+                                          else "fp16 (default; matrix-core operands are fp16 in both modes)",
+                       "unet_program": f"{unet.program} (ds_unet_forward: launch loop in C++)" if unet.program == "c" else "python (one ctypes call per kernel)",
                        "bit_repeatable": "yes, in every mode (streams x hipGraph included): the cause of round 1's run-to-run "
                                          "differences under concurrent graph replays is fixed (profiles/r2_notes.md section 1)"},
             "sec_per_50_step_panorama": full_s if full_s is not None else 50 * elapsed / args.steps,

@@ -110,7 +110,8 @@ _FORCE_LEVELS = False      # share_mode("levels"): always share every level out 
 
 
 def share_mode(mode):
-    """'auto' (default): whole components per rank when there are enough of them; 'levels': always share levels."""
+    """'auto' (default): whole components per rank when there are enough of them, else levels shared out by tile -- or by
+    evaluation where a level has fewer tiles than ranks; 'levels': always share every level out by tile (A/B runs)."""
     global _FORCE_LEVELS
     _FORCE_LEVELS = mode == "levels"
 
@@ -235,7 +236,7 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
         return "components"
     mode = "levels"
     for level in levels:
-        if units is not None and len(level) < world and units.branches > 1:
+        if units is not None and not _FORCE_LEVELS and len(level) < world and units.branches > 1:
             # fewer tiles than ranks: share the level out by (tile, branch) evaluation -- the cross-rank CFG split
             mode = "units"
             n, nb = len(level), units.branches

@@ -411,6 +411,8 @@ class UNetModel(nn.Module):
         timesteps = timesteps.to(dev, torch.int64).reshape(-1)
         if timesteps.numel() == 1 and B > 1:
             timesteps = timesteps.expand(B).contiguous()
+        if pairs and (2 * pairs != B or not any(b.kind == "st" for g in self._inputs for b in g)):
+            raise ValueError(f"cfg_pairs={pairs} needs a batch of {2 * pairs} (got {B}) and a SpatialTransformer in the input path")
         if (self.program == "c" and not tracing and self._tap is None and ops._timing_hook is None and isinstance(fps, int)
                 and self.fold_layernorm != "kernel" and x.dtype in ops._DT):
             return self._forward_c(x, timesteps.contiguous(), context, fps, int(pairs or 0))
@@ -443,8 +445,6 @@ class UNetModel(nn.Module):
             ctx = (context.to(torch.float16).reshape(B * L, -1).contiguous(), None, L, 0)
 
         shared = bool(pairs)                      # still on the context-free prefix of a [cond | uncond] pair batch
-        if shared and (2 * pairs != B or not any(b.kind == "st" for g in self._inputs for b in g)):
-            raise ValueError(f"cfg_pairs={pairs} needs a batch of {2 * pairs} (got {B}) and a SpatialTransformer in the input path")
 
         def dup(t):
             return torch.cat([t, t], 0)

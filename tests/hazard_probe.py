@@ -40,6 +40,7 @@ def toy_unet():
     m = UNetModel(**params)
     m.load_state_dict(synth_state_dict(param_shapes(params), 5), strict=True)
     m = m.to(d).eval()
+    m.program = "python"     # the probe interposes on single kernel calls
     m.prepare(d)
     return m, params
 

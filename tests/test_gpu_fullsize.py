@@ -239,14 +239,16 @@ def test_no_kernel_reads_uninitialised_cu_state(size):
         else:
             x, ctx, kw = tiles, synth_normal((n, 77, cdim), 61).to(d), {}
         ts = torch.full((x.shape[0],), 500, device=d, dtype=torch.long)
-        clean = m(x, ts, context=ctx, fps=8, **kw).clone()
+        clean = m(x, ts, context=ctx, fps=8, **kw).clone()          # the default program (ds_unet_forward)
         proxy = Poisoned(lib)
         _lib._lib = proxy
+        prog, m.program = m.program, "python"      # one ctypes call per kernel: the poison launch goes in front of each
         try:
             dirty = m(x, ts, context=ctx, fps=8, **kw).clone()
             torch.cuda.synchronize()
         finally:
             _lib._lib = lib
+            m.program = prog
         assert proxy.calls > 100
         assert bool(torch.isfinite(clean).all())
         assert torch.equal(clean, dirty), f"{size} {shape}: {int((clean != dirty).sum())} elements changed by the poison run " \
@@ -304,6 +306,7 @@ def test_concurrent_graph_replays_repeatable(size):
         m = UNetModel(**params)
         m.load_state_dict(synth_state_dict(param_shapes(params), 5), strict=True)
         m = m.to(d).eval()
+        m.program = "python"           # per-kernel outputs are kept through the ops wrappers below
         m.prepare(d)
         shape, cdim, n, rounds = (2, 4, 4, 8, 16), 64, 2, 120
     else:

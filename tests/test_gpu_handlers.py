@@ -1,6 +1,9 @@
-"""-m gpu: the reference's panorama tensor handlers by name (dynamicscaler_amd/panorama_tensors.py) against vectors recorded
-from the reference's own classes (tests/golden/panorama_handlers.npz, make_golden.py g24) -- data movement only, so every
-result is bit-exact."""
+"""-m gpu: the reference's panorama tensor handlers by name (dynamicscaler_amd/panorama_tensors.py).
+
+Data movement only, so the product equals the CPU restatement (oracle/handlers.py, pinned on the reference's own classes by
+tests/golden/panorama_handlers.npz, tests/test_oracle_golden.py) BIT FOR BIT when both compute their index maps on the same
+host.  Against the golden itself (maps computed on the build host) single pixels may differ -- fp32 trigonometry is not
+bit-identical across CPU vendors -- so that comparison allows MAP_MISMATCH of the elements to differ."""
 import os
 
 import numpy as np
@@ -10,6 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(__file__), "golden")
+MAP_MISMATCH = 0.03
 
 
 def dev():
@@ -22,30 +26,47 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
+def near(a, golden, rtol=0.0):
+    """At most MAP_MISMATCH of the elements differ (by more than rtol: the splat's weights come from the same host trigonometry,
+    so its sums differ in the last bits between hosts even where the index map agrees)."""
+    a, golden = a.float().cpu(), T(golden).float()
+    assert tuple(a.shape) == tuple(golden.shape)
+    return float(((a - golden).abs() > rtol * golden.abs().clamp_min(1.0)).float().mean()) <= MAP_MISMATCH
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-def test_panorama_tensor_vs_reference(dtype):
+def test_panorama_tensor_vs_oracle_and_reference_golden(dtype):
     """PanoramaTensor (utils/panorama_tensor_utils.py:5-247): nearest gather + mask, floor scatter with the last-writer rule,
     4-tap splat; with leading dims, [C,H,W] and [H,W] inputs.  fp16: the same movement of the rounded values."""
     from dynamicscaler_amd.panorama_tensors import PanoramaTensor
+    from oracle import handlers as oh
     d = dev()
     z = np.load(os.path.join(G, "panorama_handlers.npz"))
     views = [tuple(float(a) for a in v) for v in z["views"]]
-    q = (lambda t: t.to(dtype).float()) if dtype == torch.float16 else (lambda t: t)
     for tag in ("p4", "p3", "p2"):
-        x = T(z[f"{tag}_x"])
-        h = PanoramaTensor(x.to(d, dtype))
+        x = T(z[f"{tag}_x"]).to(dtype)
+        h, o = PanoramaTensor(x.to(d)), oh.PanoramaTensor(x.float())
         assert tuple(h.equirect_tensor.shape) == tuple(z[f"{tag}_after_set0"].shape)
         for vi, (fov, th, ph) in enumerate(views):
             v, m = h.get_view_tensor_no_interpolate(fov, th, ph, 12, 10)
+            ov, om = o.get_view_tensor_no_interpolate(fov, th, ph, 12, 10)
             assert tuple(v.shape) == tuple(z[f"{tag}_get{vi}"].shape) and v.dtype == dtype and m.dtype == dtype
-            assert torch.equal(v.float().cpu(), q(T(z[f"{tag}_get{vi}"]))) and torch.equal(m.float().cpu(), T(z[f"{tag}_mask{vi}"]))
-        if dtype == torch.float16:
-            continue                      # sets in fp16 move rounded values: checked through the fp32 path's index maps
+            assert torch.equal(v.float().cpu(), ov) and torch.equal(m.float().cpu(), om), (tag, vi)
+            if dtype == torch.float32:
+                assert near(v, z[f"{tag}_get{vi}"]) and near(m, z[f"{tag}_mask{vi}"])
         for vi, (fov, th, ph) in enumerate(views):
-            h.set_view_tensor_no_interpolation(T(z[f"{tag}_src{vi}"]).to(d), fov, th, ph)
-            assert torch.equal(h.equirect_tensor.cpu(), T(z[f"{tag}_after_set{vi}"])), (tag, vi)
-        h.set_view_tensor_bilinear(T(z[f"{tag}_splat_src"]).to(d), 90.0, 45.0, -30.0)
-        assert torch.equal(h.equirect_tensor.cpu(), T(z[f"{tag}_after_splat"])), tag
+            src = T(z[f"{tag}_src{vi}"]).to(dtype)
+            h.set_view_tensor_no_interpolation(src.to(d), fov, th, ph)
+            o.set_view_tensor_no_interpolation(src.float(), fov, th, ph)
+            assert torch.equal(h.equirect_tensor.float().cpu(), o.equirect_tensor), (tag, vi)
+            if dtype == torch.float32:
+                assert near(h.equirect_tensor, z[f"{tag}_after_set{vi}"])
+        if dtype == torch.float32:           # the splat's weighted sums: fp32 only (bit-exact in the reference's index_add_ order)
+            src = T(z[f"{tag}_splat_src"])
+            h.set_view_tensor_bilinear(src.to(d), 90.0, 45.0, -30.0)
+            o.set_view_tensor_bilinear(src, 90.0, 45.0, -30.0)
+            assert torch.equal(h.equirect_tensor.cpu(), o.equirect_tensor), tag
+            assert near(h.equirect_tensor, z[f"{tag}_after_splat"], rtol=1e-4)
     with pytest.raises(NotImplementedError):
         h.get_view_tensor_interpolate(90.0, 0.0, 0.0, 12, 10)
     with pytest.raises(AssertionError):
@@ -54,14 +75,15 @@ def test_panorama_tensor_vs_reference(dtype):
         PanoramaTensor(torch.zeros((3, 16, 32)))                      # no CPU path
 
 
-def test_ring_handlers_vs_reference():
+def test_ring_handlers_vs_oracle_and_reference_golden():
     """RingLatentProxy / RingPanoramaTensor / RingPanoramaLatentProxy (utils/ring_panorama_tensor_utils.py): wrapping frame
-    windows (incl. a window longer than the ring and the default full window), scatter into a wrapped window."""
+    windows (incl. the default full window), scatter into a wrapped window."""
     from dynamicscaler_amd.panorama_tensors import RingLatentProxy, RingPanoramaTensor, RingPanoramaLatentProxy
+    from oracle import handlers as oh
     d = dev()
     z = np.load(os.path.join(G, "panorama_handlers.npz"))
     views = [tuple(float(a) for a in v) for v in z["views"]]
-    r = RingLatentProxy(T(z["rl_x"]).to(d))
+    r = RingLatentProxy(T(z["rl_x"]).to(d))                            # pure ring arithmetic: no trigonometry, golden bit-exact
     assert torch.equal(r.get_window_latent(3, 8).cpu(), T(z["rl_win_3_8"]))
     assert torch.equal(r.get_window_latent(None, None).cpu(), T(z["rl_win_none"]))
     assert torch.equal(r.get_window_latent(1, 10).cpu(), T(z["rl_win_1_10"]))
@@ -73,15 +95,21 @@ def test_ring_handlers_vs_reference():
     with pytest.raises(AssertionError):
         r.set_window_latent(torch.zeros((1, 6, 3, 16, 32), device=d), 0, 6)   # "warp should not occur"
     windows = ((3, 7), (None, None), (4, 9))
-    for tag, cls in (("rp", RingPanoramaTensor), ("rpl", RingPanoramaLatentProxy)):
-        h = cls(T(z[f"{tag}_x"]).to(d))
+    for tag, cls, ocls in (("rp", RingPanoramaTensor, oh.RingPanoramaTensor), ("rpl", RingPanoramaLatentProxy, oh.RingPanoramaLatentProxy)):
+        h, o = cls(T(z[f"{tag}_x"]).to(d)), ocls(T(z[f"{tag}_x"]))
         for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views, windows)):
             v, m = h.get_view_tensor_no_interpolate(fov, th, ph, 12, 10, frame_begin=fb, frame_end=fe)
+            ov, om = o.get_view_tensor_no_interpolate(fov, th, ph, 12, 10, frame_begin=fb, frame_end=fe)
             assert tuple(v.shape) == tuple(z[f"{tag}_get{vi}"].shape)
-            assert torch.equal(v.cpu(), T(z[f"{tag}_get{vi}"])) and torch.equal(m.cpu(), T(z[f"{tag}_mask{vi}"])), (tag, vi)
+            assert torch.equal(v.cpu(), ov) and torch.equal(m.cpu(), om), (tag, vi)
+            assert near(v, z[f"{tag}_get{vi}"]) and near(m, z[f"{tag}_mask{vi}"])
         for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views, windows)):
-            h.set_view_tensor_no_interpolation(T(z[f"{tag}_src{vi}"]).to(d), fov, th, ph, frame_begin=fb, frame_end=fe)
+            src = T(z[f"{tag}_src{vi}"])
+            h.set_view_tensor_no_interpolation(src.to(d), fov, th, ph, frame_begin=fb, frame_end=fe)
+            o.set_view_tensor_no_interpolation(src, fov, th, ph, frame_begin=fb, frame_end=fe)
             full = h.get_equirect_tensor() if tag == "rpl" else h.equirect_tensor_handler.get_torch_latent()
-            assert torch.equal(full.cpu(), T(z[f"{tag}_after_set{vi}"])), (tag, vi)
+            ofull = o.get_equirect_tensor() if tag == "rpl" else o.equirect_tensor_handler.get_torch_latent()
+            assert torch.equal(full.cpu(), ofull), (tag, vi)
+            assert near(full, z[f"{tag}_after_set{vi}"])
         with pytest.raises(NotImplementedError):
             h.set_view_tensor_bilinear(None, 0, 0, 0)

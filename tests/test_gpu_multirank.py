@@ -32,12 +32,15 @@ def _torchrun(nproc, script_and_args, env_extra=None, timeout=900):
 
 
 @pytest.mark.parametrize("geom,rng,share", [("grid4x2", "reference", "auto"), ("grid4x2", "reference", "levels"),
-                                            ("overlapw", "device", "auto")])
+                                            ("overlapw", "device", "auto"), ("overlapw", "reference", "auto"),
+                                            ("overlapw", "reference", "levels")])
 def test_two_ranks_equal_single_process(tmp_path, geom, rng, share):
     """Both replicas of a rank-sharded run equal the single-process panorama bit for bit (host RNG with the same seed on
     every rank, or the in-kernel Philox streams keyed by tile number).  grid4x2 has 4 independent columns: `auto` gives each
     rank whole columns with ONE all-gather per step, `levels` forces a strided share of every level (one all-gather per
-    level); overlapw is one chain (W overlap), so `auto` falls back to levels."""
+    level); overlapw is one chain (W overlap) whose levels hold ONE tile each: `auto` shares such a level out by UNet evaluation
+    -- rank 0 runs the cond forward, rank 1 the uncond forward of the same tile, the eps tensors are all-gathered and both
+    ranks finish CFG + DDIM + scatter (parallel.run_step "units": the cross-rank CFG split) -- while `levels` leaves rank 1 idle."""
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
     worker = os.path.join(REPO, "tests", "multirank_worker.py")
@@ -47,7 +50,7 @@ def test_two_ranks_equal_single_process(tmp_path, geom, rng, share):
     assert r.returncode == 0, r.stderr[-2000:]
     r = _torchrun(2, [worker, str(two), geom, rng], env_extra={"DS_SHARE_MODE": share})
     assert r.returncode == 0, r.stderr[-2000:]
-    want = "components" if (geom == "grid4x2" and share == "auto") else "levels"
+    want = "components" if (geom == "grid4x2" and share == "auto") else ("units" if (geom == "overlapw" and share == "auto") else "levels")
     ref = np.load(one / "rank0.npz")
     for rank in (0, 1):
         got = np.load(two / f"rank{rank}.npz")

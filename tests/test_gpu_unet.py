@@ -449,8 +449,8 @@ def test_ring_pipeline_baseline_geometries_fake_eps_bit_exact(name):
     """BASELINE.json's full-size geometries (configs 2, 3, 3 with W overlap, 5: up to an 8192x1024x24f panorama, 64 tiles
     per step) through the HIP tile engine with the fake eps-model in fp32: the final pred-x0 panorama EQUALS the CPU
     oracle's run on this host (which is pinned to the reference's SHA-256 in the build container,
-    test_oracle_golden.py::test_g9_baseline_geometry_final_panorama_sha); 50-step schedules are cut to 6 steps of the
-    same shifted-window sequence."""
+    test_oracle_golden.py::test_g9_baseline_geometry_final_panorama_sha); 50-step schedules are cut to 9 steps of the
+    same shifted-window sequence -- every shift phase i % loop_step = 0..7 of the window grid, and the wrap back to 0."""
     import hashlib
     from oracle import loops as oloops, ddim as oddim
     from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
@@ -460,7 +460,7 @@ def test_ring_pipeline_baseline_geometries_fake_eps_bit_exact(name):
     geom = dict(rec["geom"])
     full_schedule = geom["num_inference_steps"] <= 10
     if not full_schedule:
-        geom["num_inference_steps"] = 6
+        geom["num_inference_steps"] = 9
     z = np.load(os.path.join(G, "loops_small.npz"))
     cond, uncond = T(z["cond"]), T(z["uncond"])
     ld = _fake_host(cond, uncond, d)

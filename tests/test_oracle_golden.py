@@ -644,3 +644,60 @@ def test_g11_grid_pre_denoise_and_residual_merge_vs_reference_golden():
                                     guidance_scale=7.5, **meta["grid_pre_geoms"]["pre_sparse"])
     ref = T(z["gridpre_pre_sparse_tiny"])
     assert float((den - ref).abs().max()) / float(ref.abs().max()) < 1e-4
+
+
+def test_g23_50_step_schedule_golden_is_the_oracles_update():
+    """cfg1_50step_t2v.npz (make_golden.py g23: the reference's basic_sample, 50 steps, real t2v UNet): the schedule is the
+    oracle's, every teacher-forced update stored by the reference is reproduced bit for bit by oracle.ddim.ddim_step from the
+    stored (x_t, e_t) (x_prev by value, pred_x0 by SHA-256), and the free-running record is self-consistent."""
+    import hashlib
+    path = os.path.join(G, "cfg1_50step_t2v.npz")
+    if not os.path.exists(path):
+        pytest.skip("cfg1_50step_t2v.npz not generated yet (make_golden.py --full --only g23)")
+    z = np.load(path)
+    sched = oddim.DDIMSchedule(oddim.DiffusionTables(), 50)
+    assert list(np.flip(sched.ddim_timesteps)) == list(z["timesteps"])
+    for idx in [int(i) for i in z["tf_indices"]]:
+        x, e = T(z[f"tf_x_t_{idx}"]).float(), T(z[f"tf_e_t_{idx}"])
+        assert int(z[f"tf_t_{idx}"]) == int(np.flip(sched.ddim_timesteps)[49 - idx])
+        xp, x0 = oddim.ddim_step(sched, x, e, [idx] * 16, noise=torch.zeros_like(e))
+        assert torch.equal(xp, T(z[f"tf_x_prev_{idx}"]))
+        assert hashlib.sha256(np.ascontiguousarray(x0.numpy()).tobytes()).hexdigest() == str(z[f"tf_pred_x0_sha_{idx}"])
+    st = z["stats"]                                  # (index, |x_t|, |e_t|, |x_prev|, |pred_x0|) per step
+    assert st.shape == (50, 5) and list(st[:, 0]) == list(range(49, -1, -1))
+    assert np.allclose(st[1:, 1], st[:-1, 3])         # x_t of a step is x_prev of the one before
+    assert abs(float(T(z["free_x_prev_0"]).std()) - st[-1, 3]) < 1e-4 * st[-1, 3]
+
+
+def test_g24_panorama_handlers_oracle_vs_reference_golden():
+    """oracle/handlers.py (PanoramaTensor, RingLatentProxy, RingPanoramaTensor, RingPanoramaLatentProxy) against vectors recorded
+    from the reference's own classes (make_golden.py g24): every get / set / splat bit for bit."""
+    from oracle import handlers as oh
+    z = npz("panorama_handlers.npz")
+    views = [tuple(float(a) for a in v) for v in z["views"]]
+    for tag in ("p4", "p3", "p2"):
+        o = oh.PanoramaTensor(T(z[f"{tag}_x"]))
+        for vi, (fov, th, ph) in enumerate(views):
+            v, m = o.get_view_tensor_no_interpolate(fov, th, ph, 12, 10)
+            assert torch.equal(v, T(z[f"{tag}_get{vi}"])) and torch.equal(m, T(z[f"{tag}_mask{vi}"]))
+        for vi, (fov, th, ph) in enumerate(views):
+            o.set_view_tensor_no_interpolation(T(z[f"{tag}_src{vi}"]), fov, th, ph)
+            assert torch.equal(o.equirect_tensor, T(z[f"{tag}_after_set{vi}"])), (tag, vi)
+        o.set_view_tensor_bilinear(T(z[f"{tag}_splat_src"]), 90.0, 45.0, -30.0)
+        assert torch.equal(o.equirect_tensor, T(z[f"{tag}_after_splat"])), tag
+    r = oh.RingLatentProxy(T(z["rl_x"]))
+    assert torch.equal(r.get_window_latent(3, 8), T(z["rl_win_3_8"])) and torch.equal(r.get_window_latent(1, 10), T(z["rl_win_1_10"]))
+    assert torch.equal(r.get_window_latent(None, None), T(z["rl_win_none"]))
+    assert tuple(r.get_operating_shape(3, 8)) == tuple(int(a) for a in z["rl_shape_3_8"])
+    r.set_window_latent(T(z["rl_src"]), 4, 7)
+    assert torch.equal(r.get_torch_latent(), T(z["rl_after_set"]))
+    windows = ((3, 7), (None, None), (4, 9))
+    for tag, cls in (("rp", oh.RingPanoramaTensor), ("rpl", oh.RingPanoramaLatentProxy)):
+        o = cls(T(z[f"{tag}_x"]))
+        for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views, windows)):
+            v, m = o.get_view_tensor_no_interpolate(fov, th, ph, 12, 10, frame_begin=fb, frame_end=fe)
+            assert torch.equal(v, T(z[f"{tag}_get{vi}"])) and torch.equal(m, T(z[f"{tag}_mask{vi}"])), (tag, vi)
+        for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views, windows)):
+            o.set_view_tensor_no_interpolation(T(z[f"{tag}_src{vi}"]), fov, th, ph, frame_begin=fb, frame_end=fe)
+            full = o.get_equirect_tensor() if tag == "rpl" else o.equirect_tensor_handler.get_torch_latent()
+            assert torch.equal(full, T(z[f"{tag}_after_set{vi}"])), (tag, vi)

@@ -54,5 +54,9 @@ out["gemm_f16_kernel(all)"] = {
     "hbm_read_bytes_per_launch": round(sum(v["hbm_read_bytes_per_launch"] * v["launches"] for v in gem) / tot_l),
     "hbm_write_bytes_per_launch": round(sum(v["hbm_write_bytes_per_launch"] * v["launches"] for v in gem) / tot_l),
 }
+# the kernel source this summary was captured on: bench.py quotes the summary only while csrc/gemm.hip is unchanged
+import hashlib, os
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynamicscaler_amd", "csrc", "gemm.hip")
+out["gemm_hip_sha256"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

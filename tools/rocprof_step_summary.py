@@ -34,5 +34,9 @@ for f, a in sorted(agg.items(), key=lambda kv: -kv[1]["ns"]):
                           "share": a["ns"] / tot, "avg_launch_us": a["ns"] / a["calls"] / 1e3}
 fm = out["families"]
 out["norms_and_concat_share"] = sum(fm.get(k, {}).get("share", 0.0) for k in ("groupnorm", "layernorm", "concat"))
+# the kernel source this summary was captured on: bench.py quotes the summary only while csrc/gemm.hip is unchanged
+import hashlib, os
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynamicscaler_amd", "csrc", "gemm.hip")
+out["gemm_hip_sha256"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
