@@ -10,8 +10,8 @@ bench.py <same arguments>` as a CHILD process, relays rank 0's JSON line and exi
 
 Workload (BASELINE.json metric: 4096x512x16f): t2v overlapped-ring panorama, P = [1,4,16,64,512], 8x2 windows of
 512x320x16f (16 tiles / DDIM step, shifted every step), CFG 7.5 (2 UNet evaluations per tile), 50-step DDIM schedule,
-VideoCrafter2 t2v UNet (1.41 B parameters, synthetic fp16-representable weights), fp16 latents and activations
-with fp32 accumulation.  A "step" = one DDIM step over ALL tiles: ring gather -> re-noise/mix -> 32 UNet evaluations
+VideoCrafter2 t2v UNet (1.41 B parameters, synthetic fp16-representable weights), fp16 matrix-core operands and
+activations with fp32 accumulation, fp32 panorama latent (4 MB; `--latents f16` for fp16 storage).  A "step" = one DDIM step over ALL tiles: ring gather -> re-noise/mix -> 32 UNet evaluations
 -> CFG+DDIM -> scatter (+ the per-level tile all-gather when N > 1).  Inputs are resident in HBM before the timed
 region; nothing is skipped.  N > 1 shards the tiles of the SAME panorama over the ranks (strong scaling).
 
@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--tile-batch", type=int, default=int(os.environ.get("DS_TILE_BATCH", "8")))
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DS_STREAMS", "2")))
     ap.add_argument("--graph", type=int, default=int(os.environ.get("DS_GRAPH", "1")), help="hipGraph replay of the UNet evaluation")
+    ap.add_argument("--latents", choices=["f32", "f16"], default=os.environ.get("DS_LATENTS", "f32"),
+                    help="storage type of the panorama latent / tiles (fp32 like the reference: the default; the matrix-core "
+                         "operands are fp16 either way)")
     ap.add_argument("--share-cfg-prefix", type=int, default=int(os.environ.get("DS_SHARE_CFG", "1")),
                     help="evaluate the context-free UNet prefix once per [cond | uncond] pair (bit-identical result)")
     args = ap.parse_args()
@@ -195,7 +198,8 @@ def main():
     else:
         from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano as Pipe
     pipe = Pipe(ld, sched, {"params": {"unet_config": {"params": params}}})
-    pipe.to(dev, torch.float16)
+    lat_dt = {"f32": torch.float32, "f16": torch.float16}[args.latents]
+    pipe.to(dev, lat_dt)
     pipe.max_tile_batch = args.tile_batch
     pipe.num_streams = args.streams
     pipe.use_graph = bool(args.graph)
@@ -319,8 +323,10 @@ def main():
         cur = hashlib.sha256(open(os.path.join(REPO, "dynamicscaler_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
         traffic, traffic_src, traffic_stale = None, None, None
         try:
-            src = max(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic_v*.json")),
-                      key=lambda f: tuple(int(x) for x in re.findall(r"r(\d+)_pmc_hbm_traffic_v(\d+)", f)[0]))
+            def _rv(f):                    # (round, version): r3_pmc_hbm_traffic.json, r2_pmc_hbm_traffic_v14.json
+                m = re.search(r"r(\d+)_pmc_hbm_traffic(?:_v(\d+))?\.json$", f)
+                return (int(m.group(1)), int(m.group(2) or 0))
+            src = max(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic*.json")), key=_rv)
             summ = json.load(open(src))
             traffic_src = os.path.relpath(src, REPO)
             traffic_stale = summ.get("gemm_hip_sha256") != cur
@@ -412,6 +418,7 @@ def main():
                        "tiles_per_step": tiles_per_step, "unet_evals_per_step": 2 * tiles_per_step,
                        "tile_batch": args.tile_batch, "streams": args.streams, "hipgraph": bool(args.graph), "cfg_prefix_shared": bool(args.share_cfg_prefix), "parallelism": f"tiles sharded over {world} GPU(s)",
                        "rng": "philox in-kernel (perf mode)",
+                       "latents": "fp32 (as the reference)" if args.latents == "f32" else "fp16",
                        "residual_stream": "fp32 (strict precision mode, DS_RESIDUAL_DTYPE=f32)" if unet.residual_dtype == torch.float32
                                           else "fp16 (default; matrix-core operands are fp16 in both modes)",
                        "unet_program": f"{unet.program} (ds_unet_forward: launch loop in C++)" if unet.program == "c" else "python (one ctypes call per kernel)",

@@ -45,18 +45,31 @@ def _pipe(d, latent_dtype, residual_dtype):
     return ld, sched, pipe
 
 
-# measured on MI355X (round 3); asserted at <= 2x measured and never above the north star for x_prev
-TF_TOL_X0 = {"float16": 9e-3, "float32": 6e-3}          # pred_x0 = (x - sqrt(1-a) e)/sqrt(a): amplified by sqrt((1-a)/a) at high t
+# Measured on MI355X (round 3, profiles/r3_measured_parity.jsonl).  With fp32 latents (the default) x_prev per index is
+#   fp16 stream 5.6e-4 4.8e-4 3.7e-4 2.5e-4 1.0e-4 2.7e-5 1.7e-5 7e-6 1.5e-5 0;  fp32 stream 3.7e-4 3.2e-4 2.5e-4 1.6e-4 6e-5 1.3e-5 ...
+# and with fp16 latents (the stored tile's own rounding on top), x_prev / pred_x0 per schedule index:
+#   index (t)         49 (999)  48 (979)  47 (958)  45 (917)  40 (816)  30 (612)  25 (510)  10 (204)  1 (20)    0 (0)
+#   fp16 stream  x_prev  5.9e-4   5.2e-4   4.3e-4   3.2e-4   2.3e-4   2.1e-4   2.1e-4   2.1e-4   2.1e-4   ~0
+#                pred_x0 4.4e-3   3.8e-3   3.2e-3   2.3e-3   1.1e-3   4.2e-4   3.2e-4   2.2e-4   2.1e-4   2.1e-4
+#                guided e_t 1.0e-2 ... 6.7e-3 (single forward 1.66e-3 ... 8.0e-4: the UNet is most exact at low t)
+#   fp32 stream  x_prev  4.2e-4   3.8e-4   3.2e-4   2.6e-4   2.2e-4   2.1e-4 ...                              (floor 2.1e-4 =
+#                pred_x0 3.0e-3   2.5e-3   2.1e-3   1.5e-3   6.7e-4   2.7e-4 ...                               the fp16 rounding
+#                guided e_t 6.7e-3 ... 2.7e-3                                                                   of the stored tile)
+# x_prev (the latent the loop carries): inside the north star at EVERY index in both modes -- asserted at 1e-3.
+# pred_x0 = (x - sqrt(1-a) e)/sqrt(a) multiplies the guided-eps error by sqrt((1-a)/a) (14 at t = 999): it is an intermediate
+# estimate at those steps (it only matters at index 0, where it is 2.1e-4); asserted at <= 2x measured.
+TF_TOL_X0 = {"float16": 9e-3, "float32": 6e-3}
 
 
 @pytest.mark.parametrize("residual", ["float16", "float32"])
-def test_teacher_forced_updates_meet_the_north_star_at_every_index(residual):
+@pytest.mark.parametrize("latents", ["float32", "float16"])
+def test_teacher_forced_updates_meet_the_north_star_at_every_index(residual, latents):
     from oracle import ddim as oddim
     from dynamicscaler_amd import ops
     d = dev()
     z = _golden()
     rd = getattr(torch, residual)
-    ld, sched, pipe = _pipe(d, torch.float16, rd)
+    ld, sched, pipe = _pipe(d, getattr(torch, latents), rd)
     osched = oddim.DDIMSchedule(oddim.DiffusionTables(), 50)
     cond, uncond = ld.get_learned_conditioning(["a prompt"]), ld.get_learned_conditioning([""])
     g, fps = float(z["guidance"]), int(z["fps"])
@@ -65,14 +78,17 @@ def test_teacher_forced_updates_meet_the_north_star_at_every_index(residual):
         for idx in [int(i) for i in z["tf_indices"]]:
             t = int(z[f"tf_t_{idx}"])
             assert t == int(np.flip(sched.ddim_timesteps)[49 - idx])
-            x = T(z[f"tf_x_t_{idx}"]).to(d)                                      # fp16: both sides start from identical numbers
+            x = T(z[f"tf_x_t_{idx}"]).to(d, getattr(torch, latents))            # fp16-representable: both sides start from identical numbers
             eps = pipe._eps(torch.cat([x, x], 0), t, [cond, uncond], fps, 16, cfg_pairs=1, clean_cond=True)
             e_t = eps[1:] + g * (eps[:1] - eps[1:])
             xp, x0 = ops.cfg_ddim(x, eps[:1].contiguous(), eps[1:].contiguous(), (1, 4, 16, 40, 64), g, sched.step_coefficients(idx))
             e_ref = T(z[f"tf_e_t_{idx}"])
-            rxp, rx0 = oddim.ddim_step(osched, x.float().cpu(), e_ref, [idx] * 16, noise=torch.zeros_like(e_ref))
-            assert torch.equal(rxp, T(z[f"tf_x_prev_{idx}"]))                    # the oracle's update IS the reference's (bit-exact)
-            r = dict(test="sched50_teacher_forced", residual=residual, index=idx, t=t, e_cond=relerr(eps[:1], T(z[f"tf_e_cond_{idx}"]).float()),
+            # x_prev: the reference's own.  pred_x0 is stored by SHA-256 only; the oracle's ddim_step reproduces it from (x_t, e_t)
+            # bit for bit on the build host (tests/test_oracle_golden.py::test_g23_...) and to an ulp on any other CPU
+            rxp = T(z[f"tf_x_prev_{idx}"])
+            oxp, rx0 = oddim.ddim_step(osched, x.float().cpu(), e_ref, [idx] * 16, noise=torch.zeros_like(e_ref))
+            assert relerr(oxp, rxp) < 1e-6
+            r = dict(test="sched50_teacher_forced", residual=residual, latents=latents, index=idx, t=t, e_cond=relerr(eps[:1], T(z[f"tf_e_cond_{idx}"]).float()),
                      e_t=relerr(e_t, e_ref), x_prev=relerr(xp, rxp), pred_x0=relerr(x0, rx0),
                      # the same error against the size of the UPDATE (x_prev - x_t) instead of the latent it is added to: with the
                      # synthetic weights |x_t| grows along the schedule (eps stays ~0.4), which flatters x_prev's relative error
@@ -84,11 +100,19 @@ def test_teacher_forced_updates_meet_the_north_star_at_every_index(residual):
             assert r["pred_x0"] < TF_TOL_X0[residual], r
     finally:
         ld.model.diffusion_model.residual_dtype = torch.float16
-    print(f"worst teacher-forced x_prev over the schedule, {residual} residual stream: {worst:.3e}")
+    print(f"worst teacher-forced x_prev over the schedule, {residual} residual stream, {latents} latents: {worst:.3e}")
 
 
-# free-running drift: measured on MI355X (round 3), asserted at <= 2x measured
-FREE_TOL = {("float16", "float16"): 4e-3, ("float16", "float32"): 4e-3, ("float32", "float16"): 4e-3, ("float32", "float32"): 4e-3}
+# free-running drift, measured on MI355X (round 3, gpurun_out/sched50a), x_prev after 5 / 25 / 50 steps and the final pred_x0:
+#   fp32 latents (the default, as the reference)   fp16 residual stream 9.2e-4 / 9.8e-4 / 9.8e-4, final 9.8e-4
+#                                                  fp32 residual stream 6.0e-4 / 6.4e-4 / 6.4e-4, final 6.4e-4
+#   fp16 latents                                   fp16 residual stream 1.02e-3 / 1.40e-3 / 1.74e-3, final 1.75e-3
+#                                                  fp32 residual stream 7.6e-4 / 1.19e-3 / 1.58e-3, final 1.59e-3
+# fp16 STORAGE of the latent rounds it once per step (2^-11 / sqrt(3) = 2.8e-4 relative) and the roundings random-walk:
+# sqrt(50) x 2.8e-4 = 2.0e-3 -- that, not the kernels, is what the fp16-latent rows show.  With fp32 latents the whole 50-step
+# run stays inside the north star in BOTH residual-stream modes; asserted.  fp16 latents: <= 2x measured.
+FREE_TOL = {("float16", "float32"): NORTH_STAR, ("float32", "float32"): NORTH_STAR,
+            ("float16", "float16"): 3.5e-3, ("float32", "float16"): 3.2e-3}
 
 
 @pytest.mark.parametrize("residual", ["float16", "float32"])

@@ -4,6 +4,7 @@ and the product path fails loudly without a GPU."""
 import ast
 import json
 import os
+import sys
 import re
 
 import numpy as np
@@ -40,6 +41,19 @@ def test_struct_layouts_match_header():
             names += [n.strip() for n in decl.split(",")]
         assert names == [f[0] for f in cls._fields_], (struct, names)
         assert C.sizeof(cls) == 4 * len(names)
+
+
+def test_no_kernel_uses_scratch():
+    """Register spills go to scratch memory: none of the library's kernels has any (tools/kernel_resources.py reads the code
+    objects' metadata), and the big-tile GEMM variants stay within one wave per SIMD's register budget."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from kernel_resources import kernel_resources
+    from dynamicscaler_amd import build
+    rows = kernel_resources(build.build(verbose=False))
+    assert len(rows) > 100
+    bad = [(r["name"][:80], r["scratch"], r["spill_vgpr"]) for r in rows if r["scratch"] or r["spill_vgpr"]]
+    assert not bad, bad
+    assert all(r["vgpr"] <= 512 for r in rows)          # the unified register file of a wave (vgpr_count includes the AGPRs)
 
 
 def test_unet_config_struct_matches_header():
