@@ -16,6 +16,7 @@ Rounding classes (a tensor is rounded to fp16 and back where the product stores 
   mid   GEMM outputs that are not on the residual stream (ResBlock conv1, temporal convs 1-3, proj_in, q/k/v, GEGLU
         hidden, attention output, time-embedding MLP)
   p     softmax probabilities (the P operand of P.V)
+  res@C the residual stream only where it is C channels wide (per-level storage choice)
 """
 import argparse
 import json
@@ -46,7 +47,15 @@ class QNet(ou._Net):
         self.q = set(classes)
 
     def r(self, t, cls):
-        return h16(t) if cls in self.q else t
+        """Round `t` if its class is on.  "res@C" rounds the residual stream only where it is C channels wide (320 / 640 / 1280 =
+        the UNet's resolution levels 1 / 2 / 3+4): what a per-level choice of the stream's storage type would do."""
+        if cls in self.q:
+            return h16(t)
+        if cls == "res":
+            ch = t.shape[-1] if t.dim() == 3 else t.shape[1]
+            if f"res@{ch}" in self.q:
+                return h16(t)
+        return t
 
     def gn(self, x, prefix, eps):
         return super().gn(x, prefix, eps)  # rounded by the caller after the SiLU (the product fuses GN+SiLU)
