@@ -70,6 +70,27 @@ def build(force=False, verbose=True, variant=None):
     return lib
 
 
+def build_examples(verbose=True):
+    """examples/unet_host: a C++ host of the UNet that uses only include/dynscaler_hip.h and the HIP runtime (the non-Python
+    boundary of ds_unet_*); tests/test_gpu_unet_c.py runs it.  Rebuilt when its source, the header or the library is newer."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "unet_host.cpp")
+    exe = os.path.join(root, "examples", "unet_host")
+    if not os.path.exists(src):
+        return None
+    if _newer([src, os.path.join(root, "include", "dynscaler_hip.h"), LIB], exe):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), src, "-L", HERE,
+               "-ldynscaler_hip", "-Wl,-rpath,$ORIGIN/../dynamicscaler_amd", "-o", exe]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose and (r.stdout or r.stderr):
+            sys.stderr.write(r.stdout + r.stderr)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    return exe
+
+
 if __name__ == "__main__":
     v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
     print(build(force="--force" in sys.argv, variant=v))
+    if v is None:
+        print(build_examples())

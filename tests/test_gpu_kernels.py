@@ -644,6 +644,13 @@ def test_rccl_level_exchange_single_rank():
         a, b = parallel.exchange_level(xp, x0, 8, force=True)
         torch.cuda.synchronize()
         assert torch.equal(a, xp) and torch.equal(b, x0)
+        # the eps all-gather of the cross-rank CFG split (parallel.run_step "units"): fp32 tensors, one per (tile, branch) unit
+        e = rnd((6, 4, 4, 8, 16), 3).to(d)
+        g = parallel.exchange_units(e, 6)
+        parts = parallel.all_gather_tiles(xp, x0, [8])
+        torch.cuda.synchronize()
+        assert torch.equal(g, e) and g.dtype == torch.float32
+        assert torch.equal(parts[0][0], xp) and torch.equal(parts[0][1], x0)
     finally:
         if created:
             dist.destroy_process_group()

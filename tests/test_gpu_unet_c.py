@@ -155,3 +155,42 @@ def test_c_program_full_size_vs_reference_golden_and_python_program():
           f"(python program {out['python'][1] * 1e3:.1f} ms), wall {out['c'][2] * 1e3:.1f} ms (python program {out['python'][2] * 1e3:.1f} ms)")
     assert e1 < EPS_TOL and e2 < EPS_TOL
     assert torch.equal(out["c"][0], out["python"][0])
+
+
+def test_cpp_host_example_equals_the_python_binding(tmp_path):
+    """examples/unet_host (C++: only dynscaler_hip.h + the HIP runtime) on the toy i2v UNet: weights, inputs and geometry handed
+    over as raw files, eps.bin compared BIT FOR BIT with UNetModel's result (both run ds_unet_forward on identically packed
+    operands) and against the reference's golden eps."""
+    import subprocess
+    from dynamicscaler_amd import build
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    d = dev()
+    exe = build.build_examples(verbose=False)
+    z = np.load(os.path.join(G, "unet_tiny_i2v.npz"))
+    params = json.loads(bytes(z["params_json"]).decode())
+    m = build_unet(params, 5, d)
+    sd = synth_state_dict(param_shapes(params), 5)
+    x, t, ctx = T(z["x_0"]), T(z["t_0"]).to(torch.int64).reshape(-1), T(z["ctx_0"])
+    B, _, Tn, H, W = x.shape
+    cfg = m._c_config()
+    fields = []
+    for name, ctype in cfg._fields_:
+        v = getattr(cfg, name)
+        fields += list(v) if hasattr(v, "__len__") else [v]
+    with open(tmp_path / "config.txt", "w") as f:
+        f.write(" ".join(str(int(v)) for v in fields) + "\n")
+        f.write(f"{B} {Tn} {H} {W} {ctx.shape[1]} {int(z['fps_0'])} 0\n")
+    with open(tmp_path / "weights.bin", "wb") as f:
+        for k in param_shapes(params):                       # == ds_unet_weight_info order (tests/test_host_cpu.py)
+            f.write(sd[k].contiguous().numpy().astype(np.float32).tobytes())
+    (tmp_path / "x.bin").write_bytes(x.contiguous().numpy().astype(np.float32).tobytes())
+    (tmp_path / "t.bin").write_bytes(t.numpy().astype(np.int64).tobytes())
+    (tmp_path / "ctx.bin").write_bytes(ctx.contiguous().numpy().astype(np.float32).tobytes())
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout.strip())
+    eps_c = torch.from_numpy(np.fromfile(tmp_path / "eps.bin", dtype=np.float32).reshape(B, params["out_channels"], Tn, H, W))
+    eps_py = m(x.to(d), t.to(d), context=ctx.to(d), fps=int(z["fps_0"])).cpu()
+    assert torch.equal(eps_c, eps_py)
+    assert relerr(eps_c, T(z["eps_0"])) < EPS_TOL_TINY

@@ -43,6 +43,23 @@ def test_struct_layouts_match_header():
         assert C.sizeof(cls) == 4 * len(names)
 
 
+def test_header_is_plain_c_and_the_cpp_host_example_builds():
+    """include/dynscaler_hip.h is what a C / cgo / JNI binding includes: it must compile as C99 on its own; and
+    examples/unet_host.cpp -- a host of ds_unet_* that uses nothing but the header and the HIP runtime -- must build and link
+    against the library (it runs in tests/test_gpu_unet_c.py)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc:
+        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c",
+                            os.path.join(REPO, "include", "dynscaler_hip.h")], capture_output=True, text=True)
+        assert r.returncode == 0 and not r.stderr.strip(), r.stderr
+    from dynamicscaler_amd import build
+    build.build(verbose=False)
+    exe = build.build_examples(verbose=False)
+    assert exe and os.path.exists(exe)
+
+
 def test_no_kernel_uses_scratch():
     """Register spills go to scratch memory: none of the library's kernels has any (tools/kernel_resources.py reads the code
     objects' metadata), and the big-tile GEMM variants stay within one wave per SIMD's register budget."""
