@@ -906,7 +906,7 @@ struct Prog {
         Ten h16 = h, a;
         if (need_skip && h.is32()) a = groupnorm(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5f, 1, &h16);
         else a = groupnorm(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5f, 1);
-        const int off = u->emb_off[p];
+        const int off = u->emb_off.at(p);          // read-only lookup: forwards of one handle may run on several host threads
         Ten h1 = conv3(a, p + ".in_layers.2", B * T, H, W, b.cin, 1, 0, Ten(), (const float*)ptr(emb_all) + off, T * H * W, u->emb_total, 0, Ten(), nullptr, nullptr);
         a = Ten();
         Ten a2 = groupnorm(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5f, 1);
