@@ -419,8 +419,9 @@ def main():
                        "tile_batch": args.tile_batch, "streams": args.streams, "hipgraph": bool(args.graph), "cfg_prefix_shared": bool(args.share_cfg_prefix), "parallelism": f"tiles sharded over {world} GPU(s)",
                        "rng": "philox in-kernel (perf mode)",
                        "latents": "fp32 (as the reference)" if args.latents == "f32" else "fp16",
-                       "residual_stream": "fp32 (strict precision mode, DS_RESIDUAL_DTYPE=f32)" if unet.residual_dtype == torch.float32
-                                          else "fp16 (default; matrix-core operands are fp16 in both modes)",
+                       "residual_stream": ("fp16 (matrix-core operands are fp16 in every mode)" if unet.residual_dtype == torch.float16 else
+                                           "fp32 between the blocks, fp16 inside the transformers (DS_RESIDUAL_DTYPE=f32outer)"
+                                           if unet.residual_scope == "outer" else "fp32 everywhere (strict precision mode, DS_RESIDUAL_DTYPE=f32)"),
                        "unet_program": f"{unet.program} (ds_unet_forward: launch loop in C++)" if unet.program == "c" else "python (one ctypes call per kernel)",
                        "bit_repeatable": "yes, in every mode (streams x hipGraph included): the cause of round 1's run-to-run "
                                          "differences under concurrent graph replays is fixed (profiles/r2_notes.md section 1)"},

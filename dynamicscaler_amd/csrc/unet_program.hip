@@ -144,7 +144,7 @@ struct PackItem {                 // one tensor of the packed buffer
 
 struct ds_unet {
     ds_unet_config cfg;
-    bool strict = false, fold = false;
+    bool strict = false, inner32 = false, fold = false;   // strict: the stream between the blocks is fp32; inner32: inside the transformers too
     std::vector<std::vector<Block>> inputs, outputs;
     std::vector<Block> middle;
     std::vector<std::pair<int, int>> cat_ch;     // per decoder group: (channels of h, channels of the skip tensor)
@@ -840,7 +840,7 @@ struct Prog {
         long M = x.rows;
         const int inner = x.cols;
         const float scale = 0.125f;    // HEAD_DIM ** -0.5
-        const int rs = res_epi();
+        const int rs = u->inner32 ? DS_EPI_OUT_F32 : 0;     // the block's own stream (its three adds)
         auto ln_proj = [&](const Ten& xin, const std::string& ln, const std::string& name, int N, int epilogue) {
             if (u->fold) {
                 Ten stt = layernorm_stats(xin);
@@ -885,7 +885,7 @@ struct Prog {
         const int C = h.cols;
         Ten a = spatial ? groupnorm(h, prefix + ".norm", geo.B * geo.T, geo.H * geo.W, C, 1e-6f, 0)
                         : groupnorm(h, prefix + ".norm", geo.B, geo.T * geo.H * geo.W, C, 1e-6f, 0);
-        Ten x = linear(a, prefix + ".proj_in", Ten(), res_epi());
+        Ten x = linear(a, prefix + ".proj_in", Ten(), u->inner32 ? DS_EPI_OUT_F32 : 0);
         a = Ten();
         Geo g2 = geo;
         for (int d = 0; d < depth; ++d) {
@@ -1112,8 +1112,10 @@ extern "C" int ds_unet_create(const ds_unet_config* cfg, ds_unet** out) {
     DS_CHECK_ARG(c.transformer_depth > 0 && c.temporal_transformer_depth > 0 && c.context_dim > 0 && c.context_dim % 64 == 0, "ds_unet_create: transformer depth / context_dim");
     ds_unet* u = new ds_unet();
     u->cfg = c;
+    DS_CHECK_ARG(c.residual_f32 >= 0 && c.residual_f32 <= 2, "ds_unet_create: residual_f32 must be 0 (fp16 stream), 1 (fp32 everywhere) or 2 (fp32 between the blocks only)");
     u->strict = c.residual_f32 != 0;
-    u->fold = c.fold_layernorm != 0 && !u->strict;     // the fold multiplies the RAW activation on the matrix cores: needs it in fp16
+    u->inner32 = c.residual_f32 == 1;
+    u->fold = c.fold_layernorm != 0 && !u->inner32;    // the fold multiplies the RAW activation on the matrix cores: needs it in fp16
     build_program(u);
     plan_pack(u);
     *out = u;

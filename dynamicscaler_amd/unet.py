@@ -93,11 +93,17 @@ class UNetModel(nn.Module):
         # both modes.  torch.float16: everything fp16 (fastest).  torch.float32 ("strict"): the stream is stored, added and
         # normalised in fp32 -- the error budget's largest term (profiles/r2_notes.md section 2: 1.31e-3 of 1.66e-3 on eps) goes
         # away; norms read fp32 and write the fp16 operand, residual epilogues add fp32 rows (DS_EPI_RES_F32 | DS_EPI_OUT_F32).
-        # DS_RESIDUAL_DTYPE = f16 | f32; after changing the attribute call invalidate().
+        # `residual_scope` (fp32 stream only): "full" = also the stream INSIDE the transformers (proj_in output and the three adds
+        # of every block; the LayerNorm fold is then off, it needs the raw activation as an fp16 operand); "outer" = only the
+        # stream between the blocks (ResBlock / temporal-conv outputs, proj_out + x_in, conv_in, down / up-sample, the skip
+        # tensors) -- the error budget puts 1.19e-3 of the stream's 1.31e-3 there (profiles/r3_notes.md section 2) -- while
+        # the transformers keep their fp16 inner stream and the fold: most of the strict mode's gain at about a third of its cost.
+        # DS_RESIDUAL_DTYPE = f16 | f32 | f32outer; after changing the attributes call invalidate().
         rd = os.environ.get("DS_RESIDUAL_DTYPE", "f16")
-        if rd not in ("f16", "f32"):
-            raise ValueError(f"DS_RESIDUAL_DTYPE={rd!r}: expected f16 or f32")
-        self.residual_dtype = torch.float32 if rd == "f32" else torch.float16
+        if rd not in ("f16", "f32", "f32outer"):
+            raise ValueError(f"DS_RESIDUAL_DTYPE={rd!r}: expected f16, f32 or f32outer")
+        self.residual_dtype = torch.float16 if rd == "f16" else torch.float32
+        self.residual_scope = "outer" if rd == "f32outer" else "full"
         # Which launch program runs the forward: "c" = ds_unet_forward (csrc/unet_program.hip: one call, the launch loop in C++),
         # "python" = the restatement below (one ctypes call per kernel: per-launch timing hooks, taps, DS_FOLD_LN=2).  The two
         # issue the same launches on the same packed operands and are bit-identical (tests/test_gpu_unet_c.py).  DS_UNET_PROGRAM.
@@ -141,13 +147,19 @@ class UNetModel(nn.Module):
     def _strict(self):
         return self.residual_dtype == torch.float32
 
+    def _inner32(self):
+        """The stream inside the transformer blocks is fp32 too (residual_scope "full")."""
+        if self.residual_scope not in ("full", "outer"):
+            raise ValueError(f"residual_scope={self.residual_scope!r}: expected 'full' or 'outer'")
+        return self._strict() and self.residual_scope == "full"
+
     def _fold(self):
         """LayerNorm fold in effect: the fold multiplies the RAW activation on the matrix cores, which needs it in fp16 -- with an
         fp32 residual stream the LayerNorm kernel (fp32 in, fp16 operand out) runs instead."""
-        return False if self._strict() else self.fold_layernorm
+        return False if self._inner32() else self.fold_layernorm
 
     def _mode(self):
-        return (self._fold(), self.residual_dtype)
+        return (self._fold(), self.residual_dtype, self._inner32())
 
     def _c_config(self):
         """ds_unet_config of this model in the current mode."""
@@ -167,7 +179,7 @@ class UNetModel(nn.Module):
             c.attention_resolutions[i] = int(v)
         for k in ("use_linear", "temporal_conv", "temporal_attention", "addition_attention", "use_image_attention", "fps_cond"):
             setattr(c, k, int(bool(cfg[k])))
-        c.residual_f32 = int(self._strict())
+        c.residual_f32 = (1 if self._inner32() else 2) if self._strict() else 0
         c.fold_layernorm = int(bool(self._fold()))
         return c
 
@@ -290,7 +302,7 @@ class UNetModel(nn.Module):
         M, inner = x.shape
         scale = HEAD_DIM ** -0.5
         fold = self._fold()
-        rs = self._res_epi()
+        rs = DS_EPI_OUT_F32 if self._inner32() else 0       # the block's own stream (its three adds)
 
         def ln_proj(xin, ln, name, N, epilogue=0):
             """LayerNorm `ln` of xin followed by the projection `name`: the LayerNorm folded into the GEMM (row statistics +
@@ -345,7 +357,7 @@ class UNetModel(nn.Module):
             a = self._gn(h, prefix + ".norm", B * T, H * W, C, 1e-6, False)
         else:
             a = self._gn(h, prefix + ".norm", B, T * H * W, C, 1e-6, False)
-        x = self._linear(a, prefix + ".proj_in", epilogue=self._res_epi())
+        x = self._linear(a, prefix + ".proj_in", epilogue=DS_EPI_OUT_F32 if self._inner32() else 0)
         for d in range(depth):
             x = self._transformer_block(x, f"{prefix}.transformer_blocks.{d}", heads, spatial, geo, ctx,
                                         dup=dup if d == 0 else None, last=d == depth - 1)

@@ -333,8 +333,10 @@ typedef struct ds_unet_config {          /* the yaml keys of unet_config.params 
     int32_t context_dim;
     int32_t use_linear;                  /* proj_in / proj_out as nn.Linear (1) or 1x1 conv (0): same arithmetic            */
     int32_t temporal_conv, temporal_attention, addition_attention, use_image_attention, fps_cond;
-    int32_t residual_f32;                /* 0: fp16 residual stream; 1: strict mode, the stream in fp32 (DS_EPI_RES_F32)     */
-    int32_t fold_layernorm;              /* 1: LayerNorm folded into the projections (ds_gemm_f16_ln); forced off by residual_f32 */
+    int32_t residual_f32;                /* 0: fp16 residual stream; 1: strict mode, the whole stream in fp32 (DS_EPI_RES_F32); 2: fp32
+                                            only BETWEEN the blocks (ResBlock / temporal-conv outputs, proj_out + x, conv_in, down /
+                                            up-sample, skip tensors), the transformers keep their fp16 inner stream             */
+    int32_t fold_layernorm;              /* 1: LayerNorm folded into the projections (ds_gemm_f16_ln); forced off by residual_f32 = 1 */
 } ds_unet_config;
 
 /* Builds the block program; *out receives the handle.  Unsupported option combinations return DS_EINVAL. */

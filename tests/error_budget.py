@@ -17,6 +17,8 @@ Rounding classes (a tensor is rounded to fp16 and back where the product stores 
         hidden, attention output, time-embedding MLP)
   p     softmax probabilities (the P operand of P.V)
   res@C the residual stream only where it is C channels wide (per-level storage choice)
+  resin / resout  the residual stream inside the transformer blocks (their three adds) / everywhere else
+  midq  the mid class without the tensors that only a GroupNorm reads (ResBlock conv1 output, temporal convs 1-3)
 """
 import argparse
 import json
@@ -55,6 +57,17 @@ class QNet(ou._Net):
             ch = t.shape[-1] if t.dim() == 3 else t.shape[1]
             if f"res@{ch}" in self.q:
                 return h16(t)
+        if cls == "resin":                                 # the stream INSIDE a transformer (the three adds of a block): part of "res",
+            if "res" in self.q or "resin" in self.q:       # selectable alone; "resout" = the res class without it
+                return h16(t)
+            ch = t.shape[-1]
+            return h16(t) if f"res@{ch}" in self.q else t
+        if cls == "res" and "resout" in self.q:
+            return h16(t)
+        if cls == "midgn" and ("mid" in self.q):          # a mid tensor that only a GroupNorm reads (conv1 out, temporal convs 1-3)
+            return h16(t)
+        if cls == "mid" and "midq" in self.q:             # "midq": every mid tensor EXCEPT the GroupNorm-fed ones
+            return h16(t)
         return t
 
     def gn(self, x, prefix, eps):
@@ -100,13 +113,13 @@ class QNet(ou._Net):
         return self.lin(out, prefix + ".to_out.0")
 
     def transformer_block(self, x, prefix, heads, context, img_cross):
-        x = self.r(self.attention(self.ln(x, prefix + ".norm1"), prefix + ".attn1", heads) + x, "res")
+        x = self.r(self.attention(self.ln(x, prefix + ".norm1"), prefix + ".attn1", heads) + x, "resin")
         x = self.r(self.attention(self.ln(x, prefix + ".norm2"), prefix + ".attn2", heads, context=context,
-                                  img_cross=img_cross) + x, "res")
+                                  img_cross=img_cross) + x, "resin")
         h = self.lin(self.ln(x, prefix + ".norm3"), prefix + ".ff.net.0.proj")
         a, gate = h.chunk(2, dim=-1)
         h = self.r(a * F.gelu(gate), "mid")
-        return self.r(self.lin(h, prefix + ".ff.net.2") + x, "res")
+        return self.r(self.lin(h, prefix + ".ff.net.2") + x, "resin")
 
     def spatial_transformer(self, x, prefix, heads, context):
         c = self.c
@@ -146,14 +159,14 @@ class QNet(ou._Net):
             x = self.r(F.silu(super().gn(x, f"{prefix}.conv{i}.0", 1e-5)), "norm")
             x = F.conv3d(x, self.p(f"{prefix}.conv{i}.{idx}.weight"), self.p(f"{prefix}.conv{i}.{idx}.bias"), padding=(1, 0, 0))
             if i < 4:
-                x = self.r(x, "mid")
+                x = self.r(x, "midgn")
         return self.r(x + identity, "res")
 
     def resblock(self, x, emb, prefix, cin, cout, b):
         h = self.r(F.silu(super().gn(x, prefix + ".in_layers.0", 1e-5)), "norm")
         h = F.conv2d(h, self.p(prefix + ".in_layers.2.weight"), self.p(prefix + ".in_layers.2.bias"), padding=1)
         emb_out = self.lin(F.silu(emb), prefix + ".emb_layers.1")
-        h = self.r(h + emb_out[..., None, None], "mid")
+        h = self.r(h + emb_out[..., None, None], "midgn")
         h = self.r(F.silu(super().gn(h, prefix + ".out_layers.0", 1e-5)), "norm")
         h = F.conv2d(h, self.p(prefix + ".out_layers.3.weight"), self.p(prefix + ".out_layers.3.bias"), padding=1)
         if cin != cout:
@@ -241,6 +254,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="the 1.41 B t2v UNet at [1,4,16,40,64] (about a minute per variant)")
     ap.add_argument("--variants", default="res;norm;mid;p;norm,mid,p;res,norm,mid,p")
+    ap.add_argument("--t", type=int, default=None, help="timestep (default: the golden's, 499)")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
     gold = os.path.join(REPO, "tests", "golden")
@@ -252,6 +266,8 @@ def main():
         x, t, fps = torch.from_numpy(z["x"]), torch.tensor([int(z["t"])]), int(z["fps"])
         ctx = synth_normal((1, 77, 1024), 1)
         ref_gold = torch.from_numpy(z["eps_cond"])
+        if args.t is not None:
+            t, ref_gold = torch.tensor([args.t]), None
     else:
         z = np.load(os.path.join(gold, "unet_tiny_t2v.npz"))
         params = json.loads(bytes(z["params_json"]).decode())
@@ -259,7 +275,8 @@ def main():
         x, ctx, t, fps = (torch.from_numpy(z["x_0"]), torch.from_numpy(z["ctx_0"]), torch.from_numpy(z["t_0"]), int(z["fps_0"]))
         ref_gold = torch.from_numpy(z["eps_0"])
     base = forward(sd, params, x, t, ctx, fps, ())
-    print(f"fp32 (no roundings) vs the reference golden: {rel(base, ref_gold):.3e}")
+    if ref_gold is not None:
+        print(f"fp32 (no roundings) vs the reference golden: {rel(base, ref_gold):.3e}")
     for v in args.variants.split(";"):
         cls = tuple(c for c in v.split(",") if c)
         e = forward(sd, params, x, t, ctx, fps, cls)

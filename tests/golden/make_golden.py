@@ -538,6 +538,30 @@ def g24_panorama_handlers():
     save_npz("panorama_handlers.npz", **A)
 
 
+RING_REAL = dict(height=320, width=512, frames=16, total_w=1024, total_h=512, num_windows_w=2, num_windows_h=2,
+                 num_windows_f=1, loop_step=4, num_inference_steps=4)
+
+
+def g25_ring_real_unet():
+    """P2 end to end with the REAL t2v UNet: VC2_Pipeline_T2V_SpherePano.basic_sample_shift_multi_windows
+    (pipeline/t2v_sphere_panorama_pipeline.py:316-660) on a 1024x512x16f ring panorama, 2x2 shifted windows of 512x320 (the
+    H windows overlap by 40 %: re-noise under the mask; every step shifts the grid across both seams), 4 DDIM steps, CFG 7.5 --
+    32 forwards of the reference on CPU (~35 min).  The init latent is passed in (fp16-representable); the re-noise draws come
+    from the global CPU generator seeded with 2333333 like gen_pano_360.py does."""
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    unet = build_reference_unet(params, seed=0)
+    cond, uncond = synth_normal((1, 77, 1024), 1), synth_normal((1, 77, 1024), 2)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    init = synth_normal((1, 4, 16, RING_REAL["total_h"] // 8, RING_REAL["total_w"] // 8), 2333334)
+    den, trace = run_ring_pipeline(ld, params, 2333333, fps=8, guidance_scale=7.5, init_panorama_latent=init.clone(), **RING_REAL)
+    save_npz("ring_real_unet.npz", init=init, denoised=den, fps=np.int64(8), guidance=np.float32(7.5))
+    with open(os.path.join(HERE, "ring_real_unet_trace.json"), "w") as f:
+        json.dump({"geom": RING_REAL, "trace": trace}, f)
+    print("wrote ring_real_unet_trace.json", float(den.std()))
+
+
 def g18_unet_t24(full=False):
     """BASELINE config 5 runs the UNet at T = 24 (`frames=24`, t2v_sphere_panorama_pipeline.py:411 -> UNetModel.forward with
     a 24-frame tile, openaimodel3d.py:657-708): one forward of the reference at T = 24, toy config and (--full) the real
@@ -1287,6 +1311,7 @@ if __name__ == "__main__":
         steps["g17"] = g17_cfg1_full
         steps["g18"] = lambda: g18_unet_t24(full=True)
         steps["g23"] = g23_cfg1_50step
+        steps["g25"] = g25_ring_real_unet
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)

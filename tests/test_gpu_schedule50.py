@@ -34,11 +34,18 @@ def _golden():
     return np.load(GOLDEN)
 
 
-def _pipe(d, latent_dtype, residual_dtype):
+RESIDUAL_MODES = {"float16": (torch.float16, "full"), "float32": (torch.float32, "full"), "outer": (torch.float32, "outer")}
+
+
+def _set_mode(unet, residual):
+    unet.residual_dtype, unet.residual_scope = RESIDUAL_MODES[residual]
+
+
+def _pipe(d, latent_dtype, residual):
     from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V
     from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
     ld, params, _ = full_host(d)
-    ld.model.diffusion_model.residual_dtype = residual_dtype
+    _set_mode(ld.model.diffusion_model, residual)
     sched = lvdm_DDIM_Scheduler(ld)
     pipe = VC2_Pipeline_T2V(ld, sched, {"params": {"unet_config": {"params": params}}}).to(d, latent_dtype)
     sched.make_schedule(50, verbose=False)
@@ -58,18 +65,17 @@ def _pipe(d, latent_dtype, residual_dtype):
 # x_prev (the latent the loop carries): inside the north star at EVERY index in both modes -- asserted at 1e-3.
 # pred_x0 = (x - sqrt(1-a) e)/sqrt(a) multiplies the guided-eps error by sqrt((1-a)/a) (14 at t = 999): it is an intermediate
 # estimate at those steps (it only matters at index 0, where it is 2.1e-4); asserted at <= 2x measured.
-TF_TOL_X0 = {"float16": 9e-3, "float32": 6e-3}
+TF_TOL_X0 = {"float16": 9e-3, "float32": 6e-3, "outer": 7e-3}
 
 
-@pytest.mark.parametrize("residual", ["float16", "float32"])
+@pytest.mark.parametrize("residual", ["float16", "outer", "float32"])
 @pytest.mark.parametrize("latents", ["float32", "float16"])
 def test_teacher_forced_updates_meet_the_north_star_at_every_index(residual, latents):
     from oracle import ddim as oddim
     from dynamicscaler_amd import ops
     d = dev()
     z = _golden()
-    rd = getattr(torch, residual)
-    ld, sched, pipe = _pipe(d, getattr(torch, latents), rd)
+    ld, sched, pipe = _pipe(d, getattr(torch, latents), residual)
     osched = oddim.DDIMSchedule(oddim.DiffusionTables(), 50)
     cond, uncond = ld.get_learned_conditioning(["a prompt"]), ld.get_learned_conditioning([""])
     g, fps = float(z["guidance"]), int(z["fps"])
@@ -103,9 +109,9 @@ def test_teacher_forced_updates_meet_the_north_star_at_every_index(residual, lat
             worst = max(worst, r["x_prev"])
             assert r["x_prev"] < NORTH_STAR, r
             assert r["pred_x0"] < TF_TOL_X0[residual], r
-            assert r["x_prev_unit_scale"] < (NORTH_STAR if residual == "float32" else 1.5e-3), r   # measured 8.5e-4 / 1.27e-3 at t = 999
+            assert r["x_prev_unit_scale"] < (1.5e-3 if residual == "float16" else NORTH_STAR), r   # measured 1.27e-3 (fp16 stream) / 8.5e-4 (fp32 stream) at t = 999
     finally:
-        ld.model.diffusion_model.residual_dtype = torch.float16
+        _set_mode(ld.model.diffusion_model, "float16")
     print(f"worst teacher-forced x_prev over the schedule, {residual} residual stream, {latents} latents: {worst:.3e}")
 
 
@@ -117,18 +123,18 @@ def test_teacher_forced_updates_meet_the_north_star_at_every_index(residual, lat
 # fp16 STORAGE of the latent rounds it once per step (2^-11 / sqrt(3) = 2.8e-4 relative) and the roundings random-walk:
 # sqrt(50) x 2.8e-4 = 2.0e-3 -- that, not the kernels, is what the fp16-latent rows show.  With fp32 latents the whole 50-step
 # run stays inside the north star in BOTH residual-stream modes; asserted.  fp16 latents: <= 2x measured.
-FREE_TOL = {("float16", "float32"): NORTH_STAR, ("float32", "float32"): NORTH_STAR,
-            ("float16", "float16"): 3.5e-3, ("float32", "float16"): 3.2e-3}
+FREE_TOL = {("float16", "float32"): NORTH_STAR, ("float32", "float32"): NORTH_STAR, ("outer", "float32"): NORTH_STAR,
+            ("float16", "float16"): 3.5e-3, ("float32", "float16"): 3.2e-3, ("outer", "float16"): 3.4e-3}
 
 
-@pytest.mark.parametrize("residual", ["float16", "float32"])
+@pytest.mark.parametrize("residual", ["float16", "outer", "float32"])
 @pytest.mark.parametrize("latents", ["float16", "float32"])
 def test_free_running_50_steps_drift_vs_the_reference(residual, latents):
     """basic_sample's loop, 50 steps end to end: every step's error feeds the next.  The curve (x_prev every 5 steps) and the final
     pred_x0 -- the latent that gets decoded."""
     d = dev()
     z = _golden()
-    ld, sched, pipe = _pipe(d, getattr(torch, latents), getattr(torch, residual))
+    ld, sched, pipe = _pipe(d, getattr(torch, latents), residual)
     cond, uncond = ld.get_learned_conditioning(["a prompt"]), ld.get_learned_conditioning([""])
     g, fps = float(z["guidance"]), int(z["fps"])
     timesteps = np.flip(sched.ddim_timesteps)
@@ -143,7 +149,7 @@ def test_free_running_50_steps_drift_vs_the_reference(residual, latents):
                 curve[idx] = relerr(lat, T(z[f"free_x_prev_{idx}"]))
         final = relerr(den, T(z["free_pred_x0_0"]))
     finally:
-        ld.model.diffusion_model.residual_dtype = torch.float16
+        _set_mode(ld.model.diffusion_model, "float16")
     r = dict(test="sched50_free_running", residual=residual, latents=latents, x_prev_by_index={str(k): v for k, v in curve.items()},
              final_pred_x0=final)
     print(r)

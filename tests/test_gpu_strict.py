@@ -110,11 +110,11 @@ def test_unet_full_size_strict_vs_reference_golden():
     sched = oddim.DDIMSchedule(oddim.DiffusionTables(), 50)
     out = {}
     m = build_unet(params, 0, d, torch.float16)
-    for rd in (torch.float16, torch.float32):
-        m.residual_dtype = rd
+    for rd, scope in ((torch.float16, "full"), (torch.float32, "outer"), (torch.float32, "full")):
+        m.residual_dtype, m.residual_scope = rd, scope
         eps = m(torch.cat([x, x]).to(d, torch.float16), torch.tensor([int(z["t"])] * 2, device=d), context=ctx.to(d),
                 fps=int(z["fps"]))
-        r = dict(test="full_strict", residual=str(rd).split(".")[1], eps_cond=relerr(eps[:1], ec), eps_uncond=relerr(eps[1:], eu))
+        r = dict(test="full_strict", residual=str(rd).split(".")[1] + ("/outer" if scope == "outer" else ""), eps_cond=relerr(eps[:1], ec), eps_uncond=relerr(eps[1:], eu))
         r["e_t"] = relerr(eps[1:] + 7.5 * (eps[:1] - eps[1:]), oddim.cfg_combine(ec, eu, 7.5))
         for index in (25, 49):
             rxp, rx0 = oddim.ddim_step(sched, x, oddim.cfg_combine(ec, eu, 7.5), [index] * 16, noise=torch.zeros_like(x))
@@ -123,7 +123,10 @@ def test_unet_full_size_strict_vs_reference_golden():
             r[f"x_prev_{index}"], r[f"pred_x0_{index}"] = relerr(xp, rxp), relerr(x0, rx0)
         print(r)
         record(**r)
-        out[rd] = r
+        out[(rd, scope)] = r
+    o = out[(torch.float32, "outer")]          # fp32 between the blocks only: measured 1.2e-3 (emulated 1.17e-3)
+    assert o["eps_cond"] < 2.4e-3 and o["eps_cond"] < 0.85 * out[(torch.float16, "full")]["eps_cond"]
+    out = {torch.float16: out[(torch.float16, "full")], torch.float32: out[(torch.float32, "full")]}
     s = out[torch.float32]
     assert s["eps_cond"] < EPS_TOL_STRICT and s["eps_uncond"] < EPS_TOL_STRICT
     assert s["eps_cond"] < 0.8 * out[torch.float16]["eps_cond"]

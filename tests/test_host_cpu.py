@@ -129,7 +129,7 @@ def test_c_unet_program_parameter_table_equals_the_reference_state_dict_keys():
     assert lib.ds_unet_create(C.byref(bad), C.byref(h)) != 0
 
 
-@pytest.mark.parametrize("strict", [False, True])
+@pytest.mark.parametrize("strict", [False, True, "outer"])
 def test_c_unet_program_issues_the_same_launches_as_the_python_program(strict):
     """The C launch program (ds_unet_trace: csrc/unet_program.hip run dry) and the Python restatement (UNetModel.forward on
     shape-only tensors with recording ops, dynamicscaler_amd/trace.py) issue the same kernel calls with the same descriptors
@@ -140,14 +140,15 @@ def test_c_unet_program_issues_the_same_launches_as_the_python_program(strict):
     for name, params in _unet_configs().items():
         m = UNetModel(**params)
         m.residual_dtype = torch.float32 if strict else torch.float16
+        m.residual_scope = "outer" if strict == "outer" else "full"
         L = 93 if params.get("use_image_attention") else 77
         geoms = [(2, 4, 8, 8, 0), (2, 4, 8, 8, 1), (6, 4, 16, 8, 3)] if name.startswith("tiny") else [(2, 16, 40, 64, 1), (2, 24, 40, 64, 0)]
         for (B, T, H, W, pairs) in geoms:
             c_lines = m.c_program_trace(B, T, H, W, L, pairs)
             a, b = trace.kernel_lines(c_lines), trace.kernel_lines(m.python_program_trace(B, T, H, W, L, pairs))
             assert len(a) > 100 and a == b, (name, (B, T, H, W, pairs), next((x, y) for x, y in zip(a, b) if x != y))
-            assert any(ln.startswith("gemm_ln ") for ln in a) == (not strict)
-            assert any(ln.startswith("cast_rows ") for ln in a) == strict
+            assert any(ln.startswith("gemm_ln ") for ln in a) == (strict is not True)      # the fold is off only with an fp32 INNER stream
+            assert any(ln.startswith("cast_rows ") for ln in a) == bool(strict)
             if pairs:
                 assert sum(ln.startswith("copy ") for ln in c_lines) >= 4       # the duplicated prefix: x, h and the skip halves
 
