@@ -907,7 +907,9 @@ struct Prog {
         if (need_skip && h.is32()) a = groupnorm(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5f, 1, &h16);
         else a = groupnorm(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5f, 1);
         const int off = u->emb_off.at(p);          // read-only lookup: forwards of one handle may run on several host threads
-        Ten h1 = conv3(a, p + ".in_layers.2", B * T, H, W, b.cin, 1, 0, Ten(), (const float*)ptr(emb_all) + off, T * H * W, u->emb_total, 0, Ten(), nullptr, nullptr);
+        // "full" strict mode: the intermediates that only a GroupNorm reads (this conv-1 output, temporal convs 1-3) stay fp32 too
+        const int mid = u->inner32 ? DS_EPI_OUT_F32 : 0;
+        Ten h1 = conv3(a, p + ".in_layers.2", B * T, H, W, b.cin, 1, 0, Ten(), (const float*)ptr(emb_all) + off, T * H * W, u->emb_total, mid, Ten(), nullptr, nullptr);
         a = Ten();
         Ten a2 = groupnorm(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5f, 1);
         h1 = Ten();
@@ -923,7 +925,7 @@ struct Prog {
                 const std::string ci = std::to_string(i == 1 ? 2 : 3);
                 Ten an = groupnorm(x, q + ".0", B, T * H * W, b.cout, 1e-5f, 1);
                 x = gemm(an, wt(q + "." + ci + ".w", b.cout, 3 * b.cout, DS_F16), (const float*)u->P(q + "." + ci + ".b"), i == 4 ? h2 : Ten(), M, b.cout, 3 * b.cout,
-                         i == 4 ? rs : 0, DS_A_TCONV, b.cout, nullptr, T, H * W, INT_MAX, 0, i == 4 ? out : Ten());
+                         i == 4 ? rs : mid, DS_A_TCONV, b.cout, nullptr, T, H * W, INT_MAX, 0, i == 4 ? out : Ten());
             }
             h2 = x;
         }

@@ -176,9 +176,16 @@ class FrozenOpenCLIPEmbedder(_KeyedModule):
     LAYERS = ["last", "penultimate"]
 
     def __init__(self, arch="ViT-H-14", version="laion2b_s32b_b79k", device="cuda", max_length=77, freeze=True,
-                 layer="last", model_cfg=None, tokenizer=None):
+                 layer="last", model_cfg=None, tokenizer=None, bpe_path=None):
+        """tokenizer: callable(list[str]) -> LongTensor [b, 77]; or bpe_path (or $DS_CLIP_BPE_PATH): open_clip's vocabulary file
+        `bpe_simple_vocab_16e6.txt.gz` for the built-in byte-level BPE (tokenizer.ClipBpeTokenizer).  The file is not shipped."""
         super().__init__()
         assert layer in self.LAYERS
+        import os as _os
+        bpe_path = bpe_path or _os.environ.get("DS_CLIP_BPE_PATH")
+        if tokenizer is None and bpe_path:
+            from .tokenizer import ClipBpeTokenizer
+            tokenizer = ClipBpeTokenizer(bpe_path, context_length=max_length)
         if model_cfg is None:
             if arch != "ViT-H-14":
                 raise ValueError(f"FrozenOpenCLIPEmbedder: no built-in config for arch {arch}; pass model_cfg")
@@ -219,8 +226,9 @@ class FrozenOpenCLIPEmbedder(_KeyedModule):
             tokens = text
         else:
             if self.tokenizer is None:
-                raise RuntimeError("FrozenOpenCLIPEmbedder: open_clip's BPE vocabulary is not shipped; pass token ids "
-                                   "[b, 77] or construct with tokenizer=callable(list[str]) -> LongTensor[b, 77]")
+                raise RuntimeError("FrozenOpenCLIPEmbedder: open_clip's BPE vocabulary file is not shipped; construct with "
+                                   "bpe_path=<bpe_simple_vocab_16e6.txt.gz> (or set DS_CLIP_BPE_PATH), pass "
+                                   "tokenizer=callable(list[str]) -> LongTensor[b, 77], or pass token ids [b, 77]")
             tokens = self.tokenizer([text] if isinstance(text, str) else list(text))
         dev = self._params["model/positional_embedding"].device if self._device is None else self._device
         if dev.type != "cuda":

@@ -377,8 +377,11 @@ class UNetModel(nn.Module):
         else:
             a = self._gn(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5, True)
         off = self._emb_off[p]
+        # "full" strict mode: the intermediates that only a GroupNorm reads (this conv-1 output, temporal convs 1-3) stay fp32 too
+        # (6.0e-4 of the error budget's "mid" class, profiles/r3_notes.md section 2); matrix-core operands remain fp16
+        mid = DS_EPI_OUT_F32 if self._inner32() else 0
         h1, _ = self._conv3(a, p + ".in_layers.2", (B * T, H, W), b.cin, bias=emb_all[:, off:], bias_rows=T * H * W,
-                            ldbias=self._emb_total)
+                            ldbias=self._emb_total, epilogue=mid)
         a2 = self._gn(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5, True)
         skip = h if not need_skip else self._linear(h16, p + ".skip_connection", epilogue=rs)
         h2, _ = self._conv3(a2, p + ".out_layers.3", (B * T, H, W), b.cout, residual=skip, epilogue=rs, out=None if b.tconv else out)
@@ -391,7 +394,7 @@ class UNetModel(nn.Module):
                 an = self._gn(x, q + ".0", B, T * H * W, b.cout, 1e-5, True)
                 w = P[f"{q}.{ci}.w"]
                 x = ops.gemm(an, w, P[f"{q}.{ci}.b"], h2 if i == 4 else None, M=M, N=w.shape[0], K=w.shape[1],
-                             a_mode=DS_A_TCONV, cin=b.cout, lda=an.stride(0), tconv=(T, H * W), epilogue=rs if i == 4 else 0,
+                             a_mode=DS_A_TCONV, cin=b.cout, lda=an.stride(0), tconv=(T, H * W), epilogue=rs if i == 4 else mid,
                              out=out if i == 4 else None)
             h2 = x
         return h2

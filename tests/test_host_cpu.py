@@ -548,3 +548,70 @@ def test_bench_self_launches_ranks_without_touching_the_gpu():
     assert r.returncode != 0
     assert "needs an MI355X" in r.stderr and "2-rank child exited with code" in r.stderr
     assert "WORLD_SIZE" not in r.stderr.split("Traceback")[0]
+
+
+def test_clip_bpe_tokenizer_vs_independent_implementation(tmp_path):
+    """dynamicscaler_amd.tokenizer.ClipBpeTokenizer (open_clip.tokenize behind FrozenOpenCLIPEmbedder, condition.py:211; open_clip
+    and its vocabulary file are absent) against an independent implementation of the same algorithm -- transformers'
+    CLIPTokenizer -- on a synthetic vocabulary: byte symbols, contraction / letter / digit / punctuation splitting, merge order,
+    end-of-word marks, start / end tokens, padding and truncation.  Plus the id anchors everybody knows from the real vocabulary
+    ("!" = 0, "a</w>" = 320, <start_of_text> = 49406 with the full merge list)."""
+    import collections
+    import json as _json
+    transformers = pytest.importorskip("transformers")
+    from dynamicscaler_amd.tokenizer import ClipBpeTokenizer, byte_symbols, N_MERGES_CLIP
+    # a small merge list learnt from a toy corpus (plain BPE training on byte symbols with the </w> mark)
+    corpus = ("a panoramic video of a surfer riding a huge wave at sunset , the camera is moving around the scene . "
+              "it's a beautiful day and they're surfing ; 360 degrees of ocean , waves , clouds and light ! "
+              "don't stop the panorama , we've seen 12 boats and 3 birds ( near the harbour ) ...").split()
+    sym = byte_symbols()
+    words = collections.Counter(tuple(sym[b] for b in w.encode("utf-8")[:-1]) + (sym[w.encode("utf-8")[-1]] + "</w>",) for w in corpus)
+    merges = []
+    for _ in range(150):
+        pairs = collections.Counter()
+        for w, c in words.items():
+            for pr in zip(w, w[1:]):
+                pairs[pr] += c
+        if not pairs:
+            break
+        best = max(sorted(pairs), key=lambda k: pairs[k])
+        merges.append(best)
+        new = collections.Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i + 1 < len(w) and (w[i], w[i + 1]) == best:
+                    out.append(w[i] + w[i + 1]); i += 2
+                else:
+                    out.append(w[i]); i += 1
+            new[tuple(out)] += c
+        words = new
+    assert len(merges) > 100
+    bpe = tmp_path / "bpe_toy.txt"
+    bpe.write_text("#version: toy\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n", encoding="utf-8")
+    tok = ClipBpeTokenizer(str(bpe))
+    assert tok.vocab_size == 512 + len(merges) + 2 and tok.sot == 512 + len(merges) and tok.eot == tok.sot + 1
+    assert tok.ids["!"] == 0 and tok.ids["a</w>"] == 320 and tok.ids["!</w>"] == 256
+    assert 512 + N_MERGES_CLIP == 49406                           # <start_of_text> of the real vocabulary
+    # the independent implementation on the same vocabulary (its special tokens are spelled differently, same ids)
+    vocab = {("<|startoftext|>" if t == tok.SOT else "<|endoftext|>" if t == tok.EOT else t): i for t, i in tok.ids.items()}
+    (tmp_path / "vocab.json").write_text(_json.dumps(vocab), encoding="utf-8")
+    (tmp_path / "merges.txt").write_text("#version: toy\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n", encoding="utf-8")
+    hf = transformers.CLIPTokenizer(str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt"))
+    texts = ["a panoramic video of a surfer riding a huge wave", "It's a BEAUTIFUL day,   and they're surfing!!", "don't stop: we've seen 12 boats & 3 birds (near the harbour)...",
+             "360 degrees   of ocean\twaves", "", "x", "unseenword zzz 2024 ?!", "the camera is moving around the scene . " * 12]
+    for t in texts:
+        mine = tok.encode(t)
+        theirs = hf(t, add_special_tokens=False)["input_ids"]
+        assert mine == theirs, (t, mine[:12], theirs[:12])
+    out = tok(texts)
+    assert out.shape == (len(texts), 77) and out.dtype == torch.int64
+    for row, t in zip(out, texts):
+        ids = tok.encode(t)
+        assert int(row[0]) == tok.sot
+        if len(ids) + 2 <= 77:
+            assert row[1:1 + len(ids)].tolist() == ids and int(row[1 + len(ids)]) == tok.eot and int(row[2 + len(ids):].sum()) == 0
+        else:
+            assert row[1:76].tolist() == ids[:75] and int(row[76]) == tok.eot          # cut, last id forced to <end_of_text>
+    with pytest.raises(ValueError):
+        ClipBpeTokenizer()
