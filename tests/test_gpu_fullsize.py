@@ -369,7 +369,7 @@ def test_concurrent_graph_replays_repeatable(size):
             assert not bad, f"{size}: round {r}, slot {slot}: first diverging kernel {bad[0]} ({len(bad)} of {len(kept)} outputs)"
 
 
-RING_REAL_TOL = {"float16": 7.5e-3, "outer": 6.5e-3, "float32": 5e-3}     # <= 2x measured on MI355X (round 3): 3.76e-3 / ~3e-3 / 2.52e-3
+RING_REAL_TOL = {"float16": 7.5e-3, "outer": 5.5e-3, "float32": 4.2e-3}     # <= 2x measured on MI355X (round 3): 3.76e-3 / 2.77e-3 / 2.10e-3
 
 
 @pytest.mark.parametrize("residual", ["float16", "outer", "float32"])

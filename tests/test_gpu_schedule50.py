@@ -65,7 +65,7 @@ def _pipe(d, latent_dtype, residual):
 # x_prev (the latent the loop carries): inside the north star at EVERY index in both modes -- asserted at 1e-3.
 # pred_x0 = (x - sqrt(1-a) e)/sqrt(a) multiplies the guided-eps error by sqrt((1-a)/a) (14 at t = 999): it is an intermediate
 # estimate at those steps (it only matters at index 0, where it is 2.1e-4); asserted at <= 2x measured.
-TF_TOL_X0 = {"float16": 9e-3, "float32": 6e-3, "outer": 7e-3}
+TF_TOL_X0 = {"float16": 9e-3, "float32": 5e-3, "outer": 6.6e-3}       # measured at index 49: 4.4e-3 / 2.5e-3 / 3.3e-3
 
 
 @pytest.mark.parametrize("residual", ["float16", "outer", "float32"])

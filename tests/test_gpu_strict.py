@@ -20,8 +20,9 @@ G = os.path.join(REPO, "tests", "golden")
 
 from test_gpu_fullsize import dev, T, relerr, record, t2v_params      # noqa: E402
 
-EPS_TOL_TINY_STRICT = 2.6e-3    # toy UNet eps, strict mode: measured 1.1e-3 .. 1.3e-3 (fp16 mode 2.0e-3 .. 2.2e-3)
-EPS_TOL_STRICT = 2.2e-3         # full-size t2v UNet eps, strict mode: measured 1.08e-3 / 1.10e-3 (fp16 mode 1.66e-3 / 1.70e-3)
+EPS_TOL_TINY_STRICT = 2.6e-3    # toy UNet eps, strict mode: measured 1.18e-3 .. 1.33e-3 (fp16 mode 2.1e-3 .. 2.3e-3)
+EPS_TOL_STRICT = 1e-3           # full-size t2v UNet eps, strict mode: measured 9.13e-4 / 9.30e-4 -- the north-star figure on the
+                                # UNet output itself (fp16 mode 1.66e-3 / 1.70e-3, "outer" 1.23e-3 / 1.25e-3)
 
 
 def build_unet(params, seed, device, residual_dtype):
