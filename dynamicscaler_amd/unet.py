@@ -11,7 +11,6 @@ Beyond the reference (which only runs batch 1): a batch of b inde
 (cond + uncond CFG branches, several tiles) shares one launch sequence; results per item are those of b
 separate b=1 forwards.
 """
-import math
 import os
 import threading
 
