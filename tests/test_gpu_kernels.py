@@ -26,6 +26,10 @@ def rnd(shape, seed, scale=1.0, dtype=torch.float32):
     return (torch.randn(shape, generator=g) * scale).to(dtype)
 
 
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
 def relerr(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-12))
@@ -137,6 +141,37 @@ def test_renoise_philox_statistics():
     assert abs(float(flat.std()) - 1.0) < 5e-3
     corr = torch.corrcoef(flat)                              # distinct tiles: independent streams
     assert float((corr - torch.eye(8)).abs().max()) < 0.02
+
+
+def test_renoise_philox_matches_cpu_restatement():
+    """rng_mode="device" (bench.py): the normals ds_renoise_mix draws in-kernel are the ones oracle/philox.py computes on the CPU
+    (Philox4x32-10 known-answer-tested there, same counter layout, same Box-Muller) -- value by value, to the accuracy of the
+    hardware's fast log / sin / cos -- and the re-noise + mix built on them equals the oracle's re_noise + mix fed with that noise."""
+    from dynamicscaler_amd import ops
+    from oracle import philox
+    d = dev()
+    shape, seed, offset = (3, 4, 4, 8, 16), 0x1234567890ABCDEF, 977
+    m = torch.ones(shape[:1] + shape[2:], dtype=torch.uint8, device=d)
+    z_gpu = ops.renoise_mix_(torch.zeros(shape, device=d), m, (1, 4, 4, 12, 64), 0.0, 1.0, 1.0, noise=None, mask_frame0=False, seed=seed,
+                             offset=offset).cpu()
+    z_cpu = T(philox.tile_noise(shape, seed, offset))
+    assert float((z_gpu - z_cpu).abs().max()) < 2e-5, float((z_gpu - z_cpu).abs().max())
+    # the whole fused op in device mode against the oracle with the restated noise (mask with holes, ratio 0.3)
+    x = rnd(shape, 3)
+    mk = (rnd(shape[:1] + shape[2:], 4) > 0).to(torch.uint8)
+    c, s_ = 0.83, 0.41
+    got = ops.renoise_mix_(x.clone().to(d), mk.to(d), (1, 4, 4, 12, 64), c, s_, 0.3, noise=None, mask_frame0=False, seed=seed, offset=offset).cpu()
+    noised = c * x + s_ * z_cpu
+    want = torch.stack([oddim.mix_latents_with_mask(x[i:i + 1], noised[i:i + 1], mk[i][None, None].float(), 0.3)[0] for i in range(shape[0])])
+    assert float((got - want).abs().max()) < 2e-5
+    # tile_ids: tile k of the step draws counters offset + k * numel ... (what keeps rank-sharded runs identical)
+    ids = [2, 0]
+    part = ops.renoise_mix_(torch.zeros((2,) + shape[1:], device=d), m[:2], (1, 4, 4, 12, 64), 0.0, 1.0, 1.0, noise=None, mask_frame0=False,
+                            seed=seed, offset=offset, tile_ids=ids).cpu()
+    numel = int(np.prod(shape[1:]))
+    for k, j in enumerate(ids):
+        zk = T(philox.tile_noise((1,) + shape[1:], seed, offset + j * numel))
+        assert float((part[k:k + 1] - zk).abs().max()) < 2e-5
 
 
 @pytest.mark.parametrize("dtype,edt", [(torch.float32, torch.float32), (torch.float16, torch.float32),

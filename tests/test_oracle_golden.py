@@ -701,3 +701,17 @@ def test_g24_panorama_handlers_oracle_vs_reference_golden():
             o.set_view_tensor_no_interpolation(T(z[f"{tag}_src{vi}"]), fov, th, ph, frame_begin=fb, frame_end=fe)
             full = o.get_equirect_tensor() if tag == "rpl" else o.equirect_tensor_handler.get_torch_latent()
             assert torch.equal(full, T(z[f"{tag}_after_set{vi}"])), (tag, vi)
+
+
+def test_philox_restatement_known_answer_and_moments():
+    """oracle/philox.py -- the CPU restatement of ds_renoise_mix's in-kernel noise (rng_mode="device") -- reproduces the Random123
+    known-answer vector of Philox4x32-10 (counter 0, key 0) and produces unit normals; distinct counters / seeds decorrelate."""
+    from oracle import philox
+    r = philox.philox4x32_10(np.array([0], dtype=np.uint64), 0)[0]
+    assert [int(v) for v in r] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    z = philox.tile_noise((8, 4, 16, 40, 64), 7, 0)
+    assert z.dtype == np.float32 and abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
+    assert abs(float((z.astype(np.float64) ** 4).mean()) - 3.0) < 0.05
+    z2 = philox.tile_noise((8, 4, 16, 40, 64), 8, 0)
+    assert abs(float(np.corrcoef(z.ravel(), z2.ravel())[0, 1])) < 5e-3
+    assert np.array_equal(philox.tile_noise((1, 4, 4, 8, 16), 7, 12)[0].ravel()[:16], philox.normal4(np.uint64(12) + np.arange(4, dtype=np.uint64), 7).ravel())
