@@ -396,6 +396,56 @@ def test_ring_pipeline_fake_eps_bit_exact_fp32():
         assert relerr(den, T(z[f"ring_{gname}_fake"])) < 1e-4          # and the reference's own panorama (other host's RNG)
 
 
+def test_ring_pipeline_device_rng_equals_oracle_with_the_restated_philox_stream():
+    """rng_mode="device" (what bench.py times): the in-kernel Philox draws replace the host's torch.randn.  With oracle/philox.py
+    -- the CPU restatement of that stream, counters = (step, tile within the step, element), key = the scheduler's philox_seed --
+    injected into the oracle's re_noise, the oracle's panorama equals the HIP pipeline's to the accuracy of the hardware's fast
+    log / sin / cos (fake eps, fp32 latents: every other op on the path is bit-exact).  grid4x2 (8 windows per step, wraps both
+    seams) and overlapw (10 windows, one dependency chain), every batching of the tiles."""
+    from oracle import loops as oloops, ddim as oddim, philox
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    d = dev()
+    z = np.load(os.path.join(G, "loops_small.npz"))
+    meta = json.load(open(os.path.join(G, "loops_small_traces.json")))
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    ld = _fake_host(cond, uncond, d)
+    seed = 0x5EED5EED1234
+    for gname in ("grid4x2", "overlapw"):
+        geom = meta["geoms"][gname]
+        n_tiles = geom["num_windows_w"] * geom["num_windows_h"] * geom["num_windows_f"]
+        init = torch.from_numpy(np.random.RandomState(5).randn(1, 4, geom["frames"] * geom["num_windows_f"], geom["total_h"] // 8,
+                                                                geom["total_w"] // 8).astype(np.float32))
+        calls = [0]
+        orig = oloops.re_noise
+
+        def philox_re_noise(sched, x_a, idx_a, idx_b, noise=None):
+            step, tile = divmod(calls[0], n_tiles)
+            calls[0] += 1
+            numel = x_a.numel()
+            off = lvdm_DDIM_Scheduler.tile_philox_offset(step, numel) + tile * numel
+            return orig(sched, x_a, idx_a, idx_b, noise=T(philox.tile_noise(tuple(x_a.shape), seed, off)))
+
+        oloops.re_noise = philox_re_noise
+        try:
+            ref, _, _ = oloops.t2v_ring_sample(_oracle_fake, oddim.DiffusionTables(), cond, uncond, guidance_scale=7.5,
+                                               init_panorama_latent=init, **geom)
+        finally:
+            oloops.re_noise = orig
+        assert calls[0] == n_tiles * (geom["num_inference_steps"] - 1)          # every window of every step but the last re-noises
+        for tb, streams in ((8, 1), (3, 2), (1, 1)):
+            sched = lvdm_DDIM_Scheduler(ld, rng_mode="device")
+            sched.philox_seed = seed
+            pipe = VC2_Pipeline_T2V_SpherePano(ld, sched, {"params": {"unet_config": {"params": {"in_channels": 4}}}})
+            pipe.to(d, torch.float32)
+            pipe.max_tile_batch, pipe.num_streams, pipe.use_graph = tb, streams, False
+            _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                           init_panorama_latent=init, **geom)
+            e = float((den.cpu() - ref).abs().max() / ref.abs().max())
+            print(f"device-RNG ring pipeline {gname}, tile batch {tb} x {streams} streams: max abs diff / max |ref| = {e:.2e}")
+            assert e < 2e-5, (gname, tb, e)
+
+
 def test_ring_pipeline_multi_prompt_vs_oracle_and_reference_golden():
     """R13: `window_multi_prompt_dict` (t2v_sphere_panorama_pipeline.py:561-566, utils/multi_prompt_utils.py:1-7) on the toy
     dock geometry.  Fake eps, fp32 latents: bit-equal to the oracle on this host and 1e-4 from the reference's panorama
