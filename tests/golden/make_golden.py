@@ -562,6 +562,41 @@ def g25_ring_real_unet():
     print("wrote ring_real_unet_trace.json", float(den.std()))
 
 
+def g26_updates_i2v_and_t24():
+    """One teacher-forced update of the 50-step schedule (CFG 7.5; the reference's UNet forward + lvdm_DDIM_Scheduler.ddim_step,
+    pipeline/scheduler.py:60-96) for the two model / tile variants the other BASELINE configs run: the i2v UNet with 77 text + 16
+    image tokens (config 4) at indices 49 and 25, and the t2v UNet on a 24-frame tile (config 5) at indices 49 and 25.
+    x_t = sqrt(a_t) x0 + sqrt(1 - a_t) n with synthetic unit-scale x0, n, rounded to fp16 (both sides start from identical
+    numbers).  8 forwards of the reference on CPU."""
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    A = {"guidance": np.float32(7.5), "indices": np.asarray([49, 25], np.int64)}
+    for tag, yaml_name, seed, frames, L, fps in (("i2v", "configs/inference_i2v_512_v1.0.yaml", 3, 16, 93, 16),
+                                                  ("t24", "configs/inference_t2v_512_v2.0.yaml", 0, 24, 77, 8)):
+        params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, yaml_name)))["model"]["params"]["unet_config"]["params"]
+        unet = build_reference_unet(params, seed=seed)
+        cond, uncond = synth_normal((1, L, 1024), 11), synth_normal((1, L, 1024), 12)
+        ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=frames)
+        sched = lvdm_DDIM_Scheduler(ld)
+        sched.make_schedule(50)
+        A[f"{tag}_cond"], A[f"{tag}_uncond"], A[f"{tag}_fps"] = cond.to(torch.float16), uncond.to(torch.float16), np.int64(fps)
+        for idx in (49, 25):
+            t = int(sched.ddim_timesteps[idx])
+            a_t = float(sched.ddim_alphas[idx])
+            x0, n = synth_normal((1, 4, frames, 40, 64), 700 + idx), synth_normal((1, 4, frames, 40, 64), 800 + idx)
+            x_t = (a_t ** 0.5 * x0 + (1 - a_t) ** 0.5 * n).to(torch.float16).to(torch.float32)
+            ts = torch.full((1,), t, dtype=torch.long)
+            kw = dict(fps=fps, curr_time_steps=ts, temporal_length=frames, clean_cond=True)
+            with torch.no_grad():
+                e_c = ld.model(x_t, ts, c_crossattn=[cond], **kw)
+                e_u = ld.model(x_t, ts, c_crossattn=[uncond], **kw)
+                e_t = e_u + 7.5 * (e_c - e_u)
+                xp, x0p = sched.ddim_step(sample=x_t, noise_pred=e_t, indices=[idx] * frames)
+            A.update({f"{tag}_x_t_{idx}": x_t.to(torch.float16), f"{tag}_e_t_{idx}": e_t, f"{tag}_x_prev_{idx}": xp,
+                      f"{tag}_t_{idx}": np.int64(t), f"{tag}_pred_x0_sha_{idx}": np.asarray(sha(x0p))})
+            print(tag, idx, t, float(e_t.std()), float(xp.std()), flush=True)
+    save_npz("updates_i2v_t24.npz", **A)
+
+
 def g18_unet_t24(full=False):
     """BASELINE config 5 runs the UNet at T = 24 (`frames=24`, t2v_sphere_panorama_pipeline.py:411 -> UNetModel.forward with
     a 24-frame tile, openaimodel3d.py:657-708): one forward of the reference at T = 24, toy config and (--full) the real
@@ -1312,6 +1347,7 @@ if __name__ == "__main__":
         steps["g18"] = lambda: g18_unet_t24(full=True)
         steps["g23"] = g23_cfg1_50step
         steps["g25"] = g25_ring_real_unet
+        steps["g26"] = g26_updates_i2v_and_t24
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)

@@ -156,3 +156,47 @@ def test_free_running_50_steps_drift_vs_the_reference(residual, latents):
     record(**r)
     tol = FREE_TOL[(residual, latents)]
     assert max(curve.values()) < tol and final < tol, r
+
+
+@pytest.mark.parametrize("tag", ["i2v", "t24"])
+@pytest.mark.parametrize("residual", ["float16", "float32"])
+def test_teacher_forced_updates_of_the_other_configs_models(tag, residual):
+    """The same per-update assertion for what configs 4 and 5 run: the i2v UNet with 77 text + 16 image tokens, and the t2v UNet
+    on a 24-frame tile -- one update of the 50-step schedule at indices 49 and 25 against the reference's own forward +
+    ddim_step (tests/golden/updates_i2v_t24.npz, make_golden.py g26)."""
+    import yaml
+    from oracle import ddim as oddim
+    from dynamicscaler_amd import ops
+    from dynamicscaler_amd.unet import UNetModel
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    path = os.path.join(G, "updates_i2v_t24.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/updates_i2v_t24.npz not generated (make_golden.py --full --only g26)")
+    d = dev()
+    z = np.load(path)
+    if tag == "i2v":
+        params = yaml.safe_load(open(os.path.join(REPO, "dynamicscaler_amd", "configs", "i2v_512_v1_unet.yaml")))
+        m = UNetModel(**params)
+        m.load_state_dict(synth_state_dict(param_shapes(params), 3), strict=True)
+        m = m.to(d).eval()
+    else:
+        m = full_host(d)[0].model.diffusion_model
+    _set_mode(m, residual)
+    osched = oddim.DDIMSchedule(oddim.DiffusionTables(), 50)
+    g = float(z["guidance"])
+    ctx = torch.cat([T(z[f"{tag}_cond"]), T(z[f"{tag}_uncond"])]).float().to(d)
+    try:
+        for idx in [int(i) for i in z["indices"]]:
+            x = T(z[f"{tag}_x_t_{idx}"]).float().to(d)
+            t = int(z[f"{tag}_t_{idx}"])
+            eps = m(torch.cat([x, x]), torch.tensor([t, t], device=d), context=ctx, fps=int(z[f"{tag}_fps"]), cfg_pairs=1)
+            e_t = eps[1:] + g * (eps[:1] - eps[1:])
+            xp, x0 = ops.cfg_ddim(x, eps[:1].contiguous(), eps[1:].contiguous(), (1,) + tuple(x.shape[1:]), g, osched.step_coefficients(idx))
+            r = dict(test="update_other_models", model=tag, residual=residual, index=idx, t=t, e_t=relerr(e_t, T(z[f"{tag}_e_t_{idx}"])),
+                     x_prev=relerr(xp, T(z[f"{tag}_x_prev_{idx}"])))
+            print(r)
+            record(**r)
+            assert r["x_prev"] < NORTH_STAR, r
+    finally:
+        _set_mode(m, "float16")
