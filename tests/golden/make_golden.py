@@ -26,6 +26,13 @@ so parity is pinned by what this script captures from the imported reference cod
   G17 cfg1_full_t2v.npz      (--full) BASELINE config 1: basic_sample, real t2v UNet, 512x320x16f, 4 steps, CFG 7.5;
                              per-step x_t / e_t / x_prev / pred_x0 (8 forwards, ~8 min)
 
+  G23 cfg1_50step_t2v.npz    (--full) the metric's 50-step schedule: basic_sample of the reference, real t2v UNet, one tile, free-running
+                             (x_prev every 5 steps, final pred_x0) + teacher-forced updates at 10 schedule indices (120 forwards, ~2 h)
+  G24 panorama_handlers.npz  PanoramaTensor / RingLatentProxy / RingPanoramaTensor / RingPanoramaLatentProxy: gets / sets / splat
+  G25 ring_real_unet.npz     (--full) the t2v ring loop with the REAL UNet: 1024x512x16f, 2x2 shifted windows, 4 steps (32 forwards)
+  G26 updates_i2v_t24.npz    (--full) one update of the 50-step schedule for the i2v UNet (93 tokens) and for 24-frame tiles (8 forwards)
+  G27 i2v_ring_real_unet.npz (--full) the i2v ring loop with the REAL i2v UNet: per-window image tokens, merge-prev (32 forwards)
+
   G16 encoders_{toy,full}.npz  Resampler (the reference's module, ip_resampler.py) and the CLIP ViT-H/14 text / image
                              towers -- open_clip is absent, so the tower vectors come from transformers' CLIP
                              implementation carrying the same synthetic weights (independent anchor, not the reference)
@@ -595,6 +602,47 @@ def g26_updates_i2v_and_t24():
                       f"{tag}_t_{idx}": np.int64(t), f"{tag}_pred_x0_sha_{idx}": np.asarray(sha(x0p))})
             print(tag, idx, t, float(e_t.std()), float(xp.std()), flush=True)
     save_npz("updates_i2v_t24.npz", **A)
+
+
+I2V_RING_REAL = dict(height=320, width=512, frames=16, total_w=1024, total_h=512, total_f=16, num_windows_w=2, num_windows_h=2,
+                     num_windows_f=1, loop_step=4, num_inference_steps=4, overlap_ratio_list_f=[0.0] * 4,
+                     merge_prev_denoised_ratio_list=[0.5, 0.4, 0.3, 0.2])
+
+
+def g27_i2v_ring_real_unet():
+    """P3 end to end with the REAL i2v UNet (image cross-attention, 77 text + 16 image tokens per window): the reference's
+    VC2_Pipeline_I2V_SpherePano.basic_sample_shift_multi_windows (pipeline/i2v_sphere_panorama_pipeline.py:564-996) on a
+    1024x512x16f ring panorama, 2x2 shifted windows, per-window image crops of a synthetic panorama image through the synthetic
+    embedder, merge-prev, 4 DDIM steps, CFG 7.5 -- 32 forwards of the reference on CPU.  Init latent passed in."""
+    import utils.shift_window_utils as swu
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_i2v_512_v1.0.yaml")))["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    unet = build_reference_unet(params, seed=3)
+    cond, uncond = synth_normal((1, 77, 1024), 11), synth_normal((1, 77, 1024), 12)
+    embed = synth_image_embedder(1024)
+    pano_img = synth_normal((3, 512, 1024), 189).clamp(-1, 1)
+    init = synth_normal((1, 4, 16, 64, 128), 2333335)
+    orig_loader = swu.load_image_tensor_from_path
+    swu.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: pano_img   # I/O stub (cv2 absent)
+    try:
+        ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+        ld.get_image_embeds = embed
+        ld.embedder = object()
+        pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+        pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+        buf = io.StringIO()
+        torch.manual_seed(2333333)
+        with contextlib.redirect_stdout(buf):
+            _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", img_cond_path="unused.png", fps=16, guidance_scale=7.5,
+                                                           pano_image_path="unused.png", output_type="latent",
+                                                           init_panorama_latent=init.clone(), **I2V_RING_REAL)
+    finally:
+        swu.load_image_tensor_from_path = orig_loader
+    save_npz("i2v_ring_real_unet.npz", init=init, denoised=den, pano_img_seed=np.int64(189), fps=np.int64(16), guidance=np.float32(7.5))
+    with open(os.path.join(HERE, "i2v_ring_real_unet_trace.json"), "w") as f:
+        json.dump({"geom": I2V_RING_REAL, "trace": parse_trace(buf.getvalue())}, f)
+    print("wrote i2v_ring_real_unet_trace.json", float(den.std()))
 
 
 def g18_unet_t24(full=False):
@@ -1348,6 +1396,7 @@ if __name__ == "__main__":
         steps["g23"] = g23_cfg1_50step
         steps["g25"] = g25_ring_real_unet
         steps["g26"] = g26_updates_i2v_and_t24
+        steps["g27"] = g27_i2v_ring_real_unet
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)
