@@ -558,7 +558,10 @@ def test_clip_bpe_tokenizer_vs_independent_implementation(tmp_path):
     ("!" = 0, "a</w>" = 320, <start_of_text> = 49406 with the full merge list)."""
     import collections
     import json as _json
-    transformers = pytest.importorskip("transformers")
+    import importlib.util
+    import subprocess
+    if importlib.util.find_spec("transformers") is None:
+        pytest.skip("transformers not installed")
     from dynamicscaler_amd.tokenizer import ClipBpeTokenizer, byte_symbols, N_MERGES_CLIP
     # a small merge list learnt from a toy corpus (plain BPE training on byte symbols with the </w> mark)
     corpus = ("a panoramic video of a surfer riding a huge wave at sunset , the camera is moving around the scene . "
@@ -597,12 +600,21 @@ def test_clip_bpe_tokenizer_vs_independent_implementation(tmp_path):
     vocab = {("<|startoftext|>" if t == tok.SOT else "<|endoftext|>" if t == tok.EOT else t): i for t, i in tok.ids.items()}
     (tmp_path / "vocab.json").write_text(_json.dumps(vocab), encoding="utf-8")
     (tmp_path / "merges.txt").write_text("#version: toy\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n", encoding="utf-8")
-    hf = transformers.CLIPTokenizer(str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt"))
     texts = ["a panoramic video of a surfer riding a huge wave", "It's a BEAUTIFUL day,   and they're surfing!!", "don't stop: we've seen 12 boats & 3 birds (near the harbour)...",
              "360 degrees   of ocean\twaves", "", "x", "unseenword zzz 2024 ?!", "the camera is moving around the scene . " * 12]
-    for t in texts:
+    (tmp_path / "texts.json").write_text(_json.dumps(texts), encoding="utf-8")
+    # transformers runs in a CHILD interpreter: importing it into the test process loads a second OpenMP runtime next to
+    # torch's, after which the CPU oracle tests of this suite crawl (spinning worker threads)
+    child = ("import json, sys, transformers\n"
+             "d = sys.argv[1]\n"
+             "hf = transformers.CLIPTokenizer(d + '/vocab.json', d + '/merges.txt')\n"
+             "texts = json.load(open(d + '/texts.json', encoding='utf-8'))\n"
+             "print(json.dumps([hf(t, add_special_tokens=False)['input_ids'] for t in texts]))\n")
+    r = subprocess.run([sys.executable, "-c", child, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    theirs_all = _json.loads(r.stdout.strip().splitlines()[-1])
+    for t, theirs in zip(texts, theirs_all):
         mine = tok.encode(t)
-        theirs = hf(t, add_special_tokens=False)["input_ids"]
         assert mine == theirs, (t, mine[:12], theirs[:12])
     out = tok(texts)
     assert out.shape == (len(texts), 77) and out.dtype == torch.int64
