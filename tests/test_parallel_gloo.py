@@ -92,6 +92,8 @@ def _free_port():
     ("cfg3_overlap_nw10", 2, 2, "levels", False),     # W overlap: one chain -> a strided share of every level
     ("cfg2_2048x512", 2, 5, "units", True),           # 4 columns < 5 ranks: levels of 4 tiles shared out as 8 evaluations (2/2/2/1/1)
     ("cfg3_overlap_nw10", 1, 3, "units", True),       # one chain: levels of 1-2 tiles over 3 ranks, by evaluation
+    ("cfg3_4096x512", 2, 8, "components", True),      # the bench's panorama on 8 ranks: one column (2 dependent tiles) per rank
+    ("cfg2_2048x512", 2, 8, "units", True),           # config 2 on 8 ranks: 4 tiles per level = 8 evaluations, one per rank
 ])
 def test_ranks_equal_single_process(geom_name, steps, world, mode, with_units):
     mgr = mp.Manager()
