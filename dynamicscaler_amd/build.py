@@ -30,7 +30,9 @@ def _newer(src_list, target):
 # diagnostic variants of the library (same ABI, loaded through DS_HIP_LIBRARY by tests/hazard_probe.py only):
 # "barebarrier" = round 1's K-step barrier without the lgkmcnt(0) in front of it (profiles/r2_notes.md)
 VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"], "attnplain": ["-DDS_ATTN_NO_XCD_REMAP"], "nt0": ["-DDS_EXP_NT=0", "-DDS_EXP_STREAM_NT=0"],
-            "attnnarrow": ["-DDS_ATTN_NARROW_STORES"]}
+            "attnnarrow": ["-DDS_ATTN_NARROW_STORES"],
+            # round 2's GroupNorm kernel choice (by instance COUNT): breaks batch invariance at full size (profiles/r3_notes.md section 7)
+            "gncount": ["-DDS_EXP_GN_COUNT_THRESHOLD"]}
 
 
 def build(force=False, verbose=True, variant=None):

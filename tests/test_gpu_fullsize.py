@@ -288,6 +288,33 @@ def test_unet_t24_vs_reference_golden(size):
     assert eps.shape == x.shape and e < T24_TOL[size]
 
 
+@pytest.mark.parametrize("residual", ["float16", "float32"])
+def test_full_size_batch_equals_separate_forwards(residual):
+    """What rank sharding rests on, at the metric's tile size: a batch of 8 UNet evaluations (one GPU's cond half of a tile batch
+    of 8) gives, item for item, the bits of batches of 1 and 2 (an 8-GPU rank's share).  The toy-size form of this test
+    (test_gpu_unet.py) cannot see a kernel form chosen from the launch's instance count -- the full-size per-frame GroupNorms of
+    levels 3-4 (160 / 40 rows, 16 x batch instances) crossed such a threshold between batch 2 and batch 4 until round 3."""
+    from dynamicscaler_amd.synth import synth_normal
+    d = dev()
+    ld, params, _ = full_host(d)
+    m = ld.model.diffusion_model
+    old = (m.residual_dtype, m.residual_scope)
+    try:
+        m.residual_dtype, m.residual_scope = (torch.float32 if residual == "float32" else torch.float16), "full"
+        m.prepare(d)
+        x = synth_normal((8, 4, 16, 40, 64), 300).to(d, torch.float16)
+        ctx = torch.cat([synth_normal((1, 77, 1024), 310 + i) for i in range(8)], 0).to(d)
+        ts = torch.tensor([999, 999, 500, 500, 20, 20, 0, 0], device=d)
+        with torch.no_grad():
+            whole = m(x, ts, context=ctx, fps=16).float()
+            for lo, hi in ((0, 1), (2, 4), (4, 5), (6, 8)):
+                part = m(x[lo:hi], ts[lo:hi], context=ctx[lo:hi], fps=16).float()
+                assert torch.equal(part, whole[lo:hi]), (residual, lo, hi, relerr(part, whole[lo:hi]))
+    finally:
+        m.residual_dtype, m.residual_scope = old
+        m.prepare(d)
+
+
 @pytest.mark.parametrize("size", ["toy", "full"])
 def test_concurrent_graph_replays_repeatable(size):
     """Two hipGraphs of the batched UNet evaluation replaying CONCURRENTLY on two streams (bench.py's default mode) with

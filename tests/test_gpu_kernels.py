@@ -432,6 +432,25 @@ def test_groupnorm(ninst, rows, C, silu):
     assert y3.is_contiguous() and torch.equal(y3, y)
 
 
+@pytest.mark.parametrize("rows,C", [(40, 1280), (160, 1280), (640, 640), (2560, 320), (16 * 160, 1280)])
+@pytest.mark.parametrize("xdt", [torch.float16, torch.float32])
+def test_groupnorm_is_batch_invariant(rows, C, xdt):
+    """An instance's result must not depend on how many instances share the launch (2 evaluations x 16 frames on an 8-GPU rank,
+    16 x 16 on one GPU): the kernel form is chosen from the instance's shape only.  Per-frame norms of every UNet level and the
+    joint-T form, fp16 and fp32 input."""
+    from dynamicscaler_amd import ops
+    d = dev()
+    n_big = 256 if rows <= 640 else 16
+    x = (rnd((n_big * rows, C), 1) * 2 + 0.5).to(xdt).to(d)
+    g, b = (1 + 0.1 * rnd((C,), 2)).to(d), (0.1 * rnd((C,), 3)).to(d)
+    whole = ops.groupnorm(x, g, b, n_big, rows, C, 1e-5, True)
+    for n_small in (1, 2, 32):
+        if n_small > n_big:
+            continue
+        part = ops.groupnorm(x[:n_small * rows].contiguous(), g, b, n_small, rows, C, 1e-5, True)
+        assert torch.equal(part, whole[:n_small * rows]), (rows, C, n_small)
+
+
 @pytest.mark.parametrize("rows,C", [(1000, 320), (77, 1280), (5, 64), (333, 512)])
 def test_layernorm(rows, C):
     from dynamicscaler_amd import ops
