@@ -290,8 +290,8 @@ def test_unet_t24_vs_reference_golden(size):
 
 @pytest.mark.parametrize("residual", ["float16", "float32"])
 def test_full_size_batch_equals_separate_forwards(residual):
-    """What rank sharding rests on, at the metric's tile size: a batch of 8 UNet evaluations (one GPU's cond half of a tile batch
-    of 8) gives, item for item, the bits of batches of 1 and 2 (an 8-GPU rank's share).  The toy-size form of this test
+    """What rank sharding rests on, at the metric's tile size: a batch of 16 UNet evaluations (one GPU's [cond | uncond] batch of 8 tiles)
+    gives, item for item, the bits of batches of 8, 2 and 1 (an 8-GPU rank's share).  The toy-size form of this test
     (test_gpu_unet.py) cannot see a kernel form chosen from the launch's instance count -- the full-size per-frame GroupNorms of
     levels 3-4 (160 / 40 rows, 16 x batch instances) crossed such a threshold between batch 2 and batch 4 until round 3."""
     from dynamicscaler_amd.synth import synth_normal
@@ -302,12 +302,12 @@ def test_full_size_batch_equals_separate_forwards(residual):
     try:
         m.residual_dtype, m.residual_scope = (torch.float32 if residual == "float32" else torch.float16), "full"
         m.prepare(d)
-        x = synth_normal((8, 4, 16, 40, 64), 300).to(d, torch.float16)
-        ctx = torch.cat([synth_normal((1, 77, 1024), 310 + i) for i in range(8)], 0).to(d)
-        ts = torch.tensor([999, 999, 500, 500, 20, 20, 0, 0], device=d)
+        x = synth_normal((16, 4, 16, 40, 64), 300).to(d, torch.float16)
+        ctx = torch.cat([synth_normal((1, 77, 1024), 310 + i) for i in range(16)], 0).to(d)
+        ts = torch.tensor([999, 999, 500, 500, 20, 20, 0, 0] * 2, device=d)
         with torch.no_grad():
             whole = m(x, ts, context=ctx, fps=16).float()
-            for lo, hi in ((0, 1), (2, 4), (4, 5), (6, 8)):
+            for lo, hi in ((0, 1), (2, 4), (4, 5), (6, 8), (8, 16)):
                 part = m(x[lo:hi], ts[lo:hi], context=ctx[lo:hi], fps=16).float()
                 assert torch.equal(part, whole[lo:hi]), (residual, lo, hi, relerr(part, whole[lo:hi]))
     finally:
@@ -438,6 +438,35 @@ def test_ring_pipeline_with_the_real_unet_vs_reference_golden(residual):
     print(r)
     record(**r)
     assert tuple(den.shape) == tuple(z["denoised"].shape) and e < RING_REAL_TOL[residual], r
+
+
+def test_full_size_panorama_independent_of_the_execution_mode():
+    """The same ring panorama (real UNet, the golden's 1024x512x16f geometry, 4 steps, CFG 7.5) under the execution modes a rank
+    can find itself in -- one [cond | uncond] batch of all windows of a level on one stream (1 GPU), one window per batch on two
+    streams with hipGraph replay, cond / uncond of a single window on two streams (an 8-GPU rank's share) -- must be ONE
+    panorama, bit for bit: what lets `bench.py --gpus N` claim the single-GPU result for every N."""
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    path = os.path.join(G, "ring_real_unet.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/ring_real_unet.npz not generated (make_golden.py --full --only g25)")
+    d = dev()
+    z = np.load(path)
+    rec = json.load(open(os.path.join(G, "ring_real_unet_trace.json")))
+    ld, params, _ = full_host(d)
+    outs = {}
+    for name, tb, streams, graph, split in (("batched", 8, 1, False, 0), ("tb1_two_streams_graph", 1, 2, True, 0),
+                                            ("tb1_cfg_split", 1, 2, True, 2), ("batched_two_streams_graph", 8, 2, True, 1)):
+        pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="reference"),
+                                           {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+        pipe.max_tile_batch, pipe.num_streams, pipe.use_graph, pipe.split_cfg_over_streams = tb, streams, graph, split
+        torch.manual_seed(2333333)
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=int(z["fps"]), guidance_scale=float(z["guidance"]),
+                                                       output_type="latent", init_panorama_latent=T(z["init"]), **rec["geom"])
+        outs[name] = den.float().cpu()
+    ref = outs.pop("batched")
+    for name, den in outs.items():
+        assert torch.equal(den, ref), (name, relerr(den, ref))
 
 
 I2V_RING_REAL_TOL = {"float16": 6.9e-3, "float32": 3.8e-3}        # <= 2x measured on MI355X (round 3): 3.46e-3 / 1.92e-3
