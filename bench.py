@@ -228,6 +228,11 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert bool(torch.isfinite(st.pano.float()).all()), "non-finite latent after the timed steps"
+    # what the job computed, so that runs can be compared: the panorama latent after warmup + timed steps is a function of
+    # (config, warmup, steps, latents, residual mode) only -- not of --gpus, --tile-batch, --streams or --graph (rank sharding
+    # and batching are bit-exact: tests/test_gpu_fullsize.py, test_gpu_multirank.py)
+    import hashlib as _hl
+    digests = {"latent_after_timed_steps": _hl.sha256(st.pano.float().cpu().numpy().tobytes()).hexdigest()[:16]}
     ms_per_step = 1e3 * elapsed / args.steps
     steps_per_s = args.steps / elapsed
 
@@ -250,6 +255,7 @@ def main():
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             full_s = float(tt.item())
         assert bool(torch.isfinite(st2.pano_x0.float()).all()), "non-finite pred_x0 panorama after the 50-step run"
+        digests["pred_x0_of_the_50_step_panorama"] = _hl.sha256(st2.pano_x0.float().cpu().numpy().tobytes()).hexdigest()[:16]
         del st2
     tiles_per_step = GEOM["num_windows_w"] * GEOM["num_windows_h"]
     flops_per_step = tiles_per_step * 2 * F_UNET
@@ -429,6 +435,9 @@ def main():
             "sec_per_50_step_panorama_is": "measured: one complete 50-step loop" if full_s is not None else "50 x the timed steps' mean",
             "speedup_vs_cpu_baseline": (steps_per_s / cpu_baseline["value"]) if cpu_baseline else None,
             "setup_s": round(setup_s, 1),
+            # sha-256 prefixes of the latents this run produced: equal for every --gpus / --tile-batch / --streams at the same
+            # --config / --warmup / --steps (the N-GPU job computes the 1-GPU panorama, bit for bit)
+            "result_sha256": digests,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

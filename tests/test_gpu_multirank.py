@@ -75,6 +75,12 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "strong" and j["cpu_baseline"] is None
     assert np.isfinite(j["value"]) and j["value"] > 0 and j["unit"] == "denoising-steps/sec"
     assert j["config"]["baseline_config"] == "cfg3" and "4096x512x16f" in j["metric"]
+    # the two-rank job computed the one-GPU panorama: same latent digest from a single-process run with another tile batch
+    r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-roofline", "--no-cpu-baseline",
+                         "--full-panorama", "0", "--tile-batch", "4"], cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    j1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert j1["n_gpus"] == 1 and j1["result_sha256"]["latent_after_timed_steps"] == j["result_sha256"]["latent_after_timed_steps"], (j1["result_sha256"], j["result_sha256"])
 
 
 def test_graph_and_streams_repeatable_across_processes():
