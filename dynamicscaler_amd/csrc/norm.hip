@@ -13,8 +13,24 @@
 namespace {
 
 constexpr int MAX_C = 4096;
-constexpr int GN_CHUNK_ROWS = 256;
+// Rows per partial-sum chunk: the unit of the statistics' summation order, so a function of the instance's SHAPE only (never of
+// the launch's instance count: a batch must equal its separate forwards bit for bit).  ~160 KB of fp16 per chunk -- 256 rows at
+// C <= 320, 128 at C <= 640, 64 above -- so that the wide, short instances of levels 3-4 (2560 / 640 rows x 1280) give 40 / 10
+// workgroups per instance instead of 10 / 3 (an 8-GPU rank launches 2 instances); never more than ~160 chunks per instance
+// (every apply workgroup reduces its instance's partial sums itself).
+constexpr int GN_CHUNK_ROWS_MAX = 256;
+constexpr int GN_CHUNK_ROWS_MIN = 64;
+static inline int gn_chunk_rows(int rows_per_inst, int C) {
+    static const int rule = getenv("DS_GN_CHUNK_RULE") ? atoi(getenv("DS_GN_CHUNK_RULE")) : 1;   // diagnostic: 0 = 256 rows everywhere (rounds 1-2), 2 = 256 / 256 / 128
+    if (rule == 0) return GN_CHUNK_ROWS_MAX;
+    const int by_c = rule == 2 ? (C <= 640 ? 256 : 128) : (C <= 320 ? 256 : (C <= 640 ? 128 : 64));
+    int by_rows = GN_CHUNK_ROWS_MIN;
+    while (by_rows < GN_CHUNK_ROWS_MAX && (long)by_rows * 160 < rows_per_inst) by_rows *= 2;
+    return by_c > by_rows ? by_c : by_rows;
+}
 constexpr int GN_U = 4;   // rows in flight per thread in the streaming loops (2 and 8 measured 1-8 % slower, tools/bench_norms.py)
+constexpr int GN_U_SPARSE = 16;      // ... where a launch has at most GN_SPARSE_WGS workgroups (measured: profiles/r3_notes.md section 8)
+constexpr int GN_SPARSE_WGS = 1024;
 constexpr int GN_LDS_FLOATS = 4096;   // per array: rl*C (<= 2048 + C) when C <= 2048, C otherwise
 
 __device__ __forceinline__ float fast_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -46,28 +62,31 @@ template <> struct Row8<float> {
 // A thread owns one 8-channel vector column and every rl-th row of the chunk; four rows are loaded before they are
 // accumulated (one accumulation chain per channel, in row order: the sums do not depend on the unrolling), so a
 // workgroup keeps ~15 KB in flight instead of one 16-byte load per thread.
-template <typename XT>
+// U = rows in flight per thread: GN_U where the grid fills the chip several times over, GN_U_SPARSE where it does not (an 8-GPU
+// rank's batch of 2 evaluations: one workgroup per CU or fewer, so the bytes in flight per CU are what one workgroup keeps in
+// flight).  The accumulation chain per channel is in row order for every U: the sums are the same bits.
+template <typename XT, int U>
 __global__ void __launch_bounds__(256)
-gn_partial_kernel(const XT* __restrict__ x, float2* __restrict__ part, int rows_per_inst, int C, int groups, int ldx) {
+gn_partial_kernel(const XT* __restrict__ x, float2* __restrict__ part, int rows_per_inst, int C, int groups, int ldx, int chunk_rows) {
     typedef Row8<XT> R8;
     __shared__ float csum[GN_LDS_FLOATS];
     __shared__ float csq[GN_LDS_FLOATS];
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, inst = blockIdx.y, nchunks = gridDim.x;
-    const int r0 = chunk * GN_CHUNK_ROWS;
-    const int r1 = min(rows_per_inst, r0 + GN_CHUNK_ROWS);
+    const int r0 = chunk * chunk_rows;
+    const int r1 = min(rows_per_inst, r0 + chunk_rows);
     const int nvec = C / 8;
     const XT* base = x + (long)inst * rows_per_inst * ldx;   // input rows may sit in a wider buffer (row stride ldx >= C)
     const int rl = nvec <= 256 ? 256 / nvec : 1;  // row lanes; rl*C <= 2048 + C when rl > 1
     auto accumulate = [&](int col, int rfirst, int rstep, float* s, float* q) {
         const XT* p = base + col * 8;
         int r = rfirst;
-        for (; r + (GN_U - 1) * rstep < r1; r += GN_U * rstep) {
-            typename R8::raw v[GN_U];
+        for (; r + (U - 1) * rstep < r1; r += U * rstep) {
+            typename R8::raw v[U];
 #pragma unroll
-            for (int u = 0; u < GN_U; ++u) v[u] = R8::load(p + (long)(r + u * rstep) * ldx);
+            for (int u = 0; u < U; ++u) v[u] = R8::load(p + (long)(r + u * rstep) * ldx);
 #pragma unroll
-            for (int u = 0; u < GN_U; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = R8::get(v[u], j); s[j] += f; q[j] += f * f; }
         }
@@ -130,16 +149,18 @@ __global__ void gn_finalize_kernel(const float2* __restrict__ part, float* __res
 // order) instead of reading mean / rstd -- the separate finalize launch (1300 per DDIM step, each latency-bound) is gone.
 // `xraw` != nullptr (fp32 input only): the raw x rounded to fp16 is written next to y (dense [rows][C]) -- the fp16 A operand of
 // a projection that reads the un-normalised tensor (ResBlock skip_connection, openaimodel3d.py:186-193), for free in this pass.
-template <typename XT>
+template <typename XT, int U>
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const XT* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                 const float2* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
-                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps, int ldx, f16* __restrict__ xraw) {
+                f16* __restrict__ y, int rows_per_inst, int C, int groups, int silu, float eps, int ldx, f16* __restrict__ xraw,
+                int nchunks, int apply_rows) {
     typedef Row8<XT> R8;
     __shared__ double sred[2][8][32];
     __shared__ float smean[256], srstd[256];
     const int tid = threadIdx.x;
-    const int chunk = blockIdx.x, inst = blockIdx.y, nchunks = gridDim.x;
+    const int chunk = blockIdx.x, inst = blockIdx.y;     // nchunks = partial-sum chunks of the instance; this workgroup applies
+                                                         // rows [chunk * apply_rows, ...): elementwise, any split gives the same bits
     const int cpg = C / groups;
     if (part) {
         for (int g0 = 0; g0 < groups; g0 += 32) {
@@ -166,8 +187,8 @@ gn_apply_kernel(const XT* __restrict__ x, const float* __restrict__ mean, const 
             __syncthreads();
         }
     }
-    const int r0 = chunk * GN_CHUNK_ROWS;
-    const int r1 = min(rows_per_inst, r0 + GN_CHUNK_ROWS);
+    const int r0 = chunk * apply_rows;
+    const int r1 = min(rows_per_inst, r0 + apply_rows);
     const int nvec = C / 8;
     const long base = (long)inst * rows_per_inst * C, xbase = (long)inst * rows_per_inst * ldx;
     const int rl = nvec <= 256 ? 256 / nvec : 1;
@@ -205,15 +226,15 @@ gn_apply_kernel(const XT* __restrict__ x, const float* __restrict__ mean, const 
         f16* py = y + base + col * 8;
         f16* pr = xraw ? xraw + base + col * 8 : nullptr;
         int r = r0 + rlane;
-        for (; r + (GN_U - 1) * rl < r1; r += GN_U * rl) {
-            typename R8::raw v[GN_U];
+        for (; r + (U - 1) * rl < r1; r += U * rl) {
+            typename R8::raw v[U];
 #pragma unroll
-            for (int u = 0; u < GN_U; ++u) v[u] = R8::load_stream(px + (long)(r + u * rl) * ldx);
+            for (int u = 0; u < U; ++u) v[u] = R8::load_stream(px + (long)(r + u * rl) * ldx);
 #pragma unroll
-            for (int u = 0; u < GN_U; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)(r + u * rl) * C), one(v[u]));
+            for (int u = 0; u < U; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)(r + u * rl) * C), one(v[u]));
             if (pr) {
 #pragma unroll
-                for (int u = 0; u < GN_U; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(pr + (long)(r + u * rl) * C), rawh(v[u]));
+                for (int u = 0; u < U; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(pr + (long)(r + u * rl) * C), rawh(v[u]));
             }
         }
         for (; r < r1; r += rl) {
@@ -410,7 +431,7 @@ layernorm_kernel(const XT* __restrict__ x, const float* __restrict__ gamma, cons
 
 // The caller supplies the scratch for the per-chunk partial sums (nothing here allocates).
 extern "C" size_t ds_groupnorm_stats_workspace_floats(int ninst, int rows_per_inst, int groups) {
-    const long nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
+    const long nchunks = (rows_per_inst + GN_CHUNK_ROWS_MIN - 1) / GN_CHUNK_ROWS_MIN;   // C is not an argument: the smallest chunk
     return (size_t)ninst * groups * nchunks * 2;
 }
 
@@ -420,8 +441,9 @@ extern "C" int ds_groupnorm_stats(const void* x, float* mean, float* rstd, float
     DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0, "ds_groupnorm_stats: ninst/rows_per_inst must be positive");
     DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_stats: C=%d groups=%d unsupported", C, groups);
     hipStream_t st = (hipStream_t)stream;
-    const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
-    gn_partial_kernel<f16><<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups, C);
+    const int chunk_rows = gn_chunk_rows(rows_per_inst, C);
+    const int nchunks = (rows_per_inst + chunk_rows - 1) / chunk_rows;
+    gn_partial_kernel<f16, GN_U><<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, (float2*)workspace, rows_per_inst, C, groups, C, chunk_rows);
     DS_CHECK_LAUNCH("ds_groupnorm_stats(partial)");
     const int n = ninst * groups;
     gn_finalize_kernel<<<(n + 255) / 256, 256, 0, st>>>((const float2*)workspace, mean, rstd, ninst, nchunks, groups,
@@ -437,8 +459,9 @@ extern "C" int ds_groupnorm_apply(const void* x, const float* mean, const float*
     DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0, "ds_groupnorm_apply: ninst/rows_per_inst must be positive");
     DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && C % groups == 0, "ds_groupnorm_apply: C=%d groups=%d unsupported", C, groups);
     hipStream_t st = (hipStream_t)stream;
-    const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
-    gn_apply_kernel<f16><<<dim3(nchunks, ninst), 256, 0, st>>>((const f16*)x, mean, rstd, nullptr, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, 0.0f, C, nullptr);
+    const int nwg = (rows_per_inst + GN_CHUNK_ROWS_MAX - 1) / GN_CHUNK_ROWS_MAX;
+    gn_apply_kernel<f16, GN_U><<<dim3(nwg, ninst), 256, 0, st>>>((const f16*)x, mean, rstd, nullptr, gamma, beta, (f16*)y, rows_per_inst, C, groups, silu, 0.0f, C, nullptr,
+                                                                0, GN_CHUNK_ROWS_MAX);
     DS_CHECK_LAUNCH("ds_groupnorm_apply");
     return DS_OK;
 }
@@ -460,11 +483,28 @@ int groupnorm_rows(const XT* x, int ldx, const float* gamma, const float* beta, 
         DS_CHECK_LAUNCH("ds_groupnorm(small)");
         return DS_OK;
     }
-    const int nchunks = (rows_per_inst + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS;
-    gn_partial_kernel<XT><<<dim3(nchunks, ninst), 256, 0, st>>>(x, (float2*)workspace, rows_per_inst, C, groups, ldx);
+    const int chunk_rows = gn_chunk_rows(rows_per_inst, C);
+    const int nchunks = (rows_per_inst + chunk_rows - 1) / chunk_rows;
+    // What follows is free to depend on the launch's size -- none of it changes a sum: the rows in flight per thread (see
+    // gn_partial_kernel) and how the rows of an instance are split over the apply's workgroups (elementwise; 256 rows per
+    // workgroup on a dense grid, down to 32 where the launch would not give every CU two workgroups).
+    constexpr int US = sizeof(XT) == 2 ? GN_U_SPARSE : GN_U_SPARSE / 2;
+    static const int sparse_max = getenv("DS_GN_SPARSE_WGS") ? atoi(getenv("DS_GN_SPARSE_WGS")) : GN_SPARSE_WGS;   // 0: dense-grid forms only (diagnostic)
+    int apply_rows = GN_CHUNK_ROWS_MAX;
+    if (sparse_max > 0)
+        while (apply_rows > 32 && (long)((rows_per_inst + apply_rows - 1) / apply_rows) * ninst < 512) apply_rows /= 2;
+    const int napply = (rows_per_inst + apply_rows - 1) / apply_rows;
+    if ((long)nchunks * ninst <= sparse_max)
+        gn_partial_kernel<XT, US><<<dim3(nchunks, ninst), 256, 0, st>>>(x, (float2*)workspace, rows_per_inst, C, groups, ldx, chunk_rows);
+    else
+        gn_partial_kernel<XT, GN_U><<<dim3(nchunks, ninst), 256, 0, st>>>(x, (float2*)workspace, rows_per_inst, C, groups, ldx, chunk_rows);
     DS_CHECK_LAUNCH("ds_groupnorm(stats)");
-    gn_apply_kernel<XT><<<dim3(nchunks, ninst), 256, 0, st>>>(x, nullptr, nullptr, (const float2*)workspace, gamma, beta, y,
-                                                              rows_per_inst, C, groups, silu, eps, ldx, x_f16);
+    if ((long)napply * ninst <= sparse_max)
+        gn_apply_kernel<XT, US><<<dim3(napply, ninst), 256, 0, st>>>(x, nullptr, nullptr, (const float2*)workspace, gamma, beta, y,
+                                                                     rows_per_inst, C, groups, silu, eps, ldx, x_f16, nchunks, apply_rows);
+    else
+        gn_apply_kernel<XT, GN_U><<<dim3(napply, ninst), 256, 0, st>>>(x, nullptr, nullptr, (const float2*)workspace, gamma, beta, y,
+                                                                       rows_per_inst, C, groups, silu, eps, ldx, x_f16, nchunks, apply_rows);
     DS_CHECK_LAUNCH("ds_groupnorm(apply)");
     return DS_OK;
 }
