@@ -66,6 +66,7 @@ SIGNATURES = {
     "ds_resize_latent": (_i, [_vp, _vp, _i, C.c_long, _i, _i, _i, _i, _i, _vp]),
     "ds_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),
     "ds_groupnorm_stats_workspace_floats": (_sz, [_i, _i, _i]),
+    "ds_groupnorm_chunk_rows": (_i, [_i, _i]),
     "ds_groupnorm_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ds_groupnorm_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ds_groupnorm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

@@ -435,6 +435,8 @@ extern "C" size_t ds_groupnorm_stats_workspace_floats(int ninst, int rows_per_in
     return (size_t)ninst * groups * nchunks * 2;
 }
 
+extern "C" int ds_groupnorm_chunk_rows(int rows_per_inst, int C) { return gn_chunk_rows(rows_per_inst, C); }
+
 extern "C" int ds_groupnorm_stats(const void* x, float* mean, float* rstd, float* workspace, int ninst,
                                      int rows_per_inst, int C, int groups, float eps, void* stream) {
     DS_CHECK_ARG(x && mean && rstd && workspace, "ds_groupnorm_stats: null argument");

@@ -203,6 +203,9 @@ int ds_gemm_f16_lnk(const void* x, const void* W_gamma, float ln_eps, const floa
  * basics.py:76-86, attention.py:238) or T*H*W (5-D GroupNorm over T jointly, openaimodel3d.py:275-292,
  * attention.py:297). */
 size_t ds_groupnorm_stats_workspace_floats(int ninst, int rows_per_inst, int groups);
+/* Rows per partial-sum chunk of an instance: the unit of the statistics' summation order.  A function of the instance's SHAPE
+ * only -- never of ninst -- so that a batch equals its separate forwards bit for bit; at most ~160 chunks per instance. */
+int ds_groupnorm_chunk_rows(int rows_per_inst, int C);
 int ds_groupnorm_stats(const void* x, float* mean, float* rstd, float* workspace, int ninst, int rows_per_inst,
                        int C, int groups, float eps, void* stream);
 /* y = (x-mean)*rstd*gamma+beta, optional SiLU; fp16 out. */

@@ -15,6 +15,26 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(REPO, "tests", "golden")
 
 
+def test_groupnorm_chunking_depends_on_the_instance_shape_only():
+    """The partial-sum chunk of GroupNorm is the statistics' summation order: a pure function of (rows per instance, C) -- the
+    C ABI has no way to tell it the launch's instance count -- giving at most ~160 chunks per instance (every apply workgroup
+    reduces them itself) of about 160 KB of fp16 each, and the caller's scratch is sized for it at any C."""
+    from dynamicscaler_amd import _lib
+    lib = _lib.load()
+    for rows in (40, 160, 640, 2560, 10240, 40960, 61440, 15360, 257, 100000):
+        for C in (64, 320, 640, 960, 1280, 1920, 2560):
+            ch = lib.ds_groupnorm_chunk_rows(rows, C)
+            assert ch in (64, 128, 256), (rows, C, ch)
+            nch = -(-rows // ch)
+            assert nch <= 160 or ch == 256, (rows, C, ch, nch)
+            assert ch * C * 2 <= 256 * 1024 or ch == 64 or nch > 80, (rows, C, ch)      # ~160 KB, more only to bound the chunk count
+            for ninst in (1, 2, 256):
+                assert lib.ds_groupnorm_stats_workspace_floats(ninst, rows, 32) >= ninst * 32 * nch * 2
+    # the metric's shapes: level 1-4 joint-T and per-frame instances
+    got = {(r, c): lib.ds_groupnorm_chunk_rows(r, c) for r, c in ((40960, 320), (10240, 640), (2560, 1280), (640, 1280), (2560, 320), (640, 640))}
+    assert got == {(40960, 320): 256, (10240, 640): 128, (2560, 1280): 64, (640, 1280): 64, (2560, 320): 256, (640, 640): 128}, got
+
+
 def test_cabi_library_exports_every_declared_symbol():
     from dynamicscaler_amd import build, _lib
     build.build(verbose=False)
