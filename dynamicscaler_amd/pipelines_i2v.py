@@ -60,6 +60,15 @@ class RingImageTensor:
         crop = self.get_window_tensor(pos_left, pos_right, pos_top, pos_down)
         return pretrained_t2v.get_image_embeds(crop.to(pretrained_t2v.device).unsqueeze(0))
 
+    def get_encoded_image_conds(self, pretrained_t2v, boxes):
+        """The crops of several windows -- boxes = [(pos_left, pos_right, pos_top, pos_down), ...], all of one size -- through ONE
+        get_image_embeds call ([n,3,h,w] -> [n,16,1024]; the reference calls it once per window, ddpm3d.py:689-693 takes a batch):
+        a step's new windows cost one pass of the image tower at 257 n rows instead of n passes at 257.  Returns a list of
+        [1,16,1024] tensors, item for item what get_encoded_image_cond gives (tests/test_gpu_encoders.py)."""
+        crops = torch.stack([self.get_window_tensor(*b) for b in boxes], 0)
+        out = pretrained_t2v.get_image_embeds(crops.to(pretrained_t2v.device))
+        return [out[k:k + 1] for k in range(len(boxes))]
+
 
 class VC2_Pipeline_I2V(VC2_Pipeline_T2V):
     """Base of the i2v pipelines (pipeline/i2v_normal_pipeline.py:27): same members as the t2v base."""
@@ -120,10 +129,11 @@ class VC2_Pipeline_I2V(VC2_Pipeline_T2V):
                                                num_windows_w=num_windows_w, num_windows_f=num_windows_f, loop_step=loop_step,
                                                dock_at_h=dock_at_h)
                 ctxs = []
+                new = [k for k in dict.fromkeys(crops) if k not in img_cache]      # this step's crops not embedded yet, in order
+                if new:
+                    embs = ring_image.get_encoded_image_conds(self.pretrained_t2v, [(il, il + width, it, it + height) for (il, it) in new])
+                    img_cache.update({k: e.to(st.device) for k, e in zip(new, embs)})
                 for (il, it) in crops:
-                    if (il, it) not in img_cache:
-                        img_cache[(il, it)] = ring_image.get_encoded_image_cond(self.pretrained_t2v, il, il + width, it,
-                                                                                it + height).to(st.device)
                     ctxs.append(torch.cat([st.text_emb, img_cache[(il, it)].to(st.text_emb.dtype)], dim=1))
                 renoise = st.ratio is not None and i < total_steps - 1
                 self._denoise_windows(st, i, wins, ctxs, renoise=renoise, mask_frame0=True)
@@ -273,6 +283,11 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
         st.mask.zero_()  # reset denoised mask record (:810)
         wins = i2v_ring_windows(i, overlap_ratio_f=st.overlap_ratio_list_f[i], **st.win_args)
         ctxs = []
+        new = [k for k in dict.fromkeys((w[0], w[2]) for w in wins) if k not in st.img_cache]   # crops not embedded yet: one tower pass
+        if new:
+            embs = st.ring_image.get_encoded_image_conds(
+                self.pretrained_t2v, [(l * vs, l * vs + st.width, t * vs, t * vs + st.height) for (l, t) in new])
+            st.img_cache.update({k: e.to(st.device) for k, e in zip(new, embs)})
         for (left, _r, top, _d, _fb, _fe) in wins:
             cur_text = st.text_emb
             if st.window_multi_prompt_dict is not None:
@@ -281,10 +296,7 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
                 if cur not in st.prompt_cache:
                     st.prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(st.device)
                 cur_text = st.prompt_cache[cur]
-            key = (left, top)
-            if key not in st.img_cache:   # same crop position recurs every loop_step steps
-                st.img_cache[key] = st.ring_image.get_encoded_image_cond(
-                    self.pretrained_t2v, left * vs, left * vs + st.width, top * vs, top * vs + st.height).to(st.device)
+            key = (left, top)             # embedded above; the same crop position recurs every loop_step steps
             ctxs.append(torch.cat([cur_text, st.img_cache[key].to(cur_text.dtype)], dim=1))
         renoise = st.ratio is not None and i < st.total_steps - 1
         merge_prev = None

@@ -213,3 +213,14 @@ def test_get_image_embeds_chain_vs_oracle():
     e = relerr(emb, ref)
     print(f"get_image_embeds (320x512 crop -> [1,16,1024]): rel err {e:.3e}")
     assert emb.shape == (1, 16, 1024) and e < TOL
+    # a batch of crops in one call (what the i2v pipelines do with a step's new windows, RingImageTensor.get_encoded_image_conds)
+    # gives, item for item, the bits of the one-crop calls -- at 5 and at 16 crops (the GEMM tile choice changes with the row count)
+    from dynamicscaler_amd.pipelines_i2v import RingImageTensor
+    pano = synth_normal((3, 320, 2048), 74, scale=0.5).clamp(-1, 1)
+    ring = RingImageTensor(image_tensor=pano, height=320, width=2048, device=d)
+    for n in (5, 16):
+        boxes = [(37 * k * 8 % 2048, 37 * k * 8 % 2048 + 512, 0, 320) for k in range(n)]
+        together = ring.get_encoded_image_conds(ld, boxes)
+        for b, got in zip(boxes, together):
+            one = ring.get_encoded_image_cond(ld, *b)
+            assert got.shape == one.shape == (1, 16, 1024) and torch.equal(got, one), (n, b, relerr(got, one))
