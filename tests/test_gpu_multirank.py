@@ -83,6 +83,25 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert j1["n_gpus"] == 1 and j1["result_sha256"]["latent_after_timed_steps"] == j["result_sha256"]["latent_after_timed_steps"], (j1["result_sha256"], j["result_sha256"])
 
 
+def test_eight_gpu_layout_rehearsed_with_two_ranks():
+    """cfg3 on 8 GPUs in small: `col2` (two panorama columns of the metric's tile size) on two ranks = ONE column per rank, one tile
+    per level and rank -- the cond and the uncond forward on two streams (pipelines.split_cfg_over_streams), whole-column ownership,
+    one all-gather per step.  Both ranks on this GPU through gloo; the job's latent digest must be the one-process run's."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GLOO_SOCKET_IFNAME="lo")
+    common = ["--config", "col2", "--steps", "3", "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--full-panorama", "0"]
+    r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    env2 = dict(env, DS_DIST_BACKEND="gloo", DS_BENCH_DEVICE="0")
+    r2 = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + common, cwd=REPO, env=env2, capture_output=True, text=True, timeout=1200)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    j1, j2 = (json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0]) for r in (r1, r2))
+    assert (j1["n_gpus"], j2["n_gpus"]) == (1, 2) and j1["config"]["tiles_per_step"] == j2["config"]["tiles_per_step"] == 4
+    assert j1["result_sha256"] == j2["result_sha256"], (j1["result_sha256"], j2["result_sha256"])
+
+
 def test_graph_and_streams_repeatable_across_processes():
     """Two hipGraph replays running concurrently on two streams (the bench's mode) must give the same bits in every
     process.  An epilogue variant of the GEMM once passed every in-process equality test and still produced panoramas
