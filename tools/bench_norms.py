@@ -31,5 +31,6 @@ for E in [int(a) for a in sys.argv[1:]] or [16]:     # evaluations per launch: 1
       t1 = timeit(lambda: ops.groupnorm(x, g, be, E * T, H * W, C, 1e-5, True))
       t2 = timeit(lambda: ops.groupnorm(x, g, be, E, T * H * W, C, 1e-5, True))
       t3 = timeit(lambda: ops.layernorm(x, g, be))
+      t4 = timeit(lambda: ops.layernorm_stats(x))
       print(f"C={C:5d} {H}x{W} M={M:7d}: groupnorm per frame {t1*1e3:7.3f} ms {3.0*M*C*2/t1/1e9:7.0f} GB/s | joint-T {t2*1e3:7.3f} ms "
-            f"{3.0*M*C*2/t2/1e9:7.0f} GB/s | layernorm {t3*1e3:7.3f} ms {2.0*M*C*2/t3/1e9:7.0f} GB/s")
+            f"{3.0*M*C*2/t2/1e9:7.0f} GB/s | layernorm {t3*1e3:7.3f} ms {2.0*M*C*2/t3/1e9:7.0f} GB/s | stats only {t4*1e3:7.3f} ms {1.0*M*C*2/t4/1e9:7.0f} GB/s")
