@@ -16,7 +16,7 @@ DS_F16, DS_F32 = 0, 1
 DS_A_DENSE, DS_A_CONV3, DS_A_TCONV = 0, 1, 2
 DS_EPI_GEGLU, DS_EPI_SILU, DS_EPI_OUT_F32, DS_EPI_RES_F32 = 1, 2, 4, 8
 DS_MAX_WINDOWS = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HipLibraryMissing(RuntimeError):
@@ -43,7 +43,7 @@ class UNetConfig(C.Structure):
                 + [("channel_mult", C.c_int32 * 8), ("n_attention_resolutions", C.c_int32), ("attention_resolutions", C.c_int32 * 8)]
                 + [(n, C.c_int32) for n in ("num_head_channels", "transformer_depth", "temporal_transformer_depth", "context_dim",
                                             "use_linear", "temporal_conv", "temporal_attention", "addition_attention",
-                                            "use_image_attention", "fps_cond", "residual_f32", "fold_layernorm")])
+                                            "use_image_attention", "fps_cond", "residual_f32", "fold_layernorm", "temporal_selfatt_only")])
 
 
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
@@ -130,6 +130,15 @@ def load():
         lib = C.CDLL(LIB_PATH)
     except OSError as e:
         raise HipLibraryMissing(f"cannot load {LIB_PATH}: {e}") from e
+    # the version first: a stale prebuilt library may export every name and still disagree on a struct layout
+    try:
+        lib.ds_abi_version.restype, lib.ds_abi_version.argtypes = _i, []
+        have = lib.ds_abi_version()
+    except AttributeError as e:
+        raise HipLibraryMissing(f"{LIB_PATH} does not export ds_abi_version; rebuild it") from e
+    if have != ABI_VERSION:
+        raise HipLibraryMissing(f"ABI version mismatch: library {have} != binding {ABI_VERSION} (include/dynscaler_hip.h DS_ABI_VERSION); "
+                                "rebuild it with `python -m dynamicscaler_amd.build --force`")
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
@@ -137,8 +146,6 @@ def load():
             raise HipLibraryMissing(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.ds_abi_version() != ABI_VERSION:
-        raise HipLibraryMissing(f"ABI version mismatch: library {lib.ds_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
 

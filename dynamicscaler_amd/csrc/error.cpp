@@ -12,4 +12,4 @@ void ds_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ds_last_error(void) { return g_err; }
-extern "C" int ds_abi_version(void) { return 1; }
+extern "C" int ds_abi_version(void) { return DS_ABI_VERSION; }

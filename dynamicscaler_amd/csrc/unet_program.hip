@@ -8,7 +8,10 @@
 
 #include <functional>
 #include <type_traits>
+#include <array>
 #include <map>
+#include <mutex>
+#include <new>
 #include <memory>
 #include <string>
 #include <utility>
@@ -156,6 +159,8 @@ struct ds_unet {
     char* packed = nullptr;
     std::map<std::string, int> emb_off;
     int emb_total = 0, kpad_in = 0;
+    std::mutex peak_mu;
+    std::map<std::array<int, 6>, size_t> peak_cache;   // (B, T, H, W, ctx_tokens, cfg_pairs) -> workspace peak of the dry run
 
     const WeightSpec* w(const std::string& key) const {
         auto it = windex.find(key);
@@ -646,8 +651,13 @@ struct Arena {              // first-fit free list over [0, cap): deterministic,
 struct Buf {
     Arena* a;
     size_t off, bytes;
-    Buf(Arena* a_, size_t b) : a(a_), off(a_->alloc(b)), bytes(b) {}
-    ~Buf() { a->release(off, bytes); }
+    bool ok;                        // false: the arena had no room (offset 0 is a placeholder, never handed to a kernel and never released)
+    Buf(Arena* a_, size_t b) : a(a_), off(0), bytes(b), ok(false) {
+        if (a->failed) return;      // an earlier allocation failed: the program is being wound down, take nothing more
+        off = a->alloc(b);
+        ok = !a->failed;
+    }
+    ~Buf() { if (ok) a->release(off, bytes); }
 };
 
 struct Ten {                       // rows x cols view (row stride ld elements) of an arena buffer or of caller memory
@@ -706,7 +716,7 @@ struct Prog {
         if (!t.ext) t.ext = (char*)16;   // dry run before packing: never dereferenced
         return t;
     }
-    bool live() const { return log == nullptr; }
+    bool live() const { return log == nullptr && !arena.failed; }   // nothing is launched once an allocation has failed (ds_unet_forward returns DS_EINVAL)
     void tr(const char* fmt, ...) {
         if (!log) return;
         char line[512];
@@ -1112,15 +1122,25 @@ extern "C" int ds_unet_create(const ds_unet_config* cfg, ds_unet** out) {
                  "ds_unet_create: num_res_blocks / channel_mult / attention_resolutions out of range");
     DS_CHECK_ARG(c.num_head_channels == HEAD_DIM, "ds_unet_create: the attention kernels are built for head_dim 64 (the VideoCrafter configs)");
     DS_CHECK_ARG(c.transformer_depth > 0 && c.temporal_transformer_depth > 0 && c.context_dim > 0 && c.context_dim % 64 == 0, "ds_unet_create: transformer depth / context_dim");
-    ds_unet* u = new ds_unet();
-    u->cfg = c;
+    DS_CHECK_ARG(c.temporal_selfatt_only == 1, "ds_unet_create: temporal_selfatt_only must be 1 (TemporalTransformers with cross-attention to the context are not built)");
     DS_CHECK_ARG(c.residual_f32 >= 0 && c.residual_f32 <= 2, "ds_unet_create: residual_f32 must be 0 (fp16 stream), 1 (fp32 everywhere) or 2 (fp32 between the blocks only)");
-    u->strict = c.residual_f32 != 0;
-    u->inner32 = c.residual_f32 == 1;
-    u->fold = c.fold_layernorm != 0 && !u->inner32;    // the fold multiplies the RAW activation on the matrix cores: needs it in fp16
-    build_program(u);
-    plan_pack(u);
-    *out = u;
+    for (int i = 0; i < c.n_channel_mult; ++i) DS_CHECK_ARG(c.channel_mult[i] > 0, "ds_unet_create: channel_mult[%d] = %d must be positive", i, c.channel_mult[i]);
+    for (int i = 0; i < c.n_attention_resolutions; ++i) DS_CHECK_ARG(c.attention_resolutions[i] > 0, "ds_unet_create: attention_resolutions[%d] = %d must be positive", i, c.attention_resolutions[i]);
+    // every check above runs before the handle exists; nothing below may leave through the C boundary as an exception
+    std::unique_ptr<ds_unet> u;
+    try {
+        u.reset(new ds_unet());
+        u->cfg = c;
+        u->strict = c.residual_f32 != 0;
+        u->inner32 = c.residual_f32 == 1;
+        u->fold = c.fold_layernorm != 0 && !u->inner32;    // the fold multiplies the RAW activation on the matrix cores: needs it in fp16
+        build_program(u.get());
+        plan_pack(u.get());
+    } catch (const std::exception& e) {
+        ds_set_error("ds_unet_create: %s", e.what());
+        return DS_EINVAL;
+    }
+    *out = u.release();
     return DS_OK;
 }
 
@@ -1188,6 +1208,9 @@ extern "C" int ds_unet_pack(ds_unet* u, void* packed, size_t packed_bytes, void*
         if (rc != DS_OK) { u->packed = nullptr; return rc; }
         DS_CHECK_LAUNCH("ds_unet_pack");
     }
+    // the raw pointers are not kept: a second ds_unet_pack needs a fresh ds_unet_load_weight of every key ("missing weight"
+    // otherwise) instead of reading tensors the caller may have freed since
+    for (auto& w : u->weights) w.data = nullptr;
     return DS_OK;
 }
 
@@ -1197,12 +1220,26 @@ static int unet_check_geometry(const ds_unet* u, int B, int T, int H, int W, int
     return DS_OK;
 }
 
-extern "C" size_t ds_unet_workspace_bytes(ds_unet* u, int B, int T, int H, int W, int ctx_tokens, int cfg_pairs) {
-    if (unet_check_geometry(u, B, T, H, W, ctx_tokens, cfg_pairs) != DS_OK) return 0;
+// Peak of the dry run of the launch program for one geometry, cached on the handle (the program is a function of the
+// handle's configuration and the geometry only).  0: the dry run failed.
+static size_t unet_peak(ds_unet* u, int B, int T, int H, int W, int ctx_tokens, int cfg_pairs) {
+    const std::array<int, 6> key = {B, T, H, W, ctx_tokens, cfg_pairs};
+    {
+        std::lock_guard<std::mutex> g(u->peak_mu);
+        auto it = u->peak_cache.find(key);
+        if (it != u->peak_cache.end()) return it->second;
+    }
     std::string sink;
     Prog p(u, nullptr, 0, nullptr, &sink);
-    if (p.forward(nullptr, DS_F16, nullptr, nullptr, DS_F16, ctx_tokens, 8, B, T, H, W, cfg_pairs, nullptr) != DS_OK) return 0;
-    return p.arena.peak;
+    const size_t peak = p.forward(nullptr, DS_F16, nullptr, nullptr, DS_F16, ctx_tokens, 8, B, T, H, W, cfg_pairs, nullptr) == DS_OK ? p.arena.peak : 0;
+    std::lock_guard<std::mutex> g(u->peak_mu);
+    u->peak_cache[key] = peak;
+    return peak;
+}
+
+extern "C" size_t ds_unet_workspace_bytes(ds_unet* u, int B, int T, int H, int W, int ctx_tokens, int cfg_pairs) {
+    if (unet_check_geometry(u, B, T, H, W, ctx_tokens, cfg_pairs) != DS_OK) return 0;
+    return unet_peak(u, B, T, H, W, ctx_tokens, cfg_pairs);
 }
 
 extern "C" long ds_unet_trace(ds_unet* u, int B, int T, int H, int W, int ctx_tokens, int cfg_pairs, char* buf, size_t buf_bytes) {
@@ -1227,6 +1264,10 @@ extern "C" int ds_unet_forward(ds_unet* u, const void* x, int x_dtype, const int
     DS_CHECK_ARG((x_dtype == DS_F16 || x_dtype == DS_F32) && (ctx_dtype == DS_F16 || ctx_dtype == DS_F32), "ds_unet_forward: dtypes must be DS_F16 or DS_F32");
     DS_CHECK_ARG(u->packed, "ds_unet_forward: ds_unet_pack has not run");
     DS_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "ds_unet_forward: the workspace must be 256-byte aligned");
+    // refused BEFORE the first launch: a short workspace never sees a kernel (the arena's own failure path stops launching too)
+    const size_t need = unet_peak(u, B, T, H, W, ctx_tokens, cfg_pairs);
+    DS_CHECK_ARG(need > 0, "ds_unet_forward: the launch program could not be planned for this geometry");
+    DS_CHECK_ARG(workspace_bytes >= need, "ds_unet_forward: workspace too small: %zu bytes given, %zu needed (ds_unet_workspace_bytes gives the size)", workspace_bytes, need);
     Prog p(u, (char*)workspace, workspace_bytes, (hipStream_t)stream, nullptr);
     return p.forward(x, x_dtype, timesteps, context, ctx_dtype, ctx_tokens, fps, B, T, H, W, cfg_pairs, eps);
 }

@@ -180,6 +180,7 @@ class UNetModel(nn.Module):
             setattr(c, k, int(bool(cfg[k])))
         c.residual_f32 = (1 if self._inner32() else 2) if self._strict() else 0
         c.fold_layernorm = int(bool(self._fold()))
+        c.temporal_selfatt_only = int(bool(cfg.get("temporal_selfatt_only", True)))
         return c
 
     def _release_handle(self):

@@ -34,7 +34,9 @@ extern "C" {
 #define DS_F32 1
 
 const char* ds_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature or struct-layout change (round 4: 2 -- ds_unet_config gained
+ * temporal_selfatt_only, new entry points).  Bindings compare it with the version they were written for and refuse a stale library. */
+#define DS_ABI_VERSION 2
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -340,6 +342,8 @@ typedef struct ds_unet_config {          /* the yaml keys of unet_config.params 
                                             only BETWEEN the blocks (ResBlock / temporal-conv outputs, proj_out + x, conv_in, down /
                                             up-sample, skip tensors), the transformers keep their fp16 inner stream             */
     int32_t fold_layernorm;              /* 1: LayerNorm folded into the projections (ds_gemm_f16_ln); forced off by residual_f32 = 1 */
+    int32_t temporal_selfatt_only;       /* must be 1 (every VideoCrafter config): the TemporalTransformers attend over the frames only;
+                                            0 (cross-attention to the context inside them) is refused with DS_EINVAL            */
 } ds_unet_config;
 
 /* Builds the block program; *out receives the handle.  Unsupported option combinations return DS_EINVAL. */
@@ -349,7 +353,9 @@ int ds_unet_destroy(ds_unet* u);
 int ds_unet_num_weights(const ds_unet* u);
 int ds_unet_weight_info(const ds_unet* u, int i, const char** key, int* ndim, int64_t shape[5]);
 /* Registers one raw tensor of the reference's state dict: DEVICE pointer, contiguous, DS_F32 or DS_F16, in the reference's
- * layout ([Cout,Cin,3,3] conv weights etc.).  The pointer must stay valid until ds_unet_pack returns. */
+ * layout ([Cout,Cin,3,3] conv weights etc.).  The pointer must stay valid until the work ds_unet_pack enqueues on its stream has
+ * COMPLETED (synchronise the stream before freeing the raw tensors: the packing kernels read them asynchronously).  A successful
+ * ds_unet_pack forgets the pointers, so packing the same handle again needs every key loaded again. */
 int ds_unet_load_weight(ds_unet* u, const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
 /* Bytes of the packed-weight buffer, and the packing itself (async on `stream`): fp16 [N][K] GEMM operands (K = tap*Cin + c for
  * convolutions), fused QKV / KV matrices, GEGLU rows interleaved, the time-embedding projections of all ResBlocks in one

@@ -33,6 +33,9 @@ so parity is pinned by what this script captures from the imported reference cod
   G26 updates_i2v_t24.npz    (--full) one update of the 50-step schedule for the i2v UNet (93 tokens) and for 24-frame tiles (8 forwards)
   G27 i2v_ring_real_unet.npz (--full) the i2v ring loop with the REAL i2v UNet: per-window image tokens, merge-prev (32 forwards)
 
+  G28 ring_real_unet_50step.npz      (--full) the t2v ring loop, REAL UNet, on the metric's 50-step schedule: first and last 6 steps (96 forwards)
+  G29 i2v_ring_real_unet_50step.npz  (--full) the same for the i2v ring loop with the REAL i2v UNet (96 forwards)
+
   G16 encoders_{toy,full}.npz  Resampler (the reference's module, ip_resampler.py) and the CLIP ViT-H/14 text / image
                              towers -- open_clip is absent, so the tower vectors come from transformers' CLIP
                              implementation carrying the same synthetic weights (independent anchor, not the reference)
@@ -643,6 +646,176 @@ def g27_i2v_ring_real_unet():
     with open(os.path.join(HERE, "i2v_ring_real_unet_trace.json"), "w") as f:
         json.dump({"geom": I2V_RING_REAL, "trace": parse_trace(buf.getvalue())}, f)
     print("wrote i2v_ring_real_unet_trace.json", float(den.std()))
+
+
+# ---- the metric's 50-step schedule through the ring loops with the REAL UNets (round 4) ----------------------------------
+RING50_STEPS = 6                    # steps recorded at each end of the schedule
+RING50_LAST_KEPT = (0, 2, 5)        # panoramas kept of the last six steps (the first six are all kept)
+
+
+class _StopRun(Exception):
+    pass
+
+
+def _trim16(t):
+    """fp32 with the low 8 mantissa bits cleared after rounding (relative error <= 2^-17): what the per-step panoramas are
+    stored as, so that the deflate stream of the .npz drops a quarter of the bytes."""
+    a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+    u = a.view(np.uint32).astype(np.uint64)
+    u = ((u + 0x80) & 0xFFFFFF00).astype(np.uint32)
+    return u.view(np.float32)
+
+
+def _record_ring_run(run, n_steps):
+    """Run `run()` (a call of one of the reference's ring loops) while watching the RingLatent handlers it builds
+    (utils/shift_window_utils.py:40-46): the first two are the panorama latent and its pred-x0 twin
+    (t2v_sphere_panorama_pipeline.py:438-439, i2v_sphere_panorama_pipeline.py:730-731), every later one is a step's fresh
+    mask (:493 / :810) -- i.e. it marks the START of a step, where the panorama after the previous step is snapshotted.
+    Stops the loop at the start of step `n_steps` (None: let it finish)."""
+    import time
+    import utils.shift_window_utils as swu
+    handlers, snaps = [], []
+    orig_init = swu.RingLatent.__init__
+
+    def init(self, *a, **k):
+        orig_init(self, *a, **k)
+        handlers.append(self)
+        if len(handlers) > 3:
+            snaps.append((handlers[0].torch_latent.clone(), handlers[1].torch_latent.clone()))
+            print(f"[{time.strftime('%H:%M:%S')}] after step {len(snaps)}: |x| {float(snaps[-1][0].std()):.4f}", file=sys.stderr, flush=True)
+            if n_steps is not None and len(snaps) >= n_steps:
+                raise _StopRun()
+
+    swu.RingLatent.__init__ = init
+    buf = io.StringIO()
+    out = None
+    try:
+        with contextlib.redirect_stdout(buf):
+            out = run()
+    except _StopRun:
+        pass
+    finally:
+        swu.RingLatent.__init__ = orig_init
+    if out is not None:                                   # ran to the end: the last step has no following mask handler
+        snaps.append((handlers[0].torch_latent.clone(), handlers[1].torch_latent.clone()))
+    return snaps, parse_trace(buf.getvalue()), out
+
+
+def _late_latent(sched, shape, index, seed):
+    """A latent at the noise level of schedule index `index`: sqrt(a) x0 + sqrt(1 - a) n, synthetic unit-scale x0 and n."""
+    a = float(sched.ddim_alphas[index])
+    return (a ** 0.5 * synth_normal(shape, seed) + (1 - a) ** 0.5 * synth_normal(shape, seed + 1)).half().float()
+
+
+def g28_ring_real_unet_50step():
+    """P2 on the schedule the metric runs: the reference's t2v ring loop (pipeline/t2v_sphere_panorama_pipeline.py:481-634)
+    with the REAL t2v UNet, 1024x512x16f, 2x2 shifted windows, CFG 7.5, num_inference_steps = 50 --
+    "first": steps 0..5 (schedule indices 49..44, t = 999..897) from the init latent, the loop stopped at the start of step 6;
+    "last": the method's own use_skip_time=True, skip_time_step_idx=44 (:393-396): steps of indices 5..0 from a latent at index 5's
+    noise level, run to the end.  Both ends re-noise the overlap at the 50-step sigmas (:550-559).  The panorama latent after
+    every step (and the final pred-x0 panorama) are stored; 2 x 48 forwards of the reference on CPU."""
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"              # plumbing check on the toy UNet (seconds)
+    if dry:
+        params = dict(TINY)
+    unet = build_reference_unet(params, seed=0)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 1), synth_normal((1, 77, cd), 2)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    geom = dict(RING_REAL, num_inference_steps=50)
+    shape = (1, 4, 16, geom["total_h"] // 8, geom["total_w"] // 8)
+    A = {"fps": np.int64(8), "guidance": np.float32(7.5), "steps": np.int64(RING50_STEPS)}
+    traces = {}
+    sched = lvdm_DDIM_Scheduler(ld)
+    sched.make_schedule(50)
+    inits = {"first": synth_normal(shape, 2333336), "last": _late_latent(sched, shape, RING50_STEPS - 1, 2333340)}
+    for end in ("first", "last"):
+        pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+        kw = dict(prompt="a prompt", output_type="latent", fps=8, guidance_scale=7.5, init_panorama_latent=inits[end].clone(), **geom)
+        if end == "last":
+            kw.update(use_skip_time=True, skip_time_step_idx=50 - RING50_STEPS)
+        torch.manual_seed(2333333)
+        snaps, trace, out = _record_ring_run(lambda: pipe.basic_sample_shift_multi_windows(**kw), RING50_STEPS if end == "first" else None)
+        assert len(snaps) == RING50_STEPS and (out is None) == (end == "first")
+        A[f"{end}_init"] = inits[end]
+        for k, (x, x0) in enumerate(snaps):
+            if end == "first" or k in RING50_LAST_KEPT:
+                A[f"{end}_pano_{k}"] = _trim16(x)
+        A[f"{end}_x0_{RING50_STEPS - 1}"] = _trim16(snaps[-1][1])
+        if out is not None:
+            assert torch.equal(out[1], snaps[-1][1])
+        traces[end] = trace[:RING50_STEPS]
+        save_npz("ring_real_unet_50step.partial.npz", **A)
+    os.remove(os.path.join(HERE, "ring_real_unet_50step.partial.npz"))
+    if dry:
+        print("dry run ok", [float(np.std(A[f"last_pano_{k}"])) for k in RING50_LAST_KEPT], traces["last"][-1])
+        return
+    save_npz("ring_real_unet_50step.npz", **A)
+    with open(os.path.join(HERE, "ring_real_unet_50step_trace.json"), "w") as f:
+        json.dump({"geom": geom, "traces": traces}, f)
+
+
+def g29_i2v_ring_real_unet_50step():
+    """P3 on the 50-step schedule: the reference's i2v ring loop (pipeline/i2v_sphere_panorama_pipeline.py:777-970) with the REAL
+    i2v UNet (77 text + 16 image tokens per window, merge-prev), same geometry and the same two ends as G28
+    (use_skip_time :673-675 for the last six)."""
+    import utils.shift_window_utils as swu
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_i2v_512_v1.0.yaml")))["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"
+    if dry:
+        params = dict(TINY, use_image_attention=True)
+    unet = build_reference_unet(params, seed=3)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 11), synth_normal((1, 77, cd), 12)
+    embed = synth_image_embedder(cd)
+    pano_img = synth_normal((3, 512, 1024), 189).clamp(-1, 1)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    ld.get_image_embeds = embed
+    ld.embedder = object()
+    shape = (1, 4, 16, 64, 128)
+    sched = lvdm_DDIM_Scheduler(ld)
+    sched.make_schedule(50)
+    inits = {"first": synth_normal(shape, 2333337), "last": _late_latent(sched, shape, RING50_STEPS - 1, 2333342)}
+    merge_first = [0.5] * 50
+    merge_last = [0.3, 0.3, 0.2, 0.2, 0.1, 0.1]
+    A = {"fps": np.int64(16), "guidance": np.float32(7.5), "steps": np.int64(RING50_STEPS), "pano_img_seed": np.int64(189)}
+    traces, geoms = {}, {}
+    orig_loader = swu.load_image_tensor_from_path
+    swu.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: pano_img   # I/O stub (cv2 absent)
+    try:
+        for end in ("first", "last"):
+            n = 50 if end == "first" else RING50_STEPS
+            geom = dict(I2V_RING_REAL, num_inference_steps=50, overlap_ratio_list_f=[0.0] * n,
+                        merge_prev_denoised_ratio_list=merge_first if end == "first" else merge_last)
+            pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+            pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+            kw = dict(prompt="a prompt", img_cond_path="unused.png", fps=16, guidance_scale=7.5, pano_image_path="unused.png",
+                      output_type="latent", init_panorama_latent=inits[end].clone(), **geom)
+            if end == "last":
+                kw.update(use_skip_time=True, skip_time_step_idx=50 - RING50_STEPS)
+            torch.manual_seed(2333333)
+            snaps, trace, out = _record_ring_run(lambda: pipe.basic_sample_shift_multi_windows(**kw), RING50_STEPS if end == "first" else None)
+            assert len(snaps) == RING50_STEPS and (out is None) == (end == "first")
+            A[f"{end}_init"] = inits[end]
+            for k, (x, x0) in enumerate(snaps):
+                if end == "first" or k in RING50_LAST_KEPT:
+                    A[f"{end}_pano_{k}"] = _trim16(x)
+            A[f"{end}_x0_{RING50_STEPS - 1}"] = _trim16(snaps[-1][1])
+            traces[end], geoms[end] = trace[:RING50_STEPS], geom
+            save_npz("i2v_ring_real_unet_50step.partial.npz", **A)
+    finally:
+        swu.load_image_tensor_from_path = orig_loader
+    os.remove(os.path.join(HERE, "i2v_ring_real_unet_50step.partial.npz"))
+    if dry:
+        print("dry run ok", [float(np.std(A[f"last_pano_{k}"])) for k in RING50_LAST_KEPT], traces["last"][-1])
+        return
+    save_npz("i2v_ring_real_unet_50step.npz", **A)
+    with open(os.path.join(HERE, "i2v_ring_real_unet_50step_trace.json"), "w") as f:
+        json.dump({"geoms": geoms, "traces": traces}, f)
 
 
 def g18_unet_t24(full=False):
@@ -1397,6 +1570,8 @@ if __name__ == "__main__":
         steps["g25"] = g25_ring_real_unet
         steps["g26"] = g26_updates_i2v_and_t24
         steps["g27"] = g27_i2v_ring_real_unet
+        steps["g28"] = g28_ring_real_unet_50step
+        steps["g29"] = g29_i2v_ring_real_unet_50step
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)

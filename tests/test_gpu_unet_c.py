@@ -91,6 +91,7 @@ def test_raw_c_abi_flow_vs_reference_golden(name):
     for k in ("use_linear", "temporal_conv", "temporal_attention", "addition_attention", "use_image_attention", "fps_cond"):
         setattr(cfg, k, int(bool(params.get(k, False))))
     cfg.fold_layernorm = 1
+    cfg.temporal_selfatt_only = 1
     h = C.c_void_p()
     _lib.check(lib.ds_unet_create(C.byref(cfg), C.byref(h)), "ds_unet_create")
     try:
@@ -117,11 +118,17 @@ def test_raw_c_abi_flow_vs_reference_golden(name):
             e = relerr(eps, T(z[f"eps_{case}"]))
             print(f"raw C ABI, toy {name} case {case}: eps rel err {e:.3e}")
             assert e < EPS_TOL_TINY
-            # a workspace one byte class too small is refused, not overrun
-            rc = lib.ds_unet_forward(h, x.data_ptr(), _lib.DS_F32, t.data_ptr(), ctx.data_ptr(), _lib.DS_F32, L, 8, B, Tn, H, W, 0,
-                                     ws.data_ptr(), nws // 2, eps.data_ptr(), None)
-            torch.cuda.synchronize()
-            assert rc != 0 and b"workspace" in lib.ds_last_error()
+            # a workspace that is too small is refused BEFORE any launch, not overrun: the buffer really is that small, and the
+            # guard bytes behind it (and every byte of it) are untouched afterwards
+            for short in (nws // 2, nws - 256):
+                guard = 1 << 20
+                small = torch.full((short + guard,), 0x5A, dtype=torch.uint8, device=d)
+                eps2 = torch.full_like(eps, 7.0)
+                rc = lib.ds_unet_forward(h, x.data_ptr(), _lib.DS_F32, t.data_ptr(), ctx.data_ptr(), _lib.DS_F32, L, 8, B, Tn, H, W, 0,
+                                         small.data_ptr(), short, eps2.data_ptr(), None)
+                torch.cuda.synchronize()
+                assert rc != 0 and b"workspace too small" in lib.ds_last_error()
+                assert bool((small == 0x5A).all()) and bool((eps2 == 7.0).all())
     finally:
         lib.ds_unet_destroy(h)
 

@@ -47,6 +47,22 @@ def test_cabi_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     assert lib.ds_abi_version() == _lib.ABI_VERSION
+    assert int(re.search(r"#define DS_ABI_VERSION (\d+)", header).group(1)) == _lib.ABI_VERSION
+
+
+def test_stale_library_is_refused(tmp_path):
+    """A prebuilt library of another ABI version -- every name exported, a struct layout changed -- must not be bound: the
+    version is compared BEFORE anything else.  Played with a stub library that reports the previous version."""
+    import subprocess
+    import sys
+    src = tmp_path / "stale.c"
+    src.write_text("int ds_abi_version(void) { return %d; }\nconst char* ds_last_error(void) { return \"\"; }\n" % 1)
+    so = tmp_path / "libstale.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    code = ("import sys; sys.path.insert(0, %r)\nfrom dynamicscaler_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.HipLibraryMissing as e:\n    print('REFUSED', e)\n" % REPO)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, DS_HIP_LIBRARY=str(so)))
+    assert "REFUSED" in r.stdout and "ABI version mismatch: library 1" in r.stdout, r.stdout + r.stderr
 
 
 def test_struct_layouts_match_header():
