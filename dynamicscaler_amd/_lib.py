@@ -62,6 +62,7 @@ SIGNATURES = {
     "ds_map_gather_frames": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ds_map_scatter3_frames": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ds_map_splat": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ds_map_gather_taps": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ds_residual_merge": (_i, [_vp, _vp, _vp, _i, C.c_long, _i, _i, _f, _f, _i, _i, _vp]),
     "ds_resize_latent": (_i, [_vp, _vp, _i, C.c_long, _i, _i, _i, _i, _i, _vp]),
     "ds_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),

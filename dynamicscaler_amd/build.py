@@ -32,7 +32,9 @@ def _newer(src_list, target):
 VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"], "attnplain": ["-DDS_ATTN_NO_XCD_REMAP"], "nt0": ["-DDS_EXP_NT=0", "-DDS_EXP_STREAM_NT=0"],
             "attnnarrow": ["-DDS_ATTN_NARROW_STORES"],
             # round 2's GroupNorm kernel choice (by instance COUNT): breaks batch invariance at full size (profiles/r3_notes.md section 7)
-            "gncount": ["-DDS_EXP_GN_COUNT_THRESHOLD"]}
+            "gncount": ["-DDS_EXP_GN_COUNT_THRESHOLD"],
+            # round 3's K loop on v_mfma_f32_32x32x16_f16 (the product uses 16x16x32 since round 4: profiles/r4_notes.md)
+            "mfma32": ["-DDS_MFMA16=0"]}
 
 
 def build(force=False, verbose=True, variant=None):

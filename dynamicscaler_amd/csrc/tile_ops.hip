@@ -340,6 +340,28 @@ map_splat_kernel(T* __restrict__ pano, const T* __restrict__ view, const int* __
     }
 }
 
+// Weighted multi-tap gather: get_view_tensor_interpolate = F.grid_sample(bilinear, border) with the taps and weights resolved
+// on the host (utils/panorama_tensor_utils.py:28-51).  One thread per output element, taps summed in order in fp32.
+template <typename T>
+__global__ void __launch_bounds__(256)
+map_gather_taps_kernel(const T* __restrict__ pano, T* __restrict__ out, const int* __restrict__ idx, const float* __restrict__ wgt,
+                       int ntaps, int C, int F, int f0, int tf, int HW, int P) {
+    const long total = (long)C * tf * P;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(t % P);
+        long r = t / P;
+        const int tt = (int)(r % tf);
+        const int c = (int)(r / tf);
+        const T* plane = pano + ((long)c * F + (f0 + tt) % F) * HW;
+        float acc = 0.0f;
+        for (int k = 0; k < ntaps; ++k) {
+            const float w = wgt[(long)k * P + p];
+            if (w != 0.0f) acc = acc + (float)plane[idx[(long)k * P + p]] * w;
+        }
+        out[t] = (T)acc;
+    }
+}
+
 int fill_origins(Origins& o, const ds_ring_geom* g, const int32_t* origins, int n, const char* who) {
     DS_CHECK_ARG(g && origins, "%s: null geom/origins", who);
     DS_CHECK_ARG(n >= 1 && n <= DS_MAX_WINDOWS, "%s: n=%d out of [1,%d]", who, n, DS_MAX_WINDOWS);
@@ -563,6 +585,19 @@ extern "C" int ds_map_scatter3_frames(void* pano_latent, void* pano_x0, uint8_t*
                                       int HW, int P, int n, int dtype, void* stream) {
     return map_scatter3_impl(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, idx, f0, C, F, tf, HW, P, n, 1, dtype,
                              stream, "ds_map_scatter3_frames");
+}
+
+extern "C" int ds_map_gather_taps(const void* pano, void* out, const int32_t* idx, const float* wgt, int ntaps, int C, int F, int f0,
+                                  int tf, int HW, int P, int dtype, void* stream) {
+    DS_CHECK_ARG(pano && out && idx && wgt, "ds_map_gather_taps: null argument");
+    DS_CHECK_ARG(ntaps > 0 && C > 0 && F > 0 && tf > 0 && f0 >= 0 && HW > 0 && P > 0, "ds_map_gather_taps: sizes must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    const long work = (long)C * tf * P;
+    if (dtype == DS_F16) map_gather_taps_kernel<f16><<<grid_for(work), 256, 0, st>>>((const f16*)pano, (f16*)out, idx, wgt, ntaps, C, F, f0, tf, HW, P);
+    else if (dtype == DS_F32) map_gather_taps_kernel<float><<<grid_for(work), 256, 0, st>>>((const float*)pano, (float*)out, idx, wgt, ntaps, C, F, f0, tf, HW, P);
+    else DS_CHECK_ARG(false, "ds_map_gather_taps: bad dtype %d", dtype);
+    DS_CHECK_LAUNCH("ds_map_gather_taps");
+    return DS_OK;
 }
 
 extern "C" int ds_map_splat(void* pano, const void* view, const int32_t* tgt, const int32_t* row_ptr, const int32_t* src,

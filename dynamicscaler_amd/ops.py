@@ -234,6 +234,21 @@ def map_splat_(pano, view, tgt, row_ptr, src, wgt):
     return pano
 
 
+def map_gather_taps(pano, idx, wgt, f0=0, tf=None):
+    """pano [1,C,F,H,W]; idx int32 / wgt fp32 device [ntaps,P] -> [1,C,tf,P]: sum_k wgt[k,p] * pano[c,(f0+t)%F,idx[k,p]]."""
+    _dev(pano, "map_gather_taps")
+    lib = _lib.load()
+    _, Cc, F, H, W = pano.shape
+    tf = F if tf is None else tf
+    ntaps, P = idx.shape
+    assert idx.dtype == torch.int32 and wgt.dtype == torch.float32 and idx.is_cuda and wgt.is_cuda and tuple(wgt.shape) == (ntaps, P)
+    assert idx.is_contiguous() and wgt.is_contiguous() and pano.is_contiguous()
+    out = torch.empty((1, Cc, tf, P), dtype=pano.dtype, device=pano.device)
+    check(lib.ds_map_gather_taps(pano.data_ptr(), out.data_ptr(), idx.data_ptr(), wgt.data_ptr(), ntaps, Cc, F, int(f0), tf, H * W, P,
+                                 _DT[pano.dtype], _stream()), "ds_map_gather_taps")
+    return out
+
+
 def resize_latent(x, target_height, target_width, mode="nearest"):
     """[B,C,F,H,W] -> [B,C,F,target_height,target_width] per frame (resize_video_latent)."""
     _dev(x, "resize_latent")

@@ -15,14 +15,16 @@ classes exist so that code written against the reference's `utils.*` modules kee
 No permute copies: the reference reorders [B,C,N,H,W] <-> [B,N,C,H,W] around every call; here one latent-layout buffer
 [1,C,N,H,W] is addressed in place and the reordered shapes are returned as views.
 
-Not provided (no pipeline of the reference calls them): get_view_tensor_interpolate (grid_sample) and set_view_tensor
-(round-to-nearest scatter_) raise NotImplementedError naming the method.
+The variants no pipeline of the reference calls are built too (round 4): get_view_tensor_interpolate (F.grid_sample resolved into
+taps on the host, ds_map_gather_taps), set_view_tensor (round-to-nearest scatter_, including the reference's [B, -1] reshape of
+the target map, sphere.RoundScatterMaps) and the ring-backed set_view_tensor_bilinear (ds_map_splat per channel and contiguous
+frame run of the window).
 """
 import torch
 
 from . import ops
 from .ring import RingLatent
-from .sphere import PanoramaLatentProxy, SplatMaps, ViewMapCache
+from .sphere import PanoramaLatentProxy, RoundScatterMaps, SplatMaps, TapMaps, ViewMapCache
 
 __all__ = ["PanoramaTensor", "PanoramaLatentProxy", "RingLatentProxy", "RingPanoramaTensor", "RingPanoramaLatentProxy"]
 
@@ -30,11 +32,6 @@ __all__ = ["PanoramaTensor", "PanoramaLatentProxy", "RingLatentProxy", "RingPano
 def _need_gpu(t, who):
     if not t.is_cuda:
         raise RuntimeError(f"{who} lives on the GPU in this build (no CPU path); pass a HIP tensor")
-
-
-def _not_built(name):
-    raise NotImplementedError(f"{name}: not on the DynamicScaler hot path (no pipeline of the reference calls it); "
-                              "only the *_no_interpolate / *_no_interpolation / set_view_tensor_bilinear forms are built")
 
 
 def _shape_info(equirect_tensor):
@@ -93,11 +90,41 @@ class PanoramaTensor:
         src = view_tensor.to(self.device, self.dtype).contiguous().view(1, -1, 1, height, width)
         ops.map_splat_(self._planes(), src, m.tgt, m.row_ptr, m.src, m.wgt)
 
-    def get_view_tensor_interpolate(self, *a, **k):
-        _not_built("PanoramaTensor.get_view_tensor_interpolate")
+    def _cached(self, key, make):
+        m = self._cache._maps.get(key)
+        if m is None:
+            m = self._cache._maps[key] = make()
+        return m
 
-    def set_view_tensor(self, *a, **k):
-        _not_built("PanoramaTensor.set_view_tensor")
+    def get_view_tensor_interpolate(self, fov, theta, phi, width, height, interpolate_mode='bilinear', interpolate_align_corners=True):
+        """:28-51: F.grid_sample(pano, grid, mode, padding_mode='border', align_corners) -> [*, C, height, width]."""
+        m = self._cached(("taps", fov, theta, phi, width, height, self.W, self.H, interpolate_mode, bool(interpolate_align_corners)),
+                         lambda: TapMaps(fov, theta, phi, width, height, self.W, self.H, interpolate_mode, bool(interpolate_align_corners), self.device))
+        view = ops.map_gather_taps(self._planes(), m.idx, m.wgt)
+        lead = tuple(self.equirect_tensor.shape[:-3])
+        return view.reshape(*lead, self.C, height, width)
+
+    def set_view_tensor(self, view_tensor, fov, theta, phi):
+        """:72-96: round-to-nearest targets, scatter_ (last source wins).  With B > 1 leading planes the reference reshapes the target
+        map to [B, -1]: plane b scatters its first height*width/B pixels to the b-th chunk of the map -- kept.  Like the reference,
+        a panorama without (or with only unit) leading dims ends up as [C, H, W]."""
+        if view_tensor.dim() == 3:
+            view_tensor = view_tensor.unsqueeze(0)
+        lead = tuple(self.equirect_tensor.shape[:-3])
+        B = 1
+        for n in lead:
+            B *= int(n)
+        height, width = view_tensor.shape[-2:]
+        assert view_tensor.numel() == B * self.C * height * width, \
+            f"view {tuple(view_tensor.shape)} does not match the panorama's leading dims {lead} x {self.C} channels"
+        m = self._cached(("round", fov, theta, phi, width, height, self.W, self.H, B),
+                         lambda: RoundScatterMaps(fov, theta, phi, width, height, self.W, self.H, B, self.device))
+        src = view_tensor.to(self.device, self.dtype).contiguous().view(B, 1, self.C, 1, height * width)
+        pano = self.equirect_tensor.view(B, 1, self.C, 1, self.H, self.W)
+        for b in range(B):
+            ops.map_scatter3(pano[b], None, None, src[b], None, m.idx[b:b + 1])
+        if B == 1:
+            self.equirect_tensor = self.equirect_tensor.view(self.C, self.H, self.W)
 
 
 class RingLatentProxy:
@@ -178,14 +205,65 @@ class RingPanoramaTensor:
         src = view_tensor.reshape(1, fe - fb, self.C, height, width).permute(0, 2, 1, 3, 4).to(self.device, self.dtype).contiguous()
         ops.map_scatter3_frames(self._store(), None, None, src, None, m.scatter[None], f0, fe - fb)
 
-    def get_view_tensor_interpolate(self, *a, **k):
-        _not_built("RingPanoramaTensor.get_view_tensor_interpolate")
+    def _cached(self, key, make):
+        m = self._cache._maps.get(key)
+        if m is None:
+            m = self._cache._maps[key] = make()
+        return m
 
-    def set_view_tensor(self, *a, **k):
-        _not_built("RingPanoramaTensor.set_view_tensor")
+    def get_view_tensor_interpolate(self, fov, theta, phi, width, height, frame_begin=None, frame_end=None,
+                                    interpolate_mode='bilinear', interpolate_align_corners=True):
+        """:31-57: grid_sample of the frame window -> [1, frames, C, height, width]."""
+        fb, fe, _ = self._frames(frame_begin, frame_end)
+        m = self._cached(("taps", fov, theta, phi, width, height, self.W, self.H, interpolate_mode, bool(interpolate_align_corners)),
+                         lambda: TapMaps(fov, theta, phi, width, height, self.W, self.H, interpolate_mode, bool(interpolate_align_corners), self.device))
+        N = self._store().shape[2]
+        view = ops.map_gather_taps(self._store(), m.idx, m.wgt, f0=fb % N, tf=fe - fb)          # [1, C, tf, P]
+        return view.reshape(1, self.C, fe - fb, height, width).permute(0, 2, 1, 3, 4)
 
-    def set_view_tensor_bilinear(self, *a, **k):
-        _not_built("RingPanoramaTensor.set_view_tensor_bilinear")
+    def set_view_tensor(self, view_tensor, fov, theta, phi, frame_begin=None, frame_end=None):
+        """:80-104: round-to-nearest scatter_ into the frame window, with the reference's [B, -1] reshape of the target map (B = frames
+        of the window: frame b scatters its first height*width/B pixels to the b-th chunk of the map).  A one-frame window fails in
+        the reference (the squeezed panorama no longer has the five dims set_window_latent permutes) -- refused here as well."""
+        if view_tensor.dim() == 3:
+            view_tensor = view_tensor.unsqueeze(0)
+        fb, fe, _ = self._frames(frame_begin, frame_end)
+        tf = fe - fb
+        N = self._store().shape[2]
+        if tf == 1:
+            raise RuntimeError("RingPanoramaTensor.set_view_tensor: a one-frame window is squeezed to [C, H, W] by the reference "
+                               "(ring_panorama_tensor_utils.py:103) and its set_window_latent then fails; use a window of >= 2 frames")
+        assert tf <= N, "warp should not occur"
+        height, width = view_tensor.shape[-2:]
+        assert view_tensor.numel() == tf * self.C * height * width, \
+            f"view {tuple(view_tensor.shape)} does not match a window of {tf} frames x {self.C} channels"
+        m = self._cached(("round", fov, theta, phi, width, height, self.W, self.H, tf),
+                         lambda: RoundScatterMaps(fov, theta, phi, width, height, self.W, self.H, tf, self.device))
+        f0 = torch.tensor([(fb + b) % N for b in range(tf)], dtype=torch.int32, device=self.device)
+        src = view_tensor.to(self.device, self.dtype).contiguous().view(tf, self.C, 1, height * width)
+        ops.map_scatter3_frames(self._store(), None, None, src, None, m.idx, f0, 1)
+
+    def set_view_tensor_bilinear(self, view_tensor, fov, theta, phi, frame_begin=None, frame_end=None):
+        """:107-166: the 4-tap splat with normaliser on every (frame of the window, channel) plane."""
+        if view_tensor.dim() == 3:
+            view_tensor = view_tensor.unsqueeze(0)
+        fb, fe, _ = self._frames(frame_begin, frame_end)
+        tf = fe - fb
+        store = self._store()
+        N = store.shape[2]
+        assert tf <= N, "warp should not occur"
+        height, width = view_tensor.shape[-2:]
+        assert view_tensor.numel() == tf * self.C * height * width, \
+            f"view {tuple(view_tensor.shape)} does not match a window of {tf} frames x {self.C} channels"
+        m = self._cached(("splat", fov, theta, phi, width, height, self.W, self.H),
+                         lambda: SplatMaps(fov, theta, phi, width, height, self.W, self.H, self.device))
+        src = view_tensor.to(self.device, self.dtype).reshape(tf, self.C, height, width).permute(1, 0, 2, 3).contiguous()   # [C, tf, h, w]
+        runs = [(fb % N, 0, min(tf, N - fb % N))]                      # (first panorama frame, first window frame, frames)
+        if runs[0][2] < tf:
+            runs.append((0, runs[0][2], tf - runs[0][2]))
+        for c in range(self.C):
+            for f_p, f_w, n in runs:
+                ops.map_splat_(store[:, c:c + 1, f_p:f_p + n], src[c:c + 1, f_w:f_w + n].unsqueeze(0), m.tgt, m.row_ptr, m.src, m.wgt)
 
 
 class RingPanoramaLatentProxy:
@@ -210,11 +288,19 @@ class RingPanoramaLatentProxy:
     def get_equirect_tensor(self):
         return self.panorama_tensor.equirect_tensor_handler.get_torch_latent().permute(0, 2, 1, 3, 4)
 
-    def get_view_tensor_interpolate(self, *a, **k):
-        _not_built("RingPanoramaLatentProxy.get_view_tensor_interpolate")
+    def get_view_tensor_interpolate(self, fov, theta, phi, width, height, interpolate_mode='bilinear', interpolate_align_corners=True,
+                                    frame_begin=None, frame_end=None):
+        """:271-280 (the proxy's own argument order: the interpolation options come before the frame window)"""
+        view = self.panorama_tensor.get_view_tensor_interpolate(fov, theta, phi, width, height, frame_begin=frame_begin, frame_end=frame_end,
+                                                                interpolate_mode=interpolate_mode,
+                                                                interpolate_align_corners=interpolate_align_corners)
+        return view.permute(0, 2, 1, 3, 4)
 
-    def set_view_tensor(self, *a, **k):
-        _not_built("RingPanoramaLatentProxy.set_view_tensor")
+    def set_view_tensor(self, view_tensor, fov, theta, phi, frame_begin=None, frame_end=None):
+        """:292-297"""
+        self.panorama_tensor.set_view_tensor(view_tensor.permute(0, 2, 1, 3, 4), fov, theta, phi, frame_begin=frame_begin, frame_end=frame_end)
 
-    def set_view_tensor_bilinear(self, *a, **k):
-        _not_built("RingPanoramaLatentProxy.set_view_tensor_bilinear")
+    def set_view_tensor_bilinear(self, view_tensor, fov, theta, phi, frame_begin=None, frame_end=None):
+        """:299-304"""
+        self.panorama_tensor.set_view_tensor_bilinear(view_tensor.permute(0, 2, 1, 3, 4), fov, theta, phi,
+                                                      frame_begin=frame_begin, frame_end=frame_end)

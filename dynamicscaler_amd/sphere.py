@@ -96,6 +96,63 @@ class SplatMaps:
         self.wgt = torch.from_numpy(w_all[order]).to(dev)
 
 
+class RoundScatterMaps:
+    """Targets of set_view_tensor (panorama_tensor_utils.py:72-96, ring_panorama_tensor_utils.py:80-104): round-to-nearest,
+    clamped.  The reference reshapes the [height, width] target map to [B, -1] -- B = the panorama's leading planes (frames of
+    the ring window) -- so plane b scatters only its first P/B source pixels, to the b-th chunk of the map; reproduced as is.
+    idx[b][p] = target of source pixel p of plane b, or -1 (p >= P/B, or a later source of the same plane hits the same target:
+    torch's CPU scatter_ walks the index dimension in order, the last writer stays)."""
+
+    def __init__(self, fov, theta, phi, width, height, W, H, B, device):
+        u, v = view_uv(fov, theta, phi, width, height, W, H)
+        u_nn = torch.round(u).long().clamp(0, W - 1)
+        v_nn = torch.round(v).long().clamp(0, H - 1)
+        P = width * height
+        lin = (v_nn * W + u_nn).view(B, -1).numpy()          # raises like the reference when B does not divide height*width
+        per = lin.shape[1]
+        idx = np.full((B, P), -1, dtype=np.int32)
+        for b in range(B):
+            last = np.full(H * W, -1, dtype=np.int64)
+            last[lin[b]] = np.arange(per)                    # fancy assignment keeps the last write of a repeated index
+            winner = np.zeros(per, dtype=bool)
+            winner[last[last >= 0]] = True
+            idx[b, :per] = np.where(winner, lin[b], -1)
+        self.idx_np = idx
+        self.idx = torch.from_numpy(idx).to(device)
+
+
+class TapMaps:
+    """F.grid_sample(pano, grid(u, v), mode, padding_mode='border', align_corners) of get_view_tensor_interpolate
+    (panorama_tensor_utils.py:28-51) as taps: idx[k][p], wgt[k][p] with torch's own fp32 arithmetic for the normalised grid,
+    its un-normalisation, the border clip and the corner weights (ATen GridSampler: nw, ne, sw, se).  A corner outside the panorama
+    gets weight 0 (with border padding that only happens where its weight is 0 anyway)."""
+
+    def __init__(self, fov, theta, phi, width, height, W, H, mode, align_corners, device):
+        u, v = view_uv(fov, theta, phi, width, height, W, H)
+        gx, gy = (u / (W - 1)) * 2 - 1, (v / (H - 1)) * 2 - 1
+
+        def unnorm(g, size):
+            x = ((g + 1) / 2) * (size - 1) if align_corners else ((g + 1) * size - 1) / 2
+            return torch.clamp(x, 0, size - 1)                 # padding_mode='border'
+
+        x, y = unnorm(gx, W).view(-1), unnorm(gy, H).view(-1)
+        if mode == "bilinear":
+            x0, y0 = torch.floor(x), torch.floor(y)
+            x1, y1 = x0 + 1, y0 + 1
+            taps = [(x0, y0, (x1 - x) * (y1 - y)), (x1, y0, (x - x0) * (y1 - y)), (x0, y1, (x1 - x) * (y - y0)), (x1, y1, (x - x0) * (y - y0))]
+        elif mode == "nearest":
+            taps = [(torch.round(x), torch.round(y), torch.ones_like(x))]      # nearbyint: half to even, like torch.round
+        else:
+            raise NotImplementedError(f"get_view_tensor_interpolate: interpolate_mode {mode!r} (bilinear and nearest are built)")
+        idx, wgt = [], []
+        for tx, ty, w in taps:
+            ok = (tx >= 0) & (tx <= W - 1) & (ty >= 0) & (ty <= H - 1)
+            idx.append(torch.where(ok, ty.long() * W + tx.long(), torch.zeros_like(tx, dtype=torch.long)))
+            wgt.append(torch.where(ok, w, torch.zeros_like(w)))
+        self.idx = torch.stack(idx).to(torch.int32).contiguous().to(device)
+        self.wgt = torch.stack(wgt).to(torch.float32).contiguous().to(device)
+
+
 class _SubsampledGather:
     """Gather map of a view taken at g x the tile size and resized back with 'nearest' (F.interpolate: source index =
     g * destination index): rows and columns 0, g, 2g, ... of the big view's map."""
@@ -159,6 +216,30 @@ class PanoramaLatentProxy:
         m = self._cache.get(fov, theta, phi, width, height, W, H)
         src = view_tensor.to(self.equirect.dtype).contiguous()
         ops.map_scatter3(self.equirect, None, None, src, None, m.scatter[None])
+
+    def get_view_tensor_interpolate(self, fov, theta, phi, width, height, interpolate_mode='bilinear', interpolate_align_corners=True):
+        """:260-266 (F.grid_sample of every frame, panorama_tensor_utils.py:28-51) -> [1, C, N, height, width]."""
+        B, C, N, H, W = self.equirect.shape
+        key = ("taps", fov, theta, phi, width, height, W, H, interpolate_mode, bool(interpolate_align_corners))
+        m = self._cache._maps.get(key)
+        if m is None:
+            m = self._cache._maps[key] = TapMaps(fov, theta, phi, width, height, W, H, interpolate_mode, bool(interpolate_align_corners),
+                                                 self.equirect.device)
+        return ops.map_gather_taps(self.equirect, m.idx, m.wgt).reshape(1, C, N, height, width)
+
+    def set_view_tensor(self, view_tensor, fov, theta, phi):
+        """:276-278 -> PanoramaTensor.set_view_tensor (:72-96) with the N frames as its leading planes: frame n scatters its first
+        height*width/N pixels to the n-th chunk of the rounded target map (the reference's [B, -1] reshape, kept)."""
+        B, C, N, H, W = self.equirect.shape
+        height, width = view_tensor.shape[-2:]
+        assert tuple(view_tensor.shape[:3]) == (1, C, N), f"view {tuple(view_tensor.shape)} does not match the panorama [1, {C}, {N}, ...]"
+        key = ("round", fov, theta, phi, width, height, W, H, N)
+        m = self._cache._maps.get(key)
+        if m is None:
+            m = self._cache._maps[key] = RoundScatterMaps(fov, theta, phi, width, height, W, H, N, self.equirect.device)
+        src = view_tensor.to(self.equirect.dtype)[0].permute(1, 0, 2, 3).contiguous().view(N, C, 1, height * width)
+        f0 = torch.arange(N, dtype=torch.int32, device=self.equirect.device)
+        ops.map_scatter3_frames(self.equirect, None, None, src, None, m.idx, f0, 1)
 
 
 def plan_levels_sets(reads, writes):

@@ -120,6 +120,13 @@ int ds_map_scatter3_frames(void* pano_latent, void* pano_x0, uint8_t* mask_pano,
  * order is the reference's index_add_ order, so the kernel needs no atomics and reproduces the CPU sums bit for bit. */
 int ds_map_splat(void* pano, const void* view, const int32_t* tgt, const int32_t* row_ptr, const int32_t* src,
                  const float* wgt, int CF, int HW, int P, int ntgt, int dtype, void* stream);
+/* get_view_tensor_interpolate (utils/panorama_tensor_utils.py:28-51, utils/ring_panorama_tensor_utils.py:33-57): the view as a
+ * weighted sum of `ntaps` panorama pixels per view pixel -- F.grid_sample's bilinear / border / align_corners taps, resolved on
+ * the host into idx[ntaps][P] (DEVICE int32) and wgt[ntaps][P] (DEVICE fp32; a tap outside the panorama has weight 0):
+ * out[c][t][p] = sum_k wgt[k][p] * pano[c][(f0 + t) % F][idx[k][p]], summed in tap order in fp32, rounded once.
+ * pano [C][F][HW], out [C][tf][P]; F = tf = 1, f0 = 0 for a plain PanoramaTensor with C = all its planes. */
+int ds_map_gather_taps(const void* pano, void* out, const int32_t* idx, const float* wgt, int ntaps, int C, int F, int f0, int tf,
+                       int HW, int P, int dtype, void* stream);
 /* Per-step residual merge of the non-overlapping grid loop (VC2_Pipeline_T2V.basic_sample_shift_multi_windows,
  * pipeline/t2v_normal_pipeline.py:445-468): curr = the panorama latent, noised = the resized pre-denoised latent re-noised
  * to the step's level, both [planes][H][W] (planes = B*C*F).  sparse == 0: out = curr*r + noised*(1-r).  sparse != 0

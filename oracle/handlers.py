@@ -48,6 +48,42 @@ class PanoramaTensor:
         self.equirect_tensor = p.reshape(self.equirect_tensor.shape)
 
 
+    def get_view_tensor_interpolate(self, fov, theta, phi, width, height, interpolate_mode="bilinear", interpolate_align_corners=True):
+        """:28-51"""
+        lead = tuple(self.equirect_tensor.shape[:-3])
+        v = osphere.sphere_grid_sample(self.equirect_tensor.reshape(-1, self.C, self.H, self.W), fov, theta, phi, width, height,
+                                       interpolate_mode, interpolate_align_corners)
+        return v.view(*lead, self.C, height, width) if lead else v.squeeze(0)
+
+    def set_view_tensor(self, view_tensor, fov, theta, phi):
+        """:72-96 (a panorama whose leading planes multiply to 1 comes out as [C, H, W], like the reference's)"""
+        if view_tensor.dim() == 3:
+            view_tensor = view_tensor.unsqueeze(0)
+        lead = tuple(self.equirect_tensor.shape[:-3])
+        pano = self.equirect_tensor.reshape(-1, self.C, self.H, self.W)
+        B = pano.shape[0]
+        out = osphere.sphere_round_scatter(pano, view_tensor.reshape(-1, self.C, *view_tensor.shape[-2:]), fov, theta, phi)
+        self.equirect_tensor = out.view(*lead, self.C, self.H, self.W) if B > 1 else out.squeeze(0)
+
+
+class PanoramaLatentProxy:
+    """utils/panorama_tensor_utils.py:249-290: the [B, C, N, H, W] face of PanoramaTensor (the uncalled variants only; the others
+    are oracle.sphere's functions)."""
+
+    def __init__(self, equirect_tensor):
+        self.panorama_tensor = PanoramaTensor(equirect_tensor.permute(0, 2, 1, 3, 4))
+
+    def get_view_tensor_interpolate(self, fov, theta, phi, width, height, interpolate_mode="bilinear", interpolate_align_corners=True):
+        return self.panorama_tensor.get_view_tensor_interpolate(fov, theta, phi, width, height, interpolate_mode,
+                                                                interpolate_align_corners).permute(0, 2, 1, 3, 4).clone()
+
+    def set_view_tensor(self, view_tensor, fov, theta, phi):
+        self.panorama_tensor.set_view_tensor(view_tensor.permute(0, 2, 1, 3, 4), fov, theta, phi)
+
+    def get_equirect_tensor(self):
+        return self.panorama_tensor.equirect_tensor.permute(0, 2, 1, 3, 4)
+
+
 class RingLatentProxy:
     """Frame windows run over dim 1 of the tensor passed in (the ring holds it with dims 1 and 2 swapped)."""
 
@@ -90,6 +126,33 @@ class RingPanoramaTensor:
         self.equirect_tensor_handler.set_window_latent(p.reshape(win.shape), frame_begin, frame_end)
 
 
+    def get_view_tensor_interpolate(self, fov, theta, phi, width, height, frame_begin=None, frame_end=None,
+                                    interpolate_mode="bilinear", interpolate_align_corners=True):
+        """:31-57"""
+        win = self.equirect_tensor_handler.get_window_latent(frame_begin, frame_end)          # [1, nf, C, H, W]
+        v = osphere.sphere_grid_sample(win.reshape(-1, self.C, self.H, self.W), fov, theta, phi, width, height, interpolate_mode,
+                                       interpolate_align_corners)
+        return v.view(*win.shape[:-3], self.C, height, width)
+
+    def set_view_tensor(self, view_tensor, fov, theta, phi, frame_begin=None, frame_end=None):
+        """:80-104 (a one-frame window fails in the reference: the squeezed panorama cannot be permuted by set_window_latent)"""
+        win = self.equirect_tensor_handler.get_window_latent(frame_begin, frame_end)
+        B = win.shape[0] * win.shape[1]
+        if B == 1:
+            raise RuntimeError("set_view_tensor on a one-frame window: the reference fails in set_window_latent")
+        out = osphere.sphere_round_scatter(win.reshape(-1, self.C, self.H, self.W), view_tensor.reshape(-1, self.C, *view_tensor.shape[-2:]),
+                                           fov, theta, phi)
+        self.equirect_tensor_handler.set_window_latent(out.view(win.shape), frame_begin, frame_end)
+
+    def set_view_tensor_bilinear(self, view_tensor, fov, theta, phi, frame_begin=None, frame_end=None):
+        """:107-166"""
+        h, w = view_tensor.shape[-2:]
+        win = self.equirect_tensor_handler.get_window_latent(frame_begin, frame_end).contiguous()
+        p = _planes(win, self.H, self.W).clone()
+        osphere.sphere_splat_bilinear(p, view_tensor.reshape(1, -1, 1, h, w), fov, theta, phi)
+        self.equirect_tensor_handler.set_window_latent(p.reshape(win.shape), frame_begin, frame_end)
+
+
 class RingPanoramaLatentProxy:
     """[1, C, N, H, W] face of RingPanoramaTensor."""
 
@@ -105,3 +168,14 @@ class RingPanoramaLatentProxy:
 
     def get_equirect_tensor(self):
         return self.panorama_tensor.equirect_tensor_handler.get_torch_latent().permute(0, 2, 1, 3, 4)
+
+    def get_view_tensor_interpolate(self, fov, theta, phi, width, height, interpolate_mode="bilinear", interpolate_align_corners=True,
+                                    frame_begin=None, frame_end=None):
+        return self.panorama_tensor.get_view_tensor_interpolate(fov, theta, phi, width, height, frame_begin, frame_end, interpolate_mode,
+                                                                interpolate_align_corners).permute(0, 2, 1, 3, 4).clone()
+
+    def set_view_tensor(self, view_tensor, fov, theta, phi, frame_begin=None, frame_end=None):
+        self.panorama_tensor.set_view_tensor(view_tensor.permute(0, 2, 1, 3, 4), fov, theta, phi, frame_begin, frame_end)
+
+    def set_view_tensor_bilinear(self, view_tensor, fov, theta, phi, frame_begin=None, frame_end=None):
+        self.panorama_tensor.set_view_tensor_bilinear(view_tensor.permute(0, 2, 1, 3, 4), fov, theta, phi, frame_begin, frame_end)

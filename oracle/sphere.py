@@ -299,3 +299,29 @@ def sphere_splat_bilinear(pano, view, fov, theta, phi):
         flat[r][m] = acc[m] / wsum[m]
     pano.copy_(flat.reshape(pano.shape))
     return pano
+
+
+def sphere_grid_sample(planes, fov, theta, phi, width, height, mode="bilinear", align_corners=True):
+    """get_view_tensor_interpolate (utils/panorama_tensor_utils.py:28-51): planes [B, C, H, W] -> [B, C, height, width] through
+    F.grid_sample on the normalised (u, v) grid, padding_mode='border' -- the reference's own ops."""
+    import torch.nn.functional as F
+    B, C, H, W = planes.shape
+    u, v = view_uv(fov, theta, phi, width, height, W, H, torch.float32)
+    grid = torch.stack(((u / (W - 1)) * 2 - 1, (v / (H - 1)) * 2 - 1), dim=-1).unsqueeze(0).repeat(B, 1, 1, 1)
+    return F.grid_sample(planes, grid, mode=mode, padding_mode="border", align_corners=align_corners)
+
+
+def sphere_round_scatter(planes, view, fov, theta, phi):
+    """set_view_tensor (utils/panorama_tensor_utils.py:72-96): planes [B, C, H, W], view [B, C, height, width]; round-to-nearest
+    clamped targets, reshaped to [B, -1] like the reference (plane b takes the b-th chunk of the map and as many of its own first
+    source pixels), scatter_ along the pixel axis.  Returns the new planes."""
+    B, C, H, W = planes.shape
+    height, width = view.shape[-2:]
+    u, v = view_uv(fov, theta, phi, width, height, W, H, torch.float32)
+    u_nn = torch.round(u).long().clamp(0, W - 1)
+    v_nn = torch.round(v).long().clamp(0, H - 1)
+    flat_view = view.reshape(B, C, -1)
+    flat = planes.reshape(B, C, -1).clone()
+    lin = (v_nn * W + u_nn).view(B, -1)
+    flat.scatter_(2, lin.unsqueeze(1).expand(-1, C, -1), flat_view)
+    return flat.view(B, C, H, W)

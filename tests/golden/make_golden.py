@@ -33,6 +33,7 @@ so parity is pinned by what this script captures from the imported reference cod
   G26 updates_i2v_t24.npz    (--full) one update of the 50-step schedule for the i2v UNet (93 tokens) and for 24-frame tiles (8 forwards)
   G27 i2v_ring_real_unet.npz (--full) the i2v ring loop with the REAL i2v UNet: per-window image tokens, merge-prev (32 forwards)
 
+  G30 panorama_handlers_uncalled.npz  the handler methods no pipeline calls: get_view_tensor_interpolate, set_view_tensor, ring splat
   G28 ring_real_unet_50step.npz      (--full) the t2v ring loop, REAL UNet, on the metric's 50-step schedule: first and last 6 steps (96 forwards)
   G29 i2v_ring_real_unet_50step.npz  (--full) the same for the i2v ring loop with the REAL i2v UNet (96 forwards)
 
@@ -546,6 +547,81 @@ def g24_panorama_handlers():
             full = h.get_equirect_tensor() if tag == "rpl" else h.equirect_tensor_handler.get_torch_latent()
             A[f"{tag}_after_set{vi}"] = full.clone()
     save_npz("panorama_handlers.npz", **A)
+
+
+def g30_panorama_handlers_uncalled():
+    """The handler methods no pipeline of the reference calls (SURVEY 8-a S5's list): get_view_tensor_interpolate (F.grid_sample,
+    utils/panorama_tensor_utils.py:28-51, ring :31-57), set_view_tensor (round-to-nearest scatter_, :72-96, ring :80-104) and the
+    ring-backed set_view_tensor_bilinear (ring :107-166), on all five classes.  A call the reference itself cannot complete is
+    recorded by the name of the exception it raises."""
+    from utils.panorama_tensor_utils import PanoramaTensor, PanoramaLatentProxy
+    from utils.ring_panorama_tensor_utils import RingPanoramaTensor, RingPanoramaLatentProxy
+    A, raised = {}, {}
+    views = [(90.0, 30.0, 20.0), (120.0, -170.0, -60.0), (60.0, 0.0, 90.0)]
+    modes = [("bilinear", True), ("bilinear", False), ("nearest", True)]
+    A["views"] = np.asarray(views, np.float64)
+
+    def attempt(key, fn):
+        try:
+            return fn()
+        except Exception as e:                   # noqa: BLE001 -- the exception TYPE is the recorded behaviour
+            raised[key] = type(e).__name__
+            return None
+
+    for tag, shape in (("p4", (2, 3, 16, 32)), ("p3", (3, 16, 32)), ("p2", (16, 32)), ("p5", (1, 4, 3, 16, 32))):
+        x = synth_normal(shape, 600 + len(shape))
+        h = PanoramaTensor(x)
+        A[f"{tag}_x"] = x
+        for vi, (fov, th, ph) in enumerate(views):
+            for mi, (mode, ac) in enumerate(modes):
+                A[f"{tag}_interp{vi}_{mi}"] = h.get_view_tensor_interpolate(fov, th, ph, 12, 10, mode, ac)
+        lead = shape[:-3] if len(shape) > 3 else (1,)
+        C = shape[-3] if len(shape) >= 3 else 1
+        for vi, (fov, th, ph) in enumerate(views):
+            src = synth_normal((*lead, C, 10, 12), 620 + vi)
+            A[f"{tag}_src{vi}"] = src
+            if attempt(f"{tag}_set{vi}", lambda: h.set_view_tensor(src, fov, th, ph) or True):
+                A[f"{tag}_after_set{vi}"] = h.equirect_tensor.clone()
+    # PanoramaLatentProxy [1, C, N, H, W]
+    x = synth_normal((1, 3, 4, 16, 32), 640)
+    h = PanoramaLatentProxy(x)
+    A["pl_x"] = x
+    for vi, (fov, th, ph) in enumerate(views):
+        A[f"pl_interp{vi}"] = h.get_view_tensor_interpolate(fov, th, ph, 12, 10)
+    for vi, (fov, th, ph) in enumerate(views):
+        src = synth_normal((1, 3, 4, 10, 12), 645 + vi)
+        A[f"pl_src{vi}"] = src
+        if attempt(f"pl_set{vi}", lambda: h.set_view_tensor(src, fov, th, ph) or True):
+            A[f"pl_after_set{vi}"] = h.get_equirect_tensor().clone()
+    # ring-backed classes
+    wins = ((3, 7), (None, None), (4, 9), (2, 3))
+    for tag, cls, shape, vshape in (("rp", RingPanoramaTensor, (1, 5, 3, 16, 32), lambda nf: (1, nf, 3, 10, 12)),
+                                    ("rpl", RingPanoramaLatentProxy, (1, 3, 5, 16, 32), lambda nf: (1, 3, nf, 10, 12))):
+        x = synth_normal(shape, 650)
+        h = cls(x)
+        A[f"{tag}_x"] = x
+        full = (lambda: h.get_equirect_tensor()) if tag == "rpl" else (lambda: h.equirect_tensor_handler.get_torch_latent())
+        for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views + views[:1], wins)):
+            for mi, (mode, ac) in enumerate(modes[:2] if vi else modes):
+                v = attempt(f"{tag}_interp{vi}_{mi}", lambda: h.get_view_tensor_interpolate(fov, th, ph, 12, 10, frame_begin=fb, frame_end=fe,
+                                                                                           interpolate_mode=mode, interpolate_align_corners=ac))
+                if v is not None:
+                    A[f"{tag}_interp{vi}_{mi}"] = v.clone()
+        for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views + views[:1], wins)):
+            nf = 5 if fb is None else fe - fb
+            src = synth_normal(vshape(nf), 660 + vi)
+            A[f"{tag}_src{vi}"] = src
+            if attempt(f"{tag}_set{vi}", lambda: h.set_view_tensor(src, fov, th, ph, frame_begin=fb, frame_end=fe) or True):
+                A[f"{tag}_after_set{vi}"] = full().clone()
+        for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views + views[:1], wins)):
+            nf = 5 if fb is None else fe - fb
+            src = synth_normal(vshape(nf), 670 + vi)
+            A[f"{tag}_splat_src{vi}"] = src
+            if attempt(f"{tag}_splat{vi}", lambda: h.set_view_tensor_bilinear(src, fov, th, ph, frame_begin=fb, frame_end=fe) or True):
+                A[f"{tag}_after_splat{vi}"] = full().clone()
+    A["raised_json"] = np.frombuffer(json.dumps(raised).encode(), dtype=np.uint8)
+    print("raised:", raised)
+    save_npz("panorama_handlers_uncalled.npz", **A)
 
 
 RING_REAL = dict(height=320, width=512, frames=16, total_w=1024, total_h=512, num_windows_w=2, num_windows_h=2,
@@ -1560,7 +1636,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale, "g22": g22_i2v_sphere_view_scale, "g24": g24_panorama_handlers}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale, "g22": g22_i2v_sphere_view_scale, "g24": g24_panorama_handlers, "g30": g30_panorama_handlers_uncalled}
     if args.full:
         steps["g10"] = g10_unet_full
         steps["g10i"] = g10_unet_full_i2v

@@ -663,3 +663,30 @@ def test_clip_bpe_tokenizer_vs_independent_implementation(tmp_path):
             assert row[1:76].tolist() == ids[:75] and int(row[76]) == tok.eot          # cut, last id forced to <end_of_text>
     with pytest.raises(ValueError):
         ClipBpeTokenizer()
+
+
+def test_tap_and_round_scatter_maps_reproduce_the_oracle_on_cpu():
+    """Host logic of the uncalled handler variants (sphere.TapMaps / RoundScatterMaps): the maps, applied with plain numpy the way
+    ds_map_gather_taps / ds_map_scatter3 apply them, give the oracle's get_view_tensor_interpolate / set_view_tensor."""
+    import torch
+    from dynamicscaler_amd.sphere import TapMaps, RoundScatterMaps
+    from dynamicscaler_amd.synth import synth_normal
+    from oracle import sphere as osphere
+    H, W, h, w = 16, 32, 10, 12
+    for (fov, th, ph) in ((90.0, 30.0, 20.0), (120.0, -170.0, -60.0), (60.0, 0.0, 90.0)):
+        planes = synth_normal((3, 2, H, W), 7)
+        for mode, ac in (("bilinear", True), ("bilinear", False), ("nearest", True)):
+            m = TapMaps(fov, th, ph, w, h, W, H, mode, ac, "cpu")
+            flat = planes.reshape(6, H * W)
+            got = sum(flat[:, m.idx[k].long()] * m.wgt[k] for k in range(m.idx.shape[0])).reshape(3, 2, h, w)
+            ref = osphere.sphere_grid_sample(planes, fov, th, ph, w, h, mode, ac)
+            assert torch.allclose(got, ref, rtol=2e-6, atol=2e-6), (fov, mode, ac)
+        for B in (1, 2, 4):
+            pano = synth_normal((B, 3, H, W), 8)
+            view = synth_normal((B, 3, h, w), 9)
+            m = RoundScatterMaps(fov, th, ph, w, h, W, H, B, "cpu")
+            out = pano.clone().reshape(B, 3, H * W)
+            for b in range(B):
+                sel = (m.idx[b] >= 0).nonzero().view(-1)
+                out[b][:, m.idx[b][sel].long()] = view[b].reshape(3, -1)[:, sel]
+            assert torch.equal(out.view(B, 3, H, W), osphere.sphere_round_scatter(pano, view, fov, th, ph)), (fov, B)

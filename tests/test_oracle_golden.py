@@ -703,6 +703,56 @@ def test_g24_panorama_handlers_oracle_vs_reference_golden():
             assert torch.equal(full, T(z[f"{tag}_after_set{vi}"])), (tag, vi)
 
 
+def test_g30_uncalled_handler_methods_oracle_vs_reference_golden():
+    """The handler methods no pipeline of the reference calls -- get_view_tensor_interpolate (F.grid_sample), set_view_tensor
+    (round-to-nearest scatter_ with the reference's [B, -1] reshape of the target map) and the ring-backed set_view_tensor_bilinear
+    -- restated in oracle/handlers.py, against the reference's own classes (make_golden.py g30): scatters and splats bit for bit,
+    the interpolation to fp32 rounding; where the reference raises (a one-frame ring window), the oracle does."""
+    import json
+    from oracle import handlers as oh
+    z = npz("panorama_handlers_uncalled.npz")
+    raised = json.loads(bytes(z["raised_json"]).decode())
+    assert raised == {"rp_set3": "RuntimeError", "rpl_set3": "RuntimeError"}
+    views = [tuple(float(a) for a in v) for v in z["views"]]
+    modes = [("bilinear", True), ("bilinear", False), ("nearest", True)]
+    for tag in ("p4", "p3", "p2", "p5"):
+        o = oh.PanoramaTensor(T(z[f"{tag}_x"]))
+        for vi, (fov, th, ph) in enumerate(views):
+            for mi, (mode, ac) in enumerate(modes):
+                v = o.get_view_tensor_interpolate(fov, th, ph, 12, 10, mode, ac)
+                g = T(z[f"{tag}_interp{vi}_{mi}"])
+                assert tuple(v.shape) == tuple(g.shape) and torch.allclose(v, g, rtol=1e-6, atol=1e-6), (tag, vi, mi)
+        for vi, (fov, th, ph) in enumerate(views):
+            o.set_view_tensor(T(z[f"{tag}_src{vi}"]), fov, th, ph)
+            g = T(z[f"{tag}_after_set{vi}"])
+            assert tuple(o.equirect_tensor.shape) == tuple(g.shape) and torch.equal(o.equirect_tensor, g), (tag, vi)
+    o = oh.PanoramaLatentProxy(T(z["pl_x"]))
+    for vi, (fov, th, ph) in enumerate(views):
+        assert torch.allclose(o.get_view_tensor_interpolate(fov, th, ph, 12, 10), T(z[f"pl_interp{vi}"]), rtol=1e-6, atol=1e-6)
+    for vi, (fov, th, ph) in enumerate(views):
+        o.set_view_tensor(T(z[f"pl_src{vi}"]), fov, th, ph)
+        assert torch.equal(o.get_equirect_tensor(), T(z[f"pl_after_set{vi}"])), vi
+    wins = ((3, 7), (None, None), (4, 9), (2, 3))
+    for tag, cls in (("rp", oh.RingPanoramaTensor), ("rpl", oh.RingPanoramaLatentProxy)):
+        o = cls(T(z[f"{tag}_x"]))
+        full = (lambda: o.get_equirect_tensor()) if tag == "rpl" else (lambda: o.equirect_tensor_handler.get_torch_latent())
+        for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views + views[:1], wins)):
+            for mi, (mode, ac) in enumerate(modes[:2] if vi else modes):
+                v = o.get_view_tensor_interpolate(fov, th, ph, 12, 10, frame_begin=fb, frame_end=fe, interpolate_mode=mode, interpolate_align_corners=ac)
+                g = T(z[f"{tag}_interp{vi}_{mi}"])
+                assert tuple(v.shape) == tuple(g.shape) and torch.allclose(v, g, rtol=1e-6, atol=1e-6), (tag, vi, mi)
+        for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views + views[:1], wins)):
+            if f"{tag}_set{vi}" in raised:
+                with pytest.raises(RuntimeError):
+                    o.set_view_tensor(T(z[f"{tag}_src{vi}"]), fov, th, ph, frame_begin=fb, frame_end=fe)
+                continue
+            o.set_view_tensor(T(z[f"{tag}_src{vi}"]), fov, th, ph, frame_begin=fb, frame_end=fe)
+            assert torch.equal(full(), T(z[f"{tag}_after_set{vi}"])), (tag, vi)
+        for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views + views[:1], wins)):
+            o.set_view_tensor_bilinear(T(z[f"{tag}_splat_src{vi}"]), fov, th, ph, frame_begin=fb, frame_end=fe)
+            assert torch.equal(full(), T(z[f"{tag}_after_splat{vi}"])), (tag, vi)
+
+
 def test_philox_restatement_known_answer_and_moments():
     """oracle/philox.py -- the CPU restatement of ds_renoise_mix's in-kernel noise (rng_mode="device") -- reproduces the Random123
     known-answer vector of Philox4x32-10 (counter 0, key 0) and produces unit normals; distinct counters / seeds decorrelate."""
