@@ -124,6 +124,11 @@ def main():
     ap.add_argument("--latents", choices=["f32", "f16"], default=os.environ.get("DS_LATENTS", "f32"),
                     help="storage type of the panorama latent / tiles (fp32 like the reference: the default; the matrix-core "
                          "operands are fp16 either way)")
+    ap.add_argument("--residual", choices=["default", "f16", "f32outer", "f32"], default="default",
+                    help="residual-stream storage of the UNet: default = the library's (f32outer: fp32 between the blocks, the cheapest "
+                         "mode inside 1e-3 on every asserted bound); f16 = the fast mode; f32 = strict")
+    ap.add_argument("--other-mode", type=int, default=int(os.environ.get("DS_BENCH_OTHER_MODE", "1")),
+                    help="also time the same steps in the other residual mode (fast <-> default) and report both ms/step")
     ap.add_argument("--share-cfg-prefix", type=int, default=int(os.environ.get("DS_SHARE_CFG", "1")),
                     help="evaluate the context-free UNet prefix once per [cond | uncond] pair (bit-identical result)")
     args = ap.parse_args()
@@ -167,6 +172,13 @@ def main():
     ld = LatentDiffusionHost({"params": params}, conditioner=SyntheticConditioner(77, params["context_dim"]))
     unet = ld.model.diffusion_model
     unet.load_state_dict(sd, strict=True)
+    MODES = {"f16": (torch.float16, "full"), "f32outer": (torch.float32, "outer"), "f32": (torch.float32, "full")}
+
+    def mode_name():
+        return "f16" if unet.residual_dtype == torch.float16 else ("f32outer" if unet.residual_scope == "outer" else "f32")
+
+    if args.residual != "default":
+        unet.residual_dtype, unet.residual_scope = MODES[args.residual]
     unet.prepare(dev)                      # fp16 repack straight to HBM
     if rank != 0 or args.no_cpu_baseline or world > 1:
         del sd
@@ -210,6 +222,22 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    # who took part: one record per rank, gathered through the process group the data path uses (RCCL when --gpus > 1)
+    ranks_seen = [{"rank": 0, "device": dev_index, "name": torch.cuda.get_device_name(dev), "backend": "none (single process)"}]
+    if world > 1:
+        import torch.distributed as dist
+        try:
+            ver = ".".join(map(str, torch.cuda.nccl.version()))
+        except Exception:
+            ver = "?"
+        mine = {"rank": rank, "device": dev_index, "name": torch.cuda.get_device_name(dev), "backend": dist.get_backend(),
+                "rccl": ver, "pci": torch.cuda.get_device_properties(dev).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev), "pci_bus_id") else None}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, mine)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                       # a device collective over the same group: must count every rank
+        assert int(probe.item()) == world, f"all_reduce saw {int(probe.item())} ranks, expected {world}"
 
     nsched = GEOM["num_inference_steps"] - 1      # steps 0..48 re-noise the overlaps; the last step of a schedule does not,
     step_idx = 0                                  # so a run longer than one panorama wraps around before it
@@ -260,6 +288,32 @@ def main():
     tiles_per_step = GEOM["num_windows_w"] * GEOM["num_windows_h"]
     flops_per_step = tiles_per_step * 2 * F_UNET
 
+    # ---- the same steps in the other residual mode (outside the reported region): both ms/step on one line ----
+    timed_mode = mode_name()
+    mode_ms = {timed_mode: round(ms_per_step, 2)}
+    if args.other_mode and not profiled and timed_mode in ("f16", "f32outer"):
+        other = "f16" if timed_mode == "f32outer" else "f32outer"
+        unet.residual_dtype, unet.residual_scope = MODES[other]
+        st3 = pipe.ring_begin(prompt="a synthetic prompt", fps=8, guidance_scale=7.5, init_panorama_latent=init, **GEOM, **extra)
+        k = 0
+        for _ in range(max(1, args.warmup)):
+            pipe.ring_step(st3, k % nsched)
+            k += 1
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.ring_step(st3, k % nsched)
+            k += 1
+        barrier()
+        t_other = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([t_other], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            t_other = float(tt.item())
+        mode_ms[other] = round(1e3 * t_other / args.steps, 2)
+        del st3
+        unet.residual_dtype, unet.residual_scope = MODES[timed_mode]
+
     # ---- roofline of the dominant kernel: per-launch HIP events on one extra (untimed) step, this rank's share ----
     roofline = None
     if not args.no_roofline:
@@ -297,6 +351,23 @@ def main():
                 f.write("kernel,shape,launches,ms_per_step,tflops\n")
                 for k, a in sorted(shapes.items(), key=lambda kv: -kv[1][2]):
                     f.write(f"{k[0]},{'x'.join(map(str, k[1:]))},{a[0]},{a[2] * 1e3:.3f},{a[1] / a[2] / 1e12:.1f}\n")
+        # second roofline of SURVEY 8-d: the tile ops are HBM-bound byte movers -- algorithmic bytes / HIP-event time / 8 TB/s
+        HBM_PEAK = 8.0e12
+        tile_ops = {}
+        for (name, flops, e0, e1, info) in events:
+            if info and info[0] == "bytes":
+                a = tile_ops.setdefault(name, [0, 0, 0.0])
+                a[0] += 1
+                a[1] += info[1]
+                a[2] += e0.elapsed_time(e1) * 1e-3
+        tile_roof = {k: {"launches_per_step": a[0], "bytes_per_launch": int(a[1] / a[0]), "avg_launch_us": round(1e6 * a[2] / a[0], 2),
+                         "achieved": round(a[1] / a[2] / 1e9, 1), "frac": round(a[1] / a[2] / HBM_PEAK, 4)} for k, a in tile_ops.items()}
+        if tile_ops:
+            tb, tt_ = sum(a[1] for a in tile_ops.values()), sum(a[2] for a in tile_ops.values())
+            tile_roof["all"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9, "achieved": round(tb / tt_ / 1e9, 1),
+                                "frac": round(tb / tt_ / HBM_PEAK, 4), "bytes_per_tile_per_step": int(tb / tiles_per_step * world),
+                                "ms_per_step": round(1e3 * tt_, 3),
+                                "note": "launch-latency bound at these sizes (a few MB per launch); HIP-event bracketing adds a few us each"}
         g = agg["gemm"]
         achieved = g[1] / g[2] / 1e12
         # context for the vendor peak: what the vendor GEMM library (hipBLASLt through torch.matmul) reaches on THIS box on a
@@ -369,6 +440,7 @@ def main():
             "quoted_from_profile": {"traffic_source": traffic_src, "traffic_stale": traffic_stale, "rocprof": rocprof,
                                     "pmc_summary": "profiles/*_pmc_mfma_util.json (MFMA busy, wait / issue shares, VALU:MFMA, LDS bank "
                                                    "conflicts, clock and HBM bytes of the top shapes)"},
+            "tile_ops": tile_roof,
             "launches_per_step": g[0], "algorithmic_tflop_per_step": round(g[1] / 1e12, 2),
             "avg_launch_us": round(1e6 * g[2] / g[0], 2), "gemm_time_share_of_step": round(g[2] / (elapsed / args.steps), 3),
             "attention_tflops": round(agg["attention"][1] / agg["attention"][2] / 1e12, 2) if "attention" in agg else None,
@@ -425,6 +497,7 @@ def main():
                        "tile_batch": args.tile_batch, "streams": args.streams, "hipgraph": bool(args.graph), "cfg_prefix_shared": bool(args.share_cfg_prefix), "parallelism": f"tiles sharded over {world} GPU(s)",
                        "rng": "philox in-kernel (perf mode)",
                        "latents": "fp32 (as the reference)" if args.latents == "f32" else "fp16",
+                       "residual_mode": timed_mode, "ms_per_step_by_residual_mode": mode_ms,
                        "residual_stream": ("fp16 (matrix-core operands are fp16 in every mode)" if unet.residual_dtype == torch.float16 else
                                            "fp32 between the blocks, fp16 inside the transformers (DS_RESIDUAL_DTYPE=f32outer)"
                                            if unet.residual_scope == "outer" else "fp32 everywhere (strict precision mode, DS_RESIDUAL_DTYPE=f32)"),
@@ -438,6 +511,7 @@ def main():
             # sha-256 prefixes of the latents this run produced: equal for every --gpus / --tile-batch / --streams at the same
             # --config / --warmup / --steps (the N-GPU job computes the 1-GPU panorama, bit for bit)
             "result_sha256": digests,
+            "ranks_seen": ranks_seen,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

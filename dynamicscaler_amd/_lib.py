@@ -43,7 +43,7 @@ class UNetConfig(C.Structure):
                 + [("channel_mult", C.c_int32 * 8), ("n_attention_resolutions", C.c_int32), ("attention_resolutions", C.c_int32 * 8)]
                 + [(n, C.c_int32) for n in ("num_head_channels", "transformer_depth", "temporal_transformer_depth", "context_dim",
                                             "use_linear", "temporal_conv", "temporal_attention", "addition_attention",
-                                            "use_image_attention", "fps_cond", "residual_f32", "fold_layernorm", "temporal_selfatt_only")])
+                                            "use_image_attention", "fps_cond", "residual_f32", "fold_layernorm", "gn_from_producer", "temporal_selfatt_only")])
 
 
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
@@ -77,6 +77,8 @@ SIGNATURES = {
     "ds_cast_rows_f32_f16": (_i, [_vp, _i, _vp, _i, C.c_long, _i, _vp]),
     "ds_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ds_layernorm_stats": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "ds_gemm_f16_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _pp(GemmDesc), _vp]),
+    "ds_groupnorm_rows_colstats": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "ds_gemm_f16_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),
     "ds_gemm_f16_lnk": (_i, [_vp, _vp, _f, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),
     "ds_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),

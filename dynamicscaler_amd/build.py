@@ -34,7 +34,9 @@ VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"], "attnplain": ["-DDS_ATTN_N
             # round 2's GroupNorm kernel choice (by instance COUNT): breaks batch invariance at full size (profiles/r3_notes.md section 7)
             "gncount": ["-DDS_EXP_GN_COUNT_THRESHOLD"],
             # round 3's K loop on v_mfma_f32_32x32x16_f16 (the product uses 16x16x32 since round 4: profiles/r4_notes.md)
-            "mfma32": ["-DDS_MFMA16=0"]}
+            "mfma32": ["-DDS_MFMA16=0"],
+            # tuning variants of the 16x16x32 K loop (A/B: tools/gpu_ab.sh): where the LDS-DMA pieces go, how far ahead fragments are read
+            "m16p1": ["-DDS_M16_PSPAN4=1"], "m16p3": ["-DDS_M16_PSPAN4=3"], "m16p4": ["-DDS_M16_PSPAN4=4"], "m16a3": ["-DDS_M16_AHEAD=3"], "m16a1": ["-DDS_M16_AHEAD=1"]}
 
 
 def build(force=False, verbose=True, variant=None):

@@ -156,7 +156,7 @@ __global__ void __launch_bounds__((TileCfg<BM, BN, WGM, WGN, NS>::NT), (TileCfg<
 gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const float* __restrict__ bias,
                 const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n,
                 unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum,
-                float ln_eps, int group_m) {
+                float ln_eps, int group_m, float2* __restrict__ colstats, int ld_stats) {
     using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
     constexpr int LROWS = Cfg::LROWS, A_ROWS_PER_THREAD = Cfg::AR, B_ROWS_PER_THREAD = Cfg::BR;
@@ -557,26 +557,33 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             constexpr bool STREAM_M = TM16 >= TN16;
             constexpr int L = STREAM_M ? TM16 : TN16, S = STREAM_M ? TN16 : TM16;
             constexpr int NF = 2 * L, NSLOT = NF * S;                  // streamed fragments / MFMAs per K-step
-            constexpr int PSPAN = NSLOT * 3 / 4;
-            f16x8 sf[2][S], ring[3];
+#ifndef DS_M16_PSPAN4
+#define DS_M16_PSPAN4 2          // the pieces go out behind the MFMAs of the first half of the K-step (A/B: profiles/r4_notes.md)
+#endif
+#ifndef DS_M16_AHEAD
+#define DS_M16_AHEAD 2
+#endif
+            constexpr int PSPAN = NSLOT * DS_M16_PSPAN4 / 4;
+            constexpr int AH = DS_M16_AHEAD, RD = AH + 1;              // streamed fragments read ahead of their use / ring depth
+            f16x8 sf[2][S], ring[RD];
             auto read_s = [&](int ks, int t) { return STREAM_M ? read_b16(ks, t) : read_a16(ks, t); };
             auto read_l = [&](int f) { return STREAM_M ? read_a16(f / L, f % L) : read_b16(f / L, f % L); };
 #pragma unroll
             for (int t = 0; t < S; ++t) sf[0][t] = read_s(0, t);
-            ring[0] = read_l(0);
-            ring[1] = read_l(1);
+#pragma unroll
+            for (int f = 0; f < AH; ++f) ring[f] = read_l(f);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const int ks = f / L, li = f % L;
                 __builtin_amdgcn_sched_barrier(0);
-                if (f + 2 < NF) ring[(f + 2) % 3] = read_l(f + 2);
+                if (f + AH < NF) ring[(f + AH) % RD] = read_l(f + AH);
                 if (ks == 0 && li < S) sf[1][li] = read_s(1, li);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int si = 0; si < S; ++si) {
                     const int m16 = STREAM_M ? li : si, n16 = STREAM_M ? si : li;
-                    const f16x8& a_op = STREAM_M ? ring[f % 3] : sf[ks][si];   // activation rows
-                    const f16x8& w_op = STREAM_M ? sf[ks][si] : ring[f % 3];   // weight rows
+                    const f16x8& a_op = STREAM_M ? ring[f % RD] : sf[ks][si];   // activation rows
+                    const f16x8& w_op = STREAM_M ? sf[ks][si] : ring[f % RD];   // weight rows
                     f32x4& c = acc[n16 >> 1][m16 >> 1][2 * (m16 & 1) + (n16 & 1)];
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_op, a_op, c, 0, 0, 0);
                     if (n16 == 0) kstats(a_op, m16);
@@ -761,6 +768,38 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     };
+    // ---- per-column partial statistics of the stored tile (ds_gemm_f16_stats): the GroupNorm that reads this output takes its
+    //      (sum, sum of squares) from here instead of from a pass of its own over the tensor.  A lane of the strip sweeps owns 8
+    //      columns of every rps-th row of a 32-row block: it accumulates them over the sweeps (cs / cq), the lanes of a column
+    //      chunk are then summed through the wave's strip (fixed order: r0 = 0, 1, ...), and the first cpr lanes store
+    //      colstats[row block][column] = (sum, sumsq) of the block's valid rows -- no atomics, one writer per entry. ----
+    auto stats_flush = [&](const float (&cs)[8], const float (&cq)[8], int cpr, int rps, int ch, int r0, bool lane_on, bool col_on,
+                           int mrow0, long ocol) {
+        float* const sS = sW;                               // the strip is free: every sweep's reads have been consumed
+        const int rs = 16 * cpr;                            // floats per scratch row: cpr chunks x (8 sums + 8 squares)
+        wave_sync();
+        if (lane_on) {
+            *reinterpret_cast<f32x4*>(sS + r0 * rs + ch * 16) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+            *reinterpret_cast<f32x4*>(sS + r0 * rs + ch * 16 + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+            *reinterpret_cast<f32x4*>(sS + r0 * rs + ch * 16 + 8) = f32x4{cq[0], cq[1], cq[2], cq[3]};
+            *reinterpret_cast<f32x4*>(sS + r0 * rs + ch * 16 + 12) = f32x4{cq[4], cq[5], cq[6], cq[7]};
+        }
+        wave_sync();
+        if (lane < cpr) {
+            f32x4 t[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+            for (int r = 0; r < rps; ++r) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] += *reinterpret_cast<const f32x4*>(sS + r * rs + lane * 16 + 4 * q);
+            }
+            if (col_on && mrow0 < d.M) {
+                float2* dst = colstats + (long)(mrow0 >> 5) * ld_stats + ocol;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{t[0][0], t[2][0], t[0][1], t[2][1]};
+                *reinterpret_cast<f32x4*>(dst + 2) = f32x4{t[0][2], t[2][2], t[0][3], t[2][3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{t[1][0], t[3][0], t[1][1], t[3][1]};
+                *reinterpret_cast<f32x4*>(dst + 6) = f32x4{t[1][2], t[3][2], t[1][3], t[3][3]};
+            }
+        }
+    };
     auto epilogue = [&](auto ge_tag, auto res_tag, auto pib_tag) {
         constexpr bool GE = decltype(ge_tag)::value;
         constexpr int RMODE = decltype(res_tag)::value;  // residual add: 0 none, 1 fp16 rows, 2 fp32 rows (DS_EPI_RES_F32)
@@ -859,6 +898,26 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #endif
                             }
                         }
+                        if constexpr (!GE) {
+                            if (colstats) {        // statistics of the stored (rounded) values
+                                float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                                for (int sw = 0; sw < 8; ++sw) {
+                                    if (sw < nsw) {
+                                        const int row = sw * rps + r0;
+                                        const bool on = col_on && row < 32 && mrow0 + row < d.M;
+                                        const f16x8 hh = __builtin_bit_cast(f16x8, hv[sw]);
+#pragma unroll
+                                        for (int j = 0; j < 8; ++j) {
+                                            const float t = on ? (float)hh[j] : 0.0f;
+                                            cs[j] += t;
+                                            cq[j] = fmaf(t, t, cq[j]);
+                                        }
+                                    }
+                                }
+                                stats_flush(cs, cq, cpr, rps, ch, r0, lane_on, col_on, mrow0, ocol);
+                            }
+                        }
                         wave_sync();
                     }
                 }
@@ -901,6 +960,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                     }
                 }
                 wave_sync();
+                float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // column statistics of this 32-row block (colstats)
                 if (fast) {
                     // Batches of SB sweeps: first the global loads (residual, per-item bias), then ALL the strip reads of
                     // the batch, then the arithmetic and the stores -- straight-line code (RES / PIB are compile-time),
@@ -961,6 +1021,16 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #pragma unroll
                                     for (int j = 0; j < 8; ++j) v[j] = fast_silu(v[j]);
                                 }
+                                if constexpr (!GE) {
+                                    if (colstats) {
+#pragma unroll
+                                        for (int j = 0; j < 8; ++j) {
+                                            const float t = ok[u] ? v[j] : 0.0f;
+                                            cs[j] += t;
+                                            cq[j] = fmaf(t, t, cq[j]);
+                                        }
+                                    }
+                                }
                                 f16x8 o;
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
@@ -979,6 +1049,9 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #endif
                             }
                         }
+                    }
+                    if constexpr (!GE) {
+                        if (colstats) stats_flush(cs, cq, cpr, rps, ch, r0, lane_on, col_on, mrow0, ocol);
                     }
                 } else {
                     // generic (rare, tiny layers): scalar stores, any N, fp32 or fp16 out; GEGLU not supported here
@@ -1027,9 +1100,11 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     DS_STAMP(4);
 }
 
+struct StatOut { float2* p = nullptr; int ld = 0; };   // ds_gemm_f16_stats: where the per-column partial statistics go
+
 template <int BM, int BN, int WGM, int WGN, int AMODE, int NS = 2>
 int launch(const void* A, const void* W, const float* bias, const void* residual, void* out,
-           const ds_gemm_desc& d, hipStream_t st, const float* ln_stats, const float* ln_colsum, float ln_eps) {
+           const ds_gemm_desc& d, hipStream_t st, const float* ln_stats, const float* ln_colsum, float ln_eps, StatOut so = StatOut()) {
     using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
     constexpr size_t lds = Cfg::LDS + ((AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK) ? 2 * BN * sizeof(float) : 0);   // + staged column sums / bias
     static_assert(lds <= 163840, "LDS budget");
@@ -1057,7 +1132,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
     }
     gemm_f16_kernel<BM, BN, WGM, WGN, AMODE, NS><<<tiles_m * tiles_n, Cfg::NT, lds, st>>>(
         (const f16*)A, (const f16*)W, bias, (const f16*)residual, out, d, tiles_m, tiles_n, (unsigned)a_bytes, (unsigned)w_bytes,
-        ln_stats, ln_colsum, ln_eps, group_m);
+        ln_stats, ln_colsum, ln_eps, group_m, so.p, so.ld);
     DS_CHECK_LAUNCH("ds_gemm_f16");
     return DS_OK;
 }
@@ -1095,14 +1170,15 @@ int choose_tile(const ds_gemm_desc& d) {
 
 template <int AMODE>
 int dispatch(int tile, const void* A, const void* W, const float* bias, const void* residual, void* out,
-             const ds_gemm_desc& d, hipStream_t st, const float* ln_stats = nullptr, const float* ln_colsum = nullptr, float ln_eps = 0.0f) {
+             const ds_gemm_desc& d, hipStream_t st, const float* ln_stats = nullptr, const float* ln_colsum = nullptr, float ln_eps = 0.0f,
+             StatOut so = StatOut()) {
     switch (tile) {
-        case TILE_256x256: return launch<256, 256, 2, 4, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
-        case TILE_256x320: return launch<256, 320, 4, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
-        case TILE_128x128: return launch<128, 128, 2, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
-        case TILE_128x128_DEEP: return launch<128, 128, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
-        case TILE_128x64_DEEP: return launch<128, 64, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
-        default:           return launch<128, 64, 2, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps);
+        case TILE_256x256: return launch<256, 256, 2, 4, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
+        case TILE_256x320: return launch<256, 320, 4, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
+        case TILE_128x128: return launch<128, 128, 2, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
+        case TILE_128x128_DEEP: return launch<128, 128, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
+        case TILE_128x64_DEEP: return launch<128, 64, 2, 2, AMODE, 4>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
+        default:           return launch<128, 64, 2, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
     }
 }
 
@@ -1117,7 +1193,8 @@ extern "C" int ds_dbg_set_stamps(void* p) {
 
 // ln_colsum != nullptr: LayerNorm folded in; ln_stats == nullptr then selects the in-kernel statistics (ln_eps)
 static int gemm_entry(const void* A, const void* W, const float* bias, const void* residual, void* out,
-                      const ds_gemm_desc* desc, void* stream, const float* ln_stats, const float* ln_colsum, float ln_eps = 0.0f) {
+                      const ds_gemm_desc* desc, void* stream, const float* ln_stats, const float* ln_colsum, float ln_eps = 0.0f,
+                      StatOut so = StatOut()) {
     DS_CHECK_ARG(A && W && out && desc, "ds_gemm_f16: null argument");
     const ds_gemm_desc& d = *desc;
     DS_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "ds_gemm_f16: M,N,K must be positive (got %d,%d,%d)", d.M, d.N, d.K);
@@ -1166,9 +1243,11 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
             const char* a_p = (const char*)A + r0 * d.lda * 2;
             const char* r_p = residual ? (const char*)residual + r0 * d.ldr * ((d.epilogue & DS_EPI_RES_F32) ? 4 : 2) : nullptr;
             char* o_p = (char*)out + r0 * d.ldc * out_elt;
+            StatOut sc = so;
+            if (sc.p) sc.p += (r0 >> 5) * (long)so.ld;       // rows_max is a multiple of 256: whole 32-row blocks
             int rc = ln_stats ? dispatch<A_DENSE_LN>(tile, a_p, W, bias, r_p, o_p, c, st, ln_stats + 2 * r0, ln_colsum)
                      : ln_colsum ? dispatch<A_DENSE_LNK>(tile, a_p, W, bias, r_p, o_p, c, st, nullptr, ln_colsum, ln_eps)
-                              : dispatch<DS_A_DENSE>(tile, a_p, W, bias, r_p, o_p, c, st);
+                              : dispatch<DS_A_DENSE>(tile, a_p, W, bias, r_p, o_p, c, st, nullptr, nullptr, 0.0f, sc);
             if (rc) return rc;
         }
         return DS_OK;
@@ -1179,13 +1258,37 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
         // on the 20x32 / 10x16 levels L2 already caught the reuse and the per-K-step select costs 1-3 % (gpurun_out/conv)
         static const int ti_mode = getenv("DS_CONV_TAPS_INNER") ? atoi(getenv("DS_CONV_TAPS_INNER")) : -1;   // A/B: 0 never, 1 always
         const bool taps_inner = ti_mode < 0 ? (long)d.hin * d.win >= 2048 : ti_mode > 0;
-        if (taps_inner && d.stride == 1 && !d.upsample && !d.asym_pad) return dispatch<A_CONV3_TI>(tile, A, W, bias, residual, out, d, st);
-        return dispatch<DS_A_CONV3>(tile, A, W, bias, residual, out, d, st);
+        if (taps_inner && d.stride == 1 && !d.upsample && !d.asym_pad) return dispatch<A_CONV3_TI>(tile, A, W, bias, residual, out, d, st, nullptr, nullptr, 0.0f, so);
+        return dispatch<DS_A_CONV3>(tile, A, W, bias, residual, out, d, st, nullptr, nullptr, 0.0f, so);
     }
-    if (d.a_mode == DS_A_TCONV) return dispatch<DS_A_TCONV>(tile, A, W, bias, residual, out, d, st);
+    if (d.a_mode == DS_A_TCONV) return dispatch<DS_A_TCONV>(tile, A, W, bias, residual, out, d, st, nullptr, nullptr, 0.0f, so);
     if (ln_stats) return dispatch<A_DENSE_LN>(tile, A, W, bias, residual, out, d, st, ln_stats, ln_colsum);
     if (ln_colsum) return dispatch<A_DENSE_LNK>(tile, A, W, bias, residual, out, d, st, nullptr, ln_colsum, ln_eps);
-    return dispatch<DS_A_DENSE>(tile, A, W, bias, residual, out, d, st);
+    return dispatch<DS_A_DENSE>(tile, A, W, bias, residual, out, d, st, nullptr, nullptr, 0.0f, so);
+}
+
+// ds_gemm_f16 that also writes, for every 32-row block of the output, the per-column (sum, sum of squares) of the values it
+// stores: colstats[(m / 32) * ld_stats + n], float2.  The GroupNorm that reads this output (ds_groupnorm_rows_colstats) then needs
+// no statistics pass over the tensor.  Conditions = the epilogue's vector path: N % 8 == 0, aligned operands, no GEGLU.
+extern "C" int ds_gemm_f16_stats(const void* A, const void* W, const float* bias, const void* residual, void* out, float* colstats,
+                                 int ld_stats, const ds_gemm_desc* desc, void* stream) {
+    DS_CHECK_ARG(desc && colstats, "ds_gemm_f16_stats: null argument");
+    const ds_gemm_desc& d = *desc;
+    const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;
+    DS_CHECK_ARG(!(d.epilogue & DS_EPI_GEGLU), "ds_gemm_f16_stats: not available with GEGLU");
+    DS_CHECK_ARG(d.N % 8 == 0 && ld_stats >= d.N && ld_stats % 2 == 0 && (reinterpret_cast<uintptr_t>(colstats) & 15) == 0,
+                 "ds_gemm_f16_stats: N %% 8 == 0, ld_stats >= N and even, colstats 16-byte aligned");
+    // the conditions of the epilogue's vector path (`fast` in the kernel): the statistics are formed there
+    DS_CHECK_ARG(d.ldc % (out_f32 ? 4 : 8) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "ds_gemm_f16_stats: ldc / out alignment");
+    DS_CHECK_ARG(!out_f32 || !residual || (d.epilogue & DS_EPI_RES_F32), "ds_gemm_f16_stats: fp32 output with an fp16 residual takes the scalar epilogue");
+    DS_CHECK_ARG(!residual || ((d.epilogue & DS_EPI_RES_F32) ? (d.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0) : d.ldr % 8 == 0),
+                 "ds_gemm_f16_stats: residual alignment");
+    DS_CHECK_ARG(!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0), "ds_gemm_f16_stats: bias alignment");
+    DS_CHECK_ARG(!(out_f32 && (d.epilogue & DS_EPI_SILU)), "ds_gemm_f16_stats: fp32 output with SiLU takes the scalar epilogue");
+    StatOut so;
+    so.p = reinterpret_cast<float2*>(colstats);
+    so.ld = ld_stats;
+    return gemm_entry(A, W, bias, residual, out, desc, stream, nullptr, nullptr, 0.0f, so);
 }
 
 extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,

@@ -469,6 +469,68 @@ extern "C" int ds_groupnorm_apply(const void* x, const float* mean, const float*
 }
 
 namespace {
+// Per-column partial statistics written by the producing GEMM (ds_gemm_f16_stats: colstats[row block of 32][column] = (sum,
+// sumsq)) -> the per-chunk group partial sums gn_apply_kernel reduces: part[(inst * nchunks + chunk) * groups + g].  A chunk is
+// `rb_per_chunk` row blocks; grid (nchunks, ninst), 256 threads.  A thread owns columns tid, tid + 256, ...: it adds the chunk's
+// row blocks of a column in order (coalesced 8-byte loads, all of a column's loads independent), the column sums go through LDS
+// and thread g adds the columns of group g in order -- a fixed order throughout.
+__global__ void __launch_bounds__(256)
+gn_colstats_part_kernel(const float2* __restrict__ colstats, int ld_stats, float2* __restrict__ part, int rows_per_inst, int C, int groups,
+                        int rb_per_chunk) {
+    __shared__ float csum[MAX_C];
+    __shared__ float csq[MAX_C];
+    const int tid = threadIdx.x, chunk = blockIdx.x, inst = blockIdx.y, nchunks = gridDim.x;
+    const int cpg = C / groups;
+    const int rb_inst = rows_per_inst >> 5;                          // row blocks per instance (rows_per_inst % 32 == 0: checked on the host)
+    const int rb0 = chunk * rb_per_chunk, rb1 = min(rb_inst, rb0 + rb_per_chunk);
+    const float2* base = colstats + ((long)inst * rb_inst + rb0) * ld_stats;
+    const int n = rb1 - rb0;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.0f, q = 0.0f;
+        int r = 0;
+        for (; r + 8 <= n; r += 8) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(long)(r + u) * ld_stats + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
+        }
+        for (; r < n; ++r) { const float2 v = base[(long)r * ld_stats + c]; s += v.x; q += v.y; }
+        csum[c] = s;
+        csq[c] = q;
+    }
+    __syncthreads();
+    for (int g = tid; g < groups; g += 256) {
+        float s = 0.0f, q = 0.0f;
+        for (int j = 0; j < cpg; ++j) { s += csum[g * cpg + j]; q += csq[g * cpg + j]; }
+        part[((long)inst * nchunks + chunk) * groups + g] = make_float2(s, q);
+    }
+}
+
+template <typename XT>
+int groupnorm_rows_colstats(const XT* x, int ldx, const float2* colstats, int ld_stats, const float* gamma, const float* beta, f16* y,
+                            f16* x_f16, float* workspace, int ninst, int rows_per_inst, int C, int groups, float eps, int silu, hipStream_t st) {
+    // chunks of 8 row blocks (256 rows) like the statistics pass; the apply reduces the chunks of its instance in fp64
+    int rb_per_chunk = 8;
+    const int rb_inst = rows_per_inst >> 5;
+    while ((rb_inst + rb_per_chunk - 1) / rb_per_chunk > 160) rb_per_chunk *= 2;
+    const int nchunks = (rb_inst + rb_per_chunk - 1) / rb_per_chunk;
+    gn_colstats_part_kernel<<<dim3(nchunks, ninst), 256, 0, st>>>(colstats, ld_stats, (float2*)workspace, rows_per_inst, C, groups, rb_per_chunk);
+    DS_CHECK_LAUNCH("ds_groupnorm_rows_colstats(partials)");
+    constexpr int US = sizeof(XT) == 2 ? GN_U_SPARSE : GN_U_SPARSE / 2;
+    int apply_rows = GN_CHUNK_ROWS_MAX;
+    while (apply_rows > 32 && (long)((rows_per_inst + apply_rows - 1) / apply_rows) * ninst < 512) apply_rows /= 2;
+    const int napply = (rows_per_inst + apply_rows - 1) / apply_rows;
+    if ((long)napply * ninst <= GN_SPARSE_WGS)
+        gn_apply_kernel<XT, US><<<dim3(napply, ninst), 256, 0, st>>>(x, nullptr, nullptr, (const float2*)workspace, gamma, beta, y,
+                                                                     rows_per_inst, C, groups, silu, eps, ldx, x_f16, nchunks, apply_rows);
+    else
+        gn_apply_kernel<XT, GN_U><<<dim3(napply, ninst), 256, 0, st>>>(x, nullptr, nullptr, (const float2*)workspace, gamma, beta, y,
+                                                                       rows_per_inst, C, groups, silu, eps, ldx, x_f16, nchunks, apply_rows);
+    DS_CHECK_LAUNCH("ds_groupnorm_rows_colstats(apply)");
+    return DS_OK;
+}
+
 template <typename XT>
 int groupnorm_rows(const XT* x, int ldx, const float* gamma, const float* beta, f16* y, f16* x_f16, float* workspace, int ninst,
                    int rows_per_inst, int C, int groups, float eps, int silu, hipStream_t st) {
@@ -527,6 +589,27 @@ extern "C" int ds_groupnorm_rows(const void* x, int x_dtype, int ldx, const floa
     if (x_dtype == DS_F32)
         return groupnorm_rows<float>((const float*)x, ldx, gamma, beta, (f16*)y, (f16*)x_f16, workspace, ninst, rows_per_inst, C, groups, eps, silu, st);
     return groupnorm_rows<f16>((const f16*)x, ldx, gamma, beta, (f16*)y, nullptr, workspace, ninst, rows_per_inst, C, groups, eps, silu, st);
+}
+
+// GroupNorm whose statistics come from the producing GEMM (ds_gemm_f16_stats): colstats[(row / 32) * ld_stats + column] = (sum,
+// sumsq) over the rows of that 32-row block, for the columns of x (the pointer already offset to x's first column when x is a
+// column slice).  rows_per_inst % 32 == 0.  workspace: ds_groupnorm_stats_workspace_floats(...) floats, as for ds_groupnorm_rows.
+extern "C" int ds_groupnorm_rows_colstats(const void* x, int x_dtype, int ldx, const float* colstats, int ld_stats, const float* gamma,
+                                          const float* beta, void* y, void* x_f16, float* workspace, int ninst, int rows_per_inst, int C,
+                                          int groups, float eps, int silu, void* stream) {
+    DS_CHECK_ARG(x && colstats && gamma && beta && y && workspace, "ds_groupnorm_rows_colstats: null argument");
+    DS_CHECK_ARG(x_dtype == DS_F16 || x_dtype == DS_F32, "ds_groupnorm_rows_colstats: x_dtype must be DS_F16 or DS_F32");
+    DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0 && rows_per_inst % 32 == 0, "ds_groupnorm_rows_colstats: rows_per_inst=%d must be a positive multiple of 32", rows_per_inst);
+    DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_rows_colstats: C=%d groups=%d unsupported", C, groups);
+    DS_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "ds_groupnorm_rows_colstats: ldx=%d (>= C, multiple of 8, x 16-byte aligned)", ldx);
+    DS_CHECK_ARG(ld_stats >= C && (reinterpret_cast<uintptr_t>(colstats) & 7) == 0, "ds_groupnorm_rows_colstats: ld_stats=%d must be >= C", ld_stats);
+    DS_CHECK_ARG(!x_f16 || x_dtype == DS_F32, "ds_groupnorm_rows_colstats: the fp16 copy of x is only produced from fp32 input");
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == DS_F32)
+        return groupnorm_rows_colstats<float>((const float*)x, ldx, (const float2*)colstats, ld_stats, gamma, beta, (f16*)y, (f16*)x_f16, workspace,
+                                              ninst, rows_per_inst, C, groups, eps, silu, st);
+    return groupnorm_rows_colstats<f16>((const f16*)x, ldx, (const float2*)colstats, ld_stats, gamma, beta, (f16*)y, nullptr, workspace, ninst,
+                                        rows_per_inst, C, groups, eps, silu, st);
 }
 
 extern "C" int ds_groupnorm_f16_strided(const void* x, int ldx, const float* gamma, const float* beta, void* y, float* workspace,

@@ -147,6 +147,7 @@ struct PackItem {                 // one tensor of the packed buffer
 
 struct ds_unet {
     ds_unet_config cfg;
+    bool gn_fused = false;        // GroupNorm statistics from the producing GEMM's epilogue (ds_gemm_f16_stats) where producer and norm are adjacent
     bool strict = false, inner32 = false, fold = false;   // strict: the stream between the blocks is fp32; inner32: inside the transformers too
     std::vector<std::vector<Block>> inputs, outputs;
     std::vector<Block> middle;
@@ -732,7 +733,8 @@ struct Prog {
     // ---- kernels ----
     struct ConvGeo { int nimg = 0, hin = 0, win = 0, hout = 0, wout = 0, stride = 1, upsample = 0; };
     Ten gemm(const Ten& A, const Ten& W, const float* bias, const Ten& residual, long M, int N, int K, int epilogue, int a_mode = DS_A_DENSE,
-             int cin = 0, const ConvGeo* cg = nullptr, int t_len = 0, int hw = 0, int bias_rows = INT_MAX, int ldbias = 0, Ten out = Ten()) {
+             int cin = 0, const ConvGeo* cg = nullptr, int t_len = 0, int hw = 0, int bias_rows = INT_MAX, int ldbias = 0, Ten out = Ten(),
+             const Ten& cstats = Ten()) {
         const int n_out = (epilogue & DS_EPI_GEGLU) ? N / 2 : N;
         if (residual && residual.is32()) epilogue |= DS_EPI_RES_F32;
         if (out && out.is32()) epilogue |= DS_EPI_OUT_F32;
@@ -749,10 +751,13 @@ struct Prog {
         d.bias_rows = bias_rows;
         d.ldbias = ldbias ? ldbias : N;
         d.epilogue = epilogue;
-        tr("gemm M=%ld N=%d K=%d mode=%d cin=%d lda=%d ldc=%d ldr=%d brows=%d ldb=%d epi=%d conv=%d,%d,%d,%d,%d,%d,%d t=%d,%d bias=%d res=%d",
+        tr("gemm M=%ld N=%d K=%d mode=%d cin=%d lda=%d ldc=%d ldr=%d brows=%d ldb=%d epi=%d conv=%d,%d,%d,%d,%d,%d,%d t=%d,%d bias=%d res=%d stats=%d",
            M, N, K, a_mode, d.cin, d.lda, d.ldc, d.ldr, bias_rows, d.ldbias, epilogue, d.nimg, d.hin, d.win, d.hout, d.wout, d.stride, d.upsample, t_len,
-           hw, bias ? 1 : 0, residual ? 1 : 0);
-        if (live()) chk(ds_gemm_f16(ptr(A), ptr(W), bias, ptr(residual), ptr(out), &d, st));
+           hw, bias ? 1 : 0, residual ? 1 : 0, cstats ? cstats.ld / 2 : 0);
+        if (live()) {
+            if (cstats) chk(ds_gemm_f16_stats(ptr(A), ptr(W), bias, ptr(residual), ptr(out), (float*)ptr(cstats), cstats.ld / 2, &d, st));
+            else chk(ds_gemm_f16(ptr(A), ptr(W), bias, ptr(residual), ptr(out), &d, st));
+        }
         return out;
     }
     Ten gemm_ln(const Ten& x, const std::string& name, const Ten& stats, long M, int N, int K, int epilogue) {
@@ -768,15 +773,26 @@ struct Prog {
                                ptr(out), &d, st));
         return out;
     }
-    Ten groupnorm(const Ten& x, const std::string& prefix, int ninst, int rows_per, int C, float eps, int silu, Ten* raw16 = nullptr) {
+    // GroupNorm statistics from the producer (ds_gemm_f16_stats -> ds_groupnorm_rows_colstats): where producer and norm are adjacent
+    // in the program and the norm would otherwise run its own statistics pass (instances of <= 256 rows keep the one-launch form)
+    bool fuse_gn(int rows_per) const { return u->gn_fused && rows_per % 32 == 0 && rows_per > 256; }
+    Ten stats_table(long rows, int cols) { return make((rows + 31) / 32, 2 * cols, DS_F32); }   // (sum, sumsq) per 32-row block and column
+    Ten groupnorm(const Ten& x, const std::string& prefix, int ninst, int rows_per, int C, float eps, int silu, Ten* raw16 = nullptr,
+                  const Ten& cstats = Ten()) {
         Ten ws = raw(ds_groupnorm_stats_workspace_floats(ninst, rows_per, 32) * 4);
         Ten y = make(x.rows, C, DS_F16);
         Ten r;
         if (raw16) r = *raw16 = make(x.rows, C, DS_F16);
-        tr("groupnorm xdt=%d ldx=%d ninst=%d rows=%d C=%d silu=%d raw=%d eps=%g", x.dt, x.ld, ninst, rows_per, C, silu, raw16 ? 1 : 0, (double)eps);
-        if (live())
-            chk(ds_groupnorm_rows(ptr(x), x.dt, x.ld, (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), ptr(y), ptr(r), (float*)ptr(ws),
-                                  ninst, rows_per, C, 32, eps, silu, st));
+        tr("groupnorm xdt=%d ldx=%d ninst=%d rows=%d C=%d silu=%d raw=%d eps=%g stats=%d", x.dt, x.ld, ninst, rows_per, C, silu, raw16 ? 1 : 0, (double)eps,
+           cstats ? cstats.ld / 2 : 0);
+        if (live()) {
+            if (cstats)
+                chk(ds_groupnorm_rows_colstats(ptr(x), x.dt, x.ld, (const float*)ptr(cstats), cstats.ld / 2, (const float*)u->P(prefix + ".g"),
+                                               (const float*)u->P(prefix + ".be"), ptr(y), ptr(r), (float*)ptr(ws), ninst, rows_per, C, 32, eps, silu, st));
+            else
+                chk(ds_groupnorm_rows(ptr(x), x.dt, x.ld, (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), ptr(y), ptr(r),
+                                      (float*)ptr(ws), ninst, rows_per, C, 32, eps, silu, st));
+        }
         return y;
     }
     Ten layernorm(const Ten& x, const std::string& prefix) {
@@ -831,7 +847,7 @@ struct Prog {
                     INT_MAX, 0, out);
     }
     Ten conv3(const Ten& a, const std::string& prefix, int nimg, int hin, int win, int cin, int stride, int upsample, const Ten& residual,
-              const float* bias, int bias_rows, int ldbias, int epilogue, Ten out, int* hout_, int* wout_) {
+              const float* bias, int bias_rows, int ldbias, int epilogue, Ten out, int* hout_, int* wout_, const Ten& cstats = Ten()) {
         const WeightSpec* w = u->w(prefix + ".weight");
         const int N = (int)w->shape[0], K = 9 * cin;
         ConvGeo cg;
@@ -839,7 +855,7 @@ struct Prog {
         cg.nimg = nimg; cg.hin = hin; cg.win = win; cg.hout = (hl - 1) / stride + 1; cg.wout = (wl - 1) / stride + 1; cg.stride = stride; cg.upsample = upsample;
         if (hout_) { *hout_ = cg.hout; *wout_ = cg.wout; }
         return gemm(a, wt(prefix + ".w", N, K, DS_F16), bias ? bias : (const float*)u->P(prefix + ".b"), residual, (long)nimg * cg.hout * cg.wout, N, K, epilogue,
-                    DS_A_CONV3, cin, &cg, 0, 0, bias ? bias_rows : INT_MAX, bias ? ldbias : 0, out);
+                    DS_A_CONV3, cin, &cg, 0, 0, bias ? bias_rows : INT_MAX, bias ? ldbias : 0, out, cstats);
     }
 
     struct Ctx { Ten text, img; int ltxt = 0, limg = 0; };
@@ -919,13 +935,16 @@ struct Prog {
         const int off = u->emb_off.at(p);          // read-only lookup: forwards of one handle may run on several host threads
         // "full" strict mode: the intermediates that only a GroupNorm reads (this conv-1 output, temporal convs 1-3) stay fp32 too
         const int mid = u->inner32 ? DS_EPI_OUT_F32 : 0;
-        Ten h1 = conv3(a, p + ".in_layers.2", B * T, H, W, b.cin, 1, 0, Ten(), (const float*)ptr(emb_all) + off, T * H * W, u->emb_total, mid, Ten(), nullptr, nullptr);
+        const long Mrows = (long)B * T * H * W;
+        Ten st1 = fuse_gn(H * W) ? stats_table(Mrows, b.cout) : Ten();                  // conv-1 output -> out_layers GroupNorm (per frame)
+        Ten h1 = conv3(a, p + ".in_layers.2", B * T, H, W, b.cin, 1, 0, Ten(), (const float*)ptr(emb_all) + off, T * H * W, u->emb_total, mid, Ten(), nullptr, nullptr, st1);
         a = Ten();
-        Ten a2 = groupnorm(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5f, 1);
-        h1 = Ten();
+        Ten a2 = groupnorm(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5f, 1, nullptr, st1);
+        h1 = Ten(); st1 = Ten();
         Ten skip = need_skip ? linear(h16, p + ".skip_connection", Ten(), rs) : h;
         h16 = Ten();
-        Ten h2 = conv3(a2, p + ".out_layers.3", B * T, H, W, b.cout, 1, 0, skip, nullptr, 0, 0, rs, b.tconv ? Ten() : out, nullptr, nullptr);
+        Ten stx = (b.tconv && fuse_gn(T * H * W)) ? stats_table(Mrows, b.cout) : Ten();   // conv-2 output -> first temporal-conv GroupNorm (over T jointly)
+        Ten h2 = conv3(a2, p + ".out_layers.3", B * T, H, W, b.cout, 1, 0, skip, nullptr, 0, 0, rs, b.tconv ? Ten() : out, nullptr, nullptr, stx);
         a2 = Ten(); skip = Ten();
         if (b.tconv) {
             Ten x = h2;
@@ -933,9 +952,10 @@ struct Prog {
             for (int i = 1; i <= 4; ++i) {
                 const std::string q = p + ".temopral_conv.conv" + std::to_string(i);
                 const std::string ci = std::to_string(i == 1 ? 2 : 3);
-                Ten an = groupnorm(x, q + ".0", B, T * H * W, b.cout, 1e-5f, 1);
+                Ten an = groupnorm(x, q + ".0", B, T * H * W, b.cout, 1e-5f, 1, nullptr, stx);
+                stx = (i < 4 && fuse_gn(T * H * W)) ? stats_table(Mrows, b.cout) : Ten();   // temporal conv i -> GroupNorm of conv i + 1
                 x = gemm(an, wt(q + "." + ci + ".w", b.cout, 3 * b.cout, DS_F16), (const float*)u->P(q + "." + ci + ".b"), i == 4 ? h2 : Ten(), M, b.cout, 3 * b.cout,
-                         i == 4 ? rs : mid, DS_A_TCONV, b.cout, nullptr, T, H * W, INT_MAX, 0, i == 4 ? out : Ten());
+                         i == 4 ? rs : mid, DS_A_TCONV, b.cout, nullptr, T, H * W, INT_MAX, 0, i == 4 ? out : Ten(), stx);
             }
             h2 = x;
         }
@@ -1122,6 +1142,7 @@ extern "C" int ds_unet_create(const ds_unet_config* cfg, ds_unet** out) {
                  "ds_unet_create: num_res_blocks / channel_mult / attention_resolutions out of range");
     DS_CHECK_ARG(c.num_head_channels == HEAD_DIM, "ds_unet_create: the attention kernels are built for head_dim 64 (the VideoCrafter configs)");
     DS_CHECK_ARG(c.transformer_depth > 0 && c.temporal_transformer_depth > 0 && c.context_dim > 0 && c.context_dim % 64 == 0, "ds_unet_create: transformer depth / context_dim");
+    DS_CHECK_ARG(c.gn_from_producer == 0 || c.gn_from_producer == 1, "ds_unet_create: gn_from_producer must be 0 or 1");
     DS_CHECK_ARG(c.temporal_selfatt_only == 1, "ds_unet_create: temporal_selfatt_only must be 1 (TemporalTransformers with cross-attention to the context are not built)");
     DS_CHECK_ARG(c.residual_f32 >= 0 && c.residual_f32 <= 2, "ds_unet_create: residual_f32 must be 0 (fp16 stream), 1 (fp32 everywhere) or 2 (fp32 between the blocks only)");
     for (int i = 0; i < c.n_channel_mult; ++i) DS_CHECK_ARG(c.channel_mult[i] > 0, "ds_unet_create: channel_mult[%d] = %d must be positive", i, c.channel_mult[i]);
@@ -1134,6 +1155,7 @@ extern "C" int ds_unet_create(const ds_unet_config* cfg, ds_unet** out) {
         u->strict = c.residual_f32 != 0;
         u->inner32 = c.residual_f32 == 1;
         u->fold = c.fold_layernorm != 0 && !u->inner32;    // the fold multiplies the RAW activation on the matrix cores: needs it in fp16
+        u->gn_fused = c.gn_from_producer != 0;
         build_program(u.get());
         plan_pack(u.get());
     } catch (const std::exception& e) {

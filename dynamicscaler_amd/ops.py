@@ -23,6 +23,14 @@ def set_timing_hook(hook):
     _timing_hook = hook
 
 
+def _timed(name, nbytes, launch, info):
+    """Tile-op launches under the timing hook (bench.py's roofline.tile_ops): algorithmic bytes instead of FLOPs."""
+    if _timing_hook is not None:
+        _timing_hook(name, 0.0, launch, ("bytes", int(nbytes)) + tuple(info))
+    else:
+        launch()
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -69,8 +77,10 @@ def ring_gather(pano, origins, tile_fhw, mask_pano=None):
         _dev(mask_pano, "ring_gather(mask)")
         assert mask_pano.dtype == torch.uint8 and tuple(mask_pano.shape) == tuple(pano.shape[2:])
         mtiles = torch.empty((n, tf, th, tw), dtype=torch.uint8, device=pano.device)
-    check(lib.ds_ring_gather(pano.data_ptr(), _ptr(mask_pano), tiles.data_ptr(), _ptr(mtiles), C.byref(g), arr, n,
-                             _stream()), "ds_ring_gather")
+    st = _stream()
+    _timed("ring_gather", 2 * (tiles.numel() * tiles.element_size() + (mtiles.numel() if mtiles is not None else 0)),
+           lambda: check(lib.ds_ring_gather(pano.data_ptr(), _ptr(mask_pano), tiles.data_ptr(), _ptr(mtiles), C.byref(g), arr, n, st),
+                         "ds_ring_gather"), (n,))
     return tiles, mtiles
 
 
@@ -101,8 +111,11 @@ def ring_scatter3(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, origi
             _dev(t, "ring_scatter3(tile)")
             assert t.dtype == ref.dtype and tuple(t.shape) == tuple(src.shape)
     g = _geom(ref.shape, tile_fhw, ref.dtype)
-    check(lib.ds_ring_scatter3(_ptr(pano_latent), _ptr(pano_x0), _ptr(mask_pano), _ptr(x_prev_tiles), _ptr(x0_tiles),
-                               C.byref(g), arr, n, _stream()), "ds_ring_scatter3")
+    st = _stream()
+    ntens = (pano_latent is not None) + (pano_x0 is not None)
+    _timed("ring_scatter3", 2 * ntens * src.numel() * src.element_size() + (src.numel() // src.shape[1] if mask_pano is not None else 0),
+           lambda: check(lib.ds_ring_scatter3(_ptr(pano_latent), _ptr(pano_x0), _ptr(mask_pano), _ptr(x_prev_tiles), _ptr(x0_tiles),
+                                              C.byref(g), arr, n, st), "ds_ring_scatter3"), (n,))
 
 
 def renoise_mix_(tiles, mask_tiles, pano_shape, c, s, mix_ratio, noise=None, mask_frame0=True, seed=0, offset=0,
@@ -127,9 +140,11 @@ def renoise_mix_(tiles, mask_tiles, pano_shape, c, s, mix_ratio, noise=None, mas
         _dev(noise, "renoise_mix(noise)")
         assert noise.dtype == tiles.dtype and noise.shape == tiles.shape
     ratio = float(mix_ratio)
-    check(lib.ds_renoise_mix(tiles.data_ptr(), mask_tiles.data_ptr(), _ptr(noise), float(c), float(s), ratio,
-                             float(1 - mix_ratio), int(bool(mask_frame0)), int(seed), int(offset), C.byref(g), n,
-                             _stream()), "ds_renoise_mix")
+    st = _stream()
+    _timed("renoise_mix", tiles.numel() * tiles.element_size() * (2 + (noise is not None)) + mask_tiles.numel(),
+           lambda: check(lib.ds_renoise_mix(tiles.data_ptr(), mask_tiles.data_ptr(), _ptr(noise), float(c), float(s), ratio,
+                                            float(1 - mix_ratio), int(bool(mask_frame0)), int(seed), int(offset), C.byref(g), n, st),
+                         "ds_renoise_mix"), (n,))
     return tiles
 
 
@@ -146,10 +161,13 @@ def cfg_ddim(x, eps_c, eps_u, pano_shape, guidance, coef, noise=None):
         assert eps_u.shape == x.shape and eps_u.dtype == eps_c.dtype
     x_prev = torch.empty_like(x)
     x0 = torch.empty_like(x)
-    check(lib.ds_cfg_ddim(x.data_ptr(), eps_c.data_ptr(), _ptr(eps_u), _DT[eps_c.dtype], float(guidance),
-                          float(coef["sqrt_one_minus_at"]), float(coef["sqrt_at"]), float(coef["sqrt_a_prev"]),
-                          float(coef["dir_coef"]), float(coef["sigma"]), _ptr(noise), x_prev.data_ptr(), x0.data_ptr(),
-                          C.byref(g), n, _stream()), "ds_cfg_ddim")
+    st = _stream()
+    nb = x.numel() * (3 * x.element_size() + eps_c.element_size() * (1 + (eps_u is not None)) + (x.element_size() if noise is not None else 0))
+    _timed("cfg_ddim", nb,
+           lambda: check(lib.ds_cfg_ddim(x.data_ptr(), eps_c.data_ptr(), _ptr(eps_u), _DT[eps_c.dtype], float(guidance),
+                                         float(coef["sqrt_one_minus_at"]), float(coef["sqrt_at"]), float(coef["sqrt_a_prev"]),
+                                         float(coef["dir_coef"]), float(coef["sigma"]), _ptr(noise), x_prev.data_ptr(), x0.data_ptr(),
+                                         C.byref(g), n, st), "ds_cfg_ddim"), (n,))
     return x_prev, x0
 
 
@@ -277,11 +295,17 @@ def residual_merge(curr, noised, ratio, step, sparse=True):
 
 
 # ------------------------------------------------------------------------------------------------ UNet ops
+def colstats_table(rows, cols, device):
+    """Table for ds_gemm_f16_stats: [ceil(rows / 32), cols, 2] fp32 -- (sum, sumsq) per 32-row block and column."""
+    return torch.empty(((rows + 31) // 32, cols, 2), dtype=torch.float32, device=device)
+
+
 def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE, lda=None, cin=None,
-         conv=None, tconv=None, bias_rows=None, ldbias=None, epilogue=0, stream=None):
+         conv=None, tconv=None, bias_rows=None, ldbias=None, epilogue=0, stream=None, colstats=None):
     """out[M, N'] = gatherA[M,K] @ W[N,K]^T with fused epilogue.  conv=(nimg,hin,win,hout,wout,stride,upsample),
     tconv=(t_len,hw).  N' = N/2 for GEGLU.  An fp32 `residual` (strict-precision residual stream) sets DS_EPI_RES_F32, an fp32
-    `out` tensor DS_EPI_OUT_F32."""
+    `out` tensor DS_EPI_OUT_F32.  colstats: a [row blocks, >= N, 2] fp32 view (column slice of a colstats_table) that receives the
+    per-column partial statistics of the stored tile (ds_gemm_f16_stats)."""
     lib = _lib.load()
     n_out = N // 2 if (epilogue & DS_EPI_GEGLU) else N
     if residual is not None and residual.dtype == torch.float32:
@@ -307,7 +331,15 @@ def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE
     d.epilogue = epilogue
     st = _stream() if stream is None else stream
 
+    if colstats is not None:
+        assert colstats.dtype == torch.float32 and colstats.dim() == 3 and colstats.shape[2] == 2 and colstats.stride(2) == 1 and \
+            colstats.stride(1) == 2 and colstats.shape[0] >= (M + 31) // 32 and colstats.shape[1] >= N and colstats.stride(0) % 2 == 0
+
     def launch():
+        if colstats is not None:
+            check(lib.ds_gemm_f16_stats(A.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), colstats.data_ptr(),
+                                        colstats.stride(0) // 2, C.byref(d), st), "ds_gemm_f16_stats")
+            return
         check(lib.ds_gemm_f16(A.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), C.byref(d), st),
               "ds_gemm_f16")
 
@@ -318,10 +350,11 @@ def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE
     return out
 
 
-def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None, raw_f16=False):
+def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None, raw_f16=False, colstats=None):
     """x [ninst*rows_per_inst, Cch] fp16 or fp32, rows contiguous or a column slice of a wider row-major buffer (row stride
     x.stride(0)); returns a dense fp16 [rows, Cch] tensor.  raw_f16 (fp32 x only): also returns fp16(x) as a dense tensor,
-    written in the same pass -> (y, x16)."""
+    written in the same pass -> (y, x16).  colstats: the producer's partial-statistics view for x's columns (gemm(..., colstats=)):
+    no statistics pass over x (ds_groupnorm_rows_colstats; rows_per_inst % 32 == 0)."""
     lib = _lib.load()
     st = _stream() if stream is None else stream
     assert x.dim() == 2 and x.shape[1] == Cch and x.stride(1) == 1, "groupnorm: x must be [rows, C] with unit column stride"
@@ -329,6 +362,12 @@ def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, s
                      device=x.device)
     y = torch.empty((x.shape[0], Cch), dtype=torch.float16, device=x.device)
     x16 = torch.empty((x.shape[0], Cch), dtype=torch.float16, device=x.device) if raw_f16 else None
+    if colstats is not None:
+        assert colstats.dtype == torch.float32 and colstats.shape[1] >= Cch and colstats.stride(1) == 2 and colstats.stride(2) == 1
+        check(lib.ds_groupnorm_rows_colstats(x.data_ptr(), _DT[x.dtype], x.stride(0), colstats.data_ptr(), colstats.stride(0) // 2,
+                                             gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(x16), ws.data_ptr(), ninst, rows_per_inst,
+                                             Cch, groups, float(eps), int(bool(silu)), st), "ds_groupnorm_rows_colstats")
+        return (y, x16) if raw_f16 else y
     check(lib.ds_groupnorm_rows(x.data_ptr(), _DT[x.dtype], x.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(x16),
                                 ws.data_ptr(), ninst, rows_per_inst, Cch, groups, float(eps), int(bool(silu)), st), "ds_groupnorm_rows")
     return (y, x16) if raw_f16 else y

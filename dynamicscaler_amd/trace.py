@@ -27,7 +27,7 @@ class Recorder:
 
     # ---- the ops UNetModel.forward calls (signatures of ops.py) ----
     def gemm(self, A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE, lda=None, cin=None, conv=None,
-             tconv=None, bias_rows=None, ldbias=None, epilogue=0, stream=None):
+             tconv=None, bias_rows=None, ldbias=None, epilogue=0, stream=None, colstats=None):
         n_out = N // 2 if (epilogue & DS_EPI_GEGLU) else N
         if residual is not None and residual.dtype == torch.float32:
             epilogue |= DS_EPI_RES_F32
@@ -39,11 +39,14 @@ class Recorder:
         lda_ = cin_ if lda is None else lda
         cv = list(conv[:7]) if conv is not None else [0] * 7
         tc = list(tconv) if tconv is not None else [0, 0]
-        self.lines.append("gemm M=%d N=%d K=%d mode=%d cin=%d lda=%d ldc=%d ldr=%d brows=%d ldb=%d epi=%d conv=%d,%d,%d,%d,%d,%d,%d t=%d,%d bias=%d res=%d" % (
+        self.lines.append("gemm M=%d N=%d K=%d mode=%d cin=%d lda=%d ldc=%d ldr=%d brows=%d ldb=%d epi=%d conv=%d,%d,%d,%d,%d,%d,%d t=%d,%d bias=%d res=%d stats=%d" % (
             M, N, K, a_mode, cin_, lda_, out.stride(0), residual.stride(0) if residual is not None else 0,
             0x7FFFFFFF if bias_rows is None else bias_rows, N if ldbias is None else ldbias, epilogue, *cv, *tc,
-            int(bias is not None), int(residual is not None)))
+            int(bias is not None), int(residual is not None), colstats.stride(0) // 2 if colstats is not None else 0))
         return out
+
+    def colstats_table(self, rows, cols, device):
+        return _meta(((rows + 31) // 32, cols, 2), torch.float32)
 
     def gemm_ln(self, x, Wg, stats, colsum, colbias=None, *, M, N, K, out=None, epilogue=0, stream=None, eps=1e-5):
         n_out = N // 2 if (epilogue & DS_EPI_GEGLU) else N
@@ -51,9 +54,10 @@ class Recorder:
         self.lines.append("gemm_ln M=%d N=%d K=%d lda=%d ldc=%d epi=%d" % (M, N, K, x.stride(0), out.stride(0), epilogue))
         return out
 
-    def groupnorm(self, x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None, raw_f16=False):
-        self.lines.append("groupnorm xdt=%d ldx=%d ninst=%d rows=%d C=%d silu=%d raw=%d eps=%g" % (
-            _DT[x.dtype], x.stride(0), ninst, rows_per_inst, Cch, int(bool(silu)), int(bool(raw_f16)), eps))
+    def groupnorm(self, x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None, raw_f16=False, colstats=None):
+        self.lines.append("groupnorm xdt=%d ldx=%d ninst=%d rows=%d C=%d silu=%d raw=%d eps=%g stats=%d" % (
+            _DT[x.dtype], x.stride(0), ninst, rows_per_inst, Cch, int(bool(silu)), int(bool(raw_f16)), eps,
+            colstats.stride(0) // 2 if colstats is not None else 0))
         y = _meta((x.shape[0], Cch), torch.float16)
         return (y, _meta((x.shape[0], Cch), torch.float16)) if raw_f16 else y
 
@@ -103,7 +107,7 @@ class Recorder:
         return _meta((a.shape[0], a.shape[1] + b.shape[1]), a.dtype)
 
 
-_PATCHED = ("gemm", "gemm_ln", "groupnorm", "layernorm", "layernorm_stats", "cast_rows_f16", "attention", "temporal_attention",
+_PATCHED = ("gemm", "gemm_ln", "colstats_table", "groupnorm", "layernorm", "layernorm_stats", "cast_rows_f16", "attention", "temporal_attention",
             "im2col_in", "rows_to_ncthw", "timestep_embedding", "silu", "concat_channels")
 
 

@@ -98,6 +98,12 @@ class UNetModel(nn.Module):
         # tensors) -- the error budget puts 1.19e-3 of the stream's 1.31e-3 there (profiles/r3_notes.md section 2) -- while
         # the transformers keep their fp16 inner stream and the fold: most of the strict mode's gain at about a third of its cost.
         # DS_RESIDUAL_DTYPE = f16 | f32 | f32outer; after changing the attributes call invalidate().
+        # GroupNorm statistics from the producing GEMM's epilogue (ds_gemm_f16_stats) where producer and norm are adjacent: no
+        # statistics pass over the tensor.  The partial sums follow the producer's tile variant, which is chosen from the launch size:
+        # results are run-to-run repeatable, but a batch then equals its separate forwards to fp32 rounding only (~1e-6 on eps), not
+        # bit for bit.  DS_BATCH_INVARIANT=1 keeps every kernel form a function of the instance shape alone (rounds 1-3's rule: a
+        # rank-sharded run then reproduces the one-GPU panorama bit for bit).
+        self.batch_invariant = os.environ.get("DS_BATCH_INVARIANT", "0") == "1"
         rd = os.environ.get("DS_RESIDUAL_DTYPE", "f16")
         if rd not in ("f16", "f32", "f32outer"):
             raise ValueError(f"DS_RESIDUAL_DTYPE={rd!r}: expected f16, f32 or f32outer")
@@ -157,8 +163,15 @@ class UNetModel(nn.Module):
         fp32 residual stream the LayerNorm kernel (fp32 in, fp16 operand out) runs instead."""
         return False if self._inner32() else self.fold_layernorm
 
+    def _gn_fused(self):
+        return not self.batch_invariant
+
+    def _fuse_gn(self, rows_per):
+        """This GroupNorm takes its statistics from its producer (instances of <= 256 rows keep the one-launch kernel)."""
+        return self._gn_fused() and rows_per % 32 == 0 and rows_per > 256
+
     def _mode(self):
-        return (self._fold(), self.residual_dtype, self._inner32())
+        return (self._fold(), self.residual_dtype, self._inner32(), self._gn_fused())
 
     def _c_config(self):
         """ds_unet_config of this model in the current mode."""
@@ -180,6 +193,7 @@ class UNetModel(nn.Module):
             setattr(c, k, int(bool(cfg[k])))
         c.residual_f32 = (1 if self._inner32() else 2) if self._strict() else 0
         c.fold_layernorm = int(bool(self._fold()))
+        c.gn_from_producer = int(self._gn_fused())
         c.temporal_selfatt_only = int(bool(cfg.get("temporal_selfatt_only", True)))
         return c
 
@@ -258,9 +272,9 @@ class UNetModel(nn.Module):
         return self
 
     # ------------------------------------------------------------------ forward program
-    def _gn(self, h, prefix, ninst, rows, C, eps, silu, raw_f16=False):
+    def _gn(self, h, prefix, ninst, rows, C, eps, silu, raw_f16=False, colstats=None):
         P = self._packed
-        return ops.groupnorm(h, P[prefix + ".g"], P[prefix + ".be"], ninst, rows, C, eps, silu, raw_f16=raw_f16)
+        return ops.groupnorm(h, P[prefix + ".g"], P[prefix + ".be"], ninst, rows, C, eps, silu, raw_f16=raw_f16, colstats=colstats)
 
     def _res_epi(self, epilogue=0):
         """Epilogue flags of a launch whose output belongs to the residual stream."""
@@ -277,7 +291,7 @@ class UNetModel(nn.Module):
                         lda=a.stride(0), epilogue=epilogue, out=out)
 
     def _conv3(self, a, prefix, dims, cin, stride=1, upsample=0, residual=None, bias=None, bias_rows=None, ldbias=None,
-               epilogue=0, out=None):
+               epilogue=0, out=None, colstats=None):
         """dims = (nimg, hin, win) physical input; returns (out, (hout, wout))."""
         P = self._packed
         w = P[prefix + ".w"]
@@ -288,7 +302,7 @@ class UNetModel(nn.Module):
         M = nimg * hout * wout
         out = ops.gemm(a, w, P[prefix + ".b"] if bias is None else bias, residual, M=M, N=w.shape[0], K=w.shape[1],
                        a_mode=DS_A_CONV3, cin=cin, lda=a.stride(0), conv=(nimg, hin, win, hout, wout, stride, upsample),
-                       bias_rows=bias_rows, ldbias=ldbias, epilogue=epilogue, out=out)
+                       bias_rows=bias_rows, ldbias=ldbias, epilogue=epilogue, out=out, colstats=colstats)
         return out, (hout, wout)
 
     def _transformer_block(self, x, p, heads, spatial, geo, ctx, dup=None, last=False):
@@ -380,22 +394,28 @@ class UNetModel(nn.Module):
         # "full" strict mode: the intermediates that only a GroupNorm reads (this conv-1 output, temporal convs 1-3) stay fp32 too
         # (6.0e-4 of the error budget's "mid" class, profiles/r3_notes.md section 2); matrix-core operands remain fp16
         mid = DS_EPI_OUT_F32 if self._inner32() else 0
+        Mrows = B * T * H * W
+        table = lambda: ops.colstats_table(Mrows, b.cout, h.device)      # (sum, sumsq) per 32-row block and column, written by the producer
+        st1 = table() if self._fuse_gn(H * W) else None                  # conv-1 output -> out_layers GroupNorm (per frame)
         h1, _ = self._conv3(a, p + ".in_layers.2", (B * T, H, W), b.cin, bias=emb_all[:, off:], bias_rows=T * H * W,
-                            ldbias=self._emb_total, epilogue=mid)
-        a2 = self._gn(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5, True)
+                            ldbias=self._emb_total, epilogue=mid, colstats=st1)
+        a2 = self._gn(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5, True, colstats=st1)
         skip = h if not need_skip else self._linear(h16, p + ".skip_connection", epilogue=rs)
-        h2, _ = self._conv3(a2, p + ".out_layers.3", (B * T, H, W), b.cout, residual=skip, epilogue=rs, out=None if b.tconv else out)
+        stx = table() if (b.tconv and self._fuse_gn(T * H * W)) else None     # conv-2 output -> first temporal-conv GroupNorm (over T jointly)
+        h2, _ = self._conv3(a2, p + ".out_layers.3", (B * T, H, W), b.cout, residual=skip, epilogue=rs, out=None if b.tconv else out,
+                            colstats=stx)
         if b.tconv:
             x = h2
             M = x.shape[0]
             for i in (1, 2, 3, 4):
                 ci = 2 if i == 1 else 3
                 q = f"{p}.temopral_conv.conv{i}"
-                an = self._gn(x, q + ".0", B, T * H * W, b.cout, 1e-5, True)
+                an = self._gn(x, q + ".0", B, T * H * W, b.cout, 1e-5, True, colstats=stx)
+                stx = table() if (i < 4 and self._fuse_gn(T * H * W)) else None     # temporal conv i -> GroupNorm of conv i + 1
                 w = P[f"{q}.{ci}.w"]
                 x = ops.gemm(an, w, P[f"{q}.{ci}.b"], h2 if i == 4 else None, M=M, N=w.shape[0], K=w.shape[1],
                              a_mode=DS_A_TCONV, cin=b.cout, lda=an.stride(0), tconv=(T, H * W), epilogue=rs if i == 4 else mid,
-                             out=out if i == 4 else None)
+                             out=out if i == 4 else None, colstats=stx)
             h2 = x
         return h2
 

@@ -190,6 +190,14 @@ typedef struct ds_gemm_desc {
  * out: fp16/fp32 [M][ldc]. */
 int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,
                 const ds_gemm_desc* desc, void* stream);
+/* ds_gemm_f16 that also writes the per-column partial statistics of what it stores: colstats[(m / 32) * ld_stats + n] = (sum,
+ * sum of squares) as float pairs over the valid rows of each 32-row block (after bias / residual / SiLU; fp16 outputs without an
+ * epilogue operand: of the rounded values).  One writer per entry, fixed summation order, no atomics.  The GroupNorm that reads the
+ * output (basics.py:76-86; openaimodel3d.py:275-292) takes its statistics from there: ds_groupnorm_rows_colstats.  ld_stats >= N may
+ * be the width of a wider table (a concat buffer's: the producers of both halves fill one table).  Not with DS_EPI_GEGLU; operands
+ * aligned for the vector epilogue (N % 8 == 0, 16-byte aligned rows). */
+int ds_gemm_f16_stats(const void* A, const void* W, const float* bias, const void* residual, void* out, float* colstats, int ld_stats,
+                      const ds_gemm_desc* desc, void* stream);
 /* LayerNorm folded into the projection that consumes it (BasicTransformerBlock: norm1 -> to_q/to_k/to_v, norm2 -> to_q,
  * norm3 -> GEGLU proj; attention.py:199-220, 376-403):  out = LayerNorm(x) W^T + b  computed as
  *   rstd[m] * (x[m,:] . Wg[n,:] - mean[m] * colsum[n]) + colbias[n]
@@ -236,6 +244,12 @@ int ds_groupnorm_f16_strided(const void* x, int ldx, const float* gamma, const f
    strict-precision mode's residual stream (UNetModel.residual_dtype).                                                  */
 int ds_groupnorm_rows(const void* x, int x_dtype, int ldx, const float* gamma, const float* beta, void* y, void* x_f16,
                       float* workspace, int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream);
+/* ds_groupnorm_rows with the statistics taken from the producer's colstats table (ds_gemm_f16_stats) instead of a pass over x:
+   colstats points at the entry of x's first row block and first column; rows_per_inst % 32 == 0.  Two launches: the table is
+   folded into per-chunk group sums (1/8 of the bytes of x), the apply reduces those in fp64 as in ds_groupnorm_rows.            */
+int ds_groupnorm_rows_colstats(const void* x, int x_dtype, int ldx, const float* colstats, int ld_stats, const float* gamma,
+                               const float* beta, void* y, void* x_f16, float* workspace, int ninst, int rows_per_inst, int C,
+                               int groups, float eps, int silu, void* stream);
 /* nn.LayerNorm(C) eps 1e-5 over each row (attention.py:199-201). x,y fp16 [rows][C]. */
 int ds_layernorm(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
                  void* stream);
@@ -349,6 +363,10 @@ typedef struct ds_unet_config {          /* the yaml keys of unet_config.params 
                                             only BETWEEN the blocks (ResBlock / temporal-conv outputs, proj_out + x, conv_in, down /
                                             up-sample, skip tensors), the transformers keep their fp16 inner stream             */
     int32_t fold_layernorm;              /* 1: LayerNorm folded into the projections (ds_gemm_f16_ln); forced off by residual_f32 = 1 */
+    int32_t gn_from_producer;            /* 1: the GroupNorms whose input is written by the GEMM right before them take their statistics from
+                                            that launch's epilogue (ds_gemm_f16_stats) instead of a pass over the tensor.  The partial sums
+                                            then follow the producer's tile variant, i.e. the batch size: results stay run-to-run repeatable
+                                            but a batch equals its separate forwards only to fp32 rounding.  0 keeps them bit-identical. */
     int32_t temporal_selfatt_only;       /* must be 1 (every VideoCrafter config): the TemporalTransformers attend over the frames only;
                                             0 (cross-attention to the context inside them) is refused with DS_EINVAL            */
 } ds_unet_config;

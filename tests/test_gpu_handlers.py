@@ -146,7 +146,7 @@ def test_uncalled_handler_methods_vs_oracle_and_reference_golden(dtype):
                 v = h.get_view_tensor_interpolate(fov, th, ph, 12, 10, mode, ac)
                 assert v.dtype == dtype and close(v, o.get_view_tensor_interpolate(fov, th, ph, 12, 10, mode, ac), tol), (tag, vi, mi)
                 if f32 and mode == "bilinear":
-                    assert close(v, T(z[f"{tag}_interp{vi}_{mi}"]), 1e-4)      # other host's trigonometry: weights differ in the last bits
+                    assert near(v, z[f"{tag}_interp{vi}_{mi}"], rtol=1e-4)     # other host's trigonometry: weights differ in the last bits, single taps flip
         for vi, (fov, th, ph) in enumerate(views):
             src = T(z[f"{tag}_src{vi}"]).to(dtype)
             h.set_view_tensor(src.to(d), fov, th, ph)
@@ -178,7 +178,7 @@ def test_uncalled_handler_methods_vs_oracle_and_reference_golden(dtype):
                 v = h.get_view_tensor_interpolate(fov, th, ph, 12, 10, **kw)
                 assert close(v, o.get_view_tensor_interpolate(fov, th, ph, 12, 10, **kw), tol), (tag, vi, mi)
                 if f32 and mode == "bilinear":
-                    assert close(v, T(z[f"{tag}_interp{vi}_{mi}"]), 1e-4)
+                    assert near(v, z[f"{tag}_interp{vi}_{mi}"], rtol=1e-4)
         for vi, ((fov, th, ph), (fb, fe)) in enumerate(zip(views + views[:1], wins)):
             src = T(z[f"{tag}_src{vi}"]).to(dtype)
             if f"{tag}_set{vi}" in raised:

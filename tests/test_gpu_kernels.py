@@ -708,3 +708,81 @@ def test_rccl_level_exchange_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ GroupNorm statistics from the producer
+@pytest.mark.parametrize("M,N,K,what", [
+    (300, 320, 320, "res16"),                 # small tiles, row tail inside a 32-row block
+    (257, 256, 128, "plain"),                 # fp16 strips, no epilogue operand
+    (161 * 256 - 219, 320, 320, "res16"),     # 256x320 tiles
+    (160 * 256 + 3, 256, 64, "bias"),         # 256x256 tiles, bias in the accumulators -> fp16 strips
+    (160 * 256, 640, 128, "res32"),           # 256x320 tiles, fp32 residual + fp32 output
+    (96, 72, 64, "pib"),                      # per-item bias, a partial last column chunk group
+    (2560, 1280, 192, "silu"),                # SiLU in the epilogue
+])
+def test_gemm_column_statistics_of_the_stored_tile(M, N, K, what):
+    """ds_gemm_f16_stats: colstats[row block of 32][column] = (sum, sumsq) of the values the launch stores, for every epilogue
+    form and tile variant; the table may be a column slice of a wider one (a concat buffer's).  Checked against the sums of the
+    launch's own output (fp32 outputs: exactly those values; fp16 outputs: up to their rounding)."""
+    from dynamicscaler_amd import ops, _lib
+    d = dev()
+    A, W = _h(rnd((M, K), 1)).half().to(d), _h(rnd((N, K), 2, 0.1)).half().to(d)
+    kw, out = {}, None
+    if what == "res16":
+        kw = dict(residual=(rnd((M, N), 4) * 2).half().to(d), bias=rnd((N,), 3).to(d))
+    elif what == "bias":
+        kw = dict(bias=rnd((N,), 3).to(d))
+    elif what == "res32":
+        kw = dict(residual=(rnd((M, N), 4) * 2).to(d), bias=rnd((N,), 3).to(d))
+        out = torch.empty((M, N), dtype=torch.float32, device=d)
+    elif what == "pib":
+        kw = dict(bias=rnd((3, N), 3).to(d), bias_rows=32, ldbias=N)
+    elif what == "silu":
+        kw = dict(bias=rnd((N,), 3).to(d), epilogue=_lib.DS_EPI_SILU)
+    table = torch.full(((M + 31) // 32, N + 24, 2), 7.0, dtype=torch.float32, device=d)        # wider table: columns 16 .. 16 + N are ours
+    y = ops.gemm(A, W, M=M, N=N, K=K, out=out, colstats=table[:, 16:16 + N], **kw)
+    y_plain = ops.gemm(A, W, M=M, N=N, K=K, out=None if out is None else torch.empty_like(out), **kw)
+    assert torch.equal(y, y_plain)                                   # the statistics do not touch the output
+    assert bool((table[:, :16] == 7.0).all()) and bool((table[:, 16 + N:] == 7.0).all())
+    yf = y.float().cpu()
+    pad = (-M) % 32
+    yp = torch.cat([yf, torch.zeros((pad, N))]) if pad else yf
+    blocks = yp.view(-1, 32, N).double()
+    ref_s, ref_q = blocks.sum(1), (blocks * blocks).sum(1)
+    got = table[:, 16:16 + N].cpu().double()
+    tol = 1e-5 if y.dtype == torch.float32 else 1.5e-3               # fp16 outputs of the fp32-strip path: statistics of the unrounded values
+    scale = ref_q.sqrt().clamp_min(1e-3) * (32 ** 0.5)
+    assert float(((got[..., 0] - ref_s).abs() / scale).max()) < tol, what
+    assert float(((got[..., 1] - ref_q).abs() / ref_q.clamp_min(1e-3)).max()) < 2 * tol, what
+
+
+@pytest.mark.parametrize("ninst,rows,C,xdt", [(8, 2560, 320, torch.float16), (4, 640, 640, torch.float16), (2, 2560, 1280, torch.float32),
+                                              (3, 640, 1920, torch.float16), (16, 320, 640, torch.float16)])
+def test_groupnorm_from_producer_statistics(ninst, rows, C, xdt):
+    """ds_groupnorm_rows_colstats: GroupNorm(32) (+ SiLU) of a GEMM output whose statistics come from the producer's colstats table
+    -- a 1920-wide concat buffer whose two halves were written by two launches into one table included -- against the GroupNorm
+    that reads the tensor itself (same apply kernel; the group sums differ by the order of summation and, for fp16 tensors, by the
+    output's own rounding)."""
+    from dynamicscaler_amd import ops
+    d = dev()
+    M, K = ninst * rows, 128
+    A = _h(rnd((M, K), 1)).half().to(d)
+    g, b = (1 + 0.1 * rnd((C,), 2)).to(d), (0.1 * rnd((C,), 3)).to(d)
+    x = torch.empty((M, C), dtype=xdt, device=d)
+    table = ops.colstats_table(M, C, d)
+    split = C if C != 1920 else 1280                                  # decoder concat: [h | skip], two producers, one table
+    for c0, c1 in ((0, split), (split, C)):
+        if c0 == c1:
+            continue
+        W = _h(rnd((c1 - c0, K), 5 + c0, 0.2)).half().to(d)
+        ops.gemm(A, W, rnd((c1 - c0,), 6 + c0).to(d), M=M, N=c1 - c0, K=K, out=x[:, c0:c1], colstats=table[:, c0:c1])
+    y_ref = ops.groupnorm(x, g, b, ninst, rows, C, 1e-5, True)
+    y = ops.groupnorm(x, g, b, ninst, rows, C, 1e-5, True, colstats=table)
+    assert float((y.float() - y_ref.float()).abs().max()) <= 2e-3 * float(y_ref.float().abs().max())
+    assert relerr(y, y_ref) < 3e-4
+    # a column slice of the buffer (the encoder-side reader of a skip tensor that lives in the decoder's concat buffer)
+    if C == 1920:
+        gs, bs = g[:640].contiguous(), b[:640].contiguous()
+        ys_ref = ops.groupnorm(x[:, 1280:], gs, bs, ninst, rows, 640, 1e-5, False)
+        ys = ops.groupnorm(x[:, 1280:], gs, bs, ninst, rows, 640, 1e-5, False, colstats=table[:, 1280:])
+        assert relerr(ys, ys_ref) < 3e-4
