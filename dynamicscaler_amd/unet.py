@@ -99,11 +99,15 @@ class UNetModel(nn.Module):
         # the transformers keep their fp16 inner stream and the fold: most of the strict mode's gain at about a third of its cost.
         # DS_RESIDUAL_DTYPE = f16 | f32 | f32outer; after changing the attributes call invalidate().
         # GroupNorm statistics from the producing GEMM's epilogue (ds_gemm_f16_stats) where producer and norm are adjacent: no
-        # statistics pass over the tensor.  The partial sums follow the producer's tile variant, which is chosen from the launch size:
-        # results are run-to-run repeatable, but a batch then equals its separate forwards to fp32 rounding only (~1e-6 on eps), not
-        # bit for bit.  DS_BATCH_INVARIANT=1 keeps every kernel form a function of the instance shape alone (rounds 1-3's rule: a
-        # rank-sharded run then reproduces the one-GPU panorama bit for bit).
+        # statistics pass over the tensor.  OPT-IN (DS_GN_FROM_PRODUCER=1): measured on MI355X it does not pay -- the statistics
+        # launches shrink by 7.2 ms per cfg3 step, the producers' epilogues grow by 4.8 ms, the table reduction costs 1.6 ms and the
+        # apply pass, which the statistics pass used to leave a warm Infinity Cache for, 1.9 ms (profiles/r4_notes.md section 3).
+        # With it the partial sums follow the producer's tile variant, which is chosen from the launch size: results stay run-to-run
+        # repeatable, but a batch then equals its separate forwards to fp32 rounding only.  The default keeps every kernel form a
+        # function of the instance shape alone: a rank-sharded run reproduces the one-GPU panorama bit for bit (DS_BATCH_INVARIANT=1
+        # forces that whatever else is set).
         self.batch_invariant = os.environ.get("DS_BATCH_INVARIANT", "0") == "1"
+        self.gn_from_producer = os.environ.get("DS_GN_FROM_PRODUCER", "0") == "1"
         rd = os.environ.get("DS_RESIDUAL_DTYPE", "f16")
         if rd not in ("f16", "f32", "f32outer"):
             raise ValueError(f"DS_RESIDUAL_DTYPE={rd!r}: expected f16, f32 or f32outer")
@@ -164,7 +168,7 @@ class UNetModel(nn.Module):
         return False if self._inner32() else self.fold_layernorm
 
     def _gn_fused(self):
-        return not self.batch_invariant
+        return self.gn_from_producer and not self.batch_invariant
 
     def _fuse_gn(self, rows_per):
         """This GroupNorm takes its statistics from its producer (instances of <= 256 rows keep the one-launch kernel)."""

@@ -165,8 +165,9 @@ def test_c_unet_program_parameter_table_equals_the_reference_state_dict_keys():
     assert lib.ds_unet_create(C.byref(bad), C.byref(h)) != 0
 
 
+@pytest.mark.parametrize("gn_fused", [False, True])
 @pytest.mark.parametrize("strict", [False, True, "outer"])
-def test_c_unet_program_issues_the_same_launches_as_the_python_program(strict):
+def test_c_unet_program_issues_the_same_launches_as_the_python_program(strict, gn_fused):
     """The C launch program (ds_unet_trace: csrc/unet_program.hip run dry) and the Python restatement (UNetModel.forward on
     shape-only tensors with recording ops, dynamicscaler_amd/trace.py) issue the same kernel calls with the same descriptors
     -- toy and both real configs, plain and shared-CFG-prefix batches, T = 16 and 24, fp16 and fp32 residual stream."""
@@ -177,6 +178,7 @@ def test_c_unet_program_issues_the_same_launches_as_the_python_program(strict):
         m = UNetModel(**params)
         m.residual_dtype = torch.float32 if strict else torch.float16
         m.residual_scope = "outer" if strict == "outer" else "full"
+        m.gn_from_producer = gn_fused          # GroupNorm statistics from the producer's epilogue (opt-in, DS_GN_FROM_PRODUCER)
         L = 93 if params.get("use_image_attention") else 77
         geoms = [(2, 4, 8, 8, 0), (2, 4, 8, 8, 1), (6, 4, 16, 8, 3)] if name.startswith("tiny") else [(2, 16, 40, 64, 1), (2, 24, 40, 64, 0)]
         for (B, T, H, W, pairs) in geoms:
@@ -185,6 +187,9 @@ def test_c_unet_program_issues_the_same_launches_as_the_python_program(strict):
             assert len(a) > 100 and a == b, (name, (B, T, H, W, pairs), next((x, y) for x, y in zip(a, b) if x != y))
             assert any(ln.startswith("gemm_ln ") for ln in a) == (strict is not True)      # the fold is off only with an fp32 INNER stream
             assert any(ln.startswith("cast_rows ") for ln in a) == bool(strict)
+            fused = [ln for ln in a if ln.startswith("groupnorm ") and not ln.endswith("stats=0")]
+            assert (not fused) if not gn_fused else (bool(fused) or name.startswith("tiny")), (name, len(fused))   # instances of <= 256 rows keep the one-launch norm
+            assert sum(ln.startswith("gemm ") and not ln.endswith("stats=0") for ln in a) == len(fused)
             if pairs:
                 assert sum(ln.startswith("copy ") for ln in c_lines) >= 4       # the duplicated prefix: x, h and the skip halves
 
