@@ -77,6 +77,7 @@ SIGNATURES = {
     "ds_cast_rows_f32_f16": (_i, [_vp, _i, _vp, _i, C.c_long, _i, _vp]),
     "ds_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ds_layernorm_stats": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "ds_gemm_has_stats": (_i, []),
     "ds_gemm_f16_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _pp(GemmDesc), _vp]),
     "ds_groupnorm_rows_colstats": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "ds_gemm_f16_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),

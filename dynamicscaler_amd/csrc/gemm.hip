@@ -56,6 +56,16 @@
 #ifndef DS_MFMA16
 #define DS_MFMA16 1
 #endif
+// 1: the big tiles run persistently with the next tile's first K-step in flight under the epilogue (TileCfg::OVERLAP)
+#ifndef DS_PERSIST
+#define DS_PERSIST 1
+#endif
+// 1: the epilogue can also write per-column partial statistics of the stored tile (ds_gemm_f16_stats; profiles/r4_notes.md section 3:
+// measured, no gain).  Costs registers in every kernel's epilogue, so the product library is built without it; the "gemmstats" build
+// variant (build.py) has it and the kernel tests of the feature run against that library.
+#ifndef DS_GEMM_STATS
+#define DS_GEMM_STATS 0
+#endif
 
 namespace {
 
@@ -132,14 +142,22 @@ struct TileCfg {
     static constexpr int TM = WM / 32, TN = WN / 32;          // 32x32 MFMA tiles per wave
     static constexpr int LROWS = NT / 8;                      // rows staged per sweep (8 lanes x 16 B per 128-B row)
     static constexpr int AR = BM / LROWS, BR = BN / LROWS;    // staged rows per thread
-    static constexpr size_t STAGE = (size_t)NS * (BM + BN) * BK * sizeof(f16);
+    static constexpr size_t STAGE1 = (size_t)(BM + BN) * BK * sizeof(f16);   // one stage: [BM rows of A | BN rows of W], 128 B each
+    static constexpr size_t STAGE = (size_t)NS * STAGE1;
     // epilogue: every wave transposes its own accumulators through a private LDS strip of 32 rows x NG MFMA tiles
     // (fp32, +4 floats of padding per row) -- no workgroup barrier after the main loop
-    static constexpr int NG = TN <= 4 ? TN : (TN + (TN + 3) / 4 - 1) / ((TN + 3) / 4);   // tiles per column group
+    static constexpr int NG0 = TN <= 4 ? TN : (TN + (TN + 3) / 4 - 1) / ((TN + 3) / 4);   // tiles per column group
+    static constexpr size_t LDS0 = STAGE > (size_t)(NT / 64) * 32 * (32 * NG0 + 4) * sizeof(float) ? STAGE : (size_t)(NT / 64) * 32 * (32 * NG0 + 4) * sizeof(float);
+    static constexpr int WG_PER_CU = LDS0 <= 81920 && NT <= 256 ? 2 : 1;
+    // OVERLAP (the two-stage LDS-DMA tiles, one workgroup per CU): the kernel is persistent -- a workgroup walks tiles
+    // bid, bid + grid, ... -- and the FIRST K-step of its next tile is issued into stage 0 before the epilogue of the current one,
+    // whose strips therefore live BEHIND stage 0 (in stage 1 and the tail of the allocation), two tiles per column group at most
+    static constexpr bool OVERLAP = WG_PER_CU == 1 && NS == 2 && DS_PERSIST != 0;
+    static constexpr int NG = OVERLAP && NG0 > 2 ? 2 : NG0;
     static constexpr int STR = 32 * NG + 4;                    // floats per strip row
     static constexpr size_t EPI = (size_t)(NT / 64) * 32 * STR * sizeof(float);
-    static constexpr size_t LDS = STAGE > EPI ? STAGE : EPI;
-    static constexpr int WG_PER_CU = LDS <= 81920 && NT <= 256 ? 2 : 1;
+    static constexpr size_t STRIP_OFF = OVERLAP ? STAGE1 : 0;
+    static constexpr size_t LDS = STAGE > STRIP_OFF + EPI ? STAGE : STRIP_OFF + EPI;
     // fragment scheduling: all four k-slices of a K-step up front when that is <= 16 fragments, else one k-slice
     // ahead (double-buffered fragment registers)
     static constexpr bool HOIST_ALL = 4 * (TM + TN) <= 16;
@@ -151,49 +169,89 @@ struct TileCfg {
     static_assert(LDS <= 163840, "LDS budget");
 };
 
+// Every launch-invariant argument in ONE by-value struct = the kernarg segment from offset 0.  A persistent workgroup re-reads it
+// per tile through a laundered pointer: scalar loads instead of ~90 SGPRs kept live around the tile loop (which spilled).
+struct GemmArgs {
+    const f16* A; const f16* W; const float* bias; const f16* residual; void* out;
+    ds_gemm_desc d;
+    int tiles_m, tiles_n;
+    unsigned a_bytes, w_bytes;
+    const float* ln_stats; const float* ln_colsum;
+    float ln_eps;
+    int group_m;
+    float2* colstats;
+    int ld_stats;
+};
+typedef const GemmArgs __attribute__((address_space(4)))* GemmArgsPtr;
+
 template <int BM, int BN, int WGM, int WGN, int AMODE, int NS>
 __global__ void __launch_bounds__((TileCfg<BM, BN, WGM, WGN, NS>::NT), (TileCfg<BM, BN, WGM, WGN, NS>::WG_PER_CU))
-gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const float* __restrict__ bias,
-                const f16* __restrict__ residual, void* __restrict__ out, ds_gemm_desc d, int tiles_m, int tiles_n,
-                unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum,
-                float ln_eps, int group_m, float2* __restrict__ colstats, int ld_stats) {
+gemm_f16_kernel(GemmArgs) {
     using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
     constexpr int LROWS = Cfg::LROWS, A_ROWS_PER_THREAD = Cfg::AR, B_ROWS_PER_THREAD = Cfg::BR;
 
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
-    f16* sA = reinterpret_cast<f16*>(smem);                 // [NS][BM][64]
-    f16* sB = sA + NS * BM * BK;                            // [NS][BN][64]
-    float* sW = reinterpret_cast<float*>(smem) + (size_t)(threadIdx.x >> 6) * 32 * Cfg::STR;   // this wave's epilogue strip
+    int vtile = blockIdx.x;            // virtual block id: blockIdx.x, then + gridDim.x per further tile (TileCfg::OVERLAP)
+    bool first_tile = true;
+    for (;;) {     // tiles of this workgroup (one, unless TileCfg::OVERLAP)
+    GemmArgsPtr kp4 = (GemmArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp4));      // per tile: nothing read through it is carried around the loop
+    const GemmArgs* kp = (const GemmArgs*)kp4;     // (the address space is inferred back: scalar loads)
+    const f16* __restrict__ A = kp->A;
+    const f16* __restrict__ W = kp->W;
+    const float* __restrict__ bias = kp->bias;
+    const f16* __restrict__ residual = kp->residual;
+    void* __restrict__ out = kp->out;
+    const ds_gemm_desc d = kp->d;
+    const int tiles_m = kp->tiles_m, tiles_n = kp->tiles_n;
+    const unsigned a_bytes = kp->a_bytes, w_bytes = kp->w_bytes;
+    const float* __restrict__ ln_stats = kp->ln_stats;
+    const float* __restrict__ ln_colsum = kp->ln_colsum;
+    const float ln_eps = kp->ln_eps;
+    const int group_m = kp->group_m;
+    float2* __restrict__ colstats = kp->colstats;
+    const int ld_stats = kp->ld_stats;
+    // stage-major: stage s = [BM rows of A | BN rows of W] at smem + s * STAGE1
+    auto stA = [&](int buf) { return reinterpret_cast<f16*>(smem) + (size_t)buf * (BM + BN) * BK; };
+    auto stB = [&](int buf) { return reinterpret_cast<f16*>(smem) + ((size_t)buf * (BM + BN) + BM) * BK; };
 
     // ---- XCD-aware block remap (bijective for any grid size) ----
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
+    // virtual block id v (= blockIdx.x, and for a persistent workgroup blockIdx.x + k * gridDim.x: the grid is a multiple of 8 or
+    // the whole launch, so v % 8 still names the blocks that share an XCD) -> tile
+    auto tile_of = [&](int v, int& tile_m, int& tile_n) {
+        int bid = v;
+        {
+            const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        }
     // Within an XCD consecutive ids run concurrently (one workgroup per CU, 32 CUs): walking N fastest, a wide launch has
     // ~1 A panel against all tiles_n W panels in flight, and a W that exceeds the 4 MB L2 (GEGLU 5120x640: 6.5 MB, 10240x1280:
     // 26 MB) is streamed from beyond L2 once per A panel (3.3 GB read per launch of the level-2 GEGLU against 0.22 GB
     // algorithmic).  group_m > 1: ids walk group_m A panels x tiles_n W panels with M fastest, so the concurrent set is about
     // group_m x (32 / group_m) panels.  +3-4 % on the two wide GEGLU projections (tools/bench_wide_gemm.py), pure scheduling.
+        if (group_m > 1) {
+            const int per_group = group_m * tiles_n;
+            const int first_m = (bid / per_group) * group_m, in_group = bid % per_group;
+            const int gsz = min(tiles_m - first_m, group_m);
+            tile_m = first_m + in_group % gsz;
+            tile_n = in_group / gsz;
+        } else {
+            tile_n = bid % tiles_n;
+            tile_m = bid / tiles_n;
+        }
+    };
     int tile_m, tile_n;
-    if (group_m > 1) {
-        const int per_group = group_m * tiles_n;
-        const int first_m = (bid / per_group) * group_m, in_group = bid % per_group;
-        const int gsz = min(tiles_m - first_m, group_m);
-        tile_m = first_m + in_group % gsz;
-        tile_n = in_group / gsz;
-    } else {
-        tile_n = bid % tiles_n;
-        tile_m = bid / tiles_n;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    tile_of(vtile, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;      // the tile being computed / stored (the staging cursor moves on to the next one before the epilogue)
 
-    const int tid = threadIdx.x;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));     // per tile as well: what derives from the thread id (LDS addresses, row / column offsets) is rebuilt
+    const int tid = tid_;              // per tile instead of being hoisted out of the tile loop and held in ~25 registers around it
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
+    float* sW = reinterpret_cast<float*>(smem + Cfg::STRIP_OFF) + (size_t)wave * 32 * Cfg::STR;   // this wave's epilogue strip
     const int ld_row = tid >> 3;   // 0..LROWS-1
     const int ld_chunk = tid & 7;  // 16-byte chunk within the 64-half K-step
     // LDS-DMA writes lane l of a wave-instruction at LDS offset 16*l (8 rows x 128 B per instruction), so the physical
@@ -215,10 +273,13 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     // one K-step.  Per row: the byte offset of the CENTRE pixel and a 9-bit mask of the taps that fall inside the image;
     // the tap's displacement is wave-uniform (scalar), so a K-step costs an add, a bit test and a select per staged row.
     unsigned ctr[A_ROWS_PER_THREAD], vmask[A_ROWS_PER_THREAD];
+    unsigned b_off[B_ROWS_PER_THREAD];
+    // row bookkeeping of the tile whose operands are staged next: rows [m0_, m0_ + BM) of A, rows [n0_, n0_ + BN) of W
+    auto setup_rows = [&](int m0_, int n0_) {
     if constexpr (AMODE == A_CONV3_TI) {
 #pragma unroll
         for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
-            const int m = m0 + ld_row + LROWS * i;
+            const int m = m0_ + ld_row + LROWS * i;
             const bool valid = m < d.M;
             const int mm = valid ? m : 0;
             const int hw = d.hout * d.wout;
@@ -237,7 +298,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #pragma unroll
     for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
         if constexpr (AMODE == A_CONV3_TI) break;
-        const int m = m0 + ld_row + LROWS * i;
+        const int m = m0_ + ld_row + LROWS * i;
         ri[i].valid = m < d.M;
         const int mm = ri[i].valid ? m : 0;
         if constexpr (AMODE == DS_A_CONV3) {
@@ -255,12 +316,13 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
             ri[i].base = (unsigned)mm * (unsigned)d.lda * 2u;
         }
     }
-    unsigned b_off[B_ROWS_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
-        const int n = n0 + ld_row + LROWS * i;
+        const int n = n0_ + ld_row + LROWS * i;
         b_off[i] = n < d.N ? (unsigned)n * (unsigned)d.K * 2u + src_chunk_bytes : OOB;
     }
+    };
+    setup_rows(m0, n0);
 
     u32x4 ra[A_ROWS_PER_THREAD], rb[B_ROWS_PER_THREAD];
     const int hl = d.upsample ? 2 * d.hin : d.hin, wl = d.upsample ? 2 * d.win : d.win;
@@ -325,14 +387,14 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #pragma unroll
         for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
             if constexpr (Cfg::DMA)
-                dma16(rsA, sA + (buf * BM + LROWS * i + 8 * wave) * BK, voff_a[i], soff_a);
+                dma16(rsA, stA(buf) + (LROWS * i + 8 * wave) * BK, voff_a[i], soff_a);
             else
                 ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff_a[i], soff_a, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
             if constexpr (Cfg::DMA)
-                dma16(rsW, sB + (buf * BN + LROWS * i + 8 * wave) * BK, b_off[i], kbytes);
+                dma16(rsW, stB(buf) + (LROWS * i + 8 * wave) * BK, b_off[i], kbytes);
             else
                 rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_off[i], kbytes, 0);
         }
@@ -342,27 +404,37 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #pragma unroll
         for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
             const int row = ld_row + LROWS * i;
-            *reinterpret_cast<u32x4*>(sA + (buf * BM + row) * BK + swz_chunk(row, ld_chunk) * 8) = ra[i];
+            *reinterpret_cast<u32x4*>(stA(buf) + row * BK + swz_chunk(row, ld_chunk) * 8) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
             const int row = ld_row + LROWS * i;
-            *reinterpret_cast<u32x4*>(sB + (buf * BN + row) * BK + swz_chunk(row, ld_chunk) * 8) = rb[i];
+            *reinterpret_cast<u32x4*>(stB(buf) + row * BK + swz_chunk(row, ld_chunk) * 8) = rb[i];
         }
     };
 
     const int nk = d.K / BK;
     const int fr = lane & 31, fh = lane >> 5;
 
-    if constexpr (AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK) {   // column sums / column bias of this tile's BN columns -> LDS (read after the K loop)
-        float* sLNw = reinterpret_cast<float*>(smem + Cfg::LDS);
-        for (int c = threadIdx.x; c < BN; c += Cfg::NT) {
-            const int col = min(n0 + c, d.N - 1);
-            sLNw[c] = ln_colsum[col];
-            sLNw[BN + c] = bias ? bias[col] : 0.0f;
+    // staging cursor onto a tile: row bookkeeping, K position 0, first tap's offsets
+    auto begin_staging = [&](int m0_, int n0_) {
+        setup_rows(m0_, n0_);
+        tap = 0; cb = 0; kbytes = 0;
+        tap_offsets();
+    };
+    // first K-step(s) of the workgroup's FIRST tile.  A later tile's first K-step went out before the previous tile's epilogue, from
+    // row bookkeeping that was dropped again (nothing of it stays in registers across the epilogue): it has been rebuilt above, the
+    // cursor moves one K-step on.
+    DS_STAMP(0);
+    if (first_tile) {
+        if constexpr (Cfg::DMA) {
+            for (int s0 = 0; s0 < NS - 1 && s0 < d.K / BK; ++s0) load_global(s0);   // NS-1 K-steps in flight
+        } else {
+            load_global(0);
         }
+    } else {
+        next_k();
     }
-
 #if DS_MFMA16
     f32x4 acc[TN][TM][4];
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -481,21 +553,24 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         }
     };
 
-    DS_STAMP(0);
-    if constexpr (Cfg::DMA) {
-        for (int s0 = 0; s0 < NS - 1 && s0 < d.K / BK; ++s0) load_global(s0);   // NS-1 K-steps in flight
-        stage_sync(0, false);
-    } else {
-        load_global(0);
-        stage_sync(0, true);
-    }
+    // the tile's first K-step has landed (every wave's share) and every wave has left the previous tile's epilogue
+    if constexpr (Cfg::DMA) stage_sync(0, false);
+    else stage_sync(0, true);
     DS_STAMP(1);
+    if constexpr (AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK) {   // column sums / column bias of this tile's BN columns -> LDS (read after the K loop;
+        float* sLNw = reinterpret_cast<float*>(smem + Cfg::LDS);    //  behind the barrier above: no wave still reads the previous tile's)
+        for (int c = tid; c < BN; c += Cfg::NT) {
+            const int col = min(n0 + c, d.N - 1);
+            sLNw[c] = ln_colsum[col];
+            sLNw[BN + c] = bias ? bias[col] : 0.0f;
+        }
+    }
 
     // one LDS-DMA piece (8 rows x 128 B of this wave's share) of the next K-step, and the cursor advance after all pieces
     constexpr int NPIECE = A_ROWS_PER_THREAD + B_ROWS_PER_THREAD;
     auto dma_piece = [&](int j, int buf) {
-        if (j < A_ROWS_PER_THREAD) dma16(rsA, sA + (buf * BM + LROWS * j + 8 * wave) * BK, voff_a[j], (unsigned)cb * 2u);
-        else dma16(rsW, sB + (buf * BN + LROWS * (j - A_ROWS_PER_THREAD) + 8 * wave) * BK, b_off[j - A_ROWS_PER_THREAD], kbytes);
+        if (j < A_ROWS_PER_THREAD) dma16(rsA, stA(buf) + (LROWS * j + 8 * wave) * BK, voff_a[j], (unsigned)cb * 2u);
+        else dma16(rsW, stB(buf) + (LROWS * (j - A_ROWS_PER_THREAD) + 8 * wave) * BK, b_off[j - A_ROWS_PER_THREAD], kbytes);
     };
     auto advance_k = [&]() { next_k(); };
 
@@ -508,8 +583,8 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         } else if constexpr (Cfg::HOIST_ALL) {
             if (MORE) load_global(nbuf);                   // small wave tiles: the pieces go out in front of the reads
         }
-        const f16* a_base = sA + (buf * BM + wm * WM) * BK;
-        const f16* b_base_l = sB + (buf * BN + wn * WN) * BK;
+        const f16* a_base = stA(buf) + wm * WM * BK;
+        const f16* b_base_l = stB(buf) + wn * WN * BK;
         auto read_a = [&](int kk, int mi) {
             const int row = mi * 32 + fr;
             return *reinterpret_cast<const f16x8*>(a_base + row * BK + swz_chunk(wm * WM + row, 2 * kk + fh) * 8);
@@ -748,6 +823,21 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
     const bool bias_done = bias_in_acc || ln_fold;   // nothing left to add in the epilogue
 
     DS_STAMP(2);
+    // ---- persistent workgroup: its next tile's first K-step goes out NOW, into stage 0 -- every wave is past the K loop's last
+    //      barrier, so no fragment read of this tile is outstanding, and the epilogue below works in strips behind stage 0
+    //      (TileCfg::STRIP_OFF).  The loads (A rows from HBM, the W panel from L2) land while the epilogue reads its residual rows
+    //      and stores; the barrier at the top of the next tile waits for them and for every wave's epilogue. ----
+    int vnext = vtile, tile_m_n = 0, tile_n_n = 0;
+    bool more_tiles = false;
+    if constexpr (Cfg::OVERLAP) {
+        vnext = vtile + (int)gridDim.x;
+        more_tiles = vnext < nwg;
+        if (more_tiles) {
+            tile_of(vnext, tile_m_n, tile_n_n);
+            begin_staging(tile_m_n * BM, tile_n_n * BN);
+            load_global(0);
+        }
+    }
     const bool geglu = d.epilogue & DS_EPI_GEGLU;
     const bool silu = d.epilogue & DS_EPI_SILU;
     const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;
@@ -898,7 +988,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #endif
                             }
                         }
-                        if constexpr (!GE) {
+                        if constexpr (!GE && DS_GEMM_STATS) {
                             if (colstats) {        // statistics of the stored (rounded) values
                                 float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -1021,7 +1111,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
 #pragma unroll
                                     for (int j = 0; j < 8; ++j) v[j] = fast_silu(v[j]);
                                 }
-                                if constexpr (!GE) {
+                                if constexpr (!GE && DS_GEMM_STATS) {
                                     if (colstats) {
 #pragma unroll
                                         for (int j = 0; j < 8; ++j) {
@@ -1050,7 +1140,7 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
                             }
                         }
                     }
-                    if constexpr (!GE) {
+                    if constexpr (!GE && DS_GEMM_STATS) {
                         if (colstats) stats_flush(cs, cq, cpr, rps, ch, r0, lane_on, col_on, mrow0, ocol);
                     }
                 } else {
@@ -1098,6 +1188,10 @@ gemm_f16_kernel(const f16* __restrict__ A, const f16* __restrict__ W, const floa
         with_bias_mode(std::false_type{}, R0{});
     }
     DS_STAMP(4);
+    if (!more_tiles) break;
+    vtile = vnext;
+    first_tile = false;
+    }   // tiles
 }
 
 struct StatOut { float2* p = nullptr; int ld = 0; };   // ds_gemm_f16_stats: where the per-column partial statistics go
@@ -1130,9 +1224,21 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
         ds_set_error("ds_gemm_f16: operand of %ld / %ld bytes exceeds the 2 GiB buffer-addressing range; lower the tile batch", a_bytes, w_bytes);
         return DS_EINVAL;
     }
-    gemm_f16_kernel<BM, BN, WGM, WGN, AMODE, NS><<<tiles_m * tiles_n, Cfg::NT, lds, st>>>(
-        (const f16*)A, (const f16*)W, bias, (const f16*)residual, out, d, tiles_m, tiles_n, (unsigned)a_bytes, (unsigned)w_bytes,
-        ln_stats, ln_colsum, ln_eps, group_m, so.p, so.ld);
+    // TileCfg::OVERLAP: one persistent workgroup per CU (a multiple of 8, so that v % 8 keeps naming the XCD)
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        return n / 8 * 8;
+    }();
+    const int nblk = tiles_m * tiles_n;
+    const int grid = (Cfg::OVERLAP && nblk > ncu) ? ncu : nblk;
+    GemmArgs ka;
+    ka.A = (const f16*)A; ka.W = (const f16*)W; ka.bias = bias; ka.residual = (const f16*)residual; ka.out = out;
+    ka.d = d;
+    ka.tiles_m = tiles_m; ka.tiles_n = tiles_n; ka.a_bytes = (unsigned)a_bytes; ka.w_bytes = (unsigned)w_bytes;
+    ka.ln_stats = ln_stats; ka.ln_colsum = ln_colsum; ka.ln_eps = ln_eps; ka.group_m = group_m;
+    ka.colstats = so.p; ka.ld_stats = so.ld;
+    gemm_f16_kernel<BM, BN, WGM, WGN, AMODE, NS><<<grid, Cfg::NT, lds, st>>>(ka);
     DS_CHECK_LAUNCH("ds_gemm_f16");
     return DS_OK;
 }
@@ -1270,8 +1376,12 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
 // ds_gemm_f16 that also writes, for every 32-row block of the output, the per-column (sum, sum of squares) of the values it
 // stores: colstats[(m / 32) * ld_stats + n], float2.  The GroupNorm that reads this output (ds_groupnorm_rows_colstats) then needs
 // no statistics pass over the tensor.  Conditions = the epilogue's vector path: N % 8 == 0, aligned operands, no GEGLU.
+// 1 if this library's GEMM epilogues can write the column statistics (built with DS_GEMM_STATS)
+extern "C" int ds_gemm_has_stats(void) { return DS_GEMM_STATS != 0; }
+
 extern "C" int ds_gemm_f16_stats(const void* A, const void* W, const float* bias, const void* residual, void* out, float* colstats,
                                  int ld_stats, const ds_gemm_desc* desc, void* stream) {
+    DS_CHECK_ARG(DS_GEMM_STATS != 0, "ds_gemm_f16_stats: this library was built without DS_GEMM_STATS (build variant \"gemmstats\" has it)");
     DS_CHECK_ARG(desc && colstats, "ds_gemm_f16_stats: null argument");
     const ds_gemm_desc& d = *desc;
     const bool out_f32 = d.epilogue & DS_EPI_OUT_F32;

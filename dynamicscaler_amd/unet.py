@@ -168,7 +168,12 @@ class UNetModel(nn.Module):
         return False if self._inner32() else self.fold_layernorm
 
     def _gn_fused(self):
-        return self.gn_from_producer and not self.batch_invariant
+        if self.gn_from_producer and not self.batch_invariant:
+            if not _lib.load().ds_gemm_has_stats():
+                raise RuntimeError("gn_from_producer / DS_GN_FROM_PRODUCER=1 needs a library built with DS_GEMM_STATS: "
+                                   "`python -m dynamicscaler_amd.build --variant gemmstats` and DS_HIP_LIBRARY=.../libdynscaler_hip_gemmstats.so")
+            return True
+        return False
 
     def _fuse_gn(self, rows_per):
         """This GroupNorm takes its statistics from its producer (instances of <= 256 rows keep the one-launch kernel)."""

@@ -196,6 +196,8 @@ int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* res
  * output (basics.py:76-86; openaimodel3d.py:275-292) takes its statistics from there: ds_groupnorm_rows_colstats.  ld_stats >= N may
  * be the width of a wider table (a concat buffer's: the producers of both halves fill one table).  Not with DS_EPI_GEGLU; operands
  * aligned for the vector epilogue (N % 8 == 0, 16-byte aligned rows). */
+int ds_gemm_has_stats(void);     /* 1: this build has ds_gemm_f16_stats (the product library is built without it: the statistics cost registers
+                                    in every epilogue and measured no gain; `python -m dynamicscaler_amd.build --variant gemmstats`) */
 int ds_gemm_f16_stats(const void* A, const void* W, const float* bias, const void* residual, void* out, float* colstats, int ld_stats,
                       const ds_gemm_desc* desc, void* stream);
 /* LayerNorm folded into the projection that consumes it (BasicTransformerBlock: norm1 -> to_q/to_k/to_v, norm2 -> to_q,

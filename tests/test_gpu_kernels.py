@@ -711,6 +711,24 @@ def test_rccl_level_exchange_single_rank():
 
 
 # ------------------------------------------------------------------------------------------------ GroupNorm statistics from the producer
+def _in_gemmstats_library(request):
+    """ds_gemm_f16_stats lives in the `gemmstats` build variant (the product library is built without it, profiles/r4_notes.md
+    section 3): the test re-runs itself in a subprocess with DS_HIP_LIBRARY on that library and returns False in the parent."""
+    import subprocess
+    import sys
+    from dynamicscaler_amd import _lib
+    if _lib.load().ds_gemm_has_stats():
+        return True
+    variant = os.path.join(os.path.dirname(_lib.IN_TREE_LIB), "libdynscaler_hip_gemmstats.so")
+    if not os.path.exists(variant):
+        pytest.skip("libdynscaler_hip_gemmstats.so not built (python -m dynamicscaler_amd.build --variant gemmstats)")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", request.node.nodeid.replace("::", "::", 1)],
+                       capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       env=dict(os.environ, DS_HIP_LIBRARY=variant))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    return False
+
+
 @pytest.mark.parametrize("M,N,K,what", [
     (300, 320, 320, "res16"),                 # small tiles, row tail inside a 32-row block
     (257, 256, 128, "plain"),                 # fp16 strips, no epilogue operand
@@ -720,12 +738,14 @@ def test_rccl_level_exchange_single_rank():
     (96, 72, 64, "pib"),                      # per-item bias, a partial last column chunk group
     (2560, 1280, 192, "silu"),                # SiLU in the epilogue
 ])
-def test_gemm_column_statistics_of_the_stored_tile(M, N, K, what):
+def test_gemm_column_statistics_of_the_stored_tile(M, N, K, what, request):
     """ds_gemm_f16_stats: colstats[row block of 32][column] = (sum, sumsq) of the values the launch stores, for every epilogue
     form and tile variant; the table may be a column slice of a wider one (a concat buffer's).  Checked against the sums of the
     launch's own output (fp32 outputs: exactly those values; fp16 outputs: up to their rounding)."""
     from dynamicscaler_amd import ops, _lib
     d = dev()
+    if not _in_gemmstats_library(request):
+        return
     A, W = _h(rnd((M, K), 1)).half().to(d), _h(rnd((N, K), 2, 0.1)).half().to(d)
     kw, out = {}, None
     if what == "res16":
@@ -758,13 +778,15 @@ def test_gemm_column_statistics_of_the_stored_tile(M, N, K, what):
 
 @pytest.mark.parametrize("ninst,rows,C,xdt", [(8, 2560, 320, torch.float16), (4, 640, 640, torch.float16), (2, 2560, 1280, torch.float32),
                                               (3, 640, 1920, torch.float16), (16, 320, 640, torch.float16)])
-def test_groupnorm_from_producer_statistics(ninst, rows, C, xdt):
+def test_groupnorm_from_producer_statistics(ninst, rows, C, xdt, request):
     """ds_groupnorm_rows_colstats: GroupNorm(32) (+ SiLU) of a GEMM output whose statistics come from the producer's colstats table
     -- a 1920-wide concat buffer whose two halves were written by two launches into one table included -- against the GroupNorm
     that reads the tensor itself (same apply kernel; the group sums differ by the order of summation and, for fp16 tensors, by the
     output's own rounding)."""
     from dynamicscaler_amd import ops
     d = dev()
+    if not _in_gemmstats_library(request):
+        return
     M, K = ninst * rows, 128
     A = _h(rnd((M, K), 1)).half().to(d)
     g, b = (1 + 0.1 * rnd((C,), 2)).to(d), (0.1 * rnd((C,), 3)).to(d)
