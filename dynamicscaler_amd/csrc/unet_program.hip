@@ -1285,6 +1285,7 @@ extern "C" int ds_unet_forward(ds_unet* u, const void* x, int x_dtype, const int
     DS_CHECK_ARG(x && timesteps && context && workspace && eps, "ds_unet_forward: null argument");
     DS_CHECK_ARG((x_dtype == DS_F16 || x_dtype == DS_F32) && (ctx_dtype == DS_F16 || ctx_dtype == DS_F32), "ds_unet_forward: dtypes must be DS_F16 or DS_F32");
     DS_CHECK_ARG(u->packed, "ds_unet_forward: ds_unet_pack has not run");
+    DS_CHECK_ARG(!u->gn_fused || ds_gemm_has_stats(), "ds_unet_forward: gn_from_producer = 1 needs a library built with DS_GEMM_STATS (build variant \"gemmstats\"; the launch trace works without)");
     DS_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "ds_unet_forward: the workspace must be 256-byte aligned");
     // refused BEFORE the first launch: a short workspace never sees a kernel (the arena's own failure path stops launching too)
     const size_t need = unet_peak(u, B, T, H, W, ctx_tokens, cfg_pairs);

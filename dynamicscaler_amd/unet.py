@@ -168,12 +168,7 @@ class UNetModel(nn.Module):
         return False if self._inner32() else self.fold_layernorm
 
     def _gn_fused(self):
-        if self.gn_from_producer and not self.batch_invariant:
-            if not _lib.load().ds_gemm_has_stats():
-                raise RuntimeError("gn_from_producer / DS_GN_FROM_PRODUCER=1 needs a library built with DS_GEMM_STATS: "
-                                   "`python -m dynamicscaler_amd.build --variant gemmstats` and DS_HIP_LIBRARY=.../libdynscaler_hip_gemmstats.so")
-            return True
-        return False
+        return bool(self.gn_from_producer and not self.batch_invariant)
 
     def _fuse_gn(self, rows_per):
         """This GroupNorm takes its statistics from its producer (instances of <= 256 rows keep the one-launch kernel)."""
@@ -444,6 +439,9 @@ class UNetModel(nn.Module):
         tracing = x.device.type == "meta"          # python_program_trace: shapes only, ops replaced by recorders
         if not x.is_cuda and not tracing:
             raise RuntimeError("UNetModel.forward: input is on the CPU; this build has no CPU path (the HIP kernels are the product)")
+        if not tracing and self._gn_fused() and not _lib.load().ds_gemm_has_stats():
+            raise RuntimeError("gn_from_producer / DS_GN_FROM_PRODUCER=1 needs a library built with DS_GEMM_STATS: "
+                               "`python -m dynamicscaler_amd.build --variant gemmstats` and DS_HIP_LIBRARY=.../libdynscaler_hip_gemmstats.so")
         if not tracing and (self._packed is None or self._device != x.device or self._packed_mode != self._mode()):
             self.prepare(x.device)
         P = self._packed
