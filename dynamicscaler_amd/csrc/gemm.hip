@@ -756,6 +756,11 @@ gemm_f16_kernel(GemmArgs) {
 #endif
         stage_sync(nbuf, MORE);
     };
+#ifdef DS_SETPRIO_HI       // A/B (build variant "setprio"): static priority for the second-dispatched half of an 8-wave workgroup
+    if constexpr (WGM * WGN == 8) {
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     {
         int kt = 0;
         for (; kt + NS - 1 < nk; ++kt) kstep(kt, std::true_type{});

@@ -108,7 +108,11 @@ class UNetModel(nn.Module):
         # forces that whatever else is set).
         self.batch_invariant = os.environ.get("DS_BATCH_INVARIANT", "0") == "1"
         self.gn_from_producer = os.environ.get("DS_GN_FROM_PRODUCER", "0") == "1"
-        rd = os.environ.get("DS_RESIDUAL_DTYPE", "f16")
+        # DEFAULT (round 4): f32outer -- the cheapest mode inside the north star's 1e-3 with margin on every asserted latent bound,
+        # on the schedule the metric runs: the ring loop with the real UNet over the first six steps of the 50-step schedule ends
+        # at 7.0e-4 (fast mode 9.6e-4, strict 5.3e-4; tests/test_gpu_fullsize.py::test_ring_loops_real_unet_on_the_50_step_schedule...),
+        # free-running 50 steps 7.1e-4 (9.8e-4 / 5.3e-4), x_prev of a unit-scale model's first step 9.4e-4 (1.27e-3 / 7.1e-4).
+        rd = os.environ.get("DS_RESIDUAL_DTYPE", "f32outer")
         if rd not in ("f16", "f32", "f32outer"):
             raise ValueError(f"DS_RESIDUAL_DTYPE={rd!r}: expected f16, f32 or f32outer")
         self.residual_dtype = torch.float16 if rd == "f16" else torch.float32

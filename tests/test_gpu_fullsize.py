@@ -86,17 +86,22 @@ CFG1_TOL = {
 NORTH_STAR = 1e-3
 
 
+@pytest.mark.parametrize("residual", ["float16", "outer", "float32"])
 @pytest.mark.parametrize("latent_dtype", [torch.float16, torch.float32])
-def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype):
+def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype, residual):
     """Config 1: 4 DDIM steps of the real UNet on one 512x320x16f tile, CFG 7.5.
     Teacher-forced (every step starts from the REFERENCE's latent of that step: the error of one step in isolation, at
-    schedule indices 3, 2, 1, 0 = t 999 / 666 / 333 / 0) and free-running (basic_sample end to end: errors compound)."""
+    schedule indices 3, 2, 1, 0 = t 999 / 666 / 333 / 0) and free-running (basic_sample end to end: errors compound), in every
+    residual mode.  NAMED WAIVER: the FIRST update of this 4-step schedule (999 -> 666: x_prev = 2.8 x - 1.9 e_t) multiplies the
+    guided-eps error and is outside 1e-3 in every mode (fp16 matrix-core operands); every later step is
+    asserted at 1e-3."""
     from dynamicscaler_amd import ops
     from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V
     from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
     d = dev()
     z = np.load(os.path.join(G, "cfg1_full_t2v.npz"))
     ld, params, _ = full_host(d)
+    _set_mode(ld.model.diffusion_model, residual)
     cfgd = {"params": {"unet_config": {"params": params}}}
     sched = lvdm_DDIM_Scheduler(ld)
     pipe = VC2_Pipeline_T2V(ld, sched, cfgd).to(d, latent_dtype)
@@ -116,7 +121,7 @@ def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype):
         index = int(z[f"index_{i}"])
         xp, x0 = ops.cfg_ddim(x, eps[:1].contiguous(), eps[1:].contiguous(), (1, 4, 16, 40, 64), g,
                               sched.step_coefficients(index))
-        r = dict(test="cfg1_teacher_forced", latents=name, step=i, t=int(t), e_t=relerr(e_t, T(z[f"e_t_{i}"])),
+        r = dict(test="cfg1_teacher_forced", residual=residual, latents=name, step=i, t=int(t), e_t=relerr(e_t, T(z[f"e_t_{i}"])),
                  x_prev=relerr(xp, T(z[f"x_prev_{i}"])), pred_x0=relerr(x0, T(z[f"pred_x0_{i}"])))
         print(r)
         record(**r)
@@ -128,7 +133,7 @@ def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype):
     lat = T(z["x_init"]).to(d, latent_dtype)
     for i, t in enumerate(timesteps):
         lat, den = pipe._basic_denoise_one_step(lat, t, i, 4, cond, uncond, g, int(z["fps"]), 16, {})
-        r = dict(test="cfg1_free_running", latents=name, step=i, x_prev=relerr(lat, T(z[f"x_prev_{i}"])),
+        r = dict(test="cfg1_free_running", residual=residual, latents=name, step=i, x_prev=relerr(lat, T(z[f"x_prev_{i}"])),
                  pred_x0=relerr(den, T(z[f"pred_x0_{i}"])))
         print(r)
         record(**r)
@@ -502,7 +507,7 @@ def test_i2v_ring_pipeline_with_the_real_unet_vs_reference_golden(residual):
         _HOST["i2v"] = (ld, params)
     ld, params = _HOST["i2v"]
     unet = ld.model.diffusion_model
-    unet.residual_dtype = getattr(torch, residual)
+    unet.residual_dtype, unet.residual_scope = getattr(torch, residual), "full"
     pano_img = synth_normal((3, 512, 1024), int(z["pano_img_seed"])).clamp(-1, 1)
     try:
         pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="reference"),
@@ -514,7 +519,7 @@ def test_i2v_ring_pipeline_with_the_real_unet_vs_reference_golden(residual):
                                                        step_callback=lambda i, t, w, p, p0: trace.append((i, int(t), [list(x) for x in w])),
                                                        **rec["geom"])
     finally:
-        unet.residual_dtype = torch.float16
+        unet.residual_dtype, unet.residual_scope = torch.float16, "full"
     for (i, t, wins), ref in zip(trace, rec["trace"]):
         assert i == ref["i"] and t == ref["t"] and wins == ref["windows"], (i, wins, ref)
     e = relerr(den, T(z["denoised"]))

@@ -31,7 +31,7 @@ def build_unet(params, seed, device, residual_dtype):
     from dynamicscaler_amd.synth import synth_state_dict
     m = UNetModel(**params)
     m.load_state_dict(synth_state_dict(param_shapes(params), seed), strict=True)
-    m.residual_dtype = residual_dtype
+    m.residual_dtype, m.residual_scope = residual_dtype, "full"      # strict = fp32 everywhere (the library default is the "outer" scope)
     return m.to(device).eval()
 
 
@@ -88,9 +88,9 @@ def test_unet_strict_batch_cfg_pairs_and_concat_invariants():
     # attribute switch on a live model
     m16 = build_unet(params, 5, d, torch.float16)
     ref16 = m16(x2, t2, context=cs, fps=8)
-    m.residual_dtype = torch.float16
+    m.residual_dtype, m.residual_scope = torch.float16, "full"
     assert torch.equal(m(x2, t2, context=cs, fps=8), ref16)
-    m.residual_dtype = torch.float32
+    m.residual_dtype, m.residual_scope = torch.float32, "full"
     assert torch.equal(m(x2, t2, context=cs, fps=8), plain)
     assert not torch.equal(plain, ref16)
 

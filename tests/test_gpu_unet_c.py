@@ -29,7 +29,7 @@ def build_unet(params, seed, device, residual_dtype=torch.float16, program="c"):
     from dynamicscaler_amd.synth import synth_state_dict
     m = UNetModel(**params)
     m.load_state_dict(synth_state_dict(param_shapes(params), seed), strict=True)
-    m.residual_dtype = residual_dtype
+    m.residual_dtype, m.residual_scope = residual_dtype, "full"
     m.program = program
     return m.to(device).eval()
 
