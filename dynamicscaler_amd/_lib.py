@@ -55,6 +55,8 @@ SIGNATURES = {
     "ds_abi_version": (_i, []),
     "ds_ring_gather": (_i, [_vp, _vp, _vp, _vp, C.POINTER(RingGeom), C.POINTER(C.c_int32), _i, _vp]),
     "ds_ring_scatter3": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(RingGeom), C.POINTER(C.c_int32), _i, _vp]),
+    "ds_ring_gather_renoise": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _u64, _pp(C.c_int64), C.POINTER(RingGeom), C.POINTER(C.c_int32), _i, _vp]),
+    "ds_cfg_ddim_scatter": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, C.POINTER(RingGeom), C.POINTER(C.c_int32), _i, _vp]),
     "ds_renoise_mix": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _i, _u64, _u64, C.POINTER(RingGeom), _i, _vp]),
     "ds_cfg_ddim": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, C.POINTER(RingGeom), _i, _vp]),
     "ds_map_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -193,7 +193,7 @@ gemm_f16_kernel(GemmArgs) {
 
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     int vtile = blockIdx.x;            // virtual block id: blockIdx.x, then + gridDim.x per further tile (TileCfg::OVERLAP)
-    bool first_tile = true;
+    bool first_tile = true, ln_parity = false;
     for (;;) {     // tiles of this workgroup (one, unless TileCfg::OVERLAP)
     GemmArgsPtr kp4 = (GemmArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp4));      // per tile: nothing read through it is carried around the loop
@@ -553,18 +553,22 @@ gemm_f16_kernel(GemmArgs) {
         }
     };
 
-    // the tile's first K-step has landed (every wave's share) and every wave has left the previous tile's epilogue
-    if constexpr (Cfg::DMA) stage_sync(0, false);
-    else stage_sync(0, true);
-    DS_STAMP(1);
-    if constexpr (AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK) {   // column sums / column bias of this tile's BN columns -> LDS (read after the K loop;
-        float* sLNw = reinterpret_cast<float*>(smem + Cfg::LDS);    //  behind the barrier above: no wave still reads the previous tile's)
+    // LayerNorm fold: column sums / column bias of this tile's BN columns -> LDS (read after the K loop), while the first K-step's
+    // loads are in flight.  Two copies, alternating per tile of a persistent workgroup: a slower wave may still be reading the
+    // previous tile's in its fold when this one is written; the copy before that is two barriers back.
+    const int ln_off = (AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK) && ln_parity ? 2 * BN : 0;
+    if constexpr (AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK) {
+        float* sLNw = reinterpret_cast<float*>(smem + Cfg::LDS) + ln_off;
         for (int c = tid; c < BN; c += Cfg::NT) {
             const int col = min(n0 + c, d.N - 1);
             sLNw[c] = ln_colsum[col];
             sLNw[BN + c] = bias ? bias[col] : 0.0f;
         }
     }
+    // the tile's first K-step has landed (every wave's share) and every wave has left the previous tile's epilogue
+    if constexpr (Cfg::DMA) stage_sync(0, false);
+    else stage_sync(0, true);
+    DS_STAMP(1);
 
     // one LDS-DMA piece (8 rows x 128 B of this wave's share) of the next K-step, and the cursor advance after all pieces
     constexpr int NPIECE = A_ROWS_PER_THREAD + B_ROWS_PER_THREAD;
@@ -797,7 +801,7 @@ gemm_f16_kernel(GemmArgs) {
         // cs / cb of this tile's BN columns were staged in LDS behind the operand stages at kernel start (sLN, visible after the
         // K loop's first barrier).  One 32-column tile at a time: with all 4*TN quads' vectors loaded in front of the
         // arithmetic (what the compiler does by itself) the 256x320 tile spilled ~300 B per lane.
-        const float* sLN = reinterpret_cast<const float*>(smem + Cfg::LDS);
+        const float* sLN = reinterpret_cast<const float*>(smem + Cfg::LDS) + ln_off;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
@@ -1196,6 +1200,7 @@ gemm_f16_kernel(GemmArgs) {
     if (!more_tiles) break;
     vtile = vnext;
     first_tile = false;
+    ln_parity = !ln_parity;
     }   // tiles
 }
 
@@ -1205,7 +1210,7 @@ template <int BM, int BN, int WGM, int WGN, int AMODE, int NS = 2>
 int launch(const void* A, const void* W, const float* bias, const void* residual, void* out,
            const ds_gemm_desc& d, hipStream_t st, const float* ln_stats, const float* ln_colsum, float ln_eps, StatOut so = StatOut()) {
     using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
-    constexpr size_t lds = Cfg::LDS + ((AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK) ? 2 * BN * sizeof(float) : 0);   // + staged column sums / bias
+    constexpr size_t lds = Cfg::LDS + ((AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK) ? 4 * BN * sizeof(float) : 0);   // + staged column sums / bias, two copies
     static_assert(lds <= 163840, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {

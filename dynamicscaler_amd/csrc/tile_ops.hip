@@ -266,6 +266,160 @@ __global__ void __launch_bounds__(256) cfg_ddim_kernel(const T* __restrict__ x, 
 
 
 // ---------------------------------------------------------------------------------------------
+// Fused forms of the ring step's tile ops (SURVEY R2+R5+R6 and R7+R8+R3): the window is re-noised under the mask while it is
+// gathered, and the CFG + DDIM update goes straight into the panoramas -- the tile tensors in between are never written.
+// Same fp32 operations in the same order as the separate kernels (bit-identical results), 4 elements per thread along x.
+// ---------------------------------------------------------------------------------------------
+struct TileIds { long off[DS_MAX_WINDOWS]; };     // Philox counter offset of tile i (in-kernel noise)
+
+// VEC consecutive elements (VEC = 1 or 4; 4: the address is a multiple of 4 elements) as floats and back; one rounding on the way back
+template <int VEC> __device__ inline void ldv(const float* p, float o[4]) {
+    if (VEC == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(p); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+    else o[0] = p[0];
+}
+template <int VEC> __device__ inline void ldv(const f16* p, float o[4]) {
+    if (VEC == 4) { const f16x4 v = *reinterpret_cast<const f16x4*>(p); o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
+    else o[0] = (float)p[0];
+}
+template <int VEC> __device__ inline void ldv(const uint8_t* p, float o[4]) {
+    if (VEC == 4) { const uint32_t v = *reinterpret_cast<const uint32_t*>(p); o[0] = (float)(v & 255u); o[1] = (float)((v >> 8) & 255u); o[2] = (float)((v >> 16) & 255u); o[3] = (float)(v >> 24); }
+    else o[0] = (float)p[0];
+}
+template <int VEC> __device__ inline void stv(float* p, const float v[4]) {
+    if (VEC == 4) *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    else p[0] = v[0];
+}
+template <int VEC> __device__ inline void stv(f16* p, const float v[4]) {
+    if (VEC == 4) *reinterpret_cast<f16x4*>(p) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    else p[0] = (f16)v[0];
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+ring_gather_renoise_kernel(const T* __restrict__ pano, const uint8_t* __restrict__ mask_pano, T* __restrict__ tiles,
+                           uint8_t* __restrict__ mask_tiles, const T* __restrict__ noise, float c, float s, float ratio,
+                           float one_minus_ratio, int mask_frame0, uint64_t seed, TileIds ids, ds_ring_geom g, Origins o, int aligned) {
+    // VEC = elements per thread = normals per Philox counter (4 whenever tw % 4 == 0, like ds_renoise_mix: the same stream);
+    // aligned: the group of VEC neither straddles the W seam nor is misaligned in the panorama -> vector loads, else per element
+    const int twv = g.tw / VEC;
+    const long per_tile_v = (long)g.C * g.tf * g.th * twv;
+    const long total = per_tile_v * o.n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / per_tile_v);
+        const long within = idx - (long)i * per_tile_v;
+        long r = within;
+        const int xv = (int)(r % twv); r /= twv;
+        const int y = (int)(r % g.th); r /= g.th;
+        const int f = (int)(r % g.tf);
+        const int cc = (int)(r / g.tf);
+        const int sy = (o.y0[i] + y) % g.H;
+        const int sx = (o.x0[i] + xv * VEC) % g.W;             // VEC == 1, or the group neither straddles the seam nor is misaligned
+        const int sf = (o.f0[i] + f) % g.F;
+        const int mf = (o.f0[i] + (mask_frame0 ? 0 : f)) % g.F;
+        const T* src = pano + (((long)cc * g.F + sf) * g.H + sy) * g.W + sx;
+        const uint8_t* msrc = mask_pano + ((long)mf * g.H + sy) * g.W + sx;
+        const long e0 = idx * VEC;
+        float z[4], xs[4], ms4[4], out4[4];
+        if (!noise) normal4(seed, (uint64_t)ids.off[i] + (uint64_t)within, z);
+        else ldv<VEC>(noise + e0, z);
+        if (aligned) {
+            ldv<VEC>(src, xs);
+            ldv<VEC>(msrc, ms4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int sxj = (o.x0[i] + xv * VEC + j) % g.W;
+                xs[j] = (float)pano[(((long)cc * g.F + sf) * g.H + sy) * g.W + sxj];
+                ms4[j] = (float)mask_pano[((long)mf * g.H + sy) * g.W + sxj];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float x = xs[j];
+            const float zz = z[j];
+            const float m = ms4[j];
+            // scheduler.py:108  x_b = c * x_a + s * eps
+            const float t1 = c * x;
+            const float t2 = s * zz;
+            const float noised = t1 + t2;
+            // tensor_utils.py:30-37
+            const float w1 = x * one_minus_ratio;
+            const float w2 = noised * ratio;
+            const float mixed = w1 + w2;
+            const float non_mask = x * (1.0f - m);
+            const float mask_area = mixed * m;
+            out4[j] = non_mask + mask_area;
+        }
+        stv<VEC>(tiles + e0, out4);
+        if (mask_tiles && cc == 0) {      // the window's mask itself (merge-prev reads it again after the update)
+            const uint8_t* ms = mask_pano + ((long)sf * g.H + sy) * g.W + sx;
+            uint8_t* md = mask_tiles + (((long)i * g.tf + f) * g.th + y) * g.tw + (long)xv * VEC;
+            if (VEC == 4 && aligned) *reinterpret_cast<uint32_t*>(md) = *reinterpret_cast<const uint32_t*>(ms);
+            else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) md[j] = mask_pano[((long)sf * g.H + sy) * g.W + (o.x0[i] + xv * VEC + j) % g.W];
+            }
+        }
+    }
+}
+
+template <typename T, typename E, int VEC>
+__global__ void __launch_bounds__(256)
+cfg_ddim_scatter_kernel(const T* __restrict__ x, const E* __restrict__ ec, const E* __restrict__ eu, float guidance, float sq1m,
+                        float sqrt_at, float sqrt_aprev, float dir_coef, float sigma, const T* __restrict__ noise,
+                        T* __restrict__ pano_lat, T* __restrict__ pano_x0, uint8_t* __restrict__ mask, ds_ring_geom g, Origins o) {
+    const int twv = g.tw / VEC;
+    const long per_tile_v = (long)g.C * g.tf * g.th * twv;
+    const long total = per_tile_v * o.n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / per_tile_v);
+        long r = idx - (long)i * per_tile_v;
+        const int xv = (int)(r % twv); r /= twv;
+        const int y = (int)(r % g.th); r /= g.th;
+        const int f = (int)(r % g.tf);
+        const int cc = (int)(r / g.tf);
+        const int sf = (o.f0[i] + f) % g.F;
+        const int sy = (o.y0[i] + y) % g.H;
+        const int sx = (o.x0[i] + xv * VEC) % g.W;
+        const long plane = ((long)sf * g.H + sy) * g.W + sx;
+        const long dst = (long)cc * g.F * g.H * g.W + plane;
+        const long e0 = idx * VEC;
+        float xs[4], es[4], us[4] = {0, 0, 0, 0}, ns[4] = {0, 0, 0, 0}, xp4[4], p04[4];
+        ldv<VEC>(x + e0, xs);
+        ldv<VEC>(ec + e0, es);
+        if (eu) ldv<VEC>(eu + e0, us);
+        if (noise) ldv<VEC>(noise + e0, ns);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xval = xs[j];
+            float e = es[j];
+            if (eu) {
+                const float u = us[j];
+                const float dd = e - u;          // t2v_sphere_panorama_pipeline.py:599
+                const float gd = guidance * dd;
+                e = u + gd;
+            }
+            const float a = sq1m * e;            // scheduler.py:83
+            const float num = xval - a;
+            const float p0 = num / sqrt_at;
+            const float dir = dir_coef * e;      // :85
+            const float b = sqrt_aprev * p0;     // :89
+            float xp = b + dir;
+            const float nz = noise ? sigma * ns[j] : 0.0f;
+            xp = xp + nz;
+            xp4[j] = xp;
+            p04[j] = p0;
+        }
+        stv<VEC>(pano_lat + dst, xp4);
+        stv<VEC>(pano_x0 + dst, p04);
+        if (mask && cc == 0) {
+            if (VEC == 4) *reinterpret_cast<uint32_t*>(mask + plane) = 0x01010101u;
+            else mask[plane] = 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Sphere path: perspective view <-> equirect panorama through a host-computed int32 index map
 // (utils/panorama_tensor_utils.py:154-202).  idx[i][p] < 0 = skip (invalid sample / duplicate-target loser).
 // ---------------------------------------------------------------------------------------------
@@ -468,6 +622,64 @@ extern "C" int ds_ring_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_
         }
     }
     DS_CHECK_LAUNCH("ds_ring_scatter3");
+    return DS_OK;
+}
+
+extern "C" int ds_ring_gather_renoise(const void* pano, const uint8_t* mask_pano, void* tiles, uint8_t* mask_tiles, const void* noise,
+                                      float c, float s, float ratio, float one_minus_ratio, int mask_frame0, uint64_t seed,
+                                      const int64_t* tile_offsets, const ds_ring_geom* g, const int32_t* origins, int n, void* stream) {
+    Origins o;
+    int rc = fill_origins(o, g, origins, n, "ds_ring_gather_renoise");
+    if (rc) return rc;
+    DS_CHECK_ARG(pano && mask_pano && tiles, "ds_ring_gather_renoise: null argument");
+    DS_CHECK_ARG(noise || tile_offsets, "ds_ring_gather_renoise: in-kernel noise needs the tiles' counter offsets");
+    DS_CHECK_ARG(g->dtype == DS_F16 || g->dtype == DS_F32, "ds_ring_gather_renoise: bad dtype");
+    TileIds ids;
+    for (int i = 0; i < n; ++i) ids.off[i] = tile_offsets ? (long)tile_offsets[i] : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = (g->tw % 4) == 0;                 // as ds_renoise_mix: 4 normals per counter along x
+    const int aligned = vec_ok(g, o, 4) ? 1 : 0;
+    const long work = (long)n * g->C * g->tf * g->th * (v4 ? g->tw / 4 : g->tw);
+    if (g->dtype == DS_F16) {
+        if (v4) ring_gather_renoise_kernel<f16, 4><<<grid_for(work), 256, 0, st>>>((const f16*)pano, mask_pano, (f16*)tiles, mask_tiles, (const f16*)noise, c, s, ratio, one_minus_ratio, mask_frame0, seed, ids, *g, o, aligned);
+        else ring_gather_renoise_kernel<f16, 1><<<grid_for(work), 256, 0, st>>>((const f16*)pano, mask_pano, (f16*)tiles, mask_tiles, (const f16*)noise, c, s, ratio, one_minus_ratio, mask_frame0, seed, ids, *g, o, 0);
+    } else {
+        if (v4) ring_gather_renoise_kernel<float, 4><<<grid_for(work), 256, 0, st>>>((const float*)pano, mask_pano, (float*)tiles, mask_tiles, (const float*)noise, c, s, ratio, one_minus_ratio, mask_frame0, seed, ids, *g, o, aligned);
+        else ring_gather_renoise_kernel<float, 1><<<grid_for(work), 256, 0, st>>>((const float*)pano, mask_pano, (float*)tiles, mask_tiles, (const float*)noise, c, s, ratio, one_minus_ratio, mask_frame0, seed, ids, *g, o, 0);
+    }
+    DS_CHECK_LAUNCH("ds_ring_gather_renoise");
+    return DS_OK;
+}
+
+extern "C" int ds_cfg_ddim_scatter(const void* x, const void* eps_c, const void* eps_u, int eps_dtype, float guidance,
+                                   float sqrt_one_minus_at, float sqrt_at, float sqrt_a_prev, float dir_coef, float sigma, const void* noise,
+                                   void* pano_latent, void* pano_x0, uint8_t* mask_pano, const ds_ring_geom* g, const int32_t* origins,
+                                   int n, void* stream) {
+    Origins o;
+    int rc = fill_origins(o, g, origins, n, "ds_cfg_ddim_scatter");
+    if (rc) return rc;
+    DS_CHECK_ARG(x && eps_c && pano_latent && pano_x0, "ds_cfg_ddim_scatter: null argument");
+    DS_CHECK_ARG(g->tw <= g->W && g->th <= g->H && g->tf <= g->F, "ds_cfg_ddim_scatter: warp should not occur");
+    DS_CHECK_ARG(sigma == 0.0f || noise, "ds_cfg_ddim_scatter: sigma != 0 needs a noise tensor");
+    DS_CHECK_ARG(eps_dtype == DS_F16 || eps_dtype == DS_F32, "ds_cfg_ddim_scatter: bad eps dtype");
+    DS_CHECK_ARG(g->dtype == DS_F16 || g->dtype == DS_F32, "ds_cfg_ddim_scatter: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = vec_ok(g, o, 4);
+    const long work = (long)n * g->C * g->tf * g->th * (v4 ? g->tw / 4 : g->tw);
+    const int grid = grid_for(work);
+#define DS_LAUNCH_CDS(T, E, V)                                                                                                            \
+    cfg_ddim_scatter_kernel<T, E, V><<<grid, 256, 0, st>>>((const T*)x, (const E*)eps_c, (const E*)eps_u, guidance, sqrt_one_minus_at,       \
+                                                           sqrt_at, sqrt_a_prev, dir_coef, sigma, (const T*)noise, (T*)pano_latent,        \
+                                                           (T*)pano_x0, mask_pano, *g, o)
+    if (g->dtype == DS_F16) {
+        if (eps_dtype == DS_F16) { if (v4) DS_LAUNCH_CDS(f16, f16, 4); else DS_LAUNCH_CDS(f16, f16, 1); }
+        else { if (v4) DS_LAUNCH_CDS(f16, float, 4); else DS_LAUNCH_CDS(f16, float, 1); }
+    } else {
+        if (eps_dtype == DS_F16) { if (v4) DS_LAUNCH_CDS(float, f16, 4); else DS_LAUNCH_CDS(float, f16, 1); }
+        else { if (v4) DS_LAUNCH_CDS(float, float, 4); else DS_LAUNCH_CDS(float, float, 1); }
+    }
+#undef DS_LAUNCH_CDS
+    DS_CHECK_LAUNCH("ds_cfg_ddim_scatter");
     return DS_OK;
 }
 

@@ -118,6 +118,57 @@ def ring_scatter3(pano_latent, pano_x0, mask_pano, x_prev_tiles, x0_tiles, origi
                                               C.byref(g), arr, n, st), "ds_ring_scatter3"), (n,))
 
 
+def ring_gather_renoise(pano, mask_pano, origins, tile_fhw, c, s, mix_ratio, noise=None, mask_frame0=True, seed=0, tile_offsets=None,
+                        want_mask_tiles=False):
+    """ring_gather + renoise_mix_ in one kernel (ds_ring_gather_renoise): tiles [n,C,tf,th,tw] = the windows, re-noised under the
+    mask panorama u8 [F,H,W].  noise [n,C,tf,th,tw] or None = in-kernel Philox with tile k drawing from counter tile_offsets[k] on
+    (the stream of renoise_mix_(..., tile_ids=...)).  -> (tiles, mask tiles | None)."""
+    _dev(pano, "ring_gather_renoise")
+    _dev(mask_pano, "ring_gather_renoise(mask)")
+    lib = _lib.load()
+    arr, n = _origins(origins)
+    tf, th, tw = tile_fhw
+    g = _geom(pano.shape, tile_fhw, pano.dtype)
+    assert mask_pano.dtype == torch.uint8 and tuple(mask_pano.shape) == tuple(pano.shape[2:])
+    tiles = torch.empty((n, pano.shape[1], tf, th, tw), dtype=pano.dtype, device=pano.device)
+    mtiles = torch.empty((n, tf, th, tw), dtype=torch.uint8, device=pano.device) if want_mask_tiles else None
+    offs = None
+    if noise is None:
+        assert tile_offsets is not None and len(tile_offsets) == n
+        offs = (C.c_int64 * n)(*[int(v) for v in tile_offsets])
+    else:
+        _dev(noise, "ring_gather_renoise(noise)")
+        assert noise.dtype == pano.dtype and tuple(noise.shape) == tuple(tiles.shape) and noise.is_contiguous()
+    st = _stream()
+    nb = tiles.numel() * tiles.element_size() * (2 + (noise is not None)) + n * tf * th * tw * (1 + bool(want_mask_tiles))
+    _timed("ring_gather_renoise", nb,
+           lambda: check(lib.ds_ring_gather_renoise(pano.data_ptr(), mask_pano.data_ptr(), tiles.data_ptr(), _ptr(mtiles), _ptr(noise), float(c),
+                                                    float(s), float(mix_ratio), float(1 - mix_ratio), int(bool(mask_frame0)), int(seed), offs,
+                                                    C.byref(g), arr, n, st), "ds_ring_gather_renoise"), (n,))
+    return tiles, mtiles
+
+
+def cfg_ddim_scatter_(pano_latent, pano_x0, mask_pano, x, eps_c, eps_u, guidance, coef, origins, noise=None):
+    """cfg_ddim + ring_scatter3 in one kernel (ds_cfg_ddim_scatter): the update of the pairwise-disjoint windows `origins` goes straight
+    into the panoramas (x_prev -> pano_latent, pred_x0 -> pano_x0, mask_pano <- 1)."""
+    _dev(x, "cfg_ddim_scatter")
+    _dev(eps_c, "cfg_ddim_scatter(eps_c)")
+    _dev(pano_latent, "cfg_ddim_scatter(pano)")
+    lib = _lib.load()
+    arr, n = _origins(origins)
+    assert x.shape[0] == n and eps_c.shape == x.shape and pano_latent.dtype == x.dtype and pano_x0.dtype == x.dtype
+    assert x.is_contiguous() and eps_c.is_contiguous() and (eps_u is None or (eps_u.is_contiguous() and eps_u.shape == x.shape and eps_u.dtype == eps_c.dtype))
+    g = _geom(pano_latent.shape, tuple(x.shape[2:]), x.dtype)
+    st = _stream()
+    nb = x.numel() * (3 * x.element_size() + eps_c.element_size() * (1 + (eps_u is not None)) + (x.element_size() if noise is not None else 0)) + \
+        (x.numel() // x.shape[1] if mask_pano is not None else 0)
+    _timed("cfg_ddim_scatter", nb,
+           lambda: check(lib.ds_cfg_ddim_scatter(x.data_ptr(), eps_c.data_ptr(), _ptr(eps_u), _DT[eps_c.dtype], float(guidance),
+                                                 float(coef["sqrt_one_minus_at"]), float(coef["sqrt_at"]), float(coef["sqrt_a_prev"]),
+                                                 float(coef["dir_coef"]), float(coef["sigma"]), _ptr(noise), pano_latent.data_ptr(),
+                                                 pano_x0.data_ptr(), _ptr(mask_pano), C.byref(g), arr, n, st), "ds_cfg_ddim_scatter"), (n,))
+
+
 def renoise_mix_(tiles, mask_tiles, pano_shape, c, s, mix_ratio, noise=None, mask_frame0=True, seed=0, offset=0,
                  tile_ids=None):
     """In place: tiles <- mix(tiles, c*tiles + s*noise, mask, mix_ratio).

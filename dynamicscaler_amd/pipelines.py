@@ -76,6 +76,9 @@ class VC2_Pipeline_T2V:
         # the 8-GPU share of cfg3, tools/gpu_gn_sparse.sh, profiles/r3_notes.md sections 4 and 8; bit-identical, a batch equals its separate forwards).  1 (default):
         # only such levels; 0: never; 2: every batch, one after the other (emulates a rank's single-batch levels on one GPU).
         self.split_cfg_over_streams = int(os.environ.get("DS_SPLIT_CFG", "1"))
+        # gather + re-noise and CFG + DDIM + scatter as one kernel each (ds_ring_gather_renoise / ds_cfg_ddim_scatter; bit-identical
+        # to the separate kernels, 0 = those)
+        self.fuse_tile_ops = os.environ.get("DS_FUSE_TILE_OPS", "1") != "0"
         self.verbose = False
 
     # -- the bits of DiffusionPipeline the reference relies on --
@@ -269,10 +272,26 @@ class VC2_Pipeline_T2V:
         mask = st.mask if use_mask else None
 
         split_cfg = [False]
+        # the tile ops around the UNet fused (round 4; `fuse_tile_ops`, bit-identical to the separate kernels): the window is
+        # re-noised while it is gathered (unless merge-prev needs the window as it was), and on one rank the update goes straight
+        # into the panoramas -- windows of a level are pairwise disjoint, so a batch may scatter while the level's other batch
+        # still gathers; over several ranks the tiles themselves are what is exchanged
+        fuse_gather = self.fuse_tile_ops and renoise and mask is not None and merge_prev_ratio is None
+        fuse_scatter = self.fuse_tile_ops and st.world == 1 and merge_prev_ratio is None
 
         def prepare(ids):
             """Gather + re-noise of the windows `ids` -> (tiles, mask tiles, the windows before the re-noise | None)."""
             origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in ids]
+            if fuse_gather:
+                nz = None
+                if noises[ids[0]][0] is not None:
+                    nz = torch.cat([noises[j][0] for j in ids], 0).to(device=device, dtype=pano.dtype)
+                numel = st.tile_shape[1] * st.tile_fhw[0] * st.tile_fhw[1] * st.tile_fhw[2]
+                base = sched.tile_philox_offset(i, numel)
+                tiles, mtiles = ops.ring_gather_renoise(pano, mask, origins, st.tile_fhw, c_rn, s_rn, st.ratio, noise=nz,
+                                                        mask_frame0=mask_frame0, seed=sched.philox_seed,
+                                                        tile_offsets=[base + j * numel for j in ids])
+                return ids, tiles, mtiles, None
             tiles, mtiles = ops.ring_gather(pano, origins, st.tile_fhw, mask)
             prev = tiles.clone() if merge_prev_ratio is not None else None
             if renoise:
@@ -284,12 +303,21 @@ class VC2_Pipeline_T2V:
                                  offset=sched.tile_philox_offset(i, tiles[0].numel()), tile_ids=ids)
             return ids, tiles, mtiles, prev
 
-        def finish(ctx, e_c, e_u):
-            """CFG + DDIM update (+ merge-prev) of prepared tiles from their eps tensors."""
+        def finish(ctx, e_c, e_u, from_units=False):
+            """CFG + DDIM update (+ merge-prev) of prepared tiles from their eps tensors -> (x_prev, x0) tiles, or (None, None) when
+            the update went straight into the panoramas."""
             ids, tiles, mtiles, prev = ctx
             sn = None
             if coef["sigma"] != 0.0:
                 sn = torch.cat([noises[j][1] for j in ids], 0).to(device=device, dtype=pano.dtype)
+            if fuse_scatter and not from_units:
+                for s0 in range(0, len(ids), ops.DS_MAX_WINDOWS):
+                    part = ids[s0:s0 + ops.DS_MAX_WINDOWS]
+                    n_ = len(part)
+                    ops.cfg_ddim_scatter_(pano, st.pano_x0, mask, tiles[s0:s0 + n_].contiguous(), e_c[s0:s0 + n_].contiguous(),
+                                          None if e_u is None else e_u[s0:s0 + n_].contiguous(), st.guidance_scale, coef,
+                                          [(wins[j][4], wins[j][2], wins[j][0]) for j in part], None if sn is None else sn[s0:s0 + n_].contiguous())
+                return None, None
             x_prev, x0 = ops.cfg_ddim(tiles, e_c, e_u, st.total_shape, st.guidance_scale, coef, sn)
             if merge_prev_ratio is not None:
                 # merge-prev (i2v_sphere_panorama_pipeline.py:938-943): mix(x_prev, window_before_renoise, mask, r_i)
@@ -330,7 +358,7 @@ class VC2_Pipeline_T2V:
             return self._eps(x, t, cl, st.fps, st.frames, **st.kwargs).float()
 
         def unit_finish(ctx, e_all):
-            return finish(ctx, e_all[:, 0].contiguous(), e_all[:, 1].contiguous())
+            return finish(ctx, e_all[:, 0].contiguous(), e_all[:, 1].contiguous(), from_units=True)
 
         units = parallel.EvalUnits(2, prepare, unit_eps, unit_finish) if (st.guidance_scale != 1.0 and st.world > 1) else None
 
@@ -351,9 +379,13 @@ class VC2_Pipeline_T2V:
                                                       on_slot=lambda k: setattr(self, "_slot", k))
             else:
                 parts = [run_batch(ids) for ids in batches]
+            if parts and parts[0][0] is None:       # already in the panoramas (fuse_scatter)
+                return None, None
             return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
 
         def scatter(ids, xp, x0):
+            if xp is None:
+                return
             for s in range(0, len(ids), ops.DS_MAX_WINDOWS):
                 part = ids[s:s + ops.DS_MAX_WINDOWS]
                 origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in part]

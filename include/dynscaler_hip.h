@@ -69,6 +69,23 @@ int ds_ring_scatter3(void* pano_latent, void* pano_x0, uint8_t* mask_pano, const
                      const void* x0_tiles, const ds_ring_geom* geom, const int32_t* origins, int n,
                      void* stream);
 
+/* The ring step's tile ops fused around the UNet (round 4): the same fp32 operations in the same order as ds_ring_gather +
+ * ds_renoise_mix and ds_cfg_ddim + ds_ring_scatter3, without the tile tensors in between.
+ * ds_ring_gather_renoise (utils/shift_window_utils.py:48-114 + pipeline/scheduler.py:98-110 + utils/tensor_utils.py:19-39; call site
+ * pipeline/t2v_sphere_panorama_pipeline.py:538-559): tiles[i] = mix(window_i, c*window_i + s*noise, mask window_i, ratio); the mask
+ * is read straight from the mask panorama [F][H][W] (frame f0 of the window for every frame when mask_frame0); mask_tiles (may be
+ * NULL) receives the window's mask.  noise: [n][C][tf][th][tw] or NULL = in-kernel Philox, tile i drawing from counter
+ * tile_offsets[i] (HOST int64 [n]) on -- the stream of one ds_renoise_mix call per tile with that offset.
+ * ds_cfg_ddim_scatter (t2v_sphere_panorama_pipeline.py:599-632, pipeline/scheduler.py:60-96, shift_window_utils.py:116-206): the
+ * CFG-combined DDIM update of n pairwise-disjoint windows written into pano_latent (x_prev) and pano_x0 (pred_x0), mask_pano set to 1
+ * over the windows. */
+int ds_ring_gather_renoise(const void* pano, const uint8_t* mask_pano, void* tiles, uint8_t* mask_tiles, const void* noise, float c,
+                           float s, float ratio, float one_minus_ratio, int mask_frame0, uint64_t seed, const int64_t* tile_offsets,
+                           const ds_ring_geom* geom, const int32_t* origins, int n, void* stream);
+int ds_cfg_ddim_scatter(const void* x, const void* eps_c, const void* eps_u, int eps_dtype, float guidance, float sqrt_one_minus_at,
+                        float sqrt_at, float sqrt_a_prev, float dir_coef, float sigma, const void* noise, void* pano_latent,
+                        void* pano_x0, uint8_t* mask_pano, const ds_ring_geom* geom, const int32_t* origins, int n, void* stream);
+
 /* re_noise + mix_latents_with_mask fused (pipeline/scheduler.py:98-110, utils/tensor_utils.py:19-39;
  * call site pipeline/t2v_sphere_panorama_pipeline.py:550-559):
  *   noised = c*x + s*noise ;  out = x*(1-m) + (x*(1-ratio) + noised*ratio)*m     (fp32, same op order)

@@ -808,3 +808,49 @@ def test_groupnorm_from_producer_statistics(ninst, rows, C, xdt, request):
         ys_ref = ops.groupnorm(x[:, 1280:], gs, bs, ninst, rows, 640, 1e-5, False)
         ys = ops.groupnorm(x[:, 1280:], gs, bs, ninst, rows, 640, 1e-5, False, colstats=table[:, 1280:])
         assert relerr(ys, ys_ref) < 3e-4
+
+
+# ------------------------------------------------------------------------------------------------ fused tile ops (round 4)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("x0s", [(56, 8), (5, 61)])          # aligned (wrapping) and misaligned window origins along W
+@pytest.mark.parametrize("host_noise", [True, False])
+def test_fused_tile_ops_equal_the_separate_kernels(dtype, x0s, host_noise):
+    """ds_ring_gather_renoise == ds_ring_gather + ds_renoise_mix and ds_cfg_ddim_scatter == ds_cfg_ddim + ds_ring_scatter3, bit for
+    bit: host noise and the in-kernel Philox stream (tile k from its own counter offset, like one ds_renoise_mix call per tile),
+    fp32 / fp16, windows wrapping all three axes, origins that do not allow vector loads, mask frame 0 or per frame."""
+    from dynamicscaler_amd import ops
+    d = dev()
+    pano = rnd((1, 4, 6, 12, 64), 1).to(dtype).to(d)
+    maskp = (rnd((6, 12, 64), 2) > 0).to(torch.uint8).to(d)
+    origins = [(4, 10, x0s[0]), (1, 2, x0s[1])]                # (f0, y0, x0); tile 4 x 4 x 16: the first wraps F, H and W; disjoint in H
+    tile = (4, 4, 16)
+    n, numel = len(origins), 4 * 4 * 4 * 16
+    c, s, ratio = 0.9, 0.43588989, 0.75
+    for mask_frame0 in (True, False):
+        noise = rnd((n, 4) + tile, 3).to(dtype).to(d) if host_noise else None
+        offs = [1000 + 7 * numel, 1000 + 2 * numel]
+        t_f, m_f = ops.ring_gather_renoise(pano, maskp, origins, tile, c, s, ratio, noise=noise, mask_frame0=mask_frame0, seed=11,
+                                           tile_offsets=offs, want_mask_tiles=True)
+        t_s, m_s = ops.ring_gather(pano, origins, tile, maskp)
+        if host_noise:
+            ops.renoise_mix_(t_s, m_s, tuple(pano.shape), c, s, ratio, noise=noise, mask_frame0=mask_frame0)
+        else:
+            ops.renoise_mix_(t_s, m_s, tuple(pano.shape), c, s, ratio, noise=None, mask_frame0=mask_frame0, seed=11, offset=1000,
+                             tile_ids=[7, 2])
+        assert torch.equal(t_f, t_s) and torch.equal(m_f, m_s), (mask_frame0, host_noise)
+    # the update, straight into the panoramas (the two windows are disjoint)
+    from oracle import ddim as oddim
+    sched = oddim.DDIMSchedule(oddim.DiffusionTables(), 10)
+    for eta_noise in (False, True):
+        coef = dict(sched.step_coefficients(5))
+        sn = None
+        if eta_noise:
+            coef["sigma"] = 0.3
+            sn = rnd((n, 4) + tile, 9).to(dtype).to(d)
+        e_c, e_u = rnd((n, 4) + tile, 4).to(d), rnd((n, 4) + tile, 5).to(d)
+        p1, p1x, k1 = pano.clone(), torch.zeros_like(pano), maskp.clone()
+        p2, p2x, k2 = pano.clone(), torch.zeros_like(pano), maskp.clone()
+        ops.cfg_ddim_scatter_(p1, p1x, k1, t_s, e_c, e_u, 7.5, coef, origins, sn)
+        xp, x0 = ops.cfg_ddim(t_s, e_c, e_u, tuple(pano.shape), 7.5, coef, sn)
+        ops.ring_scatter3(p2, p2x, k2, xp, x0, origins)
+        assert torch.equal(p1, p2) and torch.equal(p1x, p2x) and torch.equal(k1, k2), eta_noise
