@@ -417,8 +417,8 @@ def main():
         try:
             cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_rocprof_step_summary_cfg3_1stream.json")))
             src = cands[-1] if cands else ""
-            if args.config == "cfg3" and os.path.exists(src) and unet.residual_dtype == torch.float16:
-                summ = json.load(open(src))
+            summ = json.load(open(src)) if (args.config == "cfg3" and os.path.exists(src)) else None
+            if summ is not None and summ.get("residual_mode", "f16") == timed_mode:
                 fam = summ["families"]["gemm"]
                 rp = g[1] / (fam["ms_per_step"] * 1e-3) / 1e12
                 rocprof = {"avg_launch_us": round(fam["avg_launch_us"], 1), "achieved": round(rp, 1),

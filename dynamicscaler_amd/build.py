@@ -105,3 +105,6 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv, variant=v))
     if v is None:
         print(build_examples())
+        for name in VARIANTS:          # variant libraries already in the tree are kept in step with the sources (a stale one is refused at load)
+            if os.path.exists(os.path.join(HERE, f"libdynscaler_hip_{name}.so")):
+                print(build(force="--force" in sys.argv, variant=name))

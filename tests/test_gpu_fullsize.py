@@ -69,20 +69,18 @@ def full_host(d):
     return _HOST["ld"], _HOST["params"], _HOST["sd"]
 
 
-# Measured on MI355X (round 2, gpurun_out/measured_parity.jsonl -> DESIGN.md section 5); asserted at <= 2x measured.
-# Per DDIM step of the 4-step schedule (t = 999, 666, 333, 0), fp16 latents (fp32 latents are never worse):
-#   measured e_t (CFG-combined eps)   1.01e-2  7.2e-3  6.8e-3  6.7e-3      (single forward: 1.66e-3; CFG 7.5 amplifies 4-6x)
-#   measured x_prev, teacher-forced   3.70e-3  4.3e-4  3.2e-4  2.1e-4
-#   measured pred_x0, teacher-forced  4.45e-3  5.4e-4  3.2e-4  3.0e-4
-#   measured free-running x_prev / pred_x0: 3.7e-3 / 4.4e-3 at step 0, then 3.7e-3 (the step-0 error carried along)
-# The north-star 1e-3 holds for every step but the first, whose update x_prev = 2.8 x - 1.9 e_t (alpha 0.005 -> 0.18)
-# multiplies the eps error; DESIGN.md section 5 shows why fp16 matrix-core operands cannot reach 1e-3 there.
-CFG1_TOL = {
-    "teacher_e_t": [2.0e-2, 1.45e-2, 1.4e-2, 1.35e-2],
-    "teacher_x_prev": [7.4e-3, 8.6e-4, 6.4e-4, 4.2e-4],
-    "teacher_pred_x0": [8.9e-3, 1.0e-3, 6.5e-4, 6.0e-4],
-    "free_x_prev": [7.4e-3] * 4, "free_pred_x0": [8.9e-3, 7.4e-3, 7.4e-3, 7.4e-3],
-}
+# Measured on MI355X (round 4, profiles/r4_measured_parity.jsonl -> DESIGN.md section 5); asserted at <= 1.25x measured.
+# Per DDIM step of the 4-step schedule (t = 999, 666, 333, 0), residual modes fast / "outer" (default) / strict:
+#   measured e_t (CFG-combined eps), step 0     1.00e-2 / 7.4e-3 / 5.6e-3     (single forward: 1.67e-3 / 1.23e-3 / 9.1e-4; CFG 7.5 amplifies 4-6x)
+#   measured x_prev, teacher-forced, steps 0-3  3.68e-3, 3.1e-4, 1.3e-4, 0 / 2.72e-3, 1.7e-4, 5e-5, 0 / 2.05e-3, 1.4e-4, 5e-5, 0
+#   measured pred_x0, teacher-forced            4.43e-3, 4.6e-4, 1.3e-4, 4e-6 / 3.27e-3, 2.5e-4, 6e-5, 2e-6 / 2.47e-3, 2.1e-4, 5e-5, 2e-6
+#   free-running: the step-0 error carried along (x_prev 3.7e-3 / 2.7e-3 / 2.0e-3 after every step)
+# NAMED WAIVER (CFG1_FIRST_STEP): the north-star 1e-3 holds for every step but the first, whose update x_prev = 2.8 x - 1.9 e_t
+# (alpha 0.005 -> 0.18) multiplies the guided-eps error; with fp16 matrix-core operands no residual mode reaches 1e-3 there
+#  -- the first step is asserted at 1.25x its measured value per mode, every later step at 1e-3.
+CFG1_FIRST_STEP = {"float16": dict(e_t=1.25e-2, x_prev=4.6e-3, pred_x0=5.6e-3), "outer": dict(e_t=9.3e-3, x_prev=3.4e-3, pred_x0=4.1e-3),
+                   "float32": dict(e_t=7.0e-3, x_prev=2.6e-3, pred_x0=3.1e-3)}
+CFG1_E_T_LATER = {"float16": 9.0e-3, "outer": 4.9e-3, "float32": 4.1e-3}      # guided e_t of steps 1-3 (reported quantity; 1.25x measured)
 NORTH_STAR = 1e-3
 
 
@@ -125,10 +123,12 @@ def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype, residual)
                  x_prev=relerr(xp, T(z[f"x_prev_{i}"])), pred_x0=relerr(x0, T(z[f"pred_x0_{i}"])))
         print(r)
         record(**r)
-        assert r["e_t"] < CFG1_TOL["teacher_e_t"][i] and r["x_prev"] < CFG1_TOL["teacher_x_prev"][i] \
-            and r["pred_x0"] < CFG1_TOL["teacher_pred_x0"][i], r
-        if i > 0:       # the north-star tolerance itself, on x_prev AND pred_x0, for every step after the first
-            assert r["x_prev"] < NORTH_STAR and r["pred_x0"] < NORTH_STAR, r
+        fp16_lat = 1.0 if latent_dtype == torch.float32 else 1.1       # fp16 latents add the stored tile's own rounding
+        if i == 0:      # CFG1_FIRST_STEP waiver
+            w = CFG1_FIRST_STEP[residual]
+            assert r["e_t"] < w["e_t"] and r["x_prev"] < w["x_prev"] * fp16_lat and r["pred_x0"] < w["pred_x0"] * fp16_lat, r
+        else:           # the north-star tolerance itself, on x_prev AND pred_x0, for every step after the first
+            assert r["e_t"] < CFG1_E_T_LATER[residual] and r["x_prev"] < NORTH_STAR and r["pred_x0"] < NORTH_STAR, r
     # ---- free-running: the pipeline's own loop from the same init latent ----
     lat = T(z["x_init"]).to(d, latent_dtype)
     for i, t in enumerate(timesteps):
@@ -137,12 +137,14 @@ def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype, residual)
                  pred_x0=relerr(den, T(z[f"pred_x0_{i}"])))
         print(r)
         record(**r)
-        assert r["x_prev"] < CFG1_TOL["free_x_prev"][i] and r["pred_x0"] < CFG1_TOL["free_pred_x0"][i], r
+        w = CFG1_FIRST_STEP[residual]          # free-running: the first step's error is carried along (same waiver)
+        assert r["x_prev"] < w["x_prev"] * fp16_lat and r["pred_x0"] < w["pred_x0"] * fp16_lat, r
     # basic_sample itself (the drop-in entry point) returns the same thing bit for bit
     _, den2 = pipe.basic_sample(prompt="a prompt", height=320, width=512, frames=16, fps=int(z["fps"]), guidance_scale=g,
                                 num_inference_steps=4, output_type="latent", latents=T(z["x_init"]))
+    _set_mode(ld.model.diffusion_model, "float16")
     assert torch.equal(den2, den)
-    assert relerr(den2, T(z["denoised"])) < CFG1_TOL["free_pred_x0"][3]
+    assert relerr(den2, T(z["denoised"])) < CFG1_FIRST_STEP[residual]["pred_x0"] * fp16_lat
 
 
 def test_error_budget_layerwise_full_size():
@@ -402,7 +404,9 @@ def test_concurrent_graph_replays_repeatable(size):
             assert not bad, f"{size}: round {r}, slot {slot}: first diverging kernel {bad[0]} ({len(bad)} of {len(kept)} outputs)"
 
 
-RING_REAL_TOL = {"float16": 7.5e-3, "outer": 5.5e-3, "float32": 4.2e-3}     # <= 2x measured on MI355X (round 3): 3.76e-3 / 2.77e-3 / 2.10e-3
+# 4-step schedule: its first update carries the CFG1_FIRST_STEP waiver (the same 999 -> 666 update); <= 1.25x measured on MI355X
+# (rounds 3-4: 3.76e-3 / 2.76e-3 / 2.09e-3).  The 50-step schedule the metric runs is asserted at 1e-3 further down.
+RING_REAL_TOL = {"float16": 4.7e-3, "outer": 3.45e-3, "float32": 2.6e-3}
 
 
 @pytest.mark.parametrize("residual", ["float16", "outer", "float32"])
@@ -475,7 +479,7 @@ def test_full_size_panorama_independent_of_the_execution_mode():
         assert torch.equal(den, ref), (name, relerr(den, ref))
 
 
-I2V_RING_REAL_TOL = {"float16": 6.9e-3, "float32": 3.8e-3}        # <= 2x measured on MI355X (round 3): 3.46e-3 / 1.92e-3
+I2V_RING_REAL_TOL = {"float16": 4.3e-3, "float32": 2.4e-3}        # 4-step schedule (CFG1_FIRST_STEP waiver); <= 1.25x measured: 3.46e-3 / 1.93e-3
 
 
 @pytest.mark.parametrize("residual", ["float16", "float32"])

@@ -15,7 +15,8 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 # measured on MI355X in round 2 (gpurun_out/s2/gputest_verbose.log; DESIGN.md section 5 has the table and the error
 # budget that explains the numbers).  BASELINE.json's north_star asks for 1e-3 rel on fp16 LATENTS.
 EPS_TOL_TINY = 4.4e-3   # toy UNet eps, measured 2.0e-3 .. 2.2e-3
-EPS_TOL = 3.5e-3        # full-size t2v / i2v UNet eps, measured 1.66e-3 / 1.70e-3 / 1.72e-3
+EPS_TOL = 2.2e-3        # full-size t2v / i2v UNet eps: measured 1.67e-3 / 1.70e-3 / 1.72e-3 in the fast mode, 1.23e-3 / 1.25e-3 in the default
+                        # ("outer") mode (<= 1.3x the fast mode's; the latent tolerance of the north star is asserted on x_prev)
 LATENT_TOL = 7.2e-4     # x_prev after CFG 7.5 + one DDIM update of the 50-step schedule (index 25), measured 3.6e-4
 PRED_X0_TOL = 8e-3      # pred_x0 of the same update, measured 3.9e-3: (x - sqrt(1-a) e_t)/sqrt(a) amplifies the CFG-combined
                         # eps error by sqrt((1-a)/a); see DESIGN.md section 5 for why 1e-3 is out of reach of fp16 operands

@@ -5,10 +5,10 @@
 S=${1:-prof}; RP=${2:-r3}; R=$PWD; O=$R/gpurun_out/$S; mkdir -p $O
 export PYTHONUNBUFFERED=1
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_s1 -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline --full-panorama 0 > $O/prof_s1.log 2>&1; echo "stats 1 stream rc=$?" | tee -a $O/summary.txt
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_s2 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --full-panorama 0 > $O/prof_s2.log 2>&1; echo "stats 2 streams rc=$?" | tee -a $O/summary.txt
-timeout 1200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/stepF -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --full-panorama 0 --streams 1 --graph 0 > $O/stepF.log 2>&1; echo "stepF rc=$?" | tee -a $O/summary.txt
-timeout 1200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/stepW -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --full-panorama 0 --streams 1 --graph 0 > $O/stepW.log 2>&1; echo "stepW rc=$?" | tee -a $O/summary.txt
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_s1 -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline --full-panorama 0 --other-mode 0 > $O/prof_s1.log 2>&1; echo "stats 1 stream rc=$?" | tee -a $O/summary.txt
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_s2 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --full-panorama 0 --other-mode 0 > $O/prof_s2.log 2>&1; echo "stats 2 streams rc=$?" | tee -a $O/summary.txt
+timeout 1200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/stepF -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --full-panorama 0 --other-mode 0 --streams 1 --graph 0 > $O/stepF.log 2>&1; echo "stepF rc=$?" | tee -a $O/summary.txt
+timeout 1200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/stepW -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --full-panorama 0 --other-mode 0 --streams 1 --graph 0 > $O/stepW.log 2>&1; echo "stepW rc=$?" | tee -a $O/summary.txt
 cd $R
 for c in s1 s2; do f=$(find $O/prof_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$c.csv; find $O/prof_$c -name "*kernel_trace.csv" -delete; done
 python3 tools/rocprof_step_summary.py $O/kernel_stats_s1.csv 4 $O/${RP}_rocprof_step_summary_cfg3_1stream.json > /dev/null 2>&1; echo "summary s1 rc=$?" | tee -a $O/summary.txt

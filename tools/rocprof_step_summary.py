@@ -38,5 +38,6 @@ out["norms_and_concat_share"] = sum(fm.get(k, {}).get("share", 0.0) for k in ("g
 import hashlib, os
 _src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynamicscaler_amd", "csrc", "gemm.hip")
 out["gemm_hip_sha256"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()
+out["residual_mode"] = os.environ.get("DS_RESIDUAL_DTYPE", "f32outer")       # the library's default unless the profiled run set it
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
