@@ -38,7 +38,7 @@ VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"], "attnplain": ["-DDS_ATTN_N
             # tuning variants of the 16x16x32 K loop (A/B: tools/gpu_ab.sh): where the LDS-DMA pieces go, how far ahead fragments are read
             # one tile per workgroup, strips over stage 0 (round 3's structure) instead of the persistent big tiles
             "nopersist": ["-DDS_PERSIST=0"],
-            "setprio": ["-DDS_SETPRIO_HI=1"],
+            "setprio": ["-DDS_SETPRIO_HI=1"], "nt32": ["-DDS_EXP_NT=11"],
             # with ds_gemm_f16_stats (GroupNorm statistics from the producer's epilogue: opt-in feature, profiles/r4_notes.md section 3)
             "gemmstats": ["-DDS_GEMM_STATS=1", "-DDS_PERSIST=0"],   # (with the persistent tile loop one of its kernels spills)
             "m16p1": ["-DDS_M16_PSPAN4=1"], "m16p3": ["-DDS_M16_PSPAN4=3"], "m16p4": ["-DDS_M16_PSPAN4=4"], "m16a3": ["-DDS_M16_AHEAD=3"], "m16a1": ["-DDS_M16_AHEAD=1"]}

@@ -1139,8 +1139,13 @@ gemm_f16_kernel(GemmArgs) {
                                 if (ok[u]) {
                                     if (out_f32) {
                                         float* o32 = reinterpret_cast<float*>(out) + (long)(mrow0 + r0) * d.ldc + ocol + (sb + u) * out_step;
+#if DS_EXP_NT & 8       // A/B (variant "nt32"): the fp32 residual stream's stores non-temporal as well
+                                        DS_STORE_NT(reinterpret_cast<f32x4*>(o32), (f32x4{v[0], v[1], v[2], v[3]}));
+                                        DS_STORE_NT(reinterpret_cast<f32x4*>(o32 + 4), (f32x4{v[4], v[5], v[6], v[7]}));
+#else
                                         *reinterpret_cast<f32x4*>(o32) = f32x4{v[0], v[1], v[2], v[3]};
                                         *reinterpret_cast<f32x4*>(o32 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+#endif
                                     } else {
                                         DS_OUT_STORE_F(reinterpret_cast<f16x8*>(out_base + (sb + u) * out_step), o);
                                     }

@@ -17,7 +17,7 @@ O,A,B=sys.argv[1:4]
 def load(v):
     d={}
     for r in csv.DictReader(open(f"{O}/kernel_stats_{v}.csv")):
-        n=r["Name"]; n=re.sub(r"^_ZN12_GLOBAL__N_1\d+","",n)[:60]
+        n=r["Name"]; n=re.sub(r"^_ZN12_GLOBAL__N_1\d+","",n); n=re.sub(r"^void \(anonymous namespace\)::","",n); n=re.sub(r"\(.*$","",n)[:70]
         d[n]=(int(r["Calls"]), float(r["TotalDurationNs"])/4e6)
     return d
 a,b=load(A),load(B)
