@@ -8,6 +8,8 @@
 // so the apply can later be folded into the consumer GEMM's A-operand gather.
 // References: GroupNormSpecific lvdm/basics.py:76-86; nn.GroupNorm(32, C, eps=1e-6) attention.py:238,297;
 // nn.GroupNorm(32, C) in TemporalConvBlock openaimodel3d.py:275-292; nn.LayerNorm attention.py:199-201.
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -21,7 +23,13 @@ constexpr int MAX_C = 4096;
 constexpr int GN_CHUNK_ROWS_MAX = 256;
 constexpr int GN_CHUNK_ROWS_MIN = 64;
 static inline int gn_chunk_rows(int rows_per_inst, int C) {
-    static const int rule = getenv("DS_GN_CHUNK_RULE") ? atoi(getenv("DS_GN_CHUNK_RULE")) : 1;   // diagnostic: 0 = 256 rows everywhere (rounds 1-2), 2 = 256 / 256 / 128
+    // diagnostic: 0 = 256 rows everywhere (rounds 1-2), 2 = 256 / 256 / 128.  It CHANGES the summation order, i.e. the bits: said once on
+    // stderr when set, so that a stray value on one rank does not go unnoticed (that rank's replica would differ in the last bits)
+    static const int rule = [] {
+        const char* e = getenv("DS_GN_CHUNK_RULE");
+        if (e) fprintf(stderr, "[dynscaler_hip] DS_GN_CHUNK_RULE=%s: GroupNorm partial sums are chunked differently from the default (results differ in the last bits)\n", e);
+        return e ? atoi(e) : 1;
+    }();
     if (rule == 0) return GN_CHUNK_ROWS_MAX;
     const int by_c = rule == 2 ? (C <= 640 ? 256 : 128) : (C <= 320 ? 256 : (C <= 640 ? 128 : 64));
     int by_rows = GN_CHUNK_ROWS_MIN;

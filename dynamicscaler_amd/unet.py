@@ -128,6 +128,11 @@ class UNetModel(nn.Module):
         self._tap = None                     # optional callable(name, rows [M,C] fp16, (B,T,H,W)) after every block (tests)
         self._generation = 0                 # bumped by every prepare(): identifies the packed buffers (hipGraph cache keys)
         self._prepare_lock = threading.Lock()
+        # a repack (mode change, .to(), load_state_dict) may run while forwards on other host threads are still inside
+        # ds_unet_forward with the previous handle: a handle is destroyed only when no call uses it any more
+        self._handle_lock = threading.Lock()
+        self._handle_uses = {}          # handle value -> calls in flight
+        self._handle_retired = {}       # handle value -> handle, replaced while in use
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, *a, **k):
@@ -206,9 +211,36 @@ class UNetModel(nn.Module):
         return c
 
     def _release_handle(self):
-        h, self._handle = getattr(self, "_handle", None), None
-        if h:
-            _lib.load().ds_unet_destroy(h)
+        lock = getattr(self, "_handle_lock", None)
+        if lock is None:                       # __del__ of a half-constructed module
+            return
+        with lock:
+            h, self._handle = getattr(self, "_handle", None), None
+            if not h:
+                return
+            if self._handle_uses.get(h.value, 0) > 0:
+                self._handle_retired[h.value] = h      # destroyed by the last call that still uses it
+                return
+        _lib.load().ds_unet_destroy(h)
+
+    def _use_handle(self):
+        """The current C handle, marked in use (pair with _done_with_handle)."""
+        with self._handle_lock:
+            h = self._handle
+            if h:
+                self._handle_uses[h.value] = self._handle_uses.get(h.value, 0) + 1
+            return h
+
+    def _done_with_handle(self, h):
+        with self._handle_lock:
+            n = self._handle_uses.get(h.value, 0) - 1
+            if n > 0:
+                self._handle_uses[h.value] = n
+                return
+            self._handle_uses.pop(h.value, None)
+            dead = self._handle_retired.pop(h.value, None)
+        if dead is not None:
+            _lib.load().ds_unet_destroy(dead)
 
     def __del__(self):
         try:
@@ -598,17 +630,23 @@ class UNetModel(nn.Module):
             context = context.float()
         context = context.contiguous()
         L = context.shape[1]
-        key = (B, T, H, W, L, pairs)
-        nbytes = self._ws_bytes.get(key)
-        if nbytes is None:
-            nbytes = self._ws_bytes[key] = lib.ds_unet_workspace_bytes(self._handle, B, T, H, W, L, pairs)
-            if nbytes == 0:
-                _lib.check(-1, "ds_unet_workspace_bytes")
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        eps = torch.empty((B, self.cfg["out_channels"], T, H, W), dtype=torch.float32, device=dev)
-        _lib.check(lib.ds_unet_forward(self._handle, x.data_ptr(), ops._DT[x.dtype], timesteps.data_ptr(), context.data_ptr(),
-                                       ops._DT[context.dtype], L, int(fps), B, T, H, W, pairs, ws.data_ptr(), nbytes, eps.data_ptr(),
-                                       torch.cuda.current_stream(dev).cuda_stream), "ds_unet_forward")
+        h = self._use_handle()                # stays valid for this call even if another thread repacks meanwhile
+        if not h:
+            raise RuntimeError("UNetModel: no prepared C handle (prepare() has not run)")
+        try:
+            key = (h.value, B, T, H, W, L, pairs)
+            nbytes = self._ws_bytes.get(key)
+            if nbytes is None:
+                nbytes = self._ws_bytes[key] = lib.ds_unet_workspace_bytes(h, B, T, H, W, L, pairs)
+                if nbytes == 0:
+                    _lib.check(-1, "ds_unet_workspace_bytes")
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            eps = torch.empty((B, self.cfg["out_channels"], T, H, W), dtype=torch.float32, device=dev)
+            _lib.check(lib.ds_unet_forward(h, x.data_ptr(), ops._DT[x.dtype], timesteps.data_ptr(), context.data_ptr(),
+                                           ops._DT[context.dtype], L, int(fps), B, T, H, W, pairs, ws.data_ptr(), nbytes, eps.data_ptr(),
+                                           torch.cuda.current_stream(dev).cuda_stream), "ds_unet_forward")
+        finally:
+            self._done_with_handle(h)
         return eps
 
     def python_program_trace(self, B, T, H, W, ctx_tokens, cfg_pairs=0):
