@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # A/B of build variants against the product library on one box: alternating short cfg3 bench runs, then one run each with
 # the per-shape breakdown.   usage: tools/gpu_ab.sh <tag> <variant> [<variant> ...]
 S=$1; shift; R=$PWD; O=$R/gpurun_out/$S; mkdir -p $O

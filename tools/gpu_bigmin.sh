@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # rank-share step against the workgroup count from which choose_tile takes the one-workgroup-per-CU tiles (bit-neutral)
 O=gpurun_out/${1:-bigmin}; mkdir -p $O
 export PYTHONUNBUFFERED=1

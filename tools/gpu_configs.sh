@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # the other BASELINE.json configurations on the final build
 O=gpurun_out/${1:-configs}; mkdir -p $O
 export PYTHONUNBUFFERED=1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # batched crop embedding of the i2v pipelines: encoder + i2v pipeline tests, then cfg4 with the default warmup and at steady state
 O=gpurun_out/${1:-crops}; mkdir -p $O
 export PYTHONUNBUFFERED=1

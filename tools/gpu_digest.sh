@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 O=gpurun_out/digest; mkdir -p $O
 export PYTHONUNBUFFERED=1
 timeout 1500 python -m pytest tests/test_gpu_multirank.py -q -x -k "bench_self_launch" 2>&1 | tail -5 | tee $O/tests.txt

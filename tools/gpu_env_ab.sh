@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # A/B of an environment switch on one box: alternating short cfg3 bench runs.   usage: tools/gpu_env_ab.sh <tag> <VAR> <value> [<value> ...]
 S=$1; VAR=$2; shift 2; R=$PWD; O=$R/gpurun_out/$S; mkdir -p $O
 export PYTHONUNBUFFERED=1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # A/B of the GroupNorm chunk rule on one box: default step (tile batch 8, two streams) and the 8-GPU rank share
 O=gpurun_out/${1:-gnrule}; mkdir -p $O
 export PYTHONUNBUFFERED=1

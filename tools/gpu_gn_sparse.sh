@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # GroupNorm at an 8-GPU rank's batch sizes: rows in flight per thread chosen by grid size (bit-neutral).  Micro-bench A/B
 # (DS_GN_SPARSE_WGS=0 = the dense-grid variant everywhere), the invariance tests, the rank-share step, the default step.
 O=gpurun_out/${1:-gnsparse}; mkdir -p $O

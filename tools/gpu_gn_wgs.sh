@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # default step against the launch size up to which GroupNorm keeps 16 rows in flight per thread (bit-neutral)
 O=gpurun_out/${1:-gnwgs}; mkdir -p $O
 export PYTHONUNBUFFERED=1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # rocprofv3 kernel stats of short one-stream cfg3 runs under two values of an environment switch: per-kernel ms per step side by side.
 # usage: tools/gpu_prof_ab.sh <tag> <VAR> <value A> <value B>
 S=$1; VAR=$2; A=$3; B=$4; R=$PWD; O=$R/gpurun_out/$S; mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # rocprofv3 kernel stats of an 8-GPU rank's share of cfg3 emulated on one GPU (col2 = two columns = twice the share; one
 # tile per batch, one stream): sum of kernel time against the wall time of the step -> what part of the share is launch gaps
 S=${1:-rankshare}; R=$PWD; O=$R/gpurun_out/$S; mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # Round profile set on the final build: rocprofv3 kernel stats (1 stream = per-launch durations comparable with bench.py's HIP-event
 # figure; default 2 streams), per-family step summaries, whole-step HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes), and the
 # SQ / LDS counter table of the top shapes.  Usage: tools/gpu_profiles.sh <tag> <round-prefix, e.g. r3>

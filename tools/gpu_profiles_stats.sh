@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # the kernel-stats half of gpu_profiles.sh (after a change that does not touch csrc/gemm.hip: the PMC passes stay valid)
 S=${1:-profstats}; RP=${2:-r3}; R=$PWD; O=$R/gpurun_out/$S; mkdir -p $O
 export PYTHONUNBUFFERED=1

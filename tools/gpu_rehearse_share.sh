@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # the 8-GPU layout of cfg3 in small: col2 (two columns) on two ranks = one column per rank, one tile per level and rank (cond / uncond
 # on two streams, components mode, one all-gather per step), both ranks on this GPU through gloo; digest against the one-process run
 O=gpurun_out/${1:-rehearse}; mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # a rank's share of an 8-GPU cfg3 step (one tile per level) emulated on one GPU with two columns (twice the work):
 # one [cond | uncond] batch on one stream against cond / uncond on two streams
 O=gpurun_out/split; mkdir -p $O

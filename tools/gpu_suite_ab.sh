@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # the whole GPU suite (all failures listed), then bench alternating the C and the Python launch program
 O=gpurun_out/${1:-suite}; mkdir -p $O
 timeout 3000 python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; echo "gpu suite rc=$?" | tee -a $O/summary.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # ms per cfg3 step over --streams x --tile-batch (default residual mode), two runs each.   usage: tools/gpu_sweep_streams.sh <tag>
 S=$1; R=$PWD; O=$R/gpurun_out/$S; mkdir -p $O
 export PYTHONUNBUFFERED=1

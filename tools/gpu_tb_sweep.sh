@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # what a rank of an N-GPU run would execute per level, measured on one GPU: cfg3 step time as a function of the tile batch
 # (tiles per evaluation batch) and the number of streams -- the basis of the predicted strong-scaling curve (notes section 5)
 O=gpurun_out/tbsweep; mkdir -p $O
