@@ -39,6 +39,8 @@ VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"], "attnplain": ["-DDS_ATTN_N
             # one tile per workgroup, strips over stage 0 (round 3's structure) instead of the persistent big tiles
             "nopersist": ["-DDS_PERSIST=0"],
             "setprio": ["-DDS_SETPRIO_HI=1"], "nt32": ["-DDS_EXP_NT=11"],
+            # fp32 rows: 8 consecutive channels / columns per thread (round 3) instead of two groups of 4 contiguous across the wave
+            "now4": ["-DDS_EXP_NO_W4=1"],
             # with ds_gemm_f16_stats (GroupNorm statistics from the producer's epilogue: opt-in feature, profiles/r4_notes.md section 3)
             "gemmstats": ["-DDS_GEMM_STATS=1", "-DDS_PERSIST=0"],   # (with the persistent tile loop one of its kernels spills)
             "m16p1": ["-DDS_M16_PSPAN4=1"], "m16p3": ["-DDS_M16_PSPAN4=3"], "m16p4": ["-DDS_M16_PSPAN4=4"], "m16a3": ["-DDS_M16_AHEAD=3"], "m16a1": ["-DDS_M16_AHEAD=1"]}

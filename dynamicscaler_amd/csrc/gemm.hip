@@ -1031,18 +1031,32 @@ gemm_f16_kernel(GemmArgs) {
             const int ch = lane % cpr, r0 = lane / cpr;
             const bool lane_on = lane < rps * cpr;
             // column of this lane's chunk: in the N space (bias, bounds) and in the output
+            // W4 (fp32 residual rows, DS_EPI_RES_F32): a lane's 8 values are TWO groups of 4 columns, cpr * 4 columns apart (group A at
+            // 4 ch, group B at 4 (ch + cpr)), so that each of its 16-byte fp32 accesses -- residual loads, fp32 stores -- is contiguous
+            // across the wave; 8 consecutive fp32 columns per lane made every access instruction touch twice the lines it used.
+#ifdef DS_EXP_NO_W4        // A/B (variant "now4")
+            constexpr bool W4 = false;
+#else
+            constexpr bool W4 = RES32 && !DS_GEMM_STATS;
+#endif
+            const int dB = W4 ? cpr * 4 : 4;                    // group B = group A + dB columns (strip, bias, residual, output alike)
             const int ncol = GE ? n0 + wn * WN + 2 * (c0 * 32 + ch * 8 - (ch * 8) % 32) + (ch * 8) % 32
-                                : n0 + wn * WN + c0 * 32 + ch * 8;
+                                : n0 + wn * WN + c0 * 32 + ch * (W4 ? 4 : 8);
             const long ocol = GE ? (long)tile_n * (BN / 2) + wn * (WN / 2) + c0 * 32 + ch * 8 : (long)ncol;
             const bool col_on = lane_on && (GE ? ncol + 32 < d.N : ncol < d.N);
+            const bool col_onB = W4 ? (lane_on && ncol + dB < d.N) : col_on;
             float bx[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) bx[j] = 0.0f;
-            if (!GE && shared_bias && fast && col_on && !bias_done) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + ncol);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + ncol + 4);
-                bx[0] = b0[0]; bx[1] = b0[1]; bx[2] = b0[2]; bx[3] = b0[3];
-                bx[4] = b1[0]; bx[5] = b1[1]; bx[6] = b1[2]; bx[7] = b1[3];
+            if (!GE && shared_bias && fast && !bias_done) {
+                if (col_on) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + ncol);
+                    bx[0] = b0[0]; bx[1] = b0[1]; bx[2] = b0[2]; bx[3] = b0[3];
+                }
+                if (col_onB) {
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + ncol + dB);
+                    bx[4] = b1[0]; bx[5] = b1[1]; bx[6] = b1[2]; bx[7] = b1[3];
+                }
             }
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
@@ -1076,15 +1090,16 @@ gemm_f16_kernel(GemmArgs) {
                             f16x8 res[SB];
                             f32x4 rs0[SB], rs1[SB];
                             f32x4 pb0[SB], pb1[SB], p0[SB], p1[SB];
-                            bool ok[SB];
+                            bool ok[SB], okb[SB];
 #pragma unroll
                             for (int u = 0; u < SB; ++u) {
                                 const int row = (sb + u) * rps + r0;
                                 ok[u] = col_on && row < 32 && mrow0 + row < d.M;
+                                okb[u] = col_onB && row < 32 && mrow0 + row < d.M;
                                 if constexpr (RES32) {
-                                    const float* rp = ok[u] ? res32_base + (sb + u) * res_step : reinterpret_cast<const float*>(residual);
-                                    rs0[u] = DS_RES_LOAD(reinterpret_cast<const f32x4*>(rp));
-                                    rs1[u] = DS_RES_LOAD(reinterpret_cast<const f32x4*>(rp + 4));
+                                    const float* rp = res32_base + (sb + u) * res_step;
+                                    rs0[u] = DS_RES_LOAD(reinterpret_cast<const f32x4*>(ok[u] ? rp : reinterpret_cast<const float*>(residual)));
+                                    rs1[u] = DS_RES_LOAD(reinterpret_cast<const f32x4*>(okb[u] ? rp + dB : reinterpret_cast<const float*>(residual)));
                                 } else if constexpr (RES) {
                                     res[u] = DS_RES_LOAD(reinterpret_cast<const f16x8*>(ok[u] ? res_base + (sb + u) * res_step : residual));
                                 }
@@ -1098,8 +1113,8 @@ gemm_f16_kernel(GemmArgs) {
 #pragma unroll
                             for (int u = 0; u < SB; ++u) {
                                 const int row = min((sb + u) * rps + r0, 31);
-                                p0[u] = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * 8);
-                                p1[u] = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * 8 + 4);
+                                p0[u] = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * (W4 ? 4 : 8));
+                                p1[u] = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * (W4 ? 4 : 8) + dB);
                             }
 #pragma unroll
                             for (int u = 0; u < SB; ++u) {
@@ -1136,16 +1151,20 @@ gemm_f16_kernel(GemmArgs) {
 #ifdef DS_EXP_NOSTORE   // diagnostic builds only (tools/build_stamps.sh)
                                 asm volatile("" ::"v"(o));
 #else
-                                if (ok[u]) {
+                                if (ok[u] || okb[u]) {
                                     if (out_f32) {
                                         float* o32 = reinterpret_cast<float*>(out) + (long)(mrow0 + r0) * d.ldc + ocol + (sb + u) * out_step;
 #if DS_EXP_NT & 8       // A/B (variant "nt32"): the fp32 residual stream's stores non-temporal as well
-                                        DS_STORE_NT(reinterpret_cast<f32x4*>(o32), (f32x4{v[0], v[1], v[2], v[3]}));
-                                        DS_STORE_NT(reinterpret_cast<f32x4*>(o32 + 4), (f32x4{v[4], v[5], v[6], v[7]}));
+                                        if (ok[u]) DS_STORE_NT(reinterpret_cast<f32x4*>(o32), (f32x4{v[0], v[1], v[2], v[3]}));
+                                        if (okb[u]) DS_STORE_NT(reinterpret_cast<f32x4*>(o32 + dB), (f32x4{v[4], v[5], v[6], v[7]}));
 #else
-                                        *reinterpret_cast<f32x4*>(o32) = f32x4{v[0], v[1], v[2], v[3]};
-                                        *reinterpret_cast<f32x4*>(o32 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                                        if (ok[u]) *reinterpret_cast<f32x4*>(o32) = f32x4{v[0], v[1], v[2], v[3]};
+                                        if (okb[u]) *reinterpret_cast<f32x4*>(o32 + dB) = f32x4{v[4], v[5], v[6], v[7]};
 #endif
+                                    } else if constexpr (W4) {
+                                        f16* const o16 = out_base + (sb + u) * out_step;
+                                        if (ok[u]) DS_OUT_STORE_F(reinterpret_cast<f16x4*>(o16), (f16x4{o[0], o[1], o[2], o[3]}));
+                                        if (okb[u]) DS_OUT_STORE_F(reinterpret_cast<f16x4*>(o16 + dB), (f16x4{o[4], o[5], o[6], o[7]}));
                                     } else {
                                         DS_OUT_STORE_F(reinterpret_cast<f16x8*>(out_base + (sb + u) * out_step), o);
                                     }

@@ -47,8 +47,16 @@ __device__ __forceinline__ float fast_silu(float v) { return v * __builtin_amdgc
 // keeps the UNet's residual stream in fp32, unet.py `residual_dtype`; the norms read it and write the fp16 GEMM operand).
 struct f32x8 { f32x4 lo, hi; };
 template <typename XT> struct Row8;
+// GroupNorm kernels address a thread's 8 channels through chan() / row_load(): for fp16 rows they are 8 consecutive channels (one
+// 16-byte access, consecutive threads 16 bytes apart); for fp32 rows two groups of 4, nvec * 4 channels apart (thread `col` owns
+// channels 4 col .. 4 col + 3 and 4 (col + nvec) ..): each of its two 16-byte loads is then contiguous across the wave, where 8
+// consecutive fp32 channels per thread made every load instruction touch twice the cache lines it used.
 template <> struct Row8<f16> {
     typedef f16x8 raw;
+    static __device__ __forceinline__ int chan(int col, int j, int) { return col * 8 + j; }
+    static __device__ __forceinline__ raw row_load(const f16* row, int col, int) { return *reinterpret_cast<const f16x8*>(row + col * 8); }
+    static __device__ __forceinline__ raw row_load_stream(const f16* row, int col, int) { return DS_SLOAD(reinterpret_cast<const f16x8*>(row + col * 8)); }
+    static __device__ __forceinline__ void row_store(f16* row, int col, int, const f16x8& o) { DS_SSTORE(reinterpret_cast<f16x8*>(row + col * 8), o); }
     static __device__ __forceinline__ raw load(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
     static __device__ __forceinline__ raw load_stream(const f16* p) { return DS_SLOAD(reinterpret_cast<const f16x8*>(p)); }
     static __device__ __forceinline__ float get(const raw& v, int j) { return (float)v[j]; }
@@ -56,6 +64,24 @@ template <> struct Row8<f16> {
 };
 template <> struct Row8<float> {
     typedef f32x8 raw;
+#ifdef DS_EXP_NO_W4        // A/B (variant "now4"): 8 consecutive fp32 channels per thread, round 3's form
+    static __device__ __forceinline__ int chan(int col, int j, int) { return col * 8 + j; }
+    static __device__ __forceinline__ raw row_load(const float* row, int col, int) { return load(row + col * 8); }
+    static __device__ __forceinline__ raw row_load_stream(const float* row, int col, int) { return load_stream(row + col * 8); }
+    static __device__ __forceinline__ void row_store(f16* row, int col, int, const f16x8& o) { DS_SSTORE(reinterpret_cast<f16x8*>(row + col * 8), o); }
+#else
+    static __device__ __forceinline__ int chan(int col, int j, int nvec) { return (j < 4 ? col : col + nvec) * 4 + (j & 3); }
+    static __device__ __forceinline__ raw row_load(const float* row, int col, int nvec) {
+        return f32x8{*reinterpret_cast<const f32x4*>(row + col * 4), *reinterpret_cast<const f32x4*>(row + (col + nvec) * 4)};
+    }
+    static __device__ __forceinline__ raw row_load_stream(const float* row, int col, int nvec) {
+        return f32x8{DS_SLOAD(reinterpret_cast<const f32x4*>(row + col * 4)), DS_SLOAD(reinterpret_cast<const f32x4*>(row + (col + nvec) * 4))};
+    }
+    static __device__ __forceinline__ void row_store(f16* row, int col, int nvec, const f16x8& o) {      // the fp16 output of an fp32 row
+        DS_SSTORE(reinterpret_cast<f16x4*>(row + col * 4), (f16x4{o[0], o[1], o[2], o[3]}));
+        DS_SSTORE(reinterpret_cast<f16x4*>(row + (col + nvec) * 4), (f16x4{o[4], o[5], o[6], o[7]}));
+    }
+#endif
     static __device__ __forceinline__ raw load(const float* p) {
         return f32x8{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
     }
@@ -87,19 +113,19 @@ gn_partial_kernel(const XT* __restrict__ x, float2* __restrict__ part, int rows_
     const XT* base = x + (long)inst * rows_per_inst * ldx;   // input rows may sit in a wider buffer (row stride ldx >= C)
     const int rl = nvec <= 256 ? 256 / nvec : 1;  // row lanes; rl*C <= 2048 + C when rl > 1
     auto accumulate = [&](int col, int rfirst, int rstep, float* s, float* q) {
-        const XT* p = base + col * 8;
+        const XT* p = base;
         int r = rfirst;
         for (; r + (U - 1) * rstep < r1; r += U * rstep) {
             typename R8::raw v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = R8::load(p + (long)(r + u * rstep) * ldx);
+            for (int u = 0; u < U; ++u) v[u] = R8::row_load(p + (long)(r + u * rstep) * ldx, col, nvec);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = R8::get(v[u], j); s[j] += f; q[j] += f * f; }
         }
         for (; r < r1; r += rstep) {
-            const typename R8::raw v = R8::load(p + (long)r * ldx);
+            const typename R8::raw v = R8::row_load(p + (long)r * ldx, col, nvec);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = R8::get(v, j); s[j] += f; q[j] += f * f; }
         }
@@ -112,7 +138,7 @@ gn_partial_kernel(const XT* __restrict__ x, float2* __restrict__ part, int rows_
             for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
             accumulate(col, r0 + rlane, rl, s, q);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { csum[rlane * C + col * 8 + j] = s[j]; csq[rlane * C + col * 8 + j] = q[j]; }
+            for (int j = 0; j < 8; ++j) { csum[rlane * C + R8::chan(col, j, nvec)] = s[j]; csq[rlane * C + R8::chan(col, j, nvec)] = q[j]; }
         }
     } else {
         for (int col = tid; col < nvec; col += 256) {
@@ -121,7 +147,7 @@ gn_partial_kernel(const XT* __restrict__ x, float2* __restrict__ part, int rows_
             for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
             accumulate(col, r0, 1, s, q);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { csum[col * 8 + j] = s[j]; csq[col * 8 + j] = q[j]; }
+            for (int j = 0; j < 8; ++j) { csum[R8::chan(col, j, nvec)] = s[j]; csq[R8::chan(col, j, nvec)] = q[j]; }
         }
     }
     __syncthreads();
@@ -208,7 +234,7 @@ gn_apply_kernel(const XT* __restrict__ x, const float* __restrict__ mean, const 
         float a[8], b[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = col * 8 + j;
+            const int c = R8::chan(col, j, nvec);
             const int g = c / cpg;
             const float r = part ? srstd[g] : rstd[inst * groups + g], m = part ? smean[g] : mean[inst * groups + g];
             a[j] = r * gamma[c];
@@ -230,25 +256,25 @@ gn_apply_kernel(const XT* __restrict__ x, const float* __restrict__ mean, const 
             for (int j = 0; j < 8; ++j) o[j] = (f16)R8::get(v, j);
             return o;
         };
-        const XT* px = x + xbase + col * 8;
-        f16* py = y + base + col * 8;
-        f16* pr = xraw ? xraw + base + col * 8 : nullptr;
+        const XT* px = x + xbase;
+        f16* py = y + base;
+        f16* pr = xraw ? xraw + base : nullptr;
         int r = r0 + rlane;
         for (; r + (U - 1) * rl < r1; r += U * rl) {
             typename R8::raw v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = R8::load_stream(px + (long)(r + u * rl) * ldx);
+            for (int u = 0; u < U; ++u) v[u] = R8::row_load_stream(px + (long)(r + u * rl) * ldx, col, nvec);
 #pragma unroll
-            for (int u = 0; u < U; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)(r + u * rl) * C), one(v[u]));
+            for (int u = 0; u < U; ++u) R8::row_store(py + (long)(r + u * rl) * C, col, nvec, one(v[u]));
             if (pr) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(pr + (long)(r + u * rl) * C), rawh(v[u]));
+                for (int u = 0; u < U; ++u) R8::row_store(pr + (long)(r + u * rl) * C, col, nvec, rawh(v[u]));
             }
         }
         for (; r < r1; r += rl) {
-            const typename R8::raw v = R8::load_stream(px + (long)r * ldx);
-            DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(v));
-            if (pr) DS_SSTORE(reinterpret_cast<f16x8*>(pr + (long)r * C), rawh(v));
+            const typename R8::raw v = R8::row_load_stream(px + (long)r * ldx, col, nvec);
+            R8::row_store(py + (long)r * C, col, nvec, one(v));
+            if (pr) R8::row_store(pr + (long)r * C, col, nvec, rawh(v));
         }
     }
 }
@@ -281,24 +307,24 @@ gn_small_kernel(const XT* __restrict__ x, const float* __restrict__ gamma, const
         float s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
-        const XT* p = base + col * 8;
+        const XT* p = base;
         int r = rlane;
         for (; r + 3 * rlu < rows_per_inst; r += 4 * rlu) {
             typename R8::raw v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = R8::load(p + (long)(r + u * rlu) * ldx);
+            for (int u = 0; u < 4; ++u) v[u] = R8::row_load(p + (long)(r + u * rlu) * ldx, col, nvec);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = R8::get(v[u], j); s[j] += f; q[j] += f * f; }
         }
         for (; r < rows_per_inst; r += rlu) {
-            const typename R8::raw v = R8::load(p + (long)r * ldx);
+            const typename R8::raw v = R8::row_load(p + (long)r * ldx, col, nvec);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = R8::get(v, j); s[j] += f; q[j] += f * f; }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { csum[rlane * C + col * 8 + j] = s[j]; csq[rlane * C + col * 8 + j] = q[j]; }
+        for (int j = 0; j < 8; ++j) { csum[rlane * C + R8::chan(col, j, nvec)] = s[j]; csq[rlane * C + R8::chan(col, j, nvec)] = q[j]; }
     }
     __syncthreads();
     if (tid < groups) {
@@ -317,7 +343,7 @@ gn_small_kernel(const XT* __restrict__ x, const float* __restrict__ gamma, const
     float a[8], b[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int c = col * 8 + j, g = c / cpg;
+        const int c = R8::chan(col, j, nvec), g = c / cpg;
         a[j] = srstd[g] * gamma[c];
         b[j] = beta[c] - smean[g] * a[j];
     }
@@ -337,25 +363,25 @@ gn_small_kernel(const XT* __restrict__ x, const float* __restrict__ gamma, const
         for (int j = 0; j < 8; ++j) o[j] = (f16)R8::get(v, j);
         return o;
     };
-    const XT* px = base + col * 8;
-    f16* py = ybase + col * 8;
-    f16* pr = xraw ? xraw + (long)inst * rows_per_inst * C + col * 8 : nullptr;
+    const XT* px = base;
+    f16* py = ybase;
+    f16* pr = xraw ? xraw + (long)inst * rows_per_inst * C : nullptr;
     int r = rlane;
     for (; r + 3 * rlu < rows_per_inst; r += 4 * rlu) {
         typename R8::raw v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = R8::load(px + (long)(r + u * rlu) * ldx);
+        for (int u = 0; u < 4; ++u) v[u] = R8::row_load(px + (long)(r + u * rlu) * ldx, col, nvec);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)(r + u * rlu) * C), one(v[u]));
+        for (int u = 0; u < 4; ++u) R8::row_store(py + (long)(r + u * rlu) * C, col, nvec, one(v[u]));
         if (pr) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) DS_SSTORE(reinterpret_cast<f16x8*>(pr + (long)(r + u * rlu) * C), rawh(v[u]));
+            for (int u = 0; u < 4; ++u) R8::row_store(pr + (long)(r + u * rlu) * C, col, nvec, rawh(v[u]));
         }
     }
     for (; r < rows_per_inst; r += rlu) {
-        const typename R8::raw v = R8::load(px + (long)r * ldx);
-        DS_SSTORE(reinterpret_cast<f16x8*>(py + (long)r * C), one(v));
-        if (pr) DS_SSTORE(reinterpret_cast<f16x8*>(pr + (long)r * C), rawh(v));
+        const typename R8::raw v = R8::row_load(px + (long)r * ldx, col, nvec);
+        R8::row_store(py + (long)r * C, col, nvec, one(v));
+        if (pr) R8::row_store(pr + (long)r * C, col, nvec, rawh(v));
     }
 }
 

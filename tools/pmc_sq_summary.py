@@ -9,7 +9,8 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"gemm_f16_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)ELi(\d)E", name)
+    m = re.search(r"gemm_f16_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)ELi(\d)E", name) or \
+        re.search(r"gemm_f16_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\d+)>", name)          # mangled / demangled spelling
     if m:
         return f"gemm<{m.group(1)}x{m.group(2)},mode{m.group(3)},ns{m.group(4)}>"
     for k in ("attention_kernel", "temporal_attention", "gn_apply", "gn_partial", "layernorm"):
@@ -18,14 +19,28 @@ def short(name):
     return None
 
 
+# the GEMM jobs of tools/pmc_shapes.py in launch order, REPS launches each: persistent workgroups give every big launch the same grid,
+# so a shape is identified by its position in the dispatch sequence of the pass
+import ast, os
+_src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_shapes.py")).read()
+JOB_LABELS = ast.literal_eval(re.search(r"JOB_LABELS = (\[.*?\])", _src, flags=re.S).group(1))
+REPS = int(re.search(r"^REPS = (\d+)", _src, flags=re.M).group(1))
+
 acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 dur = defaultdict(lambda: [0, 0.0])
 for path in sys.argv[2:]:
-    for row in csv.DictReader(open(path)):
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Dispatch_Id"]))
+    gemm_ids = sorted({int(r["Dispatch_Id"]) for r in rows if (short(r["Kernel_Name"]) or "").startswith("gemm<")})
+    job_of = {did: i // REPS for i, did in enumerate(gemm_ids)}
+    for row in rows:
         k = short(row["Kernel_Name"])
         if k is None:
             continue
-        key = f"{k} grid={row['Grid_Size']}"
+        if k.startswith("gemm<"):
+            j = job_of[int(row["Dispatch_Id"])]
+            key = f"{k} {JOB_LABELS[j] if j < len(JOB_LABELS) else 'job%d' % j}"
+        else:
+            key = f"{k} grid={row['Grid_Size']}"
         a = acc[key][row["Counter_Name"]]
         a[0] += 1
         a[1] += float(row["Counter_Value"])

@@ -13,11 +13,13 @@ from collections import defaultdict
 
 
 def family(name):
-    m = re.search(r"(gemm_f16_kernel)ILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)E", name)
+    m = re.search(r"(gemm_f16_kernel)ILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)E", name) or \
+        re.search(r"(gemm_f16_kernel)<(\d+), (\d+), \d+, \d+, (\d+), \d+>", name)      # mangled / demangled spelling
     if m:
         return f"gemm_f16_kernel<{m.group(2)},{m.group(3)},mode{m.group(4)}>"
     for k in ("attention_kernel", "temporal_attention_kernel", "gn_apply_kernel", "gn_partial_kernel", "layernorm_kernel",
-              "concat_kernel", "ring_gather_kernel", "ring_scatter3_kernel", "renoise_mix_kernel", "cfg_ddim_kernel"):
+              "concat_kernel", "ring_gather_renoise_kernel", "cfg_ddim_scatter_kernel", "ring_gather_kernel", "ring_scatter3_kernel", "renoise_mix_kernel",
+              "cfg_ddim_kernel"):
         if k in name:
             return k
     return None
