@@ -20,6 +20,11 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
          "-fno-gpu-rdc", "-ffp-contract=on"]
 
 
+# per-source flags.  attention.hip: -O3's SLP vectoriser pairs adjacent fp32 adds / multiplies into v_pk_*_f32, which cost several
+# times their two halves in the gaps between MFMAs (csrc/attention.hip, DS_ATTN_PK)
+SOURCE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
+
+
 def _newer(src_list, target):
     if not os.path.exists(target):
         return True
@@ -31,6 +36,7 @@ def _newer(src_list, target):
 # "barebarrier" = round 1's K-step barrier without the lgkmcnt(0) in front of it (profiles/r2_notes.md)
 VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"], "attnplain": ["-DDS_ATTN_NO_XCD_REMAP"], "nt0": ["-DDS_EXP_NT=0", "-DDS_EXP_STREAM_NT=0"],
             "attnnarrow": ["-DDS_ATTN_NARROW_STORES"],
+            "attn4": ["-DDS_ATTN_WGS=4"], "attn2": ["-DDS_ATTN_WGS=2"],
             # round 2's GroupNorm kernel choice (by instance COUNT): breaks batch invariance at full size (profiles/r3_notes.md section 7)
             "gncount": ["-DDS_EXP_GN_COUNT_THRESHOLD"],
             # round 3's K loop on v_mfma_f32_32x32x16_f16 (the product uses 16x16x32 since round 4: profiles/r4_notes.md)
@@ -61,7 +67,7 @@ def build(force=False, verbose=True, variant=None):
         obj = os.path.join(obj_dir, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _newer([src] + headers, obj):
-            cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + SOURCE_FLAGS.get(s, []) + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):

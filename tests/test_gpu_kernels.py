@@ -387,6 +387,56 @@ def test_attention_matches_softmax_reference(nq, nk, batch, heads, kvdiv):
     assert relerr(out.float().cpu().reshape(batch, nq, C), 2 * ref) < 3e-3
 
 
+@pytest.mark.parametrize("case", ["ramp", "creep", "negative", "late_spike"])
+def test_attention_deferred_reference_edge_cases(case):
+    """The flash loop moves the exponent's reference only when a tile's maximum exceeds it by more than 8 (log2 units)
+    (csrc/attention.hip DEFER_LOG2).  Score profiles that stress that rule: a maximum that grows with the key index (a move in
+    every tile), one that creeps by less than the threshold per tile (p stays above 1 for many tiles), scores far below zero
+    (the first tile must set the reference, whatever its sign), and a single late key that dominates a query."""
+    from dynamicscaler_amd import ops
+    d = dev()
+    nq, nk, batch, heads = 192, 704, 2, 2
+    C = heads * 64
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn((batch, nq, C), generator=g)
+    k = torch.randn((batch, nk, C), generator=g)
+    v = torch.randn((batch, nk, C), generator=g)
+    u = torch.nn.functional.normalize(torch.randn(64, generator=g), dim=0)
+    ramp = torch.arange(nk, dtype=torch.float32) / nk
+    if case == "ramp":          # score ~ 8 * 40 * key/nk * 0.125 = up to 40 (58 in log2 units) along the keys
+        q[..., :64] = 8.0 * u
+        k[..., :64] = 0.3 * k[..., :64] + (40.0 * ramp)[None, :, None] * u
+    elif case == "creep":       # +0.4 per 64-key tile in log2 units: below the threshold for ~20 tiles
+        q[..., :64] = 4.0 * u
+        k[..., :64] = 0.1 * k[..., :64] + (6.0 * ramp)[None, :, None] * u
+    elif case == "negative":    # every score of head 0 near -60
+        q[..., :64] = 8.0 * u
+        k[..., :64] = 0.3 * k[..., :64] - 60.0 * u
+    else:                       # one key in the last tile, 12 above the rest
+        q[..., :64] = 8.0 * u
+        k[..., :64] = 0.3 * k[..., :64]
+        k[:, nk - 3, :64] += 12.0 * u
+    q, k, v = _h(q), _h(k), _h(v)
+    qh = q.reshape(batch, nq, heads, 64).permute(0, 2, 1, 3)
+    kh = k.reshape(batch, nk, heads, 64).permute(0, 2, 1, 3)
+    vh = v.reshape(batch, nk, heads, 64).permute(0, 2, 1, 3)
+    ref = _attn_ref(qh.double(), kh.double(), vh.double(), 0.125).permute(0, 2, 1, 3).reshape(batch, nq, C).float()
+    qkv = torch.cat([q, k[:, :nq] * 0, v[:, :nq] * 0], -1)        # q rows in a wider buffer (row stride 3C), k / v separate
+    qd = qkv.half().to(d).reshape(batch * nq, 3 * C)
+    kd, vd = k.half().to(d).reshape(batch * nk, C), v.half().to(d).reshape(batch * nk, C)
+    out = torch.empty((batch * nq, C), dtype=torch.float16, device=d)
+    ops.attention(qd, kd, vd, out, batch=batch, heads=heads, nq=nq, nk=nk, ldq=3 * C, ldk=C, ldv=C, ldo=C, scale=0.125)
+    got = out.float().cpu().reshape(batch, nq, C)
+    assert torch.isfinite(got).all()
+    assert relerr(got, ref) < 2e-3
+    assert float((got - ref).abs().max()) < 1e-2 * max(1.0, float(ref.abs().max()))
+    # a query's result does not depend on which other queries share its wave (the move is decided per wave): 32 queries alone, bit for bit
+    one = torch.empty((batch * 32, C), dtype=torch.float16, device=d)
+    q32 = qd.reshape(batch, nq, 3 * C)[:, 80:112].contiguous().reshape(batch * 32, 3 * C)   # half of one wave's queries, half of the next one's
+    ops.attention(q32, kd, vd, one, batch=batch, heads=heads, nq=32, nk=nk, ldq=3 * C, ldk=C, ldv=C, ldo=C, scale=0.125)
+    assert torch.equal(one.reshape(batch, 32, C), out.reshape(batch, nq, C)[:, 80:112])
+
+
 @pytest.mark.parametrize("T", [16, 4, 24, 17, 32, 1])
 def test_temporal_attention(T):
     from dynamicscaler_amd import ops
