@@ -73,7 +73,7 @@ class VC2_Pipeline_T2V:
         # a level with a SINGLE tile batch (a rank's share on 8 GPUs: one tile per level; single-chain rings): cond and uncond
         # evaluations on two streams instead of one [cond | uncond] batch -- nothing else could overlap them, and two
         # half-size forwards in flight use the CUs the other's small launches leave idle (80.5 vs 82.5 ms per rank-step measured on
-        # the 8-GPU share of cfg3, tools/gpu_gn_sparse.sh, profiles/r3_notes.md sections 4 and 8; bit-identical, a batch equals its separate forwards).  1 (default):
+        # the 8-GPU share of cfg3, tools/exp/gpu_gn_sparse.sh, profiles/r3_notes.md sections 4 and 8; bit-identical, a batch equals its separate forwards).  1 (default):
         # only such levels; 0: never; 2: every batch, one after the other (emulates a rank's single-batch levels on one GPU).
         self.split_cfg_over_streams = int(os.environ.get("DS_SPLIT_CFG", "1"))
         # gather + re-noise and CFG + DDIM + scatter as one kernel each (ds_ring_gather_renoise / ds_cfg_ddim_scatter; bit-identical

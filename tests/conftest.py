@@ -11,6 +11,12 @@ if REPO not in sys.path:
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# The oracle runs on torch's OpenMP pool.  On a shared host a preempted worker leaves the others spinning at every barrier (seen
+# here: the tiny-UNet loop tests 9 s -> 600 s while another tenant was busy); a short spin before sleeping (instead of libgomp's
+# default 300 000 iterations) keeps the suite's time bounded at no cost on an idle host.  Has to
+# be in the environment before the OpenMP runtime loads, i.e. before the first `import torch` of the session.
+os.environ.setdefault("GOMP_SPINCOUNT", "30000")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Does a GroupNorm launched in row chunks (statistics + apply per chunk) find its second read in the Infinity Cache?
-python tools/bench_norm_chunks.py"""
+python tools/exp/bench_norm_chunks.py"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dynamicscaler_amd import ops, _lib
 from dynamicscaler_amd.ops import check, _stream
 d = torch.device("cuda:0")

@@ -1,8 +1,8 @@
 """Short-K GEMM family (K = 320 / 640 / 1280 linears of the transformer path) under a forced tile (DS_GEMM_TILE, read once per
-process): does another tile than choose_tile's pick run a shape faster?   python tools/bench_tile_choice.py [evals]"""
+process): does another tile than choose_tile's pick run a shape faster?   python tools/exp/bench_tile_choice.py [evals]"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dynamicscaler_amd import ops, _lib
 
 d = torch.device("cuda:0")

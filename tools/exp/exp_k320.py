@@ -1,7 +1,7 @@
-"""Tile choice on the short-K (HBM-bound) launches: python tools/exp_k320.py [evals]  (DS_GEMM_TILE=n to force a tile).
+"""Tile choice on the short-K (HBM-bound) launches: python tools/exp/exp_k320.py [evals]  (DS_GEMM_TILE=n to force a tile).
 Checks every result against a torch fp32 matmul of the same fp16 operands."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dynamicscaler_amd import ops, _lib
 d = torch.device("cuda:0")
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 16
