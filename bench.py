@@ -403,7 +403,8 @@ def main():
             def _rv(f):                    # (round, version): r3_pmc_hbm_traffic.json, r2_pmc_hbm_traffic_v14.json
                 m = re.search(r"r(\d+)_pmc_hbm_traffic(?:_v(\d+))?\.json$", f)
                 return (int(m.group(1)), int(m.group(2) or 0))
-            src = max(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic*.json")), key=_rv)
+            pat = re.compile(r"r\d+_pmc_hbm_traffic(?:_v\d+)?\.json$")       # (not the other configs' captures, e.g. ..._cfg5.json)
+            src = max((f for f in glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic*.json")) if pat.search(f)), key=_rv)
             summ = json.load(open(src))
             traffic_src = os.path.relpath(src, REPO)
             traffic_stale = summ.get("gemm_hip_sha256") != cur
