@@ -447,6 +447,59 @@ def test_ring_pipeline_device_rng_equals_oracle_with_the_restated_philox_stream(
             assert e < 2e-5, (gname, tb, e)
 
 
+def test_ring_pipeline_device_rng_with_a_real_unet_vs_oracle():
+    """The mode bench.py times -- in-kernel Philox noise, hipGraph, two streams -- with a REAL (tiny) UNet as the eps-model: the
+    oracle's ring loop on CPU, fed the restated Philox stream (oracle/philox.py) and the fp32 oracle UNet with the same weights,
+    against the HIP pipeline.  overlapw: 10 windows per step in one dependency chain, so every re-noised overlap feeds a UNet
+    evaluation of a later window.  Tolerance = the toy pipelines' (fp16 matrix-core operands)."""
+    from oracle import loops as oloops, ddim as oddim, philox
+    from oracle.unet import unet_forward
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    d = dev()
+    z = np.load(os.path.join(G, "loops_small.npz"))
+    meta = json.load(open(os.path.join(G, "loops_small_traces.json")))
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    sd = synth_state_dict(param_shapes(params), 5)
+    ld = _host(params, 5, cond, uncond, d)
+    seed = 0x5EED5EED1234
+    geom = meta["geoms"]["overlapw"]
+    n_tiles = geom["num_windows_w"] * geom["num_windows_h"] * geom["num_windows_f"]
+    init = torch.from_numpy(np.random.RandomState(5).randn(1, 4, geom["frames"] * geom["num_windows_f"], geom["total_h"] // 8,
+                                                            geom["total_w"] // 8).astype(np.float32))
+    calls = [0]
+    orig = oloops.re_noise
+
+    def philox_re_noise(sched, x_a, idx_a, idx_b, noise=None):
+        step, tile = divmod(calls[0], n_tiles)
+        calls[0] += 1
+        numel = x_a.numel()
+        off = lvdm_DDIM_Scheduler.tile_philox_offset(step, numel) + tile * numel
+        return orig(sched, x_a, idx_a, idx_b, noise=T(philox.tile_noise(tuple(x_a.shape), seed, off)))
+
+    oloops.re_noise = philox_re_noise
+    try:
+        ref, _, _ = oloops.t2v_ring_sample(lambda x, ts, ctx: unet_forward(sd, params, x, ts, ctx, fps=8), oddim.DiffusionTables(), cond,
+                                           uncond, guidance_scale=7.5, init_panorama_latent=init, **geom)
+    finally:
+        oloops.re_noise = orig
+    for tb, streams, graph in ((8, 2, True), (1, 1, False)):
+        sched = lvdm_DDIM_Scheduler(ld, rng_mode="device")
+        sched.philox_seed = seed
+        pipe = VC2_Pipeline_T2V_SpherePano(ld, sched, {"params": {"unet_config": {"params": params}}})
+        pipe.to(d, torch.float32)
+        pipe.max_tile_batch, pipe.num_streams, pipe.use_graph = tb, streams, graph
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                       init_panorama_latent=init, **geom)
+        e = relerr(den, ref)
+        print(f"device-RNG ring pipeline with the tiny UNet, tile batch {tb} x {streams} streams, graph {graph}: rel err {e:.3e}")
+        assert e < PIPE_TOL, (tb, streams, e)
+
+
 def test_ring_pipeline_multi_prompt_vs_oracle_and_reference_golden():
     """R13: `window_multi_prompt_dict` (t2v_sphere_panorama_pipeline.py:561-566, utils/multi_prompt_utils.py:1-7) on the toy
     dock geometry.  Fake eps, fp32 latents: bit-equal to the oracle on this host and 1e-4 from the reference's panorama
