@@ -337,10 +337,11 @@ def main():
         for name, flops, e0, e1, info in events:
             dt = e0.elapsed_time(e1) * 1e-3
             nbytes = 0.0
-            if name == "gemm" and info:   # A + W + out once, fp16 (GEGLU writes N/2 columns)
-                _, M_, N_, K_, epi_ = info
+            if name == "gemm" and info:   # A + W + residual + out once each; fp16 operands, residual / out rows fp16 or fp32 as the
+                _, M_, N_, K_, epi_, res_ = info      # launch's epilogue says (GEGLU writes N/2 columns)
                 kin = K_ // 9 if info[0] == 1 else (K_ // 3 if info[0] == 2 else K_)
-                nbytes = 2.0 * (M_ * kin + N_ * K_ + M_ * (N_ // 2 if epi_ & 1 else N_))
+                nbytes = 2.0 * (M_ * kin + N_ * K_) + (4.0 if epi_ & 4 else 2.0) * M_ * (N_ // 2 if epi_ & 1 else N_) + \
+                    res_ * (4.0 if epi_ & 8 else 2.0) * M_ * N_
             for a in (agg.setdefault(name, [0, 0.0, 0.0, 0.0]), shapes.setdefault((name,) + tuple(info or ()), [0, 0.0, 0.0, 0.0])):
                 a[0] += 1
                 a[1] += flops
@@ -408,7 +409,7 @@ def main():
             summ = json.load(open(src))
             traffic_src = os.path.relpath(src, REPO)
             traffic_stale = summ.get("gemm_hip_sha256") != cur
-            if not traffic_stale:
+            if not traffic_stale and summ.get("residual_mode", "f16") == timed_mode:     # (fp32 rows move more bytes: same mode only)
                 traffic = summ["gemm_f16_kernel(all)"]["hbm_bytes_per_launch"]
         except Exception:
             pass

@@ -395,7 +395,7 @@ def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE
               "ds_gemm_f16")
 
     if _timing_hook is not None:
-        _timing_hook("gemm", 2.0 * M * N * K, launch, (a_mode, M, N, K, epilogue))
+        _timing_hook("gemm", 2.0 * M * N * K, launch, (a_mode, M, N, K, epilogue, int(residual is not None)))
     else:
         launch()
     return out
@@ -501,7 +501,7 @@ def gemm_ln(x, Wg, stats, colsum, colbias=None, *, M, N, K, out=None, epilogue=0
                                      out.data_ptr(), C.byref(d), st), "ds_gemm_f16_ln")
 
     if _timing_hook is not None:
-        _timing_hook("gemm", 2.0 * M * N * K, launch, (DS_A_DENSE, M, N, K, epilogue))
+        _timing_hook("gemm", 2.0 * M * N * K, launch, (DS_A_DENSE, M, N, K, epilogue, 0))
     else:
         launch()
     return out

@@ -6,6 +6,7 @@ side is doubled; WRITE_SIZE is exact for 16 B/lane stores.  Infinity-Cache hits 
 usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 """
 import csv
+import os
 import json
 import re
 import sys
@@ -60,5 +61,6 @@ out["gemm_f16_kernel(all)"] = {
 import hashlib, os
 _src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynamicscaler_amd", "csrc", "gemm.hip")
 out["gemm_hip_sha256"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()
+out["residual_mode"] = os.environ.get("DS_RESIDUAL_DTYPE", "f32outer")       # the library's default unless the profiled run set it
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
