@@ -12,8 +12,12 @@
 //        second MFMA (k order of a 32x32 accumulator: key = 16s + 8(j>>2) + 4*half + (j&3)); V is transposed
 //        on the way into LDS so the matching A fragment is two 8-byte LDS reads.
 //      * O^T keeps the query on the lane as well, so the online-softmax rescale is a per-lane scalar.
+//      * the loop is bound by vector-instruction issue, not by the matrix cores: scalar fp32 softmax ops (no packed ops beside
+//        the MFMAs), and the exponent's reference follows the running maximum only when a tile exceeds it by 2^8 -- the rescale
+//        of l and O lives in a separate general form of the tile (see DEFER_LOG2 and the tile lambda).
 // 2) ds_temporal_attention_f16 -- self-attention over T (<= 32) frames per pixel (TemporalTransformer,
-//    attention.py:281-373): 0.1% of the FLOPs, pure HBM traffic; one wave per (pixel, head), VALU math.
+//    attention.py:281-373): 0.1% of the FLOPs, pure HBM traffic; one wave per (pixel, head) on small MFMAs (a VALU form is
+//    kept as a diagnostic).
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
