@@ -37,6 +37,7 @@ def _newer(src_list, target):
 VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"], "attnplain": ["-DDS_ATTN_NO_XCD_REMAP"], "nt0": ["-DDS_EXP_NT=0", "-DDS_EXP_STREAM_NT=0"],
             "attnnarrow": ["-DDS_ATTN_NARROW_STORES"],
             "attn4": ["-DDS_ATTN_WGS=4"], "attn2": ["-DDS_ATTN_WGS=2"],
+            "attnvt": ["-DDS_ATTN_TRV=0"],     # V transposed on its way into LDS (rounds 1-3) instead of transposing LDS reads
             "noslp": ["-fno-slp-vectorize"],      # every file without -O3's pairing of fp32 ops (attention.hip always is)
             # round 2's GroupNorm kernel choice (by instance COUNT): breaks batch invariance at full size (profiles/r3_notes.md section 7)
             "gncount": ["-DDS_EXP_GN_COUNT_THRESHOLD"],

@@ -27,6 +27,15 @@ namespace {
 constexpr int HD = 64;
 constexpr int KT = 64;          // keys per LDS tile
 constexpr int VT_STRIDE = 68;   // halfs per V^T row (64 keys + 4 pad): 34-dword stride -> conflict-free b64 reads
+// 1: V tiles stay row-major in LDS ([key][64 d], 128-byte rows like K) and the V^T fragments of the second MFMA come from
+// ds_read_b64_tr_b16 (gfx950's transposing LDS read: a 16-lane group reads 4 keys x 16 d and lane i receives column d0 + i of the
+// 4 keys) -- no v_perm / 32-bit stores on the way in.  0: round 1's image, V transposed while it is written (build variant "attnvt").
+#ifndef DS_ATTN_TRV
+#define DS_ATTN_TRV 1
+#endif
+// 16-byte chunk of row `row` that holds d-chunk `chunk` in the row-major V image: rows key and key + 2 of a 4-key block would
+// share 16 banks (a row is 32 banks, a 32-lane half reads 64 B of each of 4 rows), so bit 2 of the chunk flips with (key >> 1) & 1
+__device__ __forceinline__ int swz_v(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
@@ -51,7 +60,11 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
                  int heads, int nq, int nk, int ldq, int ldk, int ldv, int ldo, int kv_batch_div, float scale_log2,
                  int accumulate, int q_tiles) {
     __shared__ __attribute__((aligned(256))) f16 sK2[2][KT * HD];          // double-buffered: one barrier per key tile
+#if DS_ATTN_TRV
+    __shared__ __attribute__((aligned(256))) f16 sVT2[2][KT * HD];            // (row-major V; the name is kept for the strips below)
+#else
     __shared__ __attribute__((aligned(16))) f16 sVT2[2][HD * VT_STRIDE];
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
@@ -110,7 +123,11 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         offk[i] = (unsigned)((ld_row + 32 * i) * ldk + ld_chunk * 8) * 2u;
+#if DS_ATTN_TRV
+        offv[i] = (unsigned)((ld_row + 32 * i) * ldv + ld_chunk * 8) * 2u;
+#else
         offv[i] = (unsigned)((2 * ld_row + i) * ldv + ld_chunk * 8) * 2u;
+#endif
     }
     const unsigned tile_k_bytes = (unsigned)(KT * ldk) * 2u, tile_v_bytes = (unsigned)(KT * ldv) * 2u;
     u32x4 rk[2], rv[2];
@@ -132,11 +149,19 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
             const int row = ld_row + 32 * i;
             *reinterpret_cast<u32x4*>(sK + row * HD + swz_chunk(row, ld_chunk) * 8) = rk[i];
         }
+#if DS_ATTN_TRV
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = ld_row + 32 * i;
+            *reinterpret_cast<u32x4*>(sVT + row * HD + swz_v(row, ld_chunk) * 8) = rv[i];
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const unsigned w = __builtin_amdgcn_perm(rv[1][j >> 1], rv[0][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
             *reinterpret_cast<unsigned*>(sVT + (ld_chunk * 8 + j) * VT_STRIDE + 2 * ld_row) = w;
         }
+#endif
     };
 
     const int ntiles = (nk + KT - 1) / KT;
@@ -239,8 +264,23 @@ attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16
                     for (int db = 0; db < 2; ++db) {
                         const int drow = db * 32 + fr;
                         const int key0 = kb * 32 + sstep * 16 + 4 * fh;
+#if DS_ATTN_TRV
+                        // lane 4q + p of a 16-lane group supplies the address of key key0 + q, d = 16-block + 4p .. 4p + 3, and
+                        // receives d = db * 32 + fr of the four keys (EXEC is all ones here: no lane-dependent control flow)
+                        typedef short s16x4 __attribute__((ext_vector_type(4)));
+                        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+                        const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+                        const int trow = key0 + tq, tchunk = db * 4 + 2 * tg + (tp >> 1);
+                        const f16* a0 = sVT + trow * HD + swz_v(trow, tchunk) * 8 + 4 * (tp & 1);
+                        const f16* a1 = sVT + (trow + 8) * HD + swz_v(trow + 8, tchunk) * 8 + 4 * (tp & 1);
+                        const s16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a0);
+                        const s16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a1);
+                        const f16x4 v0 = *reinterpret_cast<const f16x4*>(&w0), v1 = *reinterpret_cast<const f16x4*>(&w1);
+                        (void)drow;
+#else
                         const f16x4 v0 = *reinterpret_cast<const f16x4*>(sVT + drow * VT_STRIDE + key0);
                         const f16x4 v1 = *reinterpret_cast<const f16x4*>(sVT + drow * VT_STRIDE + key0 + 8);
+#endif
                         const f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                         o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[qb][db], 0, 0, 0);
                     }
