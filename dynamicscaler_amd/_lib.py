@@ -16,7 +16,7 @@ DS_F16, DS_F32 = 0, 1
 DS_A_DENSE, DS_A_CONV3, DS_A_TCONV = 0, 1, 2
 DS_EPI_GEGLU, DS_EPI_SILU, DS_EPI_OUT_F32, DS_EPI_RES_F32 = 1, 2, 4, 8
 DS_MAX_WINDOWS = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HipLibraryMissing(RuntimeError):
@@ -102,6 +102,17 @@ SIGNATURES = {
     "ds_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ds_dbg_poison_cu_state": (_i, [_vp]),
     "ds_cast_to_f16": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "ds_wide_lo_scale": (_f, []),
+    "ds_split_f16": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
+    "ds_gemm_wide": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),
+    "ds_groupnorm_wide": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "ds_layernorm_wide": (_i, [_vp, _vp, _vp, _vp, C.c_long, _i, _f, _vp]),
+    "ds_attention_wide": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "ds_temporal_attention_wide": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "ds_timestep_embedding_f32": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ds_silu_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "ds_cast_to_f32": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "ds_im2col_in_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ds_unet_create": (_i, [_pp(UNetConfig), _pp(_vp)]),
     "ds_unet_destroy": (_i, [_vp]),
     "ds_unet_num_weights": (_i, [_vp]),

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libdynscaler_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["error.cpp", "tile_ops.hip", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "encoders.hip", "unet_program.hip"]
+SOURCES = ["error.cpp", "tile_ops.hip", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "encoders.hip", "wide.hip", "unet_program.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=on"]
 

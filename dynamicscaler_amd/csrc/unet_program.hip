@@ -29,7 +29,7 @@ enum { L_LINEAR = 0, L_CONV3 = 1, L_TCONV = 2 };
 template <typename ST>
 __global__ void __launch_bounds__(256)
 pack_w16_kernel(f16* __restrict__ dst, long n_rows, int kdst, const ST* __restrict__ src, int ksrc, int layout, int cin,
-                const float* __restrict__ gamma, int geglu_inner) {
+                const float* __restrict__ gamma, int geglu_inner, f16* __restrict__ dst_lo, float lo_scale) {
     const long total = n_rows * kdst;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long n = idx / kdst;
@@ -49,7 +49,9 @@ pack_w16_kernel(f16* __restrict__ dst, long n_rows, int kdst, const ST* __restri
             v = (float)src[si];
             if (gamma) v *= gamma[k];
         }
-        dst[idx] = (f16)v;
+        const f16 h = (f16)v;
+        dst[idx] = h;
+        if (dst_lo) dst_lo[idx] = (f16)((v - (float)h) * lo_scale);     // the wide mode's second operand plane (csrc/wide.hip)
     }
 }
 
@@ -149,6 +151,8 @@ struct ds_unet {
     ds_unet_config cfg;
     bool gn_fused = false;        // GroupNorm statistics from the producing GEMM's epilogue (ds_gemm_f16_stats) where producer and norm are adjacent
     bool strict = false, inner32 = false, fold = false;   // strict: the stream between the blocks is fp32; inner32: inside the transformers too
+    bool wide = false;            // residual_f32 = 3: every activation fp32, split-fp16 products (csrc/wide.hip); every fp16 matrix of the packed
+                                  // buffer is followed by its lo plane of the same size
     std::vector<std::vector<Block>> inputs, outputs;
     std::vector<Block> middle;
     std::vector<std::pair<int, int>> cat_ch;     // per decoder group: (channels of h, channels of the skip tensor)
@@ -414,7 +418,8 @@ struct Planner {
         ds_unet* uu = u;
         long n_rows = 0;
         for (auto& k : keys) n_rows += uu->w(k)->shape[0];
-        item(name, (size_t)n_rows * kdst * 2, [=](char* dst, hipStream_t st) {
+        const size_t plane = (size_t)n_rows * kdst * 2;
+        item(name, uu->wide ? 2 * plane : plane, [=](char* dst, hipStream_t st) {
             long row0 = 0;
             for (auto& k : keys) {
                 const WeightSpec* w = uu->w(k);
@@ -422,8 +427,9 @@ struct Planner {
                 const int ksrc = (int)(w->numel() / rows);
                 const float* g = gamma_item.empty() ? nullptr : (const float*)uu->P(gamma_item);
                 f16* d = (f16*)dst + row0 * kdst;
+                f16* dl = uu->wide ? (f16*)(dst + plane) + row0 * kdst : nullptr;
                 with_src(w, [&](auto* src) {
-                    pack_w16_kernel<<<grid_for(rows * kdst), 256, 0, st>>>(d, rows, kdst, src, ksrc, layout, cin, g, geglu_inner);
+                    pack_w16_kernel<<<grid_for(rows * kdst), 256, 0, st>>>(d, rows, kdst, src, ksrc, layout, cin, g, geglu_inner, dl, ds_wide_lo_scale());
                     return 0;
                 });
                 row0 += rows;
@@ -583,14 +589,16 @@ void plan_pack(ds_unet* u) {
     // the time-embedding projections of all ResBlocks in ONE matrix, the conv-1 bias folded into its bias
     const int ted = 4 * c.model_channels;
     ds_unet* uu = u;
-    pl.item("emb_all.w", (size_t)off * ted * 2, [=](char* dst, hipStream_t st) {
+    const size_t emb_plane = (size_t)off * ted * 2;
+    pl.item("emb_all.w", uu->wide ? 2 * emb_plane : emb_plane, [=](char* dst, hipStream_t st) {
         long row0 = 0;
         for (auto& k : emb_keys) {
             const WeightSpec* w = uu->w(k);
             const long rows = w->shape[0];
             f16* d = (f16*)dst + row0 * ted;
+            f16* dl = uu->wide ? (f16*)(dst + emb_plane) + row0 * ted : nullptr;
             with_src(w, [&](auto* src) {
-                pack_w16_kernel<<<grid_for(rows * ted), 256, 0, st>>>(d, rows, ted, src, ted, L_LINEAR, ted, (const float*)nullptr, 0);
+                pack_w16_kernel<<<grid_for(rows * ted), 256, 0, st>>>(d, rows, ted, src, ted, L_LINEAR, ted, (const float*)nullptr, 0, dl, ds_wide_lo_scale());
                 return 0;
             });
             row0 += rows;
@@ -736,6 +744,7 @@ struct Prog {
              int cin = 0, const ConvGeo* cg = nullptr, int t_len = 0, int hw = 0, int bias_rows = INT_MAX, int ldbias = 0, Ten out = Ten(),
              const Ten& cstats = Ten()) {
         const int n_out = (epilogue & DS_EPI_GEGLU) ? N / 2 : N;
+        if (u->wide) epilogue |= DS_EPI_OUT_F32;             // the wide mode stores nothing in fp16
         if (residual && residual.is32()) epilogue |= DS_EPI_RES_F32;
         if (out && out.is32()) epilogue |= DS_EPI_OUT_F32;
         if (!out) out = make(M, n_out, (epilogue & DS_EPI_OUT_F32) ? DS_F32 : DS_F16);
@@ -754,8 +763,15 @@ struct Prog {
         tr("gemm M=%ld N=%d K=%d mode=%d cin=%d lda=%d ldc=%d ldr=%d brows=%d ldb=%d epi=%d conv=%d,%d,%d,%d,%d,%d,%d t=%d,%d bias=%d res=%d stats=%d",
            M, N, K, a_mode, d.cin, d.lda, d.ldc, d.ldr, bias_rows, d.ldbias, epilogue, d.nimg, d.hin, d.win, d.hout, d.wout, d.stride, d.upsample, t_len,
            hw, bias ? 1 : 0, residual ? 1 : 0, cstats ? cstats.ld / 2 : 0);
+        if (u->wide && (!A.is32() || !out.is32() || (residual && !residual.is32()))) {
+            ds_set_error("ds_unet_forward: the wide mode met an fp16 tensor (program error)");
+            chk(DS_EINVAL);
+            return out;
+        }
         if (live()) {
-            if (cstats) chk(ds_gemm_f16_stats(ptr(A), ptr(W), bias, ptr(residual), ptr(out), (float*)ptr(cstats), cstats.ld / 2, &d, st));
+            if (u->wide)       // the lo plane of a packed matrix follows its hi plane (Planner::w16)
+                chk(ds_gemm_wide((const float*)ptr(A), ptr(W), ptr(W) + (size_t)W.rows * W.ld * 2, bias, (const float*)ptr(residual), (float*)ptr(out), &d, st));
+            else if (cstats) chk(ds_gemm_f16_stats(ptr(A), ptr(W), bias, ptr(residual), ptr(out), (float*)ptr(cstats), cstats.ld / 2, &d, st));
             else chk(ds_gemm_f16(ptr(A), ptr(W), bias, ptr(residual), ptr(out), &d, st));
         }
         return out;
@@ -779,6 +795,16 @@ struct Prog {
     Ten stats_table(long rows, int cols) { return make((rows + 31) / 32, 2 * cols, DS_F32); }   // (sum, sumsq) per 32-row block and column
     Ten groupnorm(const Ten& x, const std::string& prefix, int ninst, int rows_per, int C, float eps, int silu, Ten* raw16 = nullptr,
                   const Ten& cstats = Ten()) {
+        if (u->wide) {
+            Ten stt = make((long)ninst * 32, 2, DS_F32);
+            Ten yw = make(x.rows, C, DS_F32);
+            tr("groupnorm_wide ldx=%d ninst=%d rows=%d C=%d silu=%d eps=%g", x.ld, ninst, rows_per, C, silu, (double)eps);
+            if (live())
+                chk(ds_groupnorm_wide((const float*)ptr(x), x.ld, (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), (float*)ptr(yw),
+                                      (float*)ptr(stt), ninst, rows_per, C, 32, eps, silu, st));
+            if (raw16) *raw16 = x;        // the un-normalised operand is the fp32 tensor itself
+            return yw;
+        }
         Ten ws = raw(ds_groupnorm_stats_workspace_floats(ninst, rows_per, 32) * 4);
         Ten y = make(x.rows, C, DS_F16);
         Ten r;
@@ -796,6 +822,13 @@ struct Prog {
         return y;
     }
     Ten layernorm(const Ten& x, const std::string& prefix) {
+        if (u->wide) {
+            Ten yw = make(x.rows, x.cols, DS_F32);
+            tr("layernorm_wide rows=%ld C=%d", x.rows, x.cols);
+            if (x.ld != x.cols) { ds_set_error("ds_unet_forward: layernorm_wide needs dense rows"); chk(DS_EINVAL); return yw; }
+            if (live()) chk(ds_layernorm_wide((const float*)ptr(x), (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), (float*)ptr(yw), x.rows, x.cols, 1e-5f, st));
+            return yw;
+        }
         Ten y = make(x.rows, x.cols, DS_F16);
         tr("layernorm xdt=%d rows=%ld C=%d", x.dt, x.rows, x.cols);
         if (live()) chk(ds_layernorm_rows(ptr(x), x.dt, (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), ptr(y), (int)x.rows, x.cols, 1e-5f, st));
@@ -809,10 +842,18 @@ struct Prog {
     }
     void attention(const Ten& q, const Ten& k, const Ten& v, const Ten& o, int batch, int heads, int nq, int nk, int kvdiv, float scale, int acc) {
         tr("attention batch=%d heads=%d nq=%d nk=%d ldq=%d ldk=%d ldv=%d ldo=%d kvdiv=%d acc=%d", batch, heads, nq, nk, q.ld, k.ld, v.ld, o.ld, kvdiv, acc);
+        if (u->wide) {
+            if (live()) chk(ds_attention_wide((const float*)ptr(q), (const float*)ptr(k), (const float*)ptr(v), (float*)ptr(o), batch, heads, nq, nk, q.ld, k.ld, v.ld, o.ld, kvdiv, scale, acc, st));
+            return;
+        }
         if (live()) chk(ds_attention_f16(ptr(q), ptr(k), ptr(v), ptr(o), batch, heads, nq, nk, q.ld, k.ld, v.ld, o.ld, kvdiv, scale, acc, st));
     }
     void tattention(const Ten& q, const Ten& k, const Ten& v, const Ten& o, int nb, int T, int hw, int heads, float scale) {
         tr("temporal_attention nb=%d T=%d hw=%d heads=%d ldq=%d ldk=%d ldv=%d ldo=%d", nb, T, hw, heads, q.ld, k.ld, v.ld, o.ld);
+        if (u->wide) {
+            if (live()) chk(ds_temporal_attention_wide((const float*)ptr(q), (const float*)ptr(k), (const float*)ptr(v), (float*)ptr(o), nb, T, hw, heads, q.ld, k.ld, v.ld, o.ld, scale, st));
+            return;
+        }
         if (live()) chk(ds_temporal_attention_f16(ptr(q), ptr(k), ptr(v), ptr(o), nb, T, hw, heads, q.ld, k.ld, v.ld, o.ld, scale, st));
     }
     Ten cast16(const Ten& x) {
@@ -821,7 +862,8 @@ struct Prog {
         if (live()) chk(ds_cast_rows_f32_f16((const float*)ptr(x), x.ld, ptr(y), y.ld, x.rows, x.cols, st));
         return y;
     }
-    Ten operand(const Ten& h) { return h.is32() ? cast16(h) : h; }
+    Ten operand(const Ten& h) { return (h.is32() && !u->wide) ? cast16(h) : h; }
+    int adt() const { return u->wide ? DS_F32 : DS_F16; }      // storage type of the tensors that are fp16 in every other mode
     // rows of src -> rows of dst (2-D device copy on the stream; capturable)
     void copy_rows(const Ten& dst, const Ten& src) {
         tr("copy rows=%ld bytes=%ld", src.rows, (long)src.cols * src.esz());
@@ -877,7 +919,7 @@ struct Prog {
         };
         auto self_attn = [&](const std::string& name, const Ten& xin) {
             Ten qkv = ln_proj(xin, name == "attn1" ? "norm1" : "norm2", p + "." + name + ".qkv", 3 * inner, 0);
-            Ten o = make(M, inner, DS_F16);
+            Ten o = make(M, inner, adt());
             if (spatial) attention(qkv, cols(qkv, inner, inner), cols(qkv, 2 * inner, inner), o, B * T, heads, H * W, H * W, 1, scale, 0);
             else tattention(qkv, cols(qkv, inner, inner), cols(qkv, 2 * inner, inner), o, B, T, H * W, heads, scale);
             qkv = Ten();
@@ -892,7 +934,7 @@ struct Prog {
             Ten q = ln_proj(x, "norm2", p + ".attn2.to_q", inner, 0);
             const int kc = u->cfg.context_dim;
             Ten kv = gemm(ctx.text, wt(p + ".attn2.kv.w", 2 * inner, kc, DS_F16), nullptr, Ten(), ctx.text.rows, 2 * inner, kc, 0);
-            Ten o = make(M, inner, DS_F16);
+            Ten o = make(M, inner, adt());
             attention(q, kv, cols(kv, inner, inner), o, B * T, heads, H * W, ctx.ltxt, T, scale, 0);
             if (ctx.img && u->hasP(p + ".attn2.kv_ip.w")) {
                 Ten kvi = gemm(ctx.img, wt(p + ".attn2.kv_ip.w", 2 * inner, kc, DS_F16), nullptr, Ten(), ctx.img.rows, 2 * inner, kc, 0);
@@ -969,9 +1011,9 @@ struct Prog {
         const int rdt = u->strict ? DS_F32 : DS_F16;
         // ---- time (+ fps) embedding -> per-ResBlock projections in one GEMM ----
         auto tstep = [&](const int64_t* t) {
-            Ten e = make(B, mc, DS_F16);
+            Ten e = make(B, mc, adt());
             tr("timestep_embedding n=%d dim=%d", B, mc);
-            if (live()) chk(ds_timestep_embedding(t, ptr(e), B, mc, st));
+            if (live()) chk(u->wide ? ds_timestep_embedding_f32(t, (float*)ptr(e), B, mc, st) : ds_timestep_embedding(t, ptr(e), B, mc, st));
             return e;
         };
         Ten t_emb = tstep(timesteps);
@@ -985,9 +1027,10 @@ struct Prog {
             emb = linear(f1, "fps_embedding.2", emb);
         }
         t_emb = Ten(); e1 = Ten();
-        Ten semb = make(emb.rows, emb.cols, DS_F16);
+        Ten semb = make(emb.rows, emb.cols, adt());
         tr("silu n=%ld", emb.rows * emb.cols);
-        if (live()) chk(ds_silu_f16(ptr(emb), ptr(semb), (size_t)emb.rows * emb.cols, st));
+        if (live()) chk(u->wide ? ds_silu_f32((const float*)ptr(emb), (float*)ptr(semb), (size_t)emb.rows * emb.cols, st)
+                                : ds_silu_f16(ptr(emb), ptr(semb), (size_t)emb.rows * emb.cols, st));
         const int ted = 4 * mc;
         Ten emb_all = gemm(semb, wt("emb_all.w", u->emb_total, ted, DS_F16), (const float*)u->P("emb_all.b"), Ten(), B, u->emb_total, ted, DS_EPI_OUT_F32);
         emb = Ten(); semb = Ten();
@@ -995,13 +1038,14 @@ struct Prog {
         Ctx ctx;
         {
             const int D = c.context_dim;
-            Ten c16 = make((long)B * L, D, DS_F16);
+            Ten c16 = make((long)B * L, D, adt());
             tr("cast n=%ld", (long)B * L * D);
-            if (live()) chk(ds_cast_to_f16(context, ctx_dtype, ptr(c16), (size_t)B * L * D, st));
+            if (live()) chk(u->wide ? ds_cast_to_f32(context, ctx_dtype, (float*)ptr(c16), (size_t)B * L * D, st)
+                                    : ds_cast_to_f16(context, ctx_dtype, ptr(c16), (size_t)B * L * D, st));
             if (c.use_image_attention && L > 77) {
                 ctx.ltxt = 77; ctx.limg = L - 77;
-                ctx.text = make((long)B * 77, D, DS_F16);
-                ctx.img = make((long)B * (L - 77), D, DS_F16);
+                ctx.text = make((long)B * 77, D, adt());
+                ctx.img = make((long)B * (L - 77), D, adt());
                 Ten all = c16;                       // B "rows" of L*D elements
                 all.rows = B; all.cols = L * D; all.ld = L * D;
                 Ten tx = ctx.text; tx.rows = B; tx.cols = 77 * D; tx.ld = 77 * D;
@@ -1021,9 +1065,10 @@ struct Prog {
                 switch (b.kind) {
                     case Block::CONV_IN: {
                         const int nb = shared ? pairs : B;
-                        Ten patches = make((long)nb * T * H * W, u->kpad_in, DS_F16);
+                        Ten patches = make((long)nb * T * H * W, u->kpad_in, adt());
                         tr("im2col_in B=%d C=%d T=%d H=%d W=%d kpad=%d", nb, c.in_channels, T, H, W, u->kpad_in);
-                        if (live()) chk(ds_im2col_in(x_in, x_dtype, ptr(patches), nb, c.in_channels, T, H, W, u->kpad_in, st));
+                        if (live()) chk(u->wide ? ds_im2col_in_f32(x_in, x_dtype, (float*)ptr(patches), nb, c.in_channels, T, H, W, u->kpad_in, st)
+                                                : ds_im2col_in(x_in, x_dtype, ptr(patches), nb, c.in_channels, T, H, W, u->kpad_in, st));
                         h = gemm(patches, wt(b.prefix + ".w", b.cout, u->kpad_in, DS_F16), (const float*)u->P(b.prefix + ".b"), Ten(), patches.rows, b.cout, u->kpad_in,
                                  res_epi(), DS_A_DENSE, 0, nullptr, 0, 0, INT_MAX, 0, o);
                         break;
@@ -1144,7 +1189,8 @@ extern "C" int ds_unet_create(const ds_unet_config* cfg, ds_unet** out) {
     DS_CHECK_ARG(c.transformer_depth > 0 && c.temporal_transformer_depth > 0 && c.context_dim > 0 && c.context_dim % 64 == 0, "ds_unet_create: transformer depth / context_dim");
     DS_CHECK_ARG(c.gn_from_producer == 0 || c.gn_from_producer == 1, "ds_unet_create: gn_from_producer must be 0 or 1");
     DS_CHECK_ARG(c.temporal_selfatt_only == 1, "ds_unet_create: temporal_selfatt_only must be 1 (TemporalTransformers with cross-attention to the context are not built)");
-    DS_CHECK_ARG(c.residual_f32 >= 0 && c.residual_f32 <= 2, "ds_unet_create: residual_f32 must be 0 (fp16 stream), 1 (fp32 everywhere) or 2 (fp32 between the blocks only)");
+    DS_CHECK_ARG(c.residual_f32 >= 0 && c.residual_f32 <= 3, "ds_unet_create: residual_f32 must be 0 (fp16 stream), 1 (fp32 everywhere), 2 (fp32 between the blocks only) or 3 (wide operands)");
+    DS_CHECK_ARG(c.residual_f32 != 3 || c.gn_from_producer == 0, "ds_unet_create: gn_from_producer is not available in the wide mode");
     for (int i = 0; i < c.n_channel_mult; ++i) DS_CHECK_ARG(c.channel_mult[i] > 0, "ds_unet_create: channel_mult[%d] = %d must be positive", i, c.channel_mult[i]);
     for (int i = 0; i < c.n_attention_resolutions; ++i) DS_CHECK_ARG(c.attention_resolutions[i] > 0, "ds_unet_create: attention_resolutions[%d] = %d must be positive", i, c.attention_resolutions[i]);
     // every check above runs before the handle exists; nothing below may leave through the C boundary as an exception
@@ -1152,8 +1198,9 @@ extern "C" int ds_unet_create(const ds_unet_config* cfg, ds_unet** out) {
     try {
         u.reset(new ds_unet());
         u->cfg = c;
+        u->wide = c.residual_f32 == 3;
         u->strict = c.residual_f32 != 0;
-        u->inner32 = c.residual_f32 == 1;
+        u->inner32 = c.residual_f32 == 1 || u->wide;
         u->fold = c.fold_layernorm != 0 && !u->inner32;    // the fold multiplies the RAW activation on the matrix cores: needs it in fp16
         u->gn_fused = c.gn_from_producer != 0;
         build_program(u.get());

@@ -677,3 +677,81 @@ def patchify(img, patch, kpad, stream=None):
     rows = torch.empty((n * g * g, kpad), dtype=torch.float16, device=img.device)
     check(lib.ds_patchify(img.data_ptr(), rows.data_ptr(), n, c, S, patch, kpad, st), "ds_patchify")
     return rows
+
+
+# ------------------------------------------------------------------------------------------------ the wide operand mode (csrc/wide.hip)
+def split_f16(x, stream=None):
+    """(hi, lo) fp16 planes of x (fp32 or fp16): hi = fp16(x), lo = fp16((x - hi) * 2^11) -- the weight operand of gemm_wide."""
+    lib = _lib.load()
+    _dev(x, "split_f16")
+    hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    check(lib.ds_split_f16(x.data_ptr(), _DT[x.dtype], hi.data_ptr(), lo.data_ptr(), x.numel(), _stream() if stream is None else stream),
+          "ds_split_f16")
+    return hi, lo
+
+
+def gemm_wide(A, W_hi, W_lo, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE, lda=None, cin=None, conv=None,
+              tconv=None, bias_rows=None, ldbias=None, epilogue=0, stream=None):
+    """gemm() with fp32 A / residual / out and split-fp16 products (ds_gemm_wide); same geometry arguments."""
+    lib = _lib.load()
+    n_out = N // 2 if (epilogue & DS_EPI_GEGLU) else N
+    assert A.dtype == torch.float32 and W_hi.dtype == torch.float16 and W_lo.dtype == torch.float16
+    assert residual is None or residual.dtype == torch.float32
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float32, device=A.device)
+    assert out.dtype == torch.float32
+    d = GemmDesc()
+    d.M, d.N, d.K, d.a_mode = M, N, K, a_mode
+    d.cin = K if cin is None else cin
+    d.lda = d.cin if lda is None else lda
+    if conv is not None:
+        d.nimg, d.hin, d.win, d.hout, d.wout, d.stride, d.upsample = conv[:7]
+        d.asym_pad = conv[7] if len(conv) > 7 else 0
+    if tconv is not None:
+        d.t_len, d.hw = tconv
+    d.ldc = out.stride(0)
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.bias_rows = 0x7FFFFFFF if bias_rows is None else bias_rows
+    d.ldbias = N if ldbias is None else ldbias
+    d.epilogue = epilogue | DS_EPI_OUT_F32 | (DS_EPI_RES_F32 if residual is not None else 0)
+    st = _stream() if stream is None else stream
+    check(lib.ds_gemm_wide(A.data_ptr(), W_hi.data_ptr(), W_lo.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), C.byref(d), st),
+          "ds_gemm_wide")
+    return out
+
+
+def groupnorm_wide(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None):
+    """GroupNorm (+ SiLU) of fp32 rows [ninst*rows_per_inst, Cch] (row stride x.stride(0)) -> dense fp32."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == Cch and x.stride(1) == 1
+    y = torch.empty((x.shape[0], Cch), dtype=torch.float32, device=x.device)
+    stats = torch.empty((ninst * groups * 2,), dtype=torch.float32, device=x.device)
+    check(lib.ds_groupnorm_wide(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), ninst,
+                                rows_per_inst, Cch, groups, float(eps), int(bool(silu)), _stream() if stream is None else stream),
+          "ds_groupnorm_wide")
+    return y
+
+
+def layernorm_wide(x, gamma, beta, eps=1e-5, stream=None):
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    y = torch.empty_like(x)
+    check(lib.ds_layernorm_wide(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], float(eps),
+                                _stream() if stream is None else stream), "ds_layernorm_wide")
+    return y
+
+
+def attention_wide(q, k, v, out, *, batch, heads, nq, nk, ldq, ldk, ldv, ldo, kv_batch_div=1, scale, accumulate=False, stream=None):
+    lib = _lib.load()
+    check(lib.ds_attention_wide(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), batch, heads, nq, nk, ldq, ldk, ldv, ldo,
+                                kv_batch_div, float(scale), int(bool(accumulate)), _stream() if stream is None else stream),
+          "ds_attention_wide")
+    return out
+
+
+def temporal_attention_wide(q, k, v, out, *, nseq_batches, T, hw, heads, ldq, ldk, ldv, ldo, scale, stream=None):
+    lib = _lib.load()
+    check(lib.ds_temporal_attention_wide(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), nseq_batches, T, hw, heads, ldq, ldk,
+                                         ldv, ldo, float(scale), _stream() if stream is None else stream), "ds_temporal_attention_wide")
+    return out

@@ -113,10 +113,17 @@ class UNetModel(nn.Module):
         # at 7.0e-4 (fast mode 9.6e-4, strict 5.3e-4; tests/test_gpu_fullsize.py::test_ring_loops_real_unet_on_the_50_step_schedule...),
         # free-running 50 steps 7.1e-4 (9.8e-4 / 5.3e-4), x_prev of a unit-scale model's first step 9.4e-4 (1.27e-3 / 7.1e-4).
         rd = os.environ.get("DS_RESIDUAL_DTYPE", "f32outer")
-        if rd not in ("f16", "f32", "f32outer"):
-            raise ValueError(f"DS_RESIDUAL_DTYPE={rd!r}: expected f16, f32 or f32outer")
+        if rd not in ("f16", "f32", "f32outer", "wide"):
+            raise ValueError(f"DS_RESIDUAL_DTYPE={rd!r}: expected f16, f32, f32outer or wide")
         self.residual_dtype = torch.float16 if rd == "f16" else torch.float32
         self.residual_scope = "outer" if rd == "f32outer" else "full"
+        # Matrix-core OPERANDS.  "f16": single fp16 operands (every mode above).  "wide" (round 5): every activation stored in fp32 and
+        # every product formed from two-term fp16 splits of both operands (csrc/wide.hip: ds_gemm_wide, fp32 norms / attention) -- an
+        # fp32 evaluation of the UNet, eps within ~1e-5 of the reference instead of ~1e-3, at ~3x the matrix-core work.  Meant for single
+        # steps: forward(..., precision="wide") routes one evaluation through a twin of this module that shares its parameters and
+        # keeps its own packed buffer (hi + lo planes) and C handle; the pipelines choose the steps (operand_policy).  C program only.
+        self.operand_mode = "wide" if rd == "wide" else "f16"
+        self._twins = {}                     # operand_mode -> twin module (shared parameters, own handle / packed buffer)
         # Which launch program runs the forward: "c" = ds_unet_forward (csrc/unet_program.hip: one call, the launch loop in C++),
         # "python" = the restatement below (one ctypes call per kernel: per-launch timing hooks, taps, DS_FOLD_LN=2).  The two
         # issue the same launches on the same packed operands and are bit-identical (tests/test_gpu_unet_c.py).  DS_UNET_PROGRAM.
@@ -136,16 +143,44 @@ class UNetModel(nn.Module):
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, *a, **k):
-        self._packed = None
+        self.invalidate()
         return super().load_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        self.invalidate()
         return super()._apply(fn, *a, **k)
 
     def invalidate(self):
         """Call after mutating parameters in place."""
         self._packed = None
+        for tw in getattr(self, "_twins", {}).values():      # they share the parameters
+            tw._packed = None
+
+    def _wide(self):
+        if self.operand_mode not in ("f16", "wide"):
+            raise ValueError(f"operand_mode={self.operand_mode!r}: expected 'f16' or 'wide'")
+        return self.operand_mode == "wide"
+
+    def twin(self, operand_mode="wide"):
+        """A module over the SAME parameters (and parameter tree) evaluated in another operand mode, with its own packed buffer and
+        C handle: both stay resident, so single evaluations can be routed to it (forward(..., precision=...))."""
+        tw = self._twins.get(operand_mode)
+        if tw is None:
+            import copy
+            tw = copy.copy(self)                 # shallow: _parameters / _modules (the parameter tree) are shared objects
+            tw._twins = {}
+            tw._packed = None
+            tw._handle = None
+            tw._tap = None
+            tw._generation = 0
+            tw._prepare_lock = threading.Lock()
+            tw._handle_lock = threading.Lock()
+            tw._handle_uses, tw._handle_retired = {}, {}
+            tw.operand_mode = operand_mode
+            tw.program = "c"
+            tw.gn_from_producer = False
+            self._twins[operand_mode] = tw
+        return tw
 
     @torch.no_grad()
     def prepare(self, device=None, force=False):
@@ -163,13 +198,13 @@ class UNetModel(nn.Module):
             return self._prepare_locked(dev)
 
     def _strict(self):
-        return self.residual_dtype == torch.float32
+        return self.residual_dtype == torch.float32 or self._wide()
 
     def _inner32(self):
-        """The stream inside the transformer blocks is fp32 too (residual_scope "full")."""
+        """The stream inside the transformer blocks is fp32 too (residual_scope "full"; always in the wide mode)."""
         if self.residual_scope not in ("full", "outer"):
             raise ValueError(f"residual_scope={self.residual_scope!r}: expected 'full' or 'outer'")
-        return self._strict() and self.residual_scope == "full"
+        return self._wide() or (self._strict() and self.residual_scope == "full")
 
     def _fold(self):
         """LayerNorm fold in effect: the fold multiplies the RAW activation on the matrix cores, which needs it in fp16 -- with an
@@ -177,14 +212,14 @@ class UNetModel(nn.Module):
         return False if self._inner32() else self.fold_layernorm
 
     def _gn_fused(self):
-        return bool(self.gn_from_producer and not self.batch_invariant)
+        return bool(self.gn_from_producer and not self.batch_invariant and not self._wide())
 
     def _fuse_gn(self, rows_per):
         """This GroupNorm takes its statistics from its producer (instances of <= 256 rows keep the one-launch kernel)."""
         return self._gn_fused() and rows_per % 32 == 0 and rows_per > 256
 
     def _mode(self):
-        return (self._fold(), self.residual_dtype, self._inner32(), self._gn_fused())
+        return (self._fold(), self.residual_dtype, self._inner32(), self._gn_fused(), self._wide())
 
     def _c_config(self):
         """ds_unet_config of this model in the current mode."""
@@ -204,7 +239,7 @@ class UNetModel(nn.Module):
             c.attention_resolutions[i] = int(v)
         for k in ("use_linear", "temporal_conv", "temporal_attention", "addition_attention", "use_image_attention", "fps_cond"):
             setattr(c, k, int(bool(cfg[k])))
-        c.residual_f32 = (1 if self._inner32() else 2) if self._strict() else 0
+        c.residual_f32 = 3 if self._wide() else ((1 if self._inner32() else 2) if self._strict() else 0)
         c.fold_layernorm = int(bool(self._fold()))
         c.gn_from_producer = int(self._gn_fused())
         c.temporal_selfatt_only = int(bool(cfg.get("temporal_selfatt_only", True)))
@@ -470,6 +505,14 @@ class UNetModel(nn.Module):
         SpatialTransformer -- never sees the context, so it is evaluated once on n items and duplicated.  Same kernels on
         the same numbers: the result is bit-identical to the plain 2n forward (a batch equals its separate forwards)."""
         pairs = kwargs.pop("cfg_pairs", None)
+        precision = kwargs.pop("precision", None)          # "wide": this evaluation with split-fp16 operands and fp32 storage (twin)
+        if precision not in (None, "f16", "wide"):
+            raise ValueError(f"precision={precision!r}: expected None, 'f16' or 'wide'")
+        if precision == "wide" and not self._wide():
+            if pairs:
+                kwargs["cfg_pairs"] = pairs
+            return self.twin("wide").forward(x, timesteps, context=context, features_adapter=features_adapter, fps=fps,
+                                             timestep_cond=timestep_cond, **kwargs)
         if features_adapter is not None or timestep_cond is not None:
             raise NotImplementedError("features_adapter / timestep_cond are not used by the DynamicScaler pipelines")
         tracing = x.device.type == "meta"          # python_program_trace: shapes only, ops replaced by recorders
@@ -492,8 +535,11 @@ class UNetModel(nn.Module):
         if pairs and (2 * pairs != B or not any(b.kind == "st" for g in self._inputs for b in g)):
             raise ValueError(f"cfg_pairs={pairs} needs a batch of {2 * pairs} (got {B}) and a SpatialTransformer in the input path")
         if (self.program == "c" and not tracing and self._tap is None and ops._timing_hook is None and isinstance(fps, int)
-                and self.fold_layernorm != "kernel" and x.dtype in ops._DT):
+                and (self.fold_layernorm != "kernel" or self._wide()) and x.dtype in ops._DT):
             return self._forward_c(x, timesteps.contiguous(), context, fps, int(pairs or 0))
+        if self._wide():
+            raise NotImplementedError("the wide operand mode runs through the C launch program only (program='c', an int fps, no taps / "
+                                      "timing hooks): csrc/unet_program.hip")
         # ---- time (+fps) embedding -> per-ResBlock projections in one GEMM ----
         t_emb = ops.timestep_embedding(timesteps, mc)
         e1 = self._linear(t_emb, "time_embed.0", epilogue=DS_EPI_SILU)

@@ -35,8 +35,9 @@ extern "C" {
 
 const char* ds_last_error(void);
 /* ABI version of this header; bumped on any signature or struct-layout change (round 4: 2 -- ds_unet_config gained
- * temporal_selfatt_only, new entry points).  Bindings compare it with the version they were written for and refuse a stale library. */
-#define DS_ABI_VERSION 2
+ * temporal_selfatt_only, new entry points; round 5: 3 -- the wide operand mode's entry points, residual_f32 = 3).  Bindings compare
+ * it with the version they were written for and refuse a stale library. */
+#define DS_ABI_VERSION 3
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -329,6 +330,42 @@ int ds_silu_f16(const void* x, void* y, size_t n, void* stream);
  * the CU before -- timing, once two hipGraphs replay concurrently). */
 int ds_dbg_poison_cu_state(void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The WIDE operand mode (round 5): the same UNet blocks evaluated as an fp32 computation -- every activation stored in fp32, every
+ * matrix product formed from two-term fp16 splits of both operands on the fp16 matrix cores (x = xh + xl / S, S = 2^11; three MFMAs
+ * per fragment pair, cross terms in their own fp32 accumulator; csrc/wide.hip).  The reference computes the UNet in fp32
+ * (openaimodel3d.py:657-708); with single fp16 operands eps is ~1e-3 away from it, which the highest-noise DDIM updates amplify past
+ * the 1e-3 budget on the latent (pipeline/scheduler.py:83-89: config 1's 999 -> 666 update multiplies the guided eps by 1.9).  A
+ * precision mode for those steps (ds_unet_config.residual_f32 = 3), ~3x the matrix-core work of the fp16 modes.
+ * ---------------------------------------------------------------------------------------------- */
+/* S of the split: lo = fp16((x - fp16(x)) * S).  2048. */
+float ds_wide_lo_scale(void);
+/* hi[i] = fp16(x[i]), lo[i] = fp16((x[i] - hi[i]) * S): the two operand planes of a weight matrix (x fp32 or fp16; ds_unet_pack
+ * writes them itself for a handle in the wide mode). */
+int ds_split_f16(const void* x, int x_dtype, void* hi, void* lo, size_t n, void* stream);
+/* ds_gemm_f16's contract (same ds_gemm_desc, A modes and epilogue flags; nn.Linear / Conv2d / Conv3d call sites listed there) with
+ * A fp32 [..][lda] (lda in fp32 elements, multiple of 4), W as two fp16 planes [N][K], fp32 residual [M][ldr], fp32 out [M][ldc]
+ * (DS_EPI_OUT_F32 / DS_EPI_RES_F32 are implied).  GELU by erff, SiLU by expf. */
+int ds_gemm_wide(const float* A, const void* W_hi, const void* W_lo, const float* bias, const float* residual, float* out,
+                 const ds_gemm_desc* desc, void* stream);
+/* GroupNorm(groups) (+ SiLU) with fp32 input rows (stride ldx) and dense fp32 output; statistics in fp64, fixed order
+ * (basics.py:76-86; openaimodel3d.py:275-292).  stats: caller scratch of 2 * ninst * groups floats. */
+int ds_groupnorm_wide(const float* x, int ldx, const float* gamma, const float* beta, float* y, float* stats, int ninst,
+                      int rows_per_inst, int C, int groups, float eps, int silu, void* stream);
+/* nn.LayerNorm(C) over dense fp32 rows, fp32 out (attention.py:199-201). */
+int ds_layernorm_wide(const float* x, const float* gamma, const float* beta, float* y, long rows, int C, float eps, void* stream);
+/* ds_attention_f16 / ds_temporal_attention_f16 on fp32 q / k / v / out, fp32 arithmetic (attention.py:76-127, 281-373). */
+int ds_attention_wide(const float* q, const float* k, const float* v, float* out, int batch, int heads, int nq, int nk, int ldq,
+                      int ldk, int ldv, int ldo, int kv_batch_div, float scale, int accumulate, void* stream);
+int ds_temporal_attention_wide(const float* q, const float* k, const float* v, float* out, int nseq_batches, int T, int hw, int heads,
+                               int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+/* fp32 forms of the glue kernels: timestep_embedding (utils_diffusion.py:8-28), SiLU (openaimodel3d.py:172-178), the context cast,
+ * conv-in patches (openaimodel3d.py:421, 682). */
+int ds_timestep_embedding_f32(const int64_t* t, float* out, int n, int dim, void* stream);
+int ds_silu_f32(const float* x, float* y, size_t n, void* stream);
+int ds_cast_to_f32(const void* x, int x_dtype, float* y, size_t n, void* stream);
+int ds_im2col_in_f32(const void* x, int x_dtype, float* patches, int B, int C, int T, int H, int W, int kpad, void* stream);
+
 /* ---- conditioning producers: OpenCLIP ViT-H/14 towers and the IP-Adapter Resampler ---- */
 /* softmax(q k^T * scale [+ causal mask]) v for head_dim 64 (text tower, open_clip Transformer behind
  * condition.py:216-224; Resampler, ip_resampler.py:62-90) or 80 (image tower, condition.py:358-360); layout as in
@@ -380,7 +417,10 @@ typedef struct ds_unet_config {          /* the yaml keys of unet_config.params 
     int32_t temporal_conv, temporal_attention, addition_attention, use_image_attention, fps_cond;
     int32_t residual_f32;                /* 0: fp16 residual stream; 1: strict mode, the whole stream in fp32 (DS_EPI_RES_F32); 2: fp32
                                             only BETWEEN the blocks (ResBlock / temporal-conv outputs, proj_out + x, conv_in, down /
-                                            up-sample, skip tensors), the transformers keep their fp16 inner stream             */
+                                            up-sample, skip tensors), the transformers keep their fp16 inner stream; 3: the WIDE
+                                            operand mode -- every activation fp32, split-fp16 products (ds_gemm_wide and the
+                                            other *_wide kernels): an fp32 evaluation, for the highest-noise steps; the packed
+                                            buffer then holds a second (lo) plane behind every fp16 matrix                        */
     int32_t fold_layernorm;              /* 1: LayerNorm folded into the projections (ds_gemm_f16_ln); forced off by residual_f32 = 1 */
     int32_t gn_from_producer;            /* 1: the GroupNorms whose input is written by the GEMM right before them take their statistics from
                                             that launch's epilogue (ds_gemm_f16_stats) instead of a pass over the tensor.  The partial sums

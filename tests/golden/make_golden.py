@@ -833,6 +833,53 @@ def g28_ring_real_unet_50step():
         json.dump({"geom": geom, "traces": traces}, f)
 
 
+RING50_MID_SKIP = 20                # g31: the loop entered at step 20 of 50 (schedule indices 29..24, t = 599..497)
+
+
+def g31_ring_real_unet_50step_mid():
+    """P2 in the MIDDLE of the 50-step schedule, on the headline geometry's window grid: the reference's t2v ring loop
+    (pipeline/t2v_sphere_panorama_pipeline.py:481-634) with the REAL t2v UNet on two columns x two rows of BASELINE config 3's
+    grid (512x320 windows, loop_step = 8 like cfg3: the grid moves 1/8 window per step, so from the second recorded step on the
+    right-hand column's windows straddle the W seam), entered through the method's own use_skip_time (:393-396) at step 20:
+    six steps at schedule indices 29..24 from a latent at index 29's noise level; the loop is stopped at the start of the seventh.
+    Panorama latent after steps 0 / 2 / 5 and the pred-x0 panorama after step 5 are stored; 48 forwards of the reference on CPU."""
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"
+    if dry:
+        params = dict(TINY)
+    unet = build_reference_unet(params, seed=0)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 1), synth_normal((1, 77, cd), 2)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    geom = dict(RING_REAL, num_inference_steps=50, loop_step=8)
+    shape = (1, 4, 16, geom["total_h"] // 8, geom["total_w"] // 8)
+    sched = lvdm_DDIM_Scheduler(ld)
+    sched.make_schedule(50)
+    first_index = 49 - RING50_MID_SKIP
+    init = _late_latent(sched, shape, first_index, 2333350)
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+    kw = dict(prompt="a prompt", output_type="latent", fps=8, guidance_scale=7.5, init_panorama_latent=init.clone(),
+              use_skip_time=True, skip_time_step_idx=RING50_MID_SKIP, **geom)
+    torch.manual_seed(2333333)
+    snaps, trace, out = _record_ring_run(lambda: pipe.basic_sample_shift_multi_windows(**kw), RING50_STEPS)
+    assert len(snaps) == RING50_STEPS and out is None
+    A = {"fps": np.int64(8), "guidance": np.float32(7.5), "steps": np.int64(RING50_STEPS), "skip": np.int64(RING50_MID_SKIP),
+         "first_index": np.int64(first_index), "init": init.numpy().astype(np.float16)}
+    assert np.array_equal(A["init"].astype(np.float32), init.numpy())
+    for k, (x, x0) in enumerate(snaps):
+        if k in RING50_LAST_KEPT:
+            A[f"pano_{k}"] = _trim16(x)
+    A[f"x0_{RING50_STEPS - 1}"] = _trim16(snaps[-1][1])
+    if dry:
+        print("dry run ok", [float(np.std(A[f"pano_{k}"])) for k in RING50_LAST_KEPT], trace[:RING50_STEPS][-1])
+        return
+    save_npz("ring_real_unet_50step_mid.npz", **A)
+    with open(os.path.join(HERE, "ring_real_unet_50step_mid_trace.json"), "w") as f:
+        json.dump({"geom": geom, "trace": trace[:RING50_STEPS]}, f)
+
+
 def g29_i2v_ring_real_unet_50step():
     """P3 on the 50-step schedule: the reference's i2v ring loop (pipeline/i2v_sphere_panorama_pipeline.py:777-970) with the REAL
     i2v UNet (77 text + 16 image tokens per window, merge-prev), same geometry and the same two ends as G28
@@ -1648,6 +1695,7 @@ if __name__ == "__main__":
         steps["g27"] = g27_i2v_ring_real_unet
         steps["g28"] = g28_ring_real_unet_50step
         steps["g29"] = g29_i2v_ring_real_unet_50step
+        steps["g31"] = g31_ring_real_unet_50step_mid
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)
