@@ -65,11 +65,14 @@ CONFIGS = {
 }
 
 
-def self_launch(argv, n):
+def self_launch(argv, n, timeout_s):
     """Start the n ranks as a child `torch.distributed.run` and relay rank 0's line.  Called before anything in this
-    process has touched the GPU (no torch.cuda call above): the parent only waits."""
+    process has touched the GPU (no torch.cuda call above): the parent only waits -- at most `timeout_s`: ranks that stall
+    (a collective some rank never enters) are killed as a process group and the parent exits 124 instead of hanging."""
+    import signal
     import socket
     import subprocess
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -77,7 +80,20 @@ def self_launch(argv, n):
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)   # fresh children, own process group
+    timed_out = []
+
+    def kill_group():
+        timed_out.append(True)
+        sys.stderr.write(f"bench.py: the {n}-rank child has not finished within {timeout_s} s (--rank-timeout): killing its process group\n")
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+
+    timer = threading.Timer(timeout_s, kill_group)
+    timer.daemon = True
+    timer.start()
     line = None
     for out in p.stdout:
         if out.lstrip().startswith("{") and '"metric"' in out:
@@ -85,6 +101,9 @@ def self_launch(argv, n):
         else:
             sys.stderr.write(out)
     rc = p.wait()
+    timer.cancel()
+    if timed_out:
+        raise SystemExit(124)
     if line is not None:
         print(line, flush=True)
     if rc != 0 or line is None:
@@ -127,8 +146,18 @@ def main():
     ap.add_argument("--residual", choices=["default", "f16", "f32outer", "f32"], default="default",
                     help="residual-stream storage of the UNet: default = the library's (f32outer: fp32 between the blocks, the cheapest "
                          "mode inside 1e-3 on every asserted bound); f16 = the fast mode; f32 = strict")
-    ap.add_argument("--other-mode", type=int, default=int(os.environ.get("DS_BENCH_OTHER_MODE", "1")),
-                    help="also time the same steps in the other residual mode (fast <-> default) and report both ms/step")
+    ap.add_argument("--other-mode", type=int, default=int(os.environ.get("DS_BENCH_OTHER_MODE", "0")),
+                    help="also time the same steps in the other residual mode (fast <-> default) and report both ms/step (off by "
+                         "default: it repacks the weights twice and runs the timed steps a second time)")
+    ap.add_argument("--other-configs", type=int, default=int(os.environ.get("DS_BENCH_OTHER_CONFIGS", "-1")),
+                    help="after the headline measurement also time the other single-GPU-runnable BASELINE configurations (cfg2, cfg4, "
+                         "cfg5: 1 warm-up + 2 timed steps each, same bracketing) and report them under other_configs; default: yes "
+                         "for the plain `python bench.py` (cfg3, one GPU, not under a profiler)")
+    ap.add_argument("--wide-step", type=int, default=int(os.environ.get("DS_BENCH_WIDE_STEP", "-1")),
+                    help="also time ONE step of the panorama in the wide operand mode (config.wide_step_ms: what a step costs where "
+                         "the operand policy selects it; none of the 50-step schedule's steps at CFG 7.5); default: yes at one GPU")
+    ap.add_argument("--rank-timeout", type=float, default=float(os.environ.get("DS_BENCH_RANK_TIMEOUT", "2400")),
+                    help="seconds after which a rank that has not finished aborts the job with exit code 124 (and says in which phase)")
     ap.add_argument("--share-cfg-prefix", type=int, default=int(os.environ.get("DS_SHARE_CFG", "1")),
                     help="evaluate the context-free UNet prefix once per [cond | uncond] pair (bit-identical result)")
     args = ap.parse_args()
@@ -136,12 +165,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(sys.argv[1:], args.gpus)          # does not return
+        self_launch(sys.argv[1:], args.gpus, args.rank_timeout + 60)          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     cfg = CONFIGS[args.config]
     GEOM, F_UNET = cfg["geom"], cfg["f_unet"]
+    # a rank that stalls (e.g. in a collective another rank never enters) must not hang the job: after --rank-timeout seconds it
+    # says where it is and leaves with 124 (under torch.distributed.run the agent then stops the other ranks)
+    import threading
+    phase = ["init"]
+
+    def _stalled():
+        sys.stderr.write(f"bench.py: rank {rank} stalled in phase '{phase[0]}' for more than {args.rank_timeout:.0f} s: aborting\n")
+        sys.stderr.flush()
+        os._exit(124)
+
+    watchdog = threading.Timer(args.rank_timeout, _stalled)
+    watchdog.daemon = True
+    watchdog.start()
+    if os.environ.get("DS_BENCH_FAULT") in (f"stall:{rank}", "stall:*"):      # fault injection for the tests of the stall path: this rank never arrives
+        phase[0] = "injected stall (DS_BENCH_FAULT)"
+        time.sleep(10 ** 6)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # one rank per GPU over RCCL.  DS_BENCH_DEVICE / DS_DIST_BACKEND exist for the single-GPU rehearsal of the N > 1 path
@@ -165,58 +210,79 @@ def main():
     from dynamicscaler_amd.unet_spec import param_shapes
     from dynamicscaler_amd.synth import synth_state_dict, synth_normal
 
-    yaml_name = {"t2v": "t2v_512_v2_unet.yaml", "i2v": "i2v_512_v1_unet.yaml"}[cfg["model"]]
-    params = yaml.safe_load(open(os.path.join(REPO, "dynamicscaler_amd", "configs", yaml_name)))
-    t0 = time.time()
-    sd = synth_state_dict(param_shapes(params), seed=0)
-    ld = LatentDiffusionHost({"params": params}, conditioner=SyntheticConditioner(77, params["context_dim"]))
-    unet = ld.model.diffusion_model
-    unet.load_state_dict(sd, strict=True)
     MODES = {"f16": (torch.float16, "full"), "f32outer": (torch.float32, "outer"), "f32": (torch.float32, "full")}
+    hosts = {}                 # model kind -> (ld, params, sd | None): built once, shared by the configurations that use it
+
+    def host_for(model, keep_sd=False):
+        if model in hosts:
+            return hosts[model]
+        yaml_name = {"t2v": "t2v_512_v2_unet.yaml", "i2v": "i2v_512_v1_unet.yaml"}[model]
+        params = yaml.safe_load(open(os.path.join(REPO, "dynamicscaler_amd", "configs", yaml_name)))
+        sd = synth_state_dict(param_shapes(params), seed=0)
+        ld = LatentDiffusionHost({"params": params}, conditioner=SyntheticConditioner(77, params["context_dim"]))
+        u = ld.model.diffusion_model
+        u.load_state_dict(sd, strict=True)
+        if args.residual != "default":
+            u.residual_dtype, u.residual_scope = MODES[args.residual]
+        u.prepare(dev)                     # fp16 repack straight to HBM
+        if model == "i2v":
+            # config 4: input/pano_surfing_1.png is absent from the reference tree, so the panorama image is
+            # synthetic; every window takes the 16 image tokens of the crop under it through the REAL conditioning path
+            # (LatentVisualDiffusion.get_image_embeds, ddpm3d.py:689-693): the HIP OpenCLIP ViT-H/14 image tower
+            # (encoders.FrozenOpenCLIPImageEmbedderV2: preprocess + 32 blocks, all 257 tokens) and the Resampler, synthetic
+            # weights, cached per crop position by the pipeline like the product does.
+            from dynamicscaler_amd.encoders import FrozenOpenCLIPImageEmbedderV2, Resampler
+            from dynamicscaler_amd.encoder_spec import CLIP_VIT_H_14, RESAMPLER_I2V, clip_vision_param_shapes, resampler_param_shapes
+            from dynamicscaler_amd.synth import synth_encoder_state_dict
+            ld.embedder = FrozenOpenCLIPImageEmbedderV2()
+            ld.embedder.load_state_dict(synth_encoder_state_dict(clip_vision_param_shapes(CLIP_VIT_H_14["vision"]), 71))
+            ld.image_proj_model = Resampler(**RESAMPLER_I2V)
+            ld.image_proj_model.load_state_dict(synth_encoder_state_dict(resampler_param_shapes(**RESAMPLER_I2V), 72))
+            ld.to(dev)
+        hosts[model] = (ld, params, sd if keep_sd else None)
+        return hosts[model]
+
+    lat_dt = {"f32": torch.float32, "f16": torch.float16}[args.latents]
+
+    def make_pipe(name):
+        """The pipeline of BASELINE configuration `name` on this rank, and begin() -> a fresh ring state on the synthetic panorama."""
+        c = CONFIGS[name]
+        g = c["geom"]
+        ld_, params_, _ = host_for(c["model"])
+        sched_ = lvdm_DDIM_Scheduler(ld_, rng_mode="device")   # Philox noise in-kernel: no host RNG in the timed loop
+        shape = (1, 4, g["frames"] * g["num_windows_f"], g["total_h"] // 8, g["total_w"] // 8)
+        init_ = synth_normal(shape, 2333333).to(dev)
+        extra_ = {}
+        if c["model"] == "i2v":
+            from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano as Pipe
+            extra_ = dict(pano_image_tensor=synth_normal((3, g["total_h"], g["total_w"]), 77).clamp(-1, 1),
+                          overlap_ratio_list_f=[0.0] * g["num_inference_steps"])
+        else:
+            from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano as Pipe
+        pp = Pipe(ld_, sched_, {"params": {"unet_config": {"params": params_}}})
+        pp.to(dev, lat_dt)
+        pp.max_tile_batch = args.tile_batch
+        pp.num_streams = args.streams
+        pp.use_graph = bool(args.graph)
+        pp.share_cfg_prefix = bool(args.share_cfg_prefix)
+
+        def begin():
+            return pp.ring_begin(prompt="a synthetic prompt", fps=8, guidance_scale=7.5, init_panorama_latent=init_, **g, **extra_)
+        return pp, begin, shape
+
+    phase[0] = "setup (weights, repack)"
+    t0 = time.time()
+    ld, params, sd = host_for(cfg["model"], keep_sd=(rank == 0 and not args.no_cpu_baseline and world == 1))
+    unet = ld.model.diffusion_model
 
     def mode_name():
         return "f16" if unet.residual_dtype == torch.float16 else ("f32outer" if unet.residual_scope == "outer" else "f32")
 
-    if args.residual != "default":
-        unet.residual_dtype, unet.residual_scope = MODES[args.residual]
-    unet.prepare(dev)                      # fp16 repack straight to HBM
-    if rank != 0 or args.no_cpu_baseline or world > 1:
-        del sd
     setup_s = time.time() - t0
-
-    sched = lvdm_DDIM_Scheduler(ld, rng_mode="device")   # Philox noise in-kernel: no host RNG in the timed loop
-    vs = 8
-    pano_shape = (1, 4, GEOM["frames"] * GEOM["num_windows_f"], GEOM["total_h"] // vs, GEOM["total_w"] // vs)
-    init = synth_normal(pano_shape, 2333333).to(dev)
-    extra = {}
-    if cfg["model"] == "i2v":
-        # config 4: input/pano_surfing_1.png is absent from the reference tree, so the panorama image is
-        # synthetic; every window takes the 16 image tokens of the crop under it through the REAL conditioning path
-        # (LatentVisualDiffusion.get_image_embeds, ddpm3d.py:689-693): the HIP OpenCLIP ViT-H/14 image tower
-        # (encoders.FrozenOpenCLIPImageEmbedderV2: preprocess + 32 blocks, all 257 tokens) and the Resampler, synthetic
-        # weights, cached per crop position by the pipeline like the product does.
-        from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano as Pipe
-        from dynamicscaler_amd.encoders import FrozenOpenCLIPImageEmbedderV2, Resampler
-        from dynamicscaler_amd.encoder_spec import CLIP_VIT_H_14, RESAMPLER_I2V, clip_vision_param_shapes, resampler_param_shapes
-        from dynamicscaler_amd.synth import synth_encoder_state_dict
-
-        ld.embedder = FrozenOpenCLIPImageEmbedderV2()
-        ld.embedder.load_state_dict(synth_encoder_state_dict(clip_vision_param_shapes(CLIP_VIT_H_14["vision"]), 71))
-        ld.image_proj_model = Resampler(**RESAMPLER_I2V)
-        ld.image_proj_model.load_state_dict(synth_encoder_state_dict(resampler_param_shapes(**RESAMPLER_I2V), 72))
-        ld.to(dev)
-        extra = dict(pano_image_tensor=synth_normal((3, GEOM["total_h"], GEOM["total_w"]), 77).clamp(-1, 1),
-                     overlap_ratio_list_f=[0.0] * GEOM["num_inference_steps"])
-    else:
-        from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano as Pipe
-    pipe = Pipe(ld, sched, {"params": {"unet_config": {"params": params}}})
-    lat_dt = {"f32": torch.float32, "f16": torch.float16}[args.latents]
-    pipe.to(dev, lat_dt)
-    pipe.max_tile_batch = args.tile_batch
-    pipe.num_streams = args.streams
-    pipe.use_graph = bool(args.graph)
-    pipe.share_cfg_prefix = bool(args.share_cfg_prefix)
-    st = pipe.ring_begin(prompt="a synthetic prompt", fps=8, guidance_scale=7.5, init_panorama_latent=init, **GEOM, **extra)
+    pipe, begin_state, pano_shape = make_pipe(args.config)
+    sched = pipe.scheduler
+    st = begin_state()
+    wide_steps_of_schedule = pipe.wide_steps_of(GEOM["num_inference_steps"], 7.5)
 
     def barrier():
         if world > 1:
@@ -231,38 +297,79 @@ def main():
             ver = ".".join(map(str, torch.cuda.nccl.version()))
         except Exception:
             ver = "?"
+        props = torch.cuda.get_device_properties(dev)
+        pci = getattr(props, "pci_bus_id", None)
+        if pci is not None:
+            pci = f"{getattr(props, 'pci_domain_id', 0):04x}:{pci:02x}:{getattr(props, 'pci_device_id', 0):02x}"
         mine = {"rank": rank, "device": dev_index, "name": torch.cuda.get_device_name(dev), "backend": dist.get_backend(),
-                "rccl": ver, "pci": torch.cuda.get_device_properties(dev).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev), "pci_bus_id") else None}
+                "rccl": ver, "pci": pci, "uuid": str(getattr(props, "uuid", "")) or None}
         ranks_seen = [None] * world
+        phase[0] = "rank census (all_gather_object + all_reduce)"
         dist.all_gather_object(ranks_seen, mine)
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)                       # a device collective over the same group: must count every rank
         assert int(probe.item()) == world, f"all_reduce saw {int(probe.item())} ranks, expected {world}"
+        # one rank per GPU: N distinct devices (by PCI address where torch reports it, else by device index).  The single-GPU
+        # rehearsal of the N > 1 path (DS_BENCH_DEVICE: every rank on one GPU, tests/test_gpu_multirank.py) is the one exception.
+        if "DS_BENCH_DEVICE" not in os.environ:
+            ids = [r.get("pci") or r.get("uuid") or f"index {r['device']}" for r in ranks_seen]
+            assert len(set(ids)) == world, f"{world} ranks on {len(set(ids))} distinct GPUs: {ids}"
+
+    import hashlib as _hl
+
+    def max_over_ranks(x):
+        if world > 1:
+            tt = torch.tensor([x], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            return float(tt.item())
+        return x
+
+    def timed_steps(pp, state, first, warmup, steps, nsched_):
+        """W untimed + K timed steps from step index `first`, bracketed by barrier + synchronize, max over ranks -> (seconds, next index)."""
+        k = first
+        for _ in range(warmup):
+            pp.ring_step(state, k % nsched_)
+            k += 1
+        barrier()
+        t_ = time.perf_counter()
+        for _ in range(steps):
+            pp.ring_step(state, k % nsched_)
+            k += 1
+        barrier()
+        return max_over_ranks(time.perf_counter() - t_), k
 
     nsched = GEOM["num_inference_steps"] - 1      # steps 0..48 re-noise the overlaps; the last step of a schedule does not,
-    step_idx = 0                                  # so a run longer than one panorama wraps around before it
-    for _ in range(args.warmup):
-        pipe.ring_step(st, step_idx % nsched)
-        step_idx += 1
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.ring_step(st, step_idx % nsched)
-        step_idx += 1
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    phase[0] = "warm-up + timed steps"            # so a run longer than one panorama wraps around before it
+    elapsed, step_idx = timed_steps(pipe, st, 0, args.warmup, args.steps, nsched)
     assert bool(torch.isfinite(st.pano.float()).all()), "non-finite latent after the timed steps"
+    assert pipe.wide_steps_run == [] or pipe.operand_policy != "auto", pipe.wide_steps_run
     # what the job computed, so that runs can be compared: the panorama latent after warmup + timed steps is a function of
     # (config, warmup, steps, latents, residual mode) only -- not of --gpus, --tile-batch, --streams or --graph (rank sharding
     # and batching are bit-exact: tests/test_gpu_fullsize.py, test_gpu_multirank.py)
-    import hashlib as _hl
     digests = {"latent_after_timed_steps": _hl.sha256(st.pano.float().cpu().numpy().tobytes()).hexdigest()[:16]}
     ms_per_step = 1e3 * elapsed / args.steps
     steps_per_s = args.steps / elapsed
+
+    # ---- per-rank account of ONE more (untimed) step: what each rank computed, how long it worked before it entered the step's
+    #      exchange(s) and how long it sat in them (device-synchronised around every exchange: wait for the slowest rank included).
+    #      A first real N-GPU run reads straight off this which rank is slow and whether compute or the exchange is. ----
+    from dynamicscaler_amd import parallel
+    phase[0] = "per-rank instrumented step"
+    barrier()
+    prof = parallel.profile_begin()
+    t_ = time.perf_counter()
+    pipe.ring_step(st, step_idx % nsched)
+    torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t_
+    parallel.profile_end()
+    step_idx += 1
+    mine_rank = {"rank": rank, "step_ms": round(1e3 * t_rank, 2), "compute_ms": round(1e3 * (t_rank - prof["exchange_s"]), 2),
+                 "exchange_ms": round(1e3 * prof["exchange_s"], 2), "exchanges": prof["exchanges"], "exchange_bytes_sent": prof["exchange_bytes"],
+                 "tiles_owned": prof["tiles_owned"], "eval_units_owned": prof["units_owned"], "share_mode": getattr(st, "share_mode", None)}
+    per_rank = [mine_rank]
+    if world > 1:
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine_rank)
 
     # ---- the metric's second figure, measured: one complete 50-step panorama (steps 0..49, the last one without re-noise),
     #      fresh state, same mode as the timed steps; bracketed like the timed region, max over ranks ----
@@ -271,17 +378,14 @@ def main():
     # profiler's own tool thread; --full-panorama 1 still forces it
     profiled = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in os.environ)
     if args.full_panorama > 0 or (args.full_panorama < 0 and args.config != "cfg5" and not profiled):
-        st2 = pipe.ring_begin(prompt="a synthetic prompt", fps=8, guidance_scale=7.5, init_panorama_latent=init, **GEOM, **extra)
+        phase[0] = "complete 50-step panorama"
+        st2 = begin_state()
         barrier()
         t0 = time.perf_counter()
         for i in range(GEOM["num_inference_steps"]):
             pipe.ring_step(st2, i)
         barrier()
-        full_s = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([full_s], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            full_s = float(tt.item())
+        full_s = max_over_ranks(time.perf_counter() - t0)
         assert bool(torch.isfinite(st2.pano_x0.float()).all()), "non-finite pred_x0 panorama after the 50-step run"
         digests["pred_x0_of_the_50_step_panorama"] = _hl.sha256(st2.pano_x0.float().cpu().numpy().tobytes()).hexdigest()[:16]
         del st2
@@ -294,22 +398,9 @@ def main():
     if args.other_mode and not profiled and timed_mode in ("f16", "f32outer"):
         other = "f16" if timed_mode == "f32outer" else "f32outer"
         unet.residual_dtype, unet.residual_scope = MODES[other]
-        st3 = pipe.ring_begin(prompt="a synthetic prompt", fps=8, guidance_scale=7.5, init_panorama_latent=init, **GEOM, **extra)
-        k = 0
-        for _ in range(max(1, args.warmup)):
-            pipe.ring_step(st3, k % nsched)
-            k += 1
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.ring_step(st3, k % nsched)
-            k += 1
-        barrier()
-        t_other = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([t_other], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            t_other = float(tt.item())
+        phase[0] = "other residual mode"
+        st3 = begin_state()
+        t_other, _ = timed_steps(pipe, st3, 0, max(1, args.warmup), args.steps, nsched)
         mode_ms[other] = round(1e3 * t_other / args.steps, 2)
         del st3
         unet.residual_dtype, unet.residual_scope = MODES[timed_mode]
@@ -453,9 +544,58 @@ def main():
                                       "FLOPs are lower -- `achieved` above counts executed GEMM FLOPs only",
         }
 
+    # ---- one step of the same panorama in the WIDE operand mode (outside the reported region): what a step costs where the operand
+    #      policy selects it -- none of the 50-step schedule at CFG 7.5 (config.wide_steps_of_schedule), config 1's first three ----
+    wide_step_ms = None
+    if (args.wide_step > 0 or (args.wide_step < 0 and world == 1 and not profiled)) and args.config != "cfg5":
+        phase[0] = "wide-mode step"
+        pipe.num_streams, pipe.use_graph = args.streams, False
+        pol = pipe.operand_policy
+        pipe.operand_policy = "wide"
+        try:
+            stw = begin_state()
+            pipe.ring_step(stw, 0)             # packs the twin's hi + lo planes, loads the kernels
+            barrier()
+            t_ = time.perf_counter()
+            pipe.ring_step(stw, 1)
+            barrier()
+            wide_step_ms = round(1e3 * max_over_ranks(time.perf_counter() - t_), 1)
+            assert bool(torch.isfinite(stw.pano.float()).all())
+            del stw
+        finally:
+            pipe.operand_policy = pol
+        unet._twins.clear()                    # the twin's 5.3 GB of planes are not needed any more
+        torch.cuda.empty_cache()
+
+    # ---- the other BASELINE configurations one GPU can run (cfg2 / cfg4 / cfg5): W = 1 + K = 2 steps each, same bracketing, so
+    #      that the driver's record holds a figure for every configuration, not only the headline's ----
+    other_configs = None
+    if args.other_configs > 0 or (args.other_configs < 0 and world == 1 and args.config == "cfg3" and not profiled):
+        other_configs = {}
+        pipe.num_streams, pipe.use_graph = args.streams, bool(args.graph)
+        pipe._graphs.clear()
+        torch.cuda.empty_cache()
+        for name in ("cfg2", "cfg4", "cfg5"):
+            if name == args.config:
+                continue
+            phase[0] = f"other configuration {name}"
+            t_setup = time.time()
+            pp, begin_o, _shape = make_pipe(name)
+            so = begin_o()
+            g_ = CONFIGS[name]["geom"]
+            t_o, _k = timed_steps(pp, so, 0, 1, 2, g_["num_inference_steps"] - 1)
+            assert bool(torch.isfinite(so.pano.float()).all()), name
+            other_configs[name] = {"workload": CONFIGS[name]["label"], "ms_per_step": round(1e3 * t_o / 2, 2), "value": round(2 / t_o, 4),
+                                   "unit": "denoising-steps/sec", "steps": 2, "warmup": 1, "tiles_per_step": g_["num_windows_w"] * g_["num_windows_h"],
+                                   "residual_mode": timed_mode, "setup_s": round(time.time() - t_setup - t_o, 1),
+                                   "result_sha256": _hl.sha256(so.pano.float().cpu().numpy().tobytes()).hexdigest()[:16]}
+            del pp, so, begin_o
+            torch.cuda.empty_cache()
+
     # ---- CPU baseline: the oracle on this host, bounded sample ----
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        phase[0] = "cpu baseline"
         from oracle.unet import unet_forward
         from oracle import ring as oring, ddim as oddim
         ncpu = usable_cpus()
@@ -500,6 +640,13 @@ def main():
                        "rng": "philox in-kernel (perf mode)",
                        "latents": "fp32 (as the reference)" if args.latents == "f32" else "fp16",
                        "residual_mode": timed_mode, "ms_per_step_by_residual_mode": mode_ms,
+                       # which steps of the schedule the operand policy evaluates in the wide mode (fp32 storage, split-fp16 products:
+                       # csrc/wide.hip) -- by schedule index, per DDIM step; [] = every step on single fp16 operands -- and what one
+                       # such step of this panorama costs (measured outside the reported region)
+                       "operand_policy": pipe.operand_policy, "wide_steps_of_schedule": wide_steps_of_schedule,
+                       "operand_mode_per_step": "f16 operands at every step of the 50-step schedule" if not wide_steps_of_schedule else
+                                                f"wide at schedule indices {wide_steps_of_schedule}, f16 operands elsewhere",
+                       "wide_step_ms": wide_step_ms,
                        "residual_stream": ("fp16 (matrix-core operands are fp16 in every mode)" if unet.residual_dtype == torch.float16 else
                                            "fp32 between the blocks, fp16 inside the transformers (DS_RESIDUAL_DTYPE=f32outer)"
                                            if unet.residual_scope == "outer" else "fp32 everywhere (strict precision mode, DS_RESIDUAL_DTYPE=f32)"),
@@ -514,11 +661,17 @@ def main():
             # --config / --warmup / --steps (the N-GPU job computes the 1-GPU panorama, bit for bit)
             "result_sha256": digests,
             "ranks_seen": ranks_seen,
+            # one instrumented step after the timed region, per rank: compute_ms = its own work up to (and between) the exchanges,
+            # exchange_ms = time inside the collectives including the wait for the slowest rank
+            "per_rank": per_rank,
+            "other_configs": other_configs,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))
+    phase[0] = "teardown"
     if world > 1:
         torch.distributed.destroy_process_group()
+    watchdog.cancel()
 
 
 if __name__ == "__main__":

@@ -100,7 +100,6 @@ SIGNATURES = {
     "ds_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ds_clip_preprocess": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ds_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "ds_dbg_poison_cu_state": (_i, [_vp]),
     "ds_cast_to_f16": (_i, [_vp, _i, _vp, _sz, _vp]),
     "ds_wide_lo_scale": (_f, []),
     "ds_split_f16": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
@@ -164,6 +163,18 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    return lib
+
+
+DIAG_LIB = os.path.join(HERE, "libdynscaler_diag.so")
+
+
+def load_diag():
+    """The diagnostics library (csrc/diag.hip: ds_dbg_poison_cu_state) -- tests / tools only, never the product path."""
+    if not os.path.exists(DIAG_LIB):
+        raise HipLibraryMissing(f"{DIAG_LIB} not found: build it with `python -m dynamicscaler_amd.build`")
+    lib = C.CDLL(DIAG_LIB)
+    lib.ds_dbg_poison_cu_state.restype, lib.ds_dbg_poison_cu_state.argtypes = _i, [_vp]
     return lib
 
 

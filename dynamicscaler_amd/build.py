@@ -34,7 +34,10 @@ def _newer(src_list, target):
 
 # diagnostic variants of the library (same ABI, loaded through DS_HIP_LIBRARY by tests/hazard_probe.py only):
 # "barebarrier" = round 1's K-step barrier without the lgkmcnt(0) in front of it (profiles/r2_notes.md)
-VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"], "attnplain": ["-DDS_ATTN_NO_XCD_REMAP"], "nt0": ["-DDS_EXP_NT=0", "-DDS_EXP_STREAM_NT=0"],
+VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"],
+            # the tuning / diagnostic environment switches (DS_GEMM_TILE, DS_GEMM_GROUP_M, DS_GEMM_BIG_MIN, DS_CONV_TAPS_INNER, DS_ATTN_QB,
+            # DS_TATTN_VALU, DS_GN_SPARSE_WGS, DS_GN_CHUNK_RULE): compiled out of the product, read by this variant (csrc/common.h)
+            "tune": ["-DDS_TUNING_ENV=1"], "attnplain": ["-DDS_ATTN_NO_XCD_REMAP"], "nt0": ["-DDS_EXP_NT=0", "-DDS_EXP_STREAM_NT=0"],
             "attnnarrow": ["-DDS_ATTN_NARROW_STORES"],
             "attn4": ["-DDS_ATTN_WGS=4"], "attn2": ["-DDS_ATTN_WGS=2"],
             "attnvt": ["-DDS_ATTN_TRV=0"],     # V transposed on its way into LDS (rounds 1-3) instead of transposing LDS reads
@@ -91,6 +94,20 @@ def build(force=False, verbose=True, variant=None):
     return lib
 
 
+def build_diag(verbose=True):
+    """libdynscaler_diag.so (csrc/diag.hip): diagnostics outside the product ABI (the LDS / register poison launch of the test suite)."""
+    src = os.path.join(CSRC, "diag.hip")
+    lib = os.path.join(HERE, "libdynscaler_diag.so")
+    if _newer([src], lib):
+        cmd = [HIPCC, "-O2", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", "-x", "hip", src, "-o", lib]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose and (r.stdout or r.stderr):
+            sys.stderr.write(r.stdout + r.stderr)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    return lib
+
+
 def build_examples(verbose=True):
     """examples/unet_host: a C++ host of the UNet that uses only include/dynscaler_hip.h and the HIP runtime (the non-Python
     boundary of ds_unet_*); tests/test_gpu_unet_c.py runs it.  Rebuilt when its source, the header or the library is newer."""
@@ -114,6 +131,7 @@ if __name__ == "__main__":
     v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
     print(build(force="--force" in sys.argv, variant=v))
     if v is None:
+        print(build_diag())
         print(build_examples())
         for name in VARIANTS:          # variant libraries already in the tree are kept in step with the sources (a stale one is refused at load)
             if os.path.exists(os.path.join(HERE, f"libdynscaler_hip_{name}.so")):

@@ -595,7 +595,7 @@ extern "C" int ds_attention_f16(const void* q, const void* k, const void* v, voi
     DS_CHECK_ARG(ldq >= heads * HD && ldk >= heads * HD && ldv >= heads * HD && ldo >= heads * HD, "ds_attention_f16: row stride < heads*64");
     hipStream_t st = (hipStream_t)stream;
     const float scale_log2 = scale * 1.4426950408889634f;
-    static const int force_qb = getenv("DS_ATTN_QB") ? atoi(getenv("DS_ATTN_QB")) : 0;
+    const int force_qb = (int)DS_TUNE_INT("DS_ATTN_QB", 0);
     // QB=1 (128 queries / workgroup, 2 waves per SIMD) measured faster than QB=2 at every UNet shape (round 1)
     if (force_qb == 2) {
         const int q_tiles = ds_cdiv(nq, 256);
@@ -620,7 +620,7 @@ extern "C" int ds_temporal_attention_f16(const void* q, const void* k, const voi
     hipStream_t st = (hipStream_t)stream;
     const long items = (long)nseq_batches * hw * heads;
     const int grid = (int)((items + 3) / 4);
-    static const int valu_kernel = getenv("DS_TATTN_VALU") ? atoi(getenv("DS_TATTN_VALU")) : 0;   // diagnostic
+    const int valu_kernel = (int)DS_TUNE_INT("DS_TATTN_VALU", 0);   // diagnostic ("tune" build variant)
     if (T <= 16 && !valu_kernel)
         temporal_attention_mfma_kernel<1><<<grid, 256, 0, st>>>((const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, items, T, hw, heads, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f);
     else if (!valu_kernel)

@@ -52,3 +52,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 
 static inline int ds_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Tuning / diagnostic switches.  The PRODUCT library has none: every choice below is a compile-time constant, so no environment
+// variable can change its speed or its bits.  The "tune" build variant (python -m dynamicscaler_amd.build --variant tune, loaded by
+// the A/B tools through DS_HIP_LIBRARY) compiles with DS_TUNING_ENV and reads the named variable once per process instead.
+#ifdef DS_TUNING_ENV
+#include <stdlib.h>
+#define DS_TUNE_INT(name, dflt) ([]() -> long { static const long v_ = getenv(name) ? atol(getenv(name)) : (long)(dflt); return v_; }())
+#else
+#define DS_TUNE_INT(name, dflt) ((long)(dflt))
+#endif

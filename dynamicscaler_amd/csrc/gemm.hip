@@ -1230,6 +1230,16 @@ gemm_f16_kernel(GemmArgs) {
 
 struct StatOut { float2* p = nullptr; int ld = 0; };   // ds_gemm_f16_stats: where the per-column partial statistics go
 
+// CUs the persistent tiles are spread over (a multiple of 8, so that v % 8 keeps naming the XCD)
+static int device_cus() {
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        return n / 8 * 8;
+    }();
+    return ncu;
+}
+
 template <int BM, int BN, int WGM, int WGN, int AMODE, int NS = 2>
 int launch(const void* A, const void* W, const float* bias, const void* residual, void* out,
            const ds_gemm_desc& d, hipStream_t st, const float* ln_stats, const float* ln_colsum, float ln_eps, StatOut so = StatOut()) {
@@ -1248,7 +1258,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
     }
     const int tiles_m = ds_cdiv(d.M, BM), tiles_n = ds_cdiv(d.N, BN);
     // grouped walk for wide one-workgroup-per-CU launches (see the kernel); DS_GEMM_GROUP_M: 0 = never (A/B runs)
-    static const int group_env = getenv("DS_GEMM_GROUP_M") ? atoi(getenv("DS_GEMM_GROUP_M")) : 6;
+    const int group_env = (int)DS_TUNE_INT("DS_GEMM_GROUP_M", 6);
     const int group_m = (Cfg::WG_PER_CU == 1 && tiles_n >= 16 && group_env > 1) ? group_env : 1;   // 10 N tiles (2560 x 320): no gain, -2 % at M = 327680
     // buffer-load addressing is 32-bit and offset 2^31 marks 'out of range': the A operand and W must each stay below 2 GiB
     const long a_rows = (AMODE == DS_A_CONV3 || AMODE == A_CONV3_TI) ? (long)d.nimg * d.hin * d.win : (long)d.M;
@@ -1259,11 +1269,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
         return DS_EINVAL;
     }
     // TileCfg::OVERLAP: one persistent workgroup per CU (a multiple of 8, so that v % 8 keeps naming the XCD)
-    static const int ncu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        return n / 8 * 8;
-    }();
+    const int ncu = device_cus();
     const int nblk = tiles_m * tiles_n;
     const int grid = (Cfg::OVERLAP && nblk > ncu) ? ncu : nblk;
     GemmArgs ka;
@@ -1283,7 +1289,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
 enum { TILE_128x64 = 0, TILE_128x128 = 1, TILE_256x256 = 2, TILE_256x320 = 3, TILE_128x128_DEEP = 4, TILE_128x64_DEEP = 5 };
 
 int choose_tile(const ds_gemm_desc& d) {
-    static const int forced = getenv("DS_GEMM_TILE") ? atoi(getenv("DS_GEMM_TILE")) : -1;
+    const int forced = (int)DS_TUNE_INT("DS_GEMM_TILE", -1);
     const bool geglu = d.epilogue & DS_EPI_GEGLU;
     const int waste128 = ds_cdiv(d.N, 128) * 128 - d.N;
     const int small = (geglu || waste128 * 8 <= d.N) ? TILE_128x128 : TILE_128x64;
@@ -1304,7 +1310,7 @@ int choose_tile(const ds_gemm_desc& d) {
     if (big < 0) return small_or_deep;
     if (forced == TILE_256x256 || forced == TILE_256x320) return big;
     const long nblk = tiles_m256 * (d.N / (big == TILE_256x256 ? 256 : 320));
-    static const long big_min = getenv("DS_GEMM_BIG_MIN") ? atol(getenv("DS_GEMM_BIG_MIN")) : 160;
+    const long big_min = DS_TUNE_INT("DS_GEMM_BIG_MIN", 160);
     return nblk >= big_min ? big : small_or_deep;
 }
 
@@ -1369,6 +1375,37 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
     }
     hipStream_t st = (hipStream_t)stream;
     const int tile = choose_tile(d);
+    // A persistent big-tile launch whose LAST round of tiles fills less than half of the CUs -- the [cond | uncond] pair of one window
+    // that an 8-GPU rank evaluates per level: 81920 rows = 320 row tiles on 256 CUs, a second round a quarter full, two rounds of time
+    // for 1.25 rounds of work -- is cut along M: the rows of the full rounds go to the big tiles (exactly one tile per CU and round),
+    // the remaining rows to a second launch with the tile chosen for THEIR count (small tiles, two workgroups per CU).  Every tile
+    // variant sums K in the same order, so the result does not depend on the cut (batch invariance, result_sha256 unchanged).
+    if (d.a_mode == DS_A_DENSE && DS_PERSIST != 0 && (tile == TILE_256x256 || tile == TILE_256x320) && !so.p && (!bias || d.bias_rows > d.M) &&
+        ((long)d.M - 1) * d.lda * 2 + (long)d.cin * 2 < 0x7FFF0000L && DS_TUNE_INT("DS_GEMM_TAIL_SPLIT", 1) != 0) {
+        const long tiles_n = d.N / (tile == TILE_256x256 ? 256 : 320), tiles_m = ds_cdiv(d.M, 256);
+        const long nblk = tiles_m * tiles_n, ncu = device_cus();
+        const long rounds = nblk / ncu, rem = nblk % ncu;
+        if (rounds >= 1 && rem > 0 && 2 * rem < ncu && (rounds * ncu) % tiles_n == 0) {
+            const long r_main = rounds * ncu / tiles_n * 256;          // < M: rem > 0
+            const long out_elt = (d.epilogue & DS_EPI_OUT_F32) ? 4 : 2, res_elt = (d.epilogue & DS_EPI_RES_F32) ? 4 : 2;
+            const long n_out = (d.epilogue & DS_EPI_GEGLU) ? d.N / 2 : d.N;
+            (void)n_out;
+            for (int part = 0; part < 2; ++part) {
+                const long r0 = part ? r_main : 0;
+                ds_gemm_desc c = d;
+                c.M = (int)(part ? d.M - r_main : r_main);
+                const int tl = part ? choose_tile(c) : tile;
+                const char* a_p = (const char*)A + r0 * d.lda * 2;
+                const char* r_p = residual ? (const char*)residual + r0 * d.ldr * res_elt : nullptr;
+                char* o_p = (char*)out + r0 * d.ldc * out_elt;
+                int rc = ln_stats ? dispatch<A_DENSE_LN>(tl, a_p, W, bias, r_p, o_p, c, st, ln_stats + 2 * r0, ln_colsum)
+                         : ln_colsum ? dispatch<A_DENSE_LNK>(tl, a_p, W, bias, r_p, o_p, c, st, nullptr, ln_colsum, ln_eps)
+                                  : dispatch<DS_A_DENSE>(tl, a_p, W, bias, r_p, o_p, c, st);
+                if (rc) return rc;
+            }
+            return DS_OK;
+        }
+    }
     // 32-bit buffer addressing with offset 2^31 as the 'out of range' marker: an A operand of 2 GiB or more (dense
     // only: e.g. the 2048-wide FF hidden of init_attn at 655k rows) is processed in row chunks.
     if (d.a_mode == DS_A_DENSE && ((long)d.M - 1) * d.lda * 2 + (long)d.cin * 2 >= 0x7FFF0000L) {
@@ -1396,7 +1433,7 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
         // taps innermost where the tap-major order thrashes the L2 (large images: a workgroup's rows x all channels no longer
         // fit next to its 31 neighbours'): level-1 tiles 40x64 fetch 0.57 GB instead of 3.8 GB per launch and run 2.5 % faster;
         // on the 20x32 / 10x16 levels L2 already caught the reuse and the per-K-step select costs 1-3 % (gpurun_out/conv)
-        static const int ti_mode = getenv("DS_CONV_TAPS_INNER") ? atoi(getenv("DS_CONV_TAPS_INNER")) : -1;   // A/B: 0 never, 1 always
+        const int ti_mode = (int)DS_TUNE_INT("DS_CONV_TAPS_INNER", -1);   // A/B ("tune" build variant): 0 never, 1 always
         const bool taps_inner = ti_mode < 0 ? (long)d.hin * d.win >= 2048 : ti_mode > 0;
         if (taps_inner && d.stride == 1 && !d.upsample && !d.asym_pad) return dispatch<A_CONV3_TI>(tile, A, W, bias, residual, out, d, st, nullptr, nullptr, 0.0f, so);
         return dispatch<DS_A_CONV3>(tile, A, W, bias, residual, out, d, st, nullptr, nullptr, 0.0f, so);

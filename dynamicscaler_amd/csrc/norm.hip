@@ -25,11 +25,7 @@ constexpr int GN_CHUNK_ROWS_MIN = 64;
 static inline int gn_chunk_rows(int rows_per_inst, int C) {
     // diagnostic: 0 = 256 rows everywhere (rounds 1-2), 2 = 256 / 256 / 128.  It CHANGES the summation order, i.e. the bits: said once on
     // stderr when set, so that a stray value on one rank does not go unnoticed (that rank's replica would differ in the last bits)
-    static const int rule = [] {
-        const char* e = getenv("DS_GN_CHUNK_RULE");
-        if (e) fprintf(stderr, "[dynscaler_hip] DS_GN_CHUNK_RULE=%s: GroupNorm partial sums are chunked differently from the default (results differ in the last bits)\n", e);
-        return e ? atoi(e) : 1;
-    }();
+    const int rule = (int)DS_TUNE_INT("DS_GN_CHUNK_RULE", 1);       // ("tune" build variant only)
     if (rule == 0) return GN_CHUNK_ROWS_MAX;
     const int by_c = rule == 2 ? (C <= 640 ? 256 : 128) : (C <= 320 ? 256 : (C <= 640 ? 128 : 64));
     int by_rows = GN_CHUNK_ROWS_MIN;
@@ -587,7 +583,7 @@ int groupnorm_rows(const XT* x, int ldx, const float* gamma, const float* beta, 
     // gn_partial_kernel) and how the rows of an instance are split over the apply's workgroups (elementwise; 256 rows per
     // workgroup on a dense grid, down to 32 where the launch would not give every CU two workgroups).
     constexpr int US = sizeof(XT) == 2 ? GN_U_SPARSE : GN_U_SPARSE / 2;
-    static const int sparse_max = getenv("DS_GN_SPARSE_WGS") ? atoi(getenv("DS_GN_SPARSE_WGS")) : GN_SPARSE_WGS;   // 0: dense-grid forms only (diagnostic)
+    const int sparse_max = (int)DS_TUNE_INT("DS_GN_SPARSE_WGS", GN_SPARSE_WGS);   // 0: dense-grid forms only (diagnostic, "tune" build variant)
     int apply_rows = GN_CHUNK_ROWS_MAX;
     if (sparse_max > 0)
         while (apply_rows > 32 && (long)((rows_per_inst + apply_rows - 1) / apply_rows) * ninst < 512) apply_rows /= 2;

@@ -107,6 +107,48 @@ def share_counts(n_items, world):
 
 _HOST_STAGED = False
 _FORCE_LEVELS = False      # share_mode("levels"): always share every level out (diagnostics / A-B runs)
+_PROFILE = None            # profile_begin(): per-rank account of one step (bench.py's per_rank diagnostics)
+
+
+def profile_begin():
+    """Start accounting the steps that follow on THIS rank: tiles / evaluation units it computes, number of exchanges and the time
+    it spends in them (device-synchronised around every exchange, so the figure includes the wait for the slowest rank -- the
+    diagnostic: a rank with little compute and a long exchange is waiting for others).  Diagnostic runs only: the
+    synchronisations serialise what a normal step overlaps."""
+    global _PROFILE
+    _PROFILE = {"tiles_owned": 0, "units_owned": 0, "exchanges": 0, "exchange_s": 0.0, "exchange_bytes": 0}
+    return _PROFILE
+
+
+def profile_end():
+    global _PROFILE
+    out, _PROFILE = _PROFILE, None
+    return out
+
+
+def _sync():
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+
+
+def _account(kind, n):
+    if _PROFILE is not None:
+        _PROFILE[kind] += int(n)
+
+
+def _exchange(fn, *tensors):
+    """Run one collective exchange; under profile_begin() bracket it with device synchronisations and a host clock."""
+    if _PROFILE is None:
+        return fn()
+    import time
+    _sync()
+    t0 = time.perf_counter()
+    out = fn()
+    _sync()
+    _PROFILE["exchange_s"] += time.perf_counter() - t0
+    _PROFILE["exchanges"] += 1
+    _PROFILE["exchange_bytes"] += sum(int(t.numel()) * t.element_size() for t in tensors if torch.is_tensor(t))
+    return out
 
 
 def share_mode(mode):
@@ -200,6 +242,7 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
     levels = plan_levels(windows, pano_fhw)
     if world <= 1:
         for level in levels:
+            _account("tiles_owned", len(level))
             xp, x0 = process(level)
             scatter(level, xp, x0)
         return "single"
@@ -209,6 +252,7 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
         for level in levels:
             ids = [j for j in level if owner[j] == rank]
             if ids:
+                _account("tiles_owned", len(ids))
                 xp, x0 = process(ids)
                 scatter(ids, xp, x0)                     # own tiles: visible to this rank's later levels at once
                 mine_xp.append(xp)
@@ -218,7 +262,7 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
         counts = [sum(len(ids) for ids in by_level[r]) for r in range(world)]
         xp_l = torch.cat(mine_xp, 0) if mine_xp else empty_tiles()
         x0_l = torch.cat(mine_x0, 0) if mine_x0 else empty_tiles()
-        parts = all_gather_tiles(xp_l, x0_l, counts, group)    # the step's ONE exchange
+        parts = _exchange(lambda: all_gather_tiles(xp_l, x0_l, counts, group), xp_l, x0_l)    # the step's ONE exchange
         # the other ranks' tiles go into this replica LEVEL BY LEVEL: one scatter call only ever holds pairwise-disjoint
         # windows (a component's later level overwrites part of its earlier one, and a batched scatter has no order)
         for li in range(len(levels)):
@@ -242,14 +286,16 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
             n, nb = len(level), units.branches
             ctx = units.prepare(level)
             mine = unit_share(n, nb, rank, world)
+            _account("units_owned", len(mine))
             e_local = units.eps(ctx, mine)
-            e_all = exchange_units(e_local, n * nb, group)
+            e_all = _exchange(lambda: exchange_units(e_local, n * nb, group), e_local)
             xp_all, x0_all = units.finish(ctx, e_all.view((n, nb) + tuple(e_all.shape[1:])))
             scatter(level, xp_all, x0_all)
             continue
         ids = rank_share(level, rank, world)
+        _account("tiles_owned", len(ids))
         xp, x0 = process(ids) if ids else (empty_tiles(), empty_tiles())
-        xp_all, x0_all = exchange_level(xp, x0, len(level), group)
+        xp_all, x0_all = _exchange(lambda: exchange_level(xp, x0, len(level), group), xp, x0)
         scatter(level, xp_all, x0_all)
     return mode
 

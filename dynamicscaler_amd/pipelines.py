@@ -29,6 +29,11 @@ def select_prompt_from_multi_prompt_dict_by_factor(prompt_dict, factor):
     return prompt_dict[keys[-1]]
 
 
+# relative error of the CFG-combined eps (guidance 7.5) at t = 999 -- where it is largest -- per residual mode of the fp16-operand
+# UNet, measured against the reference on MI355X (profiles/r4_measured_parity.jsonl, tests/test_gpu_fullsize.py)
+GUIDED_EPS_ERR = {"f16": 1.0e-2, "f32outer": 7.4e-3, "f32": 5.6e-3}
+
+
 class _ProgressBar:
     def __init__(self, total):
         self.total, self.n = total, 0
@@ -79,6 +84,26 @@ class VC2_Pipeline_T2V:
         # gather + re-noise and CFG + DDIM + scatter as one kernel each (ds_ring_gather_renoise / ds_cfg_ddim_scatter; bit-identical
         # to the separate kernels, 0 = those)
         self.fuse_tile_ops = os.environ.get("DS_FUSE_TILE_OPS", "1") != "0"
+        # Which DDIM steps evaluate the UNet in the WIDE operand mode (fp32 storage, split-fp16 products: UNetModel.forward(...,
+        # precision="wide"), csrc/wide.hip) instead of the model's own mode.  With single fp16 matrix-core operands eps sits ~1e-3
+        # from the reference's fp32 result, classifier-free guidance multiplies that 4-6x (GUIDED_EPS_ERR: measured at t = 999,
+        # CFG 7.5, the largest of a schedule), and the update multiplies it again by scheduler.eps_amplification(index): 0.61 for
+        # config 1's first update (4-step schedule, 999 -> 666; 2.7e-3 measured on the latent in the default mode: no fp16-operand
+        # mode stays inside 1e-3 there), 0.113 on the 50-step schedule's first (4.1e-4 measured).
+        #   "auto" (default): wide where  amplification x GUIDED_EPS_ERR[mode] x guidance / 7.5  -- the predicted relative error
+        #                     of x_prev for unit-scale latents (GUIDED_EPS_ERR scaled down with the noise level as measured) -- exceeds
+        #                     `operand_budget` (1e-3, the north star): steps 1-3 of a 4-step schedule, the first 4 of 10 or of 25
+        #                     steps, NONE of the 50-step schedule the headline metric runs (8.4e-4 predicted at its first step in
+        #                     the default mode);
+        #   "f16": never;  "wide": every step;  or a collection of schedule indices.
+        # A wide step costs several times an fp16-mode step (3 MFMAs per product on a plain register-staged kernel, fp32 attention
+        # and norms); its windows are evaluated `wide_tile_batch` at a time (fp32 operands: 32-bit buffer addressing bounds a
+        # launch's A operand).
+        self.operand_policy = os.environ.get("DS_OPERAND_POLICY", "auto")
+        self.operand_budget = 1e-3
+        self.wide_tile_batch = 1
+        self._step_precision = None
+        self.wide_steps_run = []             # (step i, schedule index) of the steps of the last loop that ran wide
         self.verbose = False
 
     # -- the bits of DiffusionPipeline the reference relies on --
@@ -103,6 +128,47 @@ class VC2_Pipeline_T2V:
     def _log(self, *a):
         if self.verbose:
             print(*a)
+
+    # -- operand policy --
+    def _unet(self):
+        return getattr(getattr(self.pretrained_t2v, "model", None), "diffusion_model", None)
+
+    def precision_for(self, index, guidance_scale):
+        """"wide" or None for the DDIM step at schedule index `index` (see operand_policy)."""
+        pol = self.operand_policy
+        if not hasattr(self._unet(), "twin"):          # not the HIP UNet (fake eps models of the geometry tests)
+            return None
+        if pol in (None, "f16"):
+            return None
+        if pol == "wide":
+            return "wide"
+        if pol == "auto":
+            unet = self._unet()
+            mode = "f16" if unet.residual_dtype == torch.float16 else ("f32outer" if unet.residual_scope == "outer" else "f32")
+            if getattr(unet, "operand_mode", "f16") == "wide":
+                return None                              # the model itself already evaluates wide
+            # the guided-eps error falls with the noise level (7.4e-3 at t = 999, 5.0e-3 at 816, 3.6e-3 at 612, 2.8e-3 below 200 in the
+            # default mode): 0.375 + 0.625 (t / 999)^3.5 of its t = 999 value fits the measured points within 5 %
+            t = float(self.scheduler.ddim_timesteps[index])
+            r_e = GUIDED_EPS_ERR[mode] * (0.375 + 0.625 * (t / 999.0) ** 3.5)
+            pred = self.scheduler.eps_amplification(index) * r_e * max(1.0, abs(float(guidance_scale))) / 7.5
+            return "wide" if pred > self.operand_budget else None
+        if isinstance(pol, str):
+            raise ValueError(f"operand_policy={pol!r}: expected 'auto', 'f16', 'wide' or a collection of schedule indices")
+        return "wide" if index in pol else None
+
+    def _begin_step(self, i, index, guidance_scale):
+        """Fix the operand mode of step i (schedule index `index`) for every UNet evaluation until the next call."""
+        if i == 0:
+            self.wide_steps_run = []
+        self._step_precision = self.precision_for(index, guidance_scale)
+        if self._step_precision == "wide":
+            self.wide_steps_run.append((int(i), int(index)))
+        return self._step_precision
+
+    def wide_steps_of(self, num_inference_steps, guidance_scale):
+        """Schedule indices the current policy evaluates wide on a schedule of `num_inference_steps` (make_schedule must have run)."""
+        return [ix for ix in range(num_inference_steps - 1, -1, -1) if self.precision_for(ix, guidance_scale) == "wide"]
 
     # -- conditioning --
     def _encode(self, prompt, prompt_embeds, guidance_scale):
@@ -138,6 +204,8 @@ class VC2_Pipeline_T2V:
         model = self.pretrained_t2v.model
         if cfg_pairs and self.share_cfg_prefix and hasattr(getattr(model, "diffusion_model", None), "_transformer_block"):
             kwargs = dict(kwargs, cfg_pairs=int(cfg_pairs))
+        if self._step_precision == "wide" and hasattr(getattr(model, "diffusion_model", None), "twin"):
+            kwargs = dict(kwargs, precision="wide")
         # graph replay only for signatures that a key can identify: python scalars in the kwargs (a tensor-valued kwarg would
         # be baked into the graph by pointer), an int fps
         scalar_kw = all(v is None or isinstance(v, (bool, int, float, str)) for v in kwargs.values())
@@ -212,6 +280,7 @@ class VC2_Pipeline_T2V:
         pano_shape = (1,) + tuple(latents.shape[1:])
         with self.progress_bar(total=len(timesteps)) as bar:
             for i, t in enumerate(timesteps):
+                self._begin_step(i, total_steps - i - 1, guidance_scale)
                 if guidance_scale != 1.0:
                     eps = self._eps(torch.cat([latents, latents], 0), t, [text_emb, uc_emb], fps, frames,
                                     cfg_pairs=latents.shape[0], **kwargs)
@@ -235,6 +304,7 @@ class VC2_Pipeline_T2V:
         """t2v_normal_pipeline.py:572-615: one CFG + DDIM step of a single tile at schedule index total_steps - i - 1."""
         kwargs = dict(kwargs)
         kwargs.update({"clean_cond": True})
+        self._begin_step(i, total_steps - i - 1, guidance_scale)
         if guidance_scale != 1.0:
             eps = self._eps(torch.cat([latent, latent], 0), t, [text_emb, uc_emb], fps, frames, cfg_pairs=latent.shape[0],
                             **kwargs)
@@ -259,6 +329,7 @@ class VC2_Pipeline_T2V:
         t = st.timesteps[i]
         sched, device, pano = self.scheduler, st.device, st.pano
         coef = sched.step_coefficients(st.total_steps - i - 1)
+        wide = self._begin_step(i, st.total_steps - i - 1, st.guidance_scale) == "wide"
         # host noise for the whole step in the reference's tile order (appendix B): randn_like(tile) of re_noise,
         # then `frames` per-frame draws of ddim_step -- per window.  (No host draws at all in rng_mode "device".)
         noises = []
@@ -368,6 +439,8 @@ class VC2_Pipeline_T2V:
             concurrently on separate HIP streams, so the partial last round of workgroups of one batch's kernels is filled
             by the other batch's kernels."""
             bsz = self.max_tile_batch
+            if wide:
+                bsz = max(1, min(bsz, self.wide_tile_batch))
             if self.num_streams > 1:         # spread the windows over the streams
                 bsz = max(1, min(bsz, -(-len(mine) // self.num_streams)))
             batches = [mine[s:s + bsz] for s in range(0, len(mine), bsz)]
@@ -408,6 +481,8 @@ class VC2_Pipeline_T2V:
         unet = getattr(getattr(self.pretrained_t2v, "model", None), "diffusion_model", None)
         if unet is not None and hasattr(unet, "prepare"):
             unet.prepare(device)
+            if hasattr(unet, "twin") and any(self.precision_for(len(timesteps) - i - 1, guidance_scale) == "wide" for i in range(len(timesteps))):
+                unet.twin("wide").prepare(device)          # the second packed buffer (hi + lo planes), before any side stream runs
         st = _RingState()
         st.in_device = init_panorama_latent.device    # overwritten with the execution device when the loop drew the latent itself
         st.pano = init_panorama_latent.to(device=device, dtype=self.latent_dtype).contiguous().clone()

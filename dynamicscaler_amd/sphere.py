@@ -339,6 +339,7 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
             set_maps = [cache.get(fv, th, ph, lat_w, lat_h, W, H) for (ph, th, fv) in views]          # mask gather + scatters: curr_fov
             renoise = st.ratio is not None and i < total_steps - 1
             coef = sched.step_coefficients(total_steps - i - 1)
+            self._begin_step(i, total_steps - i - 1, st.guidance_scale)
             # host noise in reference order; see scheduler.draw_renoise_noise(sphere_view=...) for the layout quirk
             noises = []
             for j in range(len(views)):
@@ -354,8 +355,9 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
             for level in plan_levels_sets(reads, writes):
                 mine = parallel.rank_share(level, st.rank, st.world)
                 xp_parts, x0_parts = [], []
-                for s0 in range(0, len(mine), self.max_tile_batch):
-                    ids = mine[s0:s0 + self.max_tile_batch]
+                tb = max(1, min(self.max_tile_batch, self.wide_tile_batch)) if self._step_precision == "wide" else self.max_tile_batch
+                for s0 in range(0, len(mine), tb):
+                    ids = mine[s0:s0 + tb]
                     n = len(ids)
                     g_idx = torch.stack([lat_maps[j].gather for j in ids])
                     m_idx = torch.stack([set_maps[j].gather for j in ids])
@@ -563,6 +565,7 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
             renoise = st.ratio is not None and live
             merge_prev = merge_prev_denoised_ratio_list[i] if (merge_prev_denoised_ratio_list is not None and live) else None
             coef = sched.step_coefficients(total_steps - i - 1)
+            self._begin_step(i, total_steps - i - 1, st.guidance_scale)
             noises = []                                            # host noise in the reference's item order
             for _ in items:
                 # (with a get scale factor the view handed to re_noise is resize_video_latent's permuted output: strided, so
@@ -577,8 +580,9 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
             for level in plan_levels_items(fsets, [(ph, th) for (_, _, ph, th) in items], pix_conflict):
                 mine = parallel.rank_share(level, st.rank, st.world)
                 xp_parts, x0_parts = [], []
-                for s0 in range(0, len(mine), self.max_tile_batch):
-                    ids = mine[s0:s0 + self.max_tile_batch]
+                tb = max(1, min(self.max_tile_batch, self.wide_tile_batch)) if self._step_precision == "wide" else self.max_tile_batch
+                for s0 in range(0, len(mine), tb):
+                    ids = mine[s0:s0 + tb]
                     n = len(ids)
                     g_idx = torch.stack([maps[j].gather for j in ids])
                     l_idx = g_idx if gsf == 1 else torch.stack([lat_maps[j].gather for j in ids])

@@ -146,15 +146,15 @@ def probe_poison():
     class Poisoned:
         def __init__(self, real):
             self._real = real
+            self._diag = _lib.load_diag()          # the poison launch lives outside the product library (csrc/diag.hip)
 
         def __getattr__(self, name):
             fn = getattr(self._real, name)
-            if not name.startswith("ds_") or name in ("ds_last_error", "ds_abi_version", "ds_dbg_poison_cu_state",
-                                                      "ds_groupnorm_stats_workspace_floats"):
+            if not name.startswith("ds_") or name in ("ds_last_error", "ds_abi_version", "ds_groupnorm_stats_workspace_floats"):
                 return fn
 
             def call(*a):
-                rc = self._real.ds_dbg_poison_cu_state(a[-1])
+                rc = self._diag.ds_dbg_poison_cu_state(a[-1])
                 assert rc == 0
                 return fn(*a)
             return call

@@ -69,30 +69,27 @@ def full_host(d):
     return _HOST["ld"], _HOST["params"], _HOST["sd"]
 
 
-# Measured on MI355X (round 4, profiles/r4_measured_parity.jsonl -> DESIGN.md section 5); asserted at <= 1.25x measured.
-# Per DDIM step of the 4-step schedule (t = 999, 666, 333, 0), residual modes fast / "outer" (default) / strict:
-#   measured e_t (CFG-combined eps), step 0     1.00e-2 / 7.4e-3 / 5.6e-3     (single forward: 1.67e-3 / 1.23e-3 / 9.1e-4; CFG 7.5 amplifies 4-6x)
-#   measured x_prev, teacher-forced, steps 0-3  3.68e-3, 3.1e-4, 1.3e-4, 0 / 2.72e-3, 1.7e-4, 5e-5, 0 / 2.05e-3, 1.4e-4, 5e-5, 0
-#   measured pred_x0, teacher-forced            4.43e-3, 4.6e-4, 1.3e-4, 4e-6 / 3.27e-3, 2.5e-4, 6e-5, 2e-6 / 2.47e-3, 2.1e-4, 5e-5, 2e-6
-#   free-running: the step-0 error carried along (x_prev 3.7e-3 / 2.7e-3 / 2.0e-3 after every step)
-# NAMED WAIVER (CFG1_FIRST_STEP): the north-star 1e-3 holds for every step but the first, whose update x_prev = 2.8 x - 1.9 e_t
-# (alpha 0.005 -> 0.18) multiplies the guided-eps error; with fp16 matrix-core operands no residual mode reaches 1e-3 there
-#  -- the first step is asserted at 1.25x its measured value per mode, every later step at 1e-3.
-CFG1_FIRST_STEP = {"float16": dict(e_t=1.25e-2, x_prev=4.6e-3, pred_x0=5.6e-3), "outer": dict(e_t=9.3e-3, x_prev=3.4e-3, pred_x0=4.1e-3),
-                   "float32": dict(e_t=7.0e-3, x_prev=2.6e-3, pred_x0=3.1e-3)}
-CFG1_E_T_LATER = {"float16": 9.0e-3, "outer": 4.9e-3, "float32": 4.1e-3}      # guided e_t of steps 1-3 (reported quantity; 1.25x measured)
+# Config 1's 4-step schedule (t = 999, 666, 333, 0).  Its first update (999 -> 666: x_prev = 6.2 x - 3.8 e_t) multiplies the guided-eps
+# error; with single fp16 matrix-core operands no residual mode stays inside 1e-3 there (measured, rounds 3-4: x_prev 3.68e-3 fast /
+# 2.72e-3 default / 2.05e-3 strict; pred_x0 4.43e-3 / 3.27e-3 / 2.47e-3).  Round 5: the pipelines' operand policy ("auto", the default)
+# evaluates those steps in the WIDE operand mode (fp32 storage, split-fp16 products; csrc/wide.hip), and every step of config 1 is
+# asserted at the north star on x_prev AND pred_x0, teacher-forced and free-running.
 NORTH_STAR = 1e-3
+# REGRESSION GUARD of the non-default policy "f16" (single fp16 operands at every step), <= 1.25x measured: not a parity claim
+F16_OPERANDS_FIRST_STEP_GUARD = {"float16": dict(e_t=1.25e-2, x_prev=4.6e-3, pred_x0=5.6e-3), "outer": dict(e_t=9.3e-3, x_prev=3.4e-3, pred_x0=4.1e-3),
+                                 "float32": dict(e_t=7.0e-3, x_prev=2.6e-3, pred_x0=3.1e-3)}
+E_T_F16_STEPS = {"float16": 9.0e-3, "outer": 4.9e-3, "float32": 4.1e-3}      # guided e_t of the steps that run on fp16 operands (reported quantity; 1.25x measured)
 
 
-@pytest.mark.parametrize("residual", ["float16", "outer", "float32"])
+@pytest.mark.parametrize("residual,policy", [("float16", "auto"), ("outer", "auto"), ("float32", "auto"), ("outer", "f16")])
 @pytest.mark.parametrize("latent_dtype", [torch.float16, torch.float32])
-def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype, residual):
-    """Config 1: 4 DDIM steps of the real UNet on one 512x320x16f tile, CFG 7.5.
-    Teacher-forced (every step starts from the REFERENCE's latent of that step: the error of one step in isolation, at
-    schedule indices 3, 2, 1, 0 = t 999 / 666 / 333 / 0) and free-running (basic_sample end to end: errors compound), in every
-    residual mode.  NAMED WAIVER: the FIRST update of this 4-step schedule (999 -> 666: x_prev = 2.8 x - 1.9 e_t) multiplies the
-    guided-eps error and is outside 1e-3 in every mode (fp16 matrix-core operands); every later step is
-    asserted at 1e-3."""
+def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype, residual, policy):
+    """Config 1: 4 DDIM steps of the real UNet on one 512x320x16f tile, CFG 7.5, against per-step vectors of the reference itself
+    (make_golden.py g17).  Teacher-forced (every step starts from the REFERENCE's latent of that step: the error of one step in
+    isolation, at schedule indices 3, 2, 1, 0) and free-running (basic_sample end to end: errors compound), in every residual mode.
+    Default operand policy: the steps whose update would carry the guided-eps error past 1e-3 (indices 3, 2, 1) run wide, and
+    EVERY step is inside 1e-3 on x_prev and pred_x0.  policy "f16" (single fp16 operands throughout): regression guard at the
+    measured values."""
     from dynamicscaler_amd import ops
     from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V
     from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
@@ -100,51 +97,62 @@ def test_cfg1_full_size_basic_sample_vs_reference_golden(latent_dtype, residual)
     z = np.load(os.path.join(G, "cfg1_full_t2v.npz"))
     ld, params, _ = full_host(d)
     _set_mode(ld.model.diffusion_model, residual)
-    cfgd = {"params": {"unet_config": {"params": params}}}
-    sched = lvdm_DDIM_Scheduler(ld)
-    pipe = VC2_Pipeline_T2V(ld, sched, cfgd).to(d, latent_dtype)
-    sched.make_schedule(4, verbose=False)
-    timesteps = np.flip(sched.ddim_timesteps)
-    assert list(timesteps) == list(z["timesteps"])
-    cond = ld.get_learned_conditioning(["a prompt"])
-    uncond = ld.get_learned_conditioning([""])
-    g = float(z["guidance"])
-    name = str(latent_dtype).split(".")[1]
-    # ---- teacher-forced, step by step ----
-    for i, t in enumerate(timesteps):
-        x_ref = T(z["x_init"]) if i == 0 else T(z[f"x_prev_{i - 1}"])
-        x = x_ref.to(d, latent_dtype)
-        eps = pipe._eps(torch.cat([x, x], 0), t, [cond, uncond], int(z["fps"]), 16, cfg_pairs=1, clean_cond=True)
-        e_t = eps[1:] + g * (eps[:1] - eps[1:])                      # test-side arithmetic, fp32
-        index = int(z[f"index_{i}"])
-        xp, x0 = ops.cfg_ddim(x, eps[:1].contiguous(), eps[1:].contiguous(), (1, 4, 16, 40, 64), g,
-                              sched.step_coefficients(index))
-        r = dict(test="cfg1_teacher_forced", residual=residual, latents=name, step=i, t=int(t), e_t=relerr(e_t, T(z[f"e_t_{i}"])),
-                 x_prev=relerr(xp, T(z[f"x_prev_{i}"])), pred_x0=relerr(x0, T(z[f"pred_x0_{i}"])))
-        print(r)
-        record(**r)
-        fp16_lat = 1.0 if latent_dtype == torch.float32 else 1.1       # fp16 latents add the stored tile's own rounding
-        if i == 0:      # CFG1_FIRST_STEP waiver
-            w = CFG1_FIRST_STEP[residual]
-            assert r["e_t"] < w["e_t"] and r["x_prev"] < w["x_prev"] * fp16_lat and r["pred_x0"] < w["pred_x0"] * fp16_lat, r
-        else:           # the north-star tolerance itself, on x_prev AND pred_x0, for every step after the first
-            assert r["e_t"] < CFG1_E_T_LATER[residual] and r["x_prev"] < NORTH_STAR and r["pred_x0"] < NORTH_STAR, r
-    # ---- free-running: the pipeline's own loop from the same init latent ----
-    lat = T(z["x_init"]).to(d, latent_dtype)
-    for i, t in enumerate(timesteps):
-        lat, den = pipe._basic_denoise_one_step(lat, t, i, 4, cond, uncond, g, int(z["fps"]), 16, {})
-        r = dict(test="cfg1_free_running", residual=residual, latents=name, step=i, x_prev=relerr(lat, T(z[f"x_prev_{i}"])),
-                 pred_x0=relerr(den, T(z[f"pred_x0_{i}"])))
-        print(r)
-        record(**r)
-        w = CFG1_FIRST_STEP[residual]          # free-running: the first step's error is carried along (same waiver)
-        assert r["x_prev"] < w["x_prev"] * fp16_lat and r["pred_x0"] < w["pred_x0"] * fp16_lat, r
-    # basic_sample itself (the drop-in entry point) returns the same thing bit for bit
-    _, den2 = pipe.basic_sample(prompt="a prompt", height=320, width=512, frames=16, fps=int(z["fps"]), guidance_scale=g,
-                                num_inference_steps=4, output_type="latent", latents=T(z["x_init"]))
-    _set_mode(ld.model.diffusion_model, "float16")
+    try:
+        cfgd = {"params": {"unet_config": {"params": params}}}
+        sched = lvdm_DDIM_Scheduler(ld)
+        pipe = VC2_Pipeline_T2V(ld, sched, cfgd).to(d, latent_dtype)
+        pipe.operand_policy = policy
+        sched.make_schedule(4, verbose=False)
+        timesteps = np.flip(sched.ddim_timesteps)
+        assert list(timesteps) == list(z["timesteps"])
+        cond = ld.get_learned_conditioning(["a prompt"])
+        uncond = ld.get_learned_conditioning([""])
+        g = float(z["guidance"])
+        assert pipe.wide_steps_of(4, g) == ([3, 2, 1] if policy == "auto" else [])
+        name = str(latent_dtype).split(".")[1]
+        fp16_lat = 1.0 if latent_dtype == torch.float32 else 1.1       # fp16 latents add the stored tile's own rounding (guard only)
+        guard = F16_OPERANDS_FIRST_STEP_GUARD[residual]
+        # ---- teacher-forced, step by step ----
+        for i, t in enumerate(timesteps):
+            x_ref = T(z["x_init"]) if i == 0 else T(z[f"x_prev_{i - 1}"])
+            x = x_ref.to(d, latent_dtype)
+            index = int(z[f"index_{i}"])
+            wide = pipe._begin_step(i, index, g) == "wide"
+            eps = pipe._eps(torch.cat([x, x], 0), t, [cond, uncond], int(z["fps"]), 16, cfg_pairs=1, clean_cond=True)
+            e_t = eps[1:] + g * (eps[:1] - eps[1:])                      # test-side arithmetic, fp32
+            xp, x0 = ops.cfg_ddim(x, eps[:1].contiguous(), eps[1:].contiguous(), (1, 4, 16, 40, 64), g,
+                                  sched.step_coefficients(index))
+            r = dict(test="cfg1_teacher_forced", residual=residual, policy=policy, wide=wide, latents=name, step=i, t=int(t),
+                     e_t=relerr(e_t, T(z[f"e_t_{i}"])), x_prev=relerr(xp, T(z[f"x_prev_{i}"])), pred_x0=relerr(x0, T(z[f"pred_x0_{i}"])))
+            print(r)
+            record(**r)
+            if policy == "f16" and i == 0:
+                assert r["e_t"] < guard["e_t"] and r["x_prev"] < guard["x_prev"] * fp16_lat and r["pred_x0"] < guard["pred_x0"] * fp16_lat, r
+            else:           # the north-star tolerance itself, on x_prev AND pred_x0
+                assert r["x_prev"] < NORTH_STAR and r["pred_x0"] < NORTH_STAR, r
+                # (fp16 latents: the tile handed to the UNet is itself rounded, 2^-11 relative, which eps inherits)
+                assert r["e_t"] < ((1e-4 if latent_dtype == torch.float32 else 5e-4) if wide else E_T_F16_STEPS[residual]), r
+        # ---- free-running: the pipeline's own loop from the same init latent ----
+        lat = T(z["x_init"]).to(d, latent_dtype)
+        for i, t in enumerate(timesteps):
+            lat, den = pipe._basic_denoise_one_step(lat, t, i, 4, cond, uncond, g, int(z["fps"]), 16, {})
+            r = dict(test="cfg1_free_running", residual=residual, policy=policy, latents=name, step=i, x_prev=relerr(lat, T(z[f"x_prev_{i}"])),
+                     pred_x0=relerr(den, T(z[f"pred_x0_{i}"])))
+            print(r)
+            record(**r)
+            if policy == "f16":            # the first step's error is carried along
+                assert r["x_prev"] < guard["x_prev"] * fp16_lat and r["pred_x0"] < guard["pred_x0"] * fp16_lat, r
+            else:
+                assert r["x_prev"] < NORTH_STAR and r["pred_x0"] < NORTH_STAR, r
+        if policy == "auto":
+            assert pipe.wide_steps_run == [(0, 3), (1, 2), (2, 1)]
+        # basic_sample itself (the drop-in entry point) returns the same thing bit for bit
+        _, den2 = pipe.basic_sample(prompt="a prompt", height=320, width=512, frames=16, fps=int(z["fps"]), guidance_scale=g,
+                                    num_inference_steps=4, output_type="latent", latents=T(z["x_init"]))
+    finally:
+        _reset_mode(ld.model.diffusion_model)
     assert torch.equal(den2, den)
-    assert relerr(den2, T(z["denoised"])) < CFG1_FIRST_STEP[residual]["pred_x0"] * fp16_lat
+    assert relerr(den2, T(z["denoised"])) < (guard["pred_x0"] * fp16_lat if policy == "f16" else NORTH_STAR)
 
 
 def test_error_budget_layerwise_full_size():
@@ -222,16 +230,16 @@ def test_no_kernel_reads_uninitialised_cu_state(size):
     class Poisoned:
         def __init__(self, real):
             self._real = real
+            self._diag = _lib.load_diag()          # the poison launch lives outside the product library (csrc/diag.hip)
             self.calls = 0
 
         def __getattr__(self, name):
             fn = getattr(self._real, name)
-            if not name.startswith("ds_") or name in ("ds_last_error", "ds_abi_version", "ds_dbg_poison_cu_state",
-                                                      "ds_groupnorm_stats_workspace_floats"):
+            if not name.startswith("ds_") or name in ("ds_last_error", "ds_abi_version", "ds_groupnorm_stats_workspace_floats"):
                 return fn
 
             def call(*a):
-                assert self._real.ds_dbg_poison_cu_state(a[-1]) == 0
+                assert self._diag.ds_dbg_poison_cu_state(a[-1]) == 0
                 self.calls += 1
                 return fn(*a)
             return call
@@ -404,20 +412,20 @@ def test_concurrent_graph_replays_repeatable(size):
             assert not bad, f"{size}: round {r}, slot {slot}: first diverging kernel {bad[0]} ({len(bad)} of {len(kept)} outputs)"
 
 
-# 4-step schedule: its first update carries the CFG1_FIRST_STEP waiver (the same 999 -> 666 update); <= 1.25x measured on MI355X
-# (rounds 3-4: 3.76e-3 / 2.76e-3 / 2.09e-3).  The 50-step schedule the metric runs is asserted at 1e-3 further down.
-RING_REAL_TOL = {"float16": 4.7e-3, "outer": 3.45e-3, "float32": 2.6e-3}
+# 4-step schedule: with single fp16 operands its first update (999 -> 666) put the panorama at 3.76e-3 / 2.76e-3 / 2.09e-3 (rounds 3-4).
+# The default operand policy runs steps 0-2 wide: asserted at the north star.  policy "f16": regression guard, <= 1.25x measured.
+RING_F16_OPERANDS_GUARD = {"outer": 3.45e-3}
 
 
-@pytest.mark.parametrize("residual", ["float16", "outer", "float32"])
-def test_ring_pipeline_with_the_real_unet_vs_reference_golden(residual):
+@pytest.mark.parametrize("residual,policy", [("float16", "auto"), ("outer", "auto"), ("float32", "auto"), ("outer", "f16")])
+def test_ring_pipeline_with_the_real_unet_vs_reference_golden(residual, policy):
     """P2 end to end with the REAL t2v UNet (1.41 B parameters): the reference's own
     VC2_Pipeline_T2V_SpherePano.basic_sample_shift_multi_windows (pipeline/t2v_sphere_panorama_pipeline.py:316-660) on a
     1024x512x16f ring panorama -- 2x2 shifted windows, 40 % H overlap re-noised under the mask, the grid shifting across both
     seams every step, 4 DDIM steps (t = 999, 666, 333, 0), CFG 7.5; 32 CPU forwards, make_golden.py g25 -- against the HIP tile
-    engine + ds_unet_forward with the same seed (host RNG in the reference's draw order).  The 4-step schedule's first update
-    (999 -> 666: x_prev = 2.8 x - 1.9 e_t) multiplies the guided-eps error like in config 1, so the distance is config 1's, not
-    the 50-step schedule's (tests/test_gpu_schedule50.py)."""
+    engine + ds_unet_forward with the same seed (host RNG in the reference's draw order).  The 4-step schedule's first updates
+    multiply the guided-eps error like in config 1: the default operand policy evaluates steps 0-2 in the wide mode (one window
+    per evaluation) and the final pred-x0 panorama AND the final latent panorama are inside 1e-3."""
     from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
     from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
     path = os.path.join(G, "ring_real_unet.npz")
@@ -428,11 +436,11 @@ def test_ring_pipeline_with_the_real_unet_vs_reference_golden(residual):
     rec = json.load(open(os.path.join(G, "ring_real_unet_trace.json")))
     ld, params, _ = full_host(d)
     unet = ld.model.diffusion_model
-    unet.residual_dtype, unet.residual_scope = {"float16": (torch.float16, "full"), "float32": (torch.float32, "full"),
-                                                "outer": (torch.float32, "outer")}[residual]
+    _set_mode(unet, residual)
     try:
         pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="reference"),
                                            {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+        pipe.operand_policy = policy
         trace = []
         torch.manual_seed(2333333)
         _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=int(z["fps"]), guidance_scale=float(z["guidance"]),
@@ -440,14 +448,18 @@ def test_ring_pipeline_with_the_real_unet_vs_reference_golden(residual):
                                                        step_callback=lambda i, t, w, p, p0: trace.append((i, int(t), [list(x) for x in w])),
                                                        **rec["geom"])
     finally:
-        unet.residual_dtype, unet.residual_scope = torch.float16, "full"
+        _reset_mode(unet)
     for (i, t, wins), ref in zip(trace, rec["trace"]):
         assert i == ref["i"] and t == ref["t"] and wins == ref["windows"], (i, wins, ref)
+    assert pipe.wide_steps_run == ([(0, 3), (1, 2), (2, 1)] if policy == "auto" else [])
     e = relerr(den, T(z["denoised"]))
-    r = dict(test="ring_real_unet", residual=residual, denoised=e)
+    # the last update (index 0: a_prev = 1, sigma = 0) leaves x_prev = pred_x0, so the golden's `denoised` also pins the final LATENT
+    e_lat = relerr(pipe.final_latent, T(z["denoised"]))
+    r = dict(test="ring_real_unet", residual=residual, policy=policy, denoised=e, final_latent=e_lat)
     print(r)
     record(**r)
-    assert tuple(den.shape) == tuple(z["denoised"].shape) and e < RING_REAL_TOL[residual], r
+    tol = NORTH_STAR if policy == "auto" else RING_F16_OPERANDS_GUARD[residual]
+    assert tuple(den.shape) == tuple(z["denoised"].shape) and e < tol and e_lat < tol, r
 
 
 def test_full_size_panorama_independent_of_the_execution_mode():
@@ -479,16 +491,18 @@ def test_full_size_panorama_independent_of_the_execution_mode():
         assert torch.equal(den, ref), (name, relerr(den, ref))
 
 
-I2V_RING_REAL_TOL = {"float16": 4.3e-3, "float32": 2.4e-3}        # 4-step schedule (CFG1_FIRST_STEP waiver); <= 1.25x measured: 3.46e-3 / 1.93e-3
+# 4-step schedule with single fp16 operands: 3.46e-3 / 1.93e-3 measured (fast / strict); the default policy runs steps 0-2 wide
+I2V_RING_F16_OPERANDS_GUARD = {"float32": 2.4e-3}
 
 
-@pytest.mark.parametrize("residual", ["float16", "float32"])
-def test_i2v_ring_pipeline_with_the_real_unet_vs_reference_golden(residual):
+@pytest.mark.parametrize("residual,policy", [("float16", "auto"), ("outer", "auto"), ("float32", "f16")])
+def test_i2v_ring_pipeline_with_the_real_unet_vs_reference_golden(residual, policy):
     """P3 end to end with the REAL i2v UNet (1.44 B parameters, image cross-attention): the reference's
     VC2_Pipeline_I2V_SpherePano.basic_sample_shift_multi_windows (pipeline/i2v_sphere_panorama_pipeline.py:564-996) on a
     1024x512x16f ring panorama -- 2x2 shifted windows, per-window crops of the panorama image -> 16 image tokens next to the 77
     text tokens, merge-prev, 4 DDIM steps, CFG 7.5; 32 CPU forwards, make_golden.py g27 -- against the HIP pipeline with the same
-    seed.  Like config 1, the 4-step schedule's first update dominates the distance."""
+    seed.  Like config 1, the 4-step schedule's first updates would dominate the distance: the default operand policy runs them
+    in the wide mode (the i2v UNet's twin: image-token branch included) and the result is inside 1e-3."""
     import yaml
     from helpers import synth_image_embedder
     from dynamicscaler_amd.host_model import LatentDiffusionHost, SyntheticConditioner
@@ -512,11 +526,12 @@ def test_i2v_ring_pipeline_with_the_real_unet_vs_reference_golden(residual):
         _HOST["i2v"] = (ld, params)
     ld, params = _HOST["i2v"]
     unet = ld.model.diffusion_model
-    unet.residual_dtype, unet.residual_scope = getattr(torch, residual), "full"
+    _set_mode(unet, residual)
     pano_img = synth_normal((3, 512, 1024), int(z["pano_img_seed"])).clamp(-1, 1)
     try:
         pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="reference"),
                                            {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+        pipe.operand_policy = policy
         trace = []
         torch.manual_seed(2333333)
         _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=int(z["fps"]), guidance_scale=float(z["guidance"]),
@@ -524,14 +539,16 @@ def test_i2v_ring_pipeline_with_the_real_unet_vs_reference_golden(residual):
                                                        step_callback=lambda i, t, w, p, p0: trace.append((i, int(t), [list(x) for x in w])),
                                                        **rec["geom"])
     finally:
-        unet.residual_dtype, unet.residual_scope = torch.float16, "full"
+        _reset_mode(unet)
     for (i, t, wins), ref in zip(trace, rec["trace"]):
         assert i == ref["i"] and t == ref["t"] and wins == ref["windows"], (i, wins, ref)
+    assert pipe.wide_steps_run == ([(0, 3), (1, 2), (2, 1)] if policy == "auto" else [])
     e = relerr(den, T(z["denoised"]))
-    r = dict(test="i2v_ring_real_unet", residual=residual, denoised=e)
+    r = dict(test="i2v_ring_real_unet", residual=residual, policy=policy, denoised=e)
     print(r)
     record(**r)
-    assert tuple(den.shape) == tuple(z["denoised"].shape) and e < I2V_RING_REAL_TOL[residual], r
+    tol = NORTH_STAR if policy == "auto" else I2V_RING_F16_OPERANDS_GUARD[residual]
+    assert tuple(den.shape) == tuple(z["denoised"].shape) and e < tol, r
 
 
 # ---- the ring loops with the REAL UNets on the schedule the metric runs (50 DDIM steps), first and last six steps ----------------
@@ -564,6 +581,11 @@ def _i2v_host(d):
 def _set_mode(unet, residual):
     unet.residual_dtype, unet.residual_scope = {"float16": (torch.float16, "full"), "float32": (torch.float32, "full"),
                                                 "outer": (torch.float32, "outer")}[residual]
+
+
+def _reset_mode(unet):
+    """Back to the LIBRARY DEFAULT (f32outer): the shared hosts are never left in a non-default mode for the tests that follow."""
+    _set_mode(unet, "outer")
 
 
 @pytest.mark.parametrize("residual", ["float16", "outer", "float32"])
@@ -626,7 +648,7 @@ def test_ring_loops_real_unet_on_the_50_step_schedule_vs_reference(model, residu
                 assert torch.equal(den.float().cpu(), snaps[-1][1])
             out[end] = errs
     finally:
-        _set_mode(unet, "float16")
+        _reset_mode(unet)
     r = dict(test="ring50_real_unet", model=model, residual=residual, first={str(k): v for k, v in out["first"].items()},
              last={str(k): v for k, v in out["last"].items()})
     print(r)

@@ -75,6 +75,13 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "strong" and j["cpu_baseline"] is None
     assert np.isfinite(j["value"]) and j["value"] > 0 and j["unit"] == "denoising-steps/sec"
     assert j["config"]["baseline_config"] == "cfg3" and "4096x512x16f" in j["metric"]
+    # the per-rank account of the instrumented step: both ranks present, each owns whole columns (8 of the 16 tiles), ONE exchange
+    # per step, and its own compute / exchange split
+    pr = j["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and all(p["share_mode"] == "components" for p in pr)
+    assert [p["tiles_owned"] for p in pr] == [8, 8] and all(p["exchanges"] == 1 and p["exchange_bytes_sent"] > 0 for p in pr)
+    assert all(p["compute_ms"] > 0 and p["exchange_ms"] > 0 and abs(p["step_ms"] - p["compute_ms"] - p["exchange_ms"]) < 0.05 for p in pr), pr
+    assert len(j["ranks_seen"]) == 2 and j["other_configs"] is None and j["config"]["wide_steps_of_schedule"] == []
     # the two-rank job computed the one-GPU panorama: same latent digest from a single-process run with another tile batch
     r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-roofline", "--no-cpu-baseline",
                          "--full-panorama", "0", "--tile-batch", "4"], cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)

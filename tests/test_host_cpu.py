@@ -591,6 +591,39 @@ def test_bench_self_launches_ranks_without_touching_the_gpu():
     assert "WORLD_SIZE" not in r.stderr.split("Traceback")[0]
 
 
+def test_bench_stalled_rank_makes_the_job_exit_nonzero():
+    """Ranks that never arrive (fault injection: DS_BENCH_FAULT=stall:*; on this CPU-only container a healthy rank would stop at
+    "needs an MI355X" before anyone could wait for it) must not hang `bench.py --gpus 2`: a stalled rank's watchdog says in which
+    phase it sits and leaves with 124 after --rank-timeout, torch.distributed.run stops the other rank, and the parent -- which has
+    its own deadline and kills the child's process group past it -- relays a non-zero exit code."""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DS_BENCH_FAULT"] = "stall:*"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rank-timeout", "8"],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "stalled in phase 'injected stall (DS_BENCH_FAULT)'" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 300
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]          # no result line from a job that did not finish
+
+
+def test_parallel_profile_accounts_tiles_and_exchanges():
+    """parallel.profile_begin / profile_end (bench.py's per_rank diagnostics) on the single-process path: every tile is owned, no
+    exchange happens."""
+    from dynamicscaler_amd import parallel
+    wins = [(0, 8, 0, 8, 0, 4), (8, 16, 0, 8, 0, 4), (0, 8, 6, 14, 0, 4)]
+    prof = parallel.profile_begin()
+    try:
+        mode = parallel.run_step(wins, (4, 16, 16), 0, 1, lambda ids: (None, None), lambda ids, a, b: None, lambda: None)
+    finally:
+        assert parallel.profile_end() is prof
+    assert mode == "single" and prof["tiles_owned"] == 3 and prof["exchanges"] == 0 and prof["exchange_s"] == 0.0
+    assert parallel._PROFILE is None
+
+
 def test_clip_bpe_tokenizer_vs_independent_implementation(tmp_path):
     """dynamicscaler_amd.tokenizer.ClipBpeTokenizer (open_clip.tokenize behind FrozenOpenCLIPEmbedder, condition.py:211; open_clip
     and its vocabulary file are absent) against an independent implementation of the same algorithm -- transformers'

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the environment switches swept here exist only in the "tune" build variant (csrc/common.h DS_TUNING_ENV): build it on the box, load it
+python -m dynamicscaler_amd.build --variant tune > /dev/null && export DS_HIP_LIBRARY=$PWD/dynamicscaler_amd/libdynscaler_hip_tune.so
 export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # A/B of the GroupNorm chunk rule on one box: default step (tile batch 8, two streams) and the 8-GPU rank share
 O=gpurun_out/${1:-gnrule}; mkdir -p $O

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the environment switches swept here exist only in the "tune" build variant (csrc/common.h DS_TUNING_ENV): build it on the box, load it
+python -m dynamicscaler_amd.build --variant tune > /dev/null && export DS_HIP_LIBRARY=$PWD/dynamicscaler_amd/libdynscaler_hip_tune.so
 export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # GroupNorm at an 8-GPU rank's batch sizes: rows in flight per thread chosen by grid size (bit-neutral).  Micro-bench A/B
 # (DS_GN_SPARSE_WGS=0 = the dense-grid variant everywhere), the invariance tests, the rank-share step, the default step.

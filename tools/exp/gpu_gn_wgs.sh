@@ -1,4 +1,6 @@
 #!/bin/bash
+# the environment switches swept here exist only in the "tune" build variant (csrc/common.h DS_TUNING_ENV): build it on the box, load it
+python -m dynamicscaler_amd.build --variant tune > /dev/null && export DS_HIP_LIBRARY=$PWD/dynamicscaler_amd/libdynscaler_hip_tune.so
 export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # default step against the launch size up to which GroupNorm keeps 16 rows in flight per thread (bit-neutral)
 O=gpurun_out/${1:-gnwgs}; mkdir -p $O

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the environment switches swept here exist only in the "tune" build variant (csrc/common.h DS_TUNING_ENV): build it on the box, load it
+python -m dynamicscaler_amd.build --variant tune > /dev/null && export DS_HIP_LIBRARY=$PWD/dynamicscaler_amd/libdynscaler_hip_tune.so
 export DS_BENCH_OTHER_MODE=${DS_BENCH_OTHER_MODE:-0}   # the A/B and sweep tools time ONE mode per bench.py run
 # A/B of an environment switch on one box: alternating short cfg3 bench runs.   usage: tools/gpu_env_ab.sh <tag> <VAR> <value> [<value> ...]
 S=$1; VAR=$2; shift 2; R=$PWD; O=$R/gpurun_out/$S; mkdir -p $O

@@ -11,7 +11,7 @@ timeout 1500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/stepF -- pytho
 timeout 1500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/stepW -- python3 $R/bench.py --config cfg5 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --full-panorama 0 --other-mode 0 --streams 1 --graph 0 > $O/stepW.log 2>&1; echo "stepW rc=$?" | tee -a $O/summary.txt
 cd $R
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_cfg5.csv; find $O/prof -name "*kernel_trace.csv" -delete
-python3 tools/rocprof_step_summary.py $O/kernel_stats_cfg5.csv 3 $O/${RP}_rocprof_step_summary_cfg5.json > /dev/null 2>&1; echo "summary rc=$?" | tee -a $O/summary.txt
+python3 tools/rocprof_step_summary.py $O/kernel_stats_cfg5.csv 4 $O/${RP}_rocprof_step_summary_cfg5.json > /dev/null 2>&1; echo "summary rc=$?" | tee -a $O/summary.txt
 sf=$(find $O/stepF -name "*counter_collection.csv" | head -1); sw=$(find $O/stepW -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_summary.py $sf $sw $O/${RP}_pmc_hbm_traffic_cfg5.json > $O/pmc_hbm_traffic.log 2>&1; echo "hbm summary rc=$?" | tee -a $O/summary.txt
 find $O -name "*counter_collection.csv" -size +20M -delete; find $O -name "*.db" -delete

@@ -8,5 +8,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout 900 python3 $R/bench.py --config col2 --steps 6 --warmup 2 --streams 1 --tile-batch 1 --no-cpu-baseline --no-roofline --full-panorama 0 > $O/wall.json 2> $O/wall.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --config col2 --steps 6 --warmup 2 --streams 1 --tile-batch 1 --no-cpu-baseline --no-roofline --full-panorama 0 > $O/prof.json 2> $O/prof.err; echo "stats rc=$?" | tee -a $O/summary.txt
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv; find $O/prof -name "*kernel_trace.csv" -delete; find $O/prof -name "*.db" -delete
-(cd $R && python3 tools/rocprof_step_summary.py $O/kernel_stats.csv 8 $O/${RP}_rocprof_step_summary_rankshare_tb1.json > /dev/null 2>&1); echo "summary rc=$?" | tee -a $O/summary.txt
+(cd $R && python3 tools/rocprof_step_summary.py $O/kernel_stats.csv 9 $O/${RP}_rocprof_step_summary_rankshare_tb1.json > /dev/null 2>&1); echo "summary rc=$?" | tee -a $O/summary.txt
 grep -h -o '"ms_per_step": [0-9.]*' $O/wall.json $O/prof.json | tee -a $O/summary.txt

@@ -38,6 +38,18 @@ out["norms_and_concat_share"] = sum(fm.get(k, {}).get("share", 0.0) for k in ("g
 import hashlib, os
 _src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynamicscaler_amd", "csrc", "gemm.hip")
 out["gemm_hip_sha256"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()
-out["residual_mode"] = os.environ.get("DS_RESIDUAL_DTYPE", "f32outer")       # the library's default unless the profiled run set it
+# the residual mode of the PROFILED run: read from its bench.py JSON line (optional 4th argument: the run's stdout log, where
+# config.residual_mode says what ran -- `--residual` on the command line or the library default); never from this process's environment
+def _mode_of(log):
+    try:
+        for ln in open(log, errors="replace"):
+            if ln.lstrip().startswith("{") and '"residual_mode"' in ln:
+                return json.loads(ln)["config"]["residual_mode"]
+    except Exception:
+        pass
+    return None
+
+
+out["residual_mode"] = (_mode_of(sys.argv[4]) if len(sys.argv) > 4 else None) or "f32outer"
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
