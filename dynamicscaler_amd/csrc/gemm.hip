@@ -181,6 +181,8 @@ struct GemmArgs {
     int group_m;
     float2* colstats;
     int ld_stats;
+    int m_base, m_total;      // a launch that covers rows [m_base, m_base + d.M) of a larger one of m_total rows (gemm_entry's cut along M):
+                              // conv / temporal row geometry and per-item bias rows are those of the WHOLE launch; 0, d.M otherwise
 };
 typedef const GemmArgs __attribute__((address_space(4)))* GemmArgsPtr;
 
@@ -212,6 +214,7 @@ gemm_f16_kernel(GemmArgs) {
     const int group_m = kp->group_m;
     float2* __restrict__ colstats = kp->colstats;
     const int ld_stats = kp->ld_stats;
+    const int m_base = kp->m_base, m_total = kp->m_total;
     // stage-major: stage s = [BM rows of A | BN rows of W] at smem + s * STAGE1
     auto stA = [&](int buf) { return reinterpret_cast<f16*>(smem) + (size_t)buf * (BM + BN) * BK; };
     auto stB = [&](int buf) { return reinterpret_cast<f16*>(smem) + ((size_t)buf * (BM + BN) + BM) * BK; };
@@ -281,7 +284,7 @@ gemm_f16_kernel(GemmArgs) {
         for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
             const int m = m0_ + ld_row + LROWS * i;
             const bool valid = m < d.M;
-            const int mm = valid ? m : 0;
+            const int mm = (valid ? m : 0) + m_base;
             const int hw = d.hout * d.wout;
             const int img = mm / hw, rem = mm - img * hw;
             const int oy = rem / d.wout, ox = rem - oy * d.wout;
@@ -300,7 +303,8 @@ gemm_f16_kernel(GemmArgs) {
         if constexpr (AMODE == A_CONV3_TI) break;
         const int m = m0_ + ld_row + LROWS * i;
         ri[i].valid = m < d.M;
-        const int mm = ri[i].valid ? m : 0;
+        // conv / temporal modes address the WHOLE operand (A is not offset by a cut along M); dense rows are relative to A
+        const int mm = (ri[i].valid ? m : 0) + ((AMODE == DS_A_CONV3 || AMODE == DS_A_TCONV) ? m_base : 0);
         if constexpr (AMODE == DS_A_CONV3) {
             const int hw = d.hout * d.wout;
             const int img = mm / hw, rem = mm - img * hw;
@@ -464,7 +468,7 @@ gemm_f16_kernel(GemmArgs) {
     constexpr bool ln_fold = AMODE == A_DENSE_LN || AMODE == A_DENSE_LNK;   // LayerNorm folded into this GEMM (ds_gemm_f16_ln / _lnk): see the transform after the K loop
     constexpr bool ln_kstats = AMODE == A_DENSE_LNK;   // row statistics from the A fragments of the K loop (no statistics launch)
     const bool res_f32 = residual && (d.epilogue & DS_EPI_RES_F32);   // fp32 residual rows (strict-precision residual stream)
-    const bool bias_in_acc = !ln_fold && bias && d.bias_rows > d.M && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.ldbias % 4 == 0) &&
+    const bool bias_in_acc = !ln_fold && bias && d.bias_rows > m_total && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.ldbias % 4 == 0) &&
                              (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && !(d.epilogue & DS_EPI_OUT_F32) &&
                              (!residual || d.ldr % 8 == 0);
     if (bias_in_acc) {
@@ -856,7 +860,7 @@ gemm_f16_kernel(GemmArgs) {
     const bool fast = (!out_f32 || fast32) && (d.N % 8 == 0) && (d.ldc % 8 == 0 || fast32) &&
                       (!residual || (res_f32 ? (d.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0) : d.ldr % 8 == 0)) &&
                       (!bias || (d.ldbias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0));
-    const bool shared_bias = bias && d.bias_rows >= d.M;   // (bias_rows == M: a per-item table covering the launch with one item)
+    const bool shared_bias = bias && d.bias_rows >= m_total;   // (bias_rows == M: a per-item table covering the launch with one item)
 
     // ---- epilogue.  D[i][j] of an MFMA tile: j = lane&31 is the output row m, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     //      the column n.  Each wave moves its own tiles through its private LDS strip (32 rows x up to NG tiles, fp32),
@@ -1104,7 +1108,7 @@ gemm_f16_kernel(GemmArgs) {
                                     res[u] = DS_RES_LOAD(reinterpret_cast<const f16x8*>(ok[u] ? res_base + (sb + u) * res_step : residual));
                                 }
                                 if constexpr (PIB) {
-                                    const int mm = ok[u] ? mrow0 + row : 0;
+                                    const int mm = ok[u] ? mrow0 + row + m_base : 0;
                                     const float* bp = bias + (long)(mm / d.bias_rows) * d.ldbias + (ok[u] ? ncol : 0);
                                     pb0[u] = *reinterpret_cast<const f32x4*>(bp);
                                     pb1[u] = *reinterpret_cast<const f32x4*>(bp + 4);
@@ -1183,7 +1187,7 @@ gemm_f16_kernel(GemmArgs) {
                         const int m = mrow0 + row, n = n0 + wn * WN + c0 * 32 + col;
                         if (m >= d.M || n >= d.N) continue;
                         float v = sW[row * STR + col];
-                        if (bias && !bias_done) v += bias[(long)(m / d.bias_rows) * d.ldbias + n];
+                        if (bias && !bias_done) v += bias[(long)((m + m_base) / d.bias_rows) * d.ldbias + n];
                         if (residual) v += res_f32 ? reinterpret_cast<const float*>(residual)[(long)m * d.ldr + n] : (float)residual[(long)m * d.ldr + n];
                         if (silu) v = fast_silu(v);
                         if (out_f32) reinterpret_cast<float*>(out)[(long)m * d.ldc + n] = v;
@@ -1228,7 +1232,7 @@ gemm_f16_kernel(GemmArgs) {
     }   // tiles
 }
 
-struct StatOut { float2* p = nullptr; int ld = 0; };   // ds_gemm_f16_stats: where the per-column partial statistics go
+struct StatOut { float2* p = nullptr; int ld = 0; int m_base = 0, m_total = 0; };   // ds_gemm_f16_stats: where the per-column partial statistics go; a cut along M
 
 // CUs the persistent tiles are spread over (a multiple of 8, so that v % 8 keeps naming the XCD)
 static int device_cus() {
@@ -1239,6 +1243,12 @@ static int device_cus() {
     }();
     return ncu;
 }
+
+// Launch share (ds_set_launch_share): n similar launch sequences run concurrently on n streams (an 8-GPU rank's cond / uncond
+// evaluations): the persistent tiles of ONE launch are planned on CUs / n, so that the n launches in flight fill the chip with whole
+// rounds of big tiles instead of each leaving a partly filled last round to the other's.
+static int g_launch_share = 1;
+static int launch_cus() { return device_cus() / g_launch_share / 8 * 8; }
 
 template <int BM, int BN, int WGM, int WGN, int AMODE, int NS = 2>
 int launch(const void* A, const void* W, const float* bias, const void* residual, void* out,
@@ -1261,7 +1271,8 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
     const int group_env = (int)DS_TUNE_INT("DS_GEMM_GROUP_M", 6);
     const int group_m = (Cfg::WG_PER_CU == 1 && tiles_n >= 16 && group_env > 1) ? group_env : 1;   // 10 N tiles (2560 x 320): no gain, -2 % at M = 327680
     // buffer-load addressing is 32-bit and offset 2^31 marks 'out of range': the A operand and W must each stay below 2 GiB
-    const long a_rows = (AMODE == DS_A_CONV3 || AMODE == A_CONV3_TI) ? (long)d.nimg * d.hin * d.win : (long)d.M;
+    const long a_rows = (AMODE == DS_A_CONV3 || AMODE == A_CONV3_TI) ? (long)d.nimg * d.hin * d.win
+                        : (AMODE == DS_A_TCONV && so.m_total) ? (long)so.m_total : (long)d.M;
     const long a_bytes = ((a_rows - 1) * d.lda + d.cin) * 2;
     const long w_bytes = (long)d.N * d.K * 2;
     if (a_bytes >= 0x7FFF0000L || w_bytes >= 0x7FFF0000L) {
@@ -1269,7 +1280,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
         return DS_EINVAL;
     }
     // TileCfg::OVERLAP: one persistent workgroup per CU (a multiple of 8, so that v % 8 keeps naming the XCD)
-    const int ncu = device_cus();
+    const int ncu = launch_cus();
     const int nblk = tiles_m * tiles_n;
     const int grid = (Cfg::OVERLAP && nblk > ncu) ? ncu : nblk;
     GemmArgs ka;
@@ -1278,6 +1289,7 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
     ka.tiles_m = tiles_m; ka.tiles_n = tiles_n; ka.a_bytes = (unsigned)a_bytes; ka.w_bytes = (unsigned)w_bytes;
     ka.ln_stats = ln_stats; ka.ln_colsum = ln_colsum; ka.ln_eps = ln_eps; ka.group_m = group_m;
     ka.colstats = so.p; ka.ld_stats = so.ld;
+    ka.m_base = so.m_base; ka.m_total = so.m_total ? so.m_total : d.M;
     gemm_f16_kernel<BM, BN, WGM, WGN, AMODE, NS><<<grid, Cfg::NT, lds, st>>>(ka);
     DS_CHECK_LAUNCH("ds_gemm_f16");
     return DS_OK;
@@ -1380,27 +1392,38 @@ static int gemm_entry(const void* A, const void* W, const float* bias, const voi
     // for 1.25 rounds of work -- is cut along M: the rows of the full rounds go to the big tiles (exactly one tile per CU and round),
     // the remaining rows to a second launch with the tile chosen for THEIR count (small tiles, two workgroups per CU).  Every tile
     // variant sums K in the same order, so the result does not depend on the cut (batch invariance, result_sha256 unchanged).
-    if (d.a_mode == DS_A_DENSE && DS_PERSIST != 0 && (tile == TILE_256x256 || tile == TILE_256x320) && !so.p && (!bias || d.bias_rows > d.M) &&
-        ((long)d.M - 1) * d.lda * 2 + (long)d.cin * 2 < 0x7FFF0000L && DS_TUNE_INT("DS_GEMM_TAIL_SPLIT", 1) != 0) {
+    if (DS_PERSIST != 0 && (tile == TILE_256x256 || tile == TILE_256x320) && !so.p && so.m_total == 0 &&
+        (d.a_mode != DS_A_DENSE || ((long)d.M - 1) * d.lda * 2 + (long)d.cin * 2 < 0x7FFF0000L) && DS_TUNE_INT("DS_GEMM_TAIL_SPLIT", 1) != 0) {
         const long tiles_n = d.N / (tile == TILE_256x256 ? 256 : 320), tiles_m = ds_cdiv(d.M, 256);
-        const long nblk = tiles_m * tiles_n, ncu = device_cus();
+        const long nblk = tiles_m * tiles_n, ncu = launch_cus();
         const long rounds = nblk / ncu, rem = nblk % ncu;
         if (rounds >= 1 && rem > 0 && 2 * rem < ncu && (rounds * ncu) % tiles_n == 0) {
             const long r_main = rounds * ncu / tiles_n * 256;          // < M: rem > 0
             const long out_elt = (d.epilogue & DS_EPI_OUT_F32) ? 4 : 2, res_elt = (d.epilogue & DS_EPI_RES_F32) ? 4 : 2;
-            const long n_out = (d.epilogue & DS_EPI_GEGLU) ? d.N / 2 : d.N;
-            (void)n_out;
+            const int ti_mode_ = (int)DS_TUNE_INT("DS_CONV_TAPS_INNER", -1);       // the same rule as the uncut launch below (it fixes the K order)
+            const bool taps_inner = d.a_mode == DS_A_CONV3 && (ti_mode_ < 0 ? (long)d.hin * d.win >= 2048 : ti_mode_ > 0) && d.stride == 1 &&
+                                    !d.upsample && !d.asym_pad;
             for (int part = 0; part < 2; ++part) {
                 const long r0 = part ? r_main : 0;
                 ds_gemm_desc c = d;
                 c.M = (int)(part ? d.M - r_main : r_main);
                 const int tl = part ? choose_tile(c) : tile;
-                const char* a_p = (const char*)A + r0 * d.lda * 2;
+                // dense rows are relative to A; the conv / temporal modes address the whole operand through m_base
+                const char* a_p = (const char*)A + (d.a_mode == DS_A_DENSE ? r0 * d.lda * 2 : 0);
                 const char* r_p = residual ? (const char*)residual + r0 * d.ldr * res_elt : nullptr;
                 char* o_p = (char*)out + r0 * d.ldc * out_elt;
-                int rc = ln_stats ? dispatch<A_DENSE_LN>(tl, a_p, W, bias, r_p, o_p, c, st, ln_stats + 2 * r0, ln_colsum)
-                         : ln_colsum ? dispatch<A_DENSE_LNK>(tl, a_p, W, bias, r_p, o_p, c, st, nullptr, ln_colsum, ln_eps)
-                                  : dispatch<DS_A_DENSE>(tl, a_p, W, bias, r_p, o_p, c, st);
+                StatOut cut;
+                cut.m_base = (int)r0; cut.m_total = d.M;
+                int rc;
+                if (d.a_mode == DS_A_CONV3)
+                    rc = taps_inner ? dispatch<A_CONV3_TI>(tl, a_p, W, bias, r_p, o_p, c, st, nullptr, nullptr, 0.0f, cut)
+                                    : dispatch<DS_A_CONV3>(tl, a_p, W, bias, r_p, o_p, c, st, nullptr, nullptr, 0.0f, cut);
+                else if (d.a_mode == DS_A_TCONV)
+                    rc = dispatch<DS_A_TCONV>(tl, a_p, W, bias, r_p, o_p, c, st, nullptr, nullptr, 0.0f, cut);
+                else
+                    rc = ln_stats ? dispatch<A_DENSE_LN>(tl, a_p, W, bias, r_p, o_p, c, st, ln_stats + 2 * r0, ln_colsum, 0.0f, cut)
+                         : ln_colsum ? dispatch<A_DENSE_LNK>(tl, a_p, W, bias, r_p, o_p, c, st, nullptr, ln_colsum, ln_eps, cut)
+                                  : dispatch<DS_A_DENSE>(tl, a_p, W, bias, r_p, o_p, c, st, nullptr, nullptr, 0.0f, cut);
                 if (rc) return rc;
             }
             return DS_OK;
@@ -1470,6 +1493,12 @@ extern "C" int ds_gemm_f16_stats(const void* A, const void* W, const float* bias
     so.p = reinterpret_cast<float2*>(colstats);
     so.ld = ld_stats;
     return gemm_entry(A, W, bias, residual, out, desc, stream, nullptr, nullptr, 0.0f, so);
+}
+
+extern "C" int ds_set_launch_share(int n) {
+    DS_CHECK_ARG(n >= 1 && n <= 8, "ds_set_launch_share: n must be 1..8");
+    g_launch_share = n;
+    return DS_OK;
 }
 
 extern "C" int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,

@@ -346,6 +346,11 @@ def residual_merge(curr, noised, ratio, step, sparse=True):
 
 
 # ------------------------------------------------------------------------------------------------ UNet ops
+def set_launch_share(n):
+    """ds_set_launch_share: n similar launch sequences run concurrently on n streams (scheduling hint of the persistent GEMM tiles)."""
+    check(_lib.load().ds_set_launch_share(int(n)), "ds_set_launch_share")
+
+
 def colstats_table(rows, cols, device):
     """Table for ds_gemm_f16_stats: [ceil(rows / 32), cols, 2] fp32 -- (sum, sumsq) per 32-row block and column."""
     return torch.empty(((rows + 31) // 32, cols, 2), dtype=torch.float32, device=device)

@@ -81,6 +81,14 @@ class VC2_Pipeline_T2V:
         # the 8-GPU share of cfg3, tools/exp/gpu_gn_sparse.sh, profiles/r3_notes.md sections 4 and 8; bit-identical, a batch equals its separate forwards).  1 (default):
         # only such levels; 0: never; 2: every batch, one after the other (emulates a rank's single-batch levels on one GPU).
         self.split_cfg_over_streams = int(os.environ.get("DS_SPLIT_CFG", "1"))
+        # ... and tell the GEMM that two equal launch sequences share the chip then (ops.set_launch_share): each plans its persistent
+        # big tiles on half of the CUs and hands the rows of a mostly empty last round to small tiles -- at a rank's size a level-1
+        # launch is 160 tiles of 256 rows: two of them in flight used to take two rounds on 256 CUs for 1.25 rounds of work
+        # OFF by default: measured on MI355X it LOSES 4 % of the rank-share step (170.5 vs 163.3 ms per two rank-steps, gpurun_out/r5c):
+        # the two streams do not stay in lockstep, and a launch planned on 128 CUs leaves the rest idle whenever its partner is
+        # between kernels (profiles/r5_notes.md section 4)
+        self.share_launches = os.environ.get("DS_SHARE_LAUNCHES", "0") != "0"
+        self._launch_share = 1
         # gather + re-noise and CFG + DDIM + scatter as one kernel each (ds_ring_gather_renoise / ds_cfg_ddim_scatter; bit-identical
         # to the separate kernels, 0 = those)
         self.fuse_tile_ops = os.environ.get("DS_FUSE_TILE_OPS", "1") != "0"
@@ -221,7 +229,7 @@ class VC2_Pipeline_T2V:
         if gen != self._graph_generation:
             self._graphs.clear()
             self._graph_generation = gen
-        key = (self._slot, tuple(x.shape), x.dtype, tuple(ctx.shape), ctx.dtype, fps, frames, tuple(sorted(kwargs.items())))
+        key = (self._slot, tuple(x.shape), x.dtype, tuple(ctx.shape), ctx.dtype, fps, frames, tuple(sorted(kwargs.items())), self._launch_share)
         ent = self._graphs.get(key)
         if ent is None:                      # first use: eager (loads code objects, sets kernel attributes)
             self._graphs[key] = "warm"
@@ -406,8 +414,16 @@ class VC2_Pipeline_T2V:
                 # the same kernels on the same numbers (a batch equals its separate forwards), without the shared prefix
                 def one(cl):
                     return self._eps(tiles, t, cl, st.fps, st.frames, **st.kwargs)
-                e_c, e_u = self._stream_pool(device).map(one, [[ctxs[j] for j in ids], [st.uc_emb] * n], inline=self.use_graph,
-                                                         on_slot=lambda k: setattr(self, "_slot", k))
+                # two equal launch sequences share the chip: the persistent GEMM tiles of each are planned on half of it
+                # (ops.set_launch_share; scheduling only, same bits).  Captured graphs keep the plan they were captured with.
+                self._launch_share = 2 if self.share_launches else 1
+                ops.set_launch_share(self._launch_share)
+                try:
+                    e_c, e_u = self._stream_pool(device).map(one, [[ctxs[j] for j in ids], [st.uc_emb] * n], inline=self.use_graph,
+                                                             on_slot=lambda k: setattr(self, "_slot", k))
+                finally:
+                    self._launch_share = 1
+                    ops.set_launch_share(1)
             elif st.guidance_scale != 1.0:
                 eps = self._eps(torch.cat([tiles, tiles], 0), t, [ctxs[j] for j in ids] + [st.uc_emb] * n,
                                 st.fps, st.frames, cfg_pairs=n, **st.kwargs)

@@ -208,6 +208,11 @@ typedef struct ds_gemm_desc {
  * out: fp16/fp32 [M][ldc]. */
 int ds_gemm_f16(const void* A, const void* W, const float* bias, const void* residual, void* out,
                 const ds_gemm_desc* desc, void* stream);
+/* Hint: n similar launch sequences share the device concurrently on n streams (an 8-GPU rank evaluates the cond and the uncond UNet
+ * of its one window per level on two streams).  Persistent big-tile launches then plan their rounds on CUs / n and hand the rows of
+ * a last, mostly empty round to small tiles, so that the n launches in flight fill the chip with whole rounds.  Scheduling only:
+ * every tile variant sums K in the same order, results do not change.  Process-wide; 1 (default) = a launch plans on the whole chip. */
+int ds_set_launch_share(int n);
 /* ds_gemm_f16 that also writes the per-column partial statistics of what it stores: colstats[(m / 32) * ld_stats + n] = (sum,
  * sum of squares) as float pairs over the valid rows of each 32-row block (after bias / residual / SiLU; fp16 outputs without an
  * epilogue operand: of the rounded values).  One writer per entry, fixed summation order, no atomics.  The GroupNorm that reads the

@@ -904,3 +904,62 @@ def test_fused_tile_ops_equal_the_separate_kernels(dtype, x0s, host_noise):
         xp, x0 = ops.cfg_ddim(t_s, e_c, e_u, tuple(pano.shape), 7.5, coef, sn)
         ops.ring_scatter3(p2, p2x, k2, xp, x0, origins)
         assert torch.equal(p1, p2) and torch.equal(p1x, p2x) and torch.equal(k1, k2), eta_noise
+
+
+def test_gemm_tail_split_and_launch_share_are_bit_identical():
+    """The cut of a persistent big-tile launch along M (gemm_entry: the rows of the full rounds on the big tiles, the rest on small
+    tiles; conv / temporal modes through m_base) and the launch-share hint (ops.set_launch_share: rounds planned on half the CUs)
+    are scheduling only: the same launch with the hint on and off, and against its two half-size launches, bit for bit -- dense with
+    bias + fp32 residual rows, the LayerNorm fold, 3x3 conv with a per-item bias table, temporal conv with a residual."""
+    from dynamicscaler_amd import ops, _lib
+    d = dev()
+    M, N, K = 81920, 320, 320                       # 320 row tiles of 256: one full round on 256 CUs + a quarter
+    A = rnd((M, K), 1).half().to(d)
+    W = rnd((N, K), 2, 0.05).half().to(d)
+    b = rnd((N,), 3).to(d)
+    R = rnd((M, N), 4).to(d)
+
+    def both(fn):
+        outs = []
+        for share in (1, 2):
+            ops.set_launch_share(share)
+            try:
+                outs.append(fn())
+            finally:
+                ops.set_launch_share(1)
+        assert torch.equal(outs[0], outs[1])
+        return outs[0]
+
+    full = both(lambda: ops.gemm(A, W, b, R, M=M, N=N, K=K, epilogue=_lib.DS_EPI_OUT_F32))
+    h = M // 2
+    halves = torch.cat([ops.gemm(A[:h], W, b, R[:h], M=h, N=N, K=K, epilogue=_lib.DS_EPI_OUT_F32),
+                        ops.gemm(A[h:], W, b, R[h:], M=h, N=N, K=K, epilogue=_lib.DS_EPI_OUT_F32)])
+    assert torch.equal(full, halves)
+    assert relerr(full, A.float().cpu() @ W.float().cpu().t() + b.cpu() + R.cpu()) < 1e-5
+    # LayerNorm fold (row statistics travel with the cut)
+    stats = ops.layernorm_stats(A)
+    cs, cb = W.float().sum(1).contiguous(), rnd((N,), 5).to(d)
+    full = both(lambda: ops.gemm_ln(A, W, stats, cs, cb, M=M, N=N, K=K))
+    halves = torch.cat([ops.gemm_ln(A[:h], W, stats[:h], cs, cb, M=h, N=N, K=K), ops.gemm_ln(A[h:], W, stats[h:], cs, cb, M=h, N=N, K=K)])
+    assert torch.equal(full, halves)
+    # 3x3 conv, per-item bias (the time-embedding add): 32 images of 40x64, items of 16 images
+    nimg, hin, win, cin, cout = 32, 40, 64, 64, 320
+    x = rnd((nimg * hin * win, cin), 6).half().to(d)
+    w = rnd((cout, 9 * cin), 7, 0.05).half().to(d)
+    table = rnd((2, cout + 64), 8).to(d)
+    conv = (nimg, hin, win, hin, win, 1, 0)
+    full = both(lambda: ops.gemm(x, w, table[:, 64:], None, M=nimg * hin * win, N=cout, K=9 * cin, a_mode=_lib.DS_A_CONV3, cin=cin, lda=cin,
+                                 conv=conv, bias_rows=16 * hin * win, ldbias=cout + 64))
+    hm = 16 * hin * win
+    parts = [ops.gemm(x[i * hm:(i + 1) * hm], w, table[i:i + 1, 64:], None, M=hm, N=cout, K=9 * cin, a_mode=_lib.DS_A_CONV3, cin=cin, lda=cin,
+                      conv=(16, hin, win, hin, win, 1, 0), bias_rows=hm, ldbias=cout + 64) for i in range(2)]
+    assert torch.equal(full, torch.cat(parts))
+    # temporal conv with a residual: 2 sequences of 16 frames x 2560 pixels
+    T_, hw = 16, 2560
+    xt = rnd((2 * T_ * hw, 320), 9).half().to(d)
+    wt = rnd((320, 3 * 320), 10, 0.05).half().to(d)
+    full = both(lambda: ops.gemm(xt, wt, b, xt, M=2 * T_ * hw, N=320, K=960, a_mode=_lib.DS_A_TCONV, cin=320, lda=320, tconv=(T_, hw)))
+    hs = T_ * hw
+    parts = [ops.gemm(xt[i * hs:(i + 1) * hs], wt, b, xt[i * hs:(i + 1) * hs], M=hs, N=320, K=960, a_mode=_lib.DS_A_TCONV, cin=320, lda=320,
+                      tconv=(T_, hw)) for i in range(2)]
+    assert torch.equal(full, torch.cat(parts))
