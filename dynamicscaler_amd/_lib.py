@@ -105,6 +105,7 @@ SIGNATURES = {
     "ds_wide_lo_scale": (_f, []),
     "ds_split_f16": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     "ds_gemm_wide": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),
+    "ds_groupnorm_wide_scratch_floats": (_sz, [_i, _i, _i]),
     "ds_groupnorm_wide": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "ds_layernorm_wide": (_i, [_vp, _vp, _vp, _vp, C.c_long, _i, _f, _vp]),
     "ds_attention_wide": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),

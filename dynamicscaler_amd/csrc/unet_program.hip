@@ -796,7 +796,7 @@ struct Prog {
     Ten groupnorm(const Ten& x, const std::string& prefix, int ninst, int rows_per, int C, float eps, int silu, Ten* raw16 = nullptr,
                   const Ten& cstats = Ten()) {
         if (u->wide) {
-            Ten stt = make((long)ninst * 32, 2, DS_F32);
+            Ten stt = raw(ds_groupnorm_wide_scratch_floats(ninst, rows_per, 32) * 4);
             Ten yw = make(x.rows, C, DS_F32);
             tr("groupnorm_wide ldx=%d ninst=%d rows=%d C=%d silu=%d eps=%g", x.ld, ninst, rows_per, C, silu, (double)eps);
             if (live())

@@ -250,35 +250,62 @@ int launch_wide(const WideArgs& ka, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ norms with fp32 outputs
-// GroupNorm statistics: one workgroup per (group, instance), double accumulators, fixed summation order
+// GroupNorm statistics in two stages, fp64 accumulators, fixed summation order.  Stage 1: one workgroup per (256-row chunk, instance);
+// a thread owns columns t, t + 256, ... (coalesced row reads), sums its columns over the chunk's rows, the columns of a group are added
+// through LDS in column order -> partial[(inst * nchunk + chunk) * groups + g] = (sum, sum of squares).  Stage 2: one thread per
+// (instance, group) adds the chunks in order -> (mean, rstd).
+constexpr int GNW_CHUNK = 256, GNW_MAXCOLS = 12;     // rows per chunk; columns per thread (C <= 3072: the widest concat input is 2560)
 __global__ void __launch_bounds__(256)
-gn_wide_stats_kernel(const float* __restrict__ x, int ldx, float* __restrict__ stats, int rows, int C, int groups, float eps) {
-    const int g = blockIdx.x, inst = blockIdx.y;
-    const int cpg = C / groups;
-    const float* xp = x + (long)inst * rows * ldx + g * cpg;
-    double s = 0.0, q = 0.0;
-    const long total = (long)rows * cpg;
-    for (long e = threadIdx.x; e < total; e += 256) {
-        const long r = e / cpg;
-        const int c = (int)(e - r * cpg);
-        const double v = (double)xp[r * ldx + c];
-        s += v;
-        q += v * v;
+gn_wide_partial_kernel(const float* __restrict__ x, int ldx, double* __restrict__ partial, int rows, int C, int groups, int nchunk) {
+    const int chunk = blockIdx.x, inst = blockIdx.y, t = threadIdx.x;
+    const int r0 = chunk * GNW_CHUNK, r1 = min(rows, r0 + GNW_CHUNK);
+    const float* xp = x + ((long)inst * rows + r0) * ldx;
+    double s[GNW_MAXCOLS], q[GNW_MAXCOLS];
+#pragma unroll
+    for (int j = 0; j < GNW_MAXCOLS; ++j) { s[j] = 0.0; q[j] = 0.0; }
+    for (int r = 0; r < r1 - r0; ++r) {
+#pragma unroll
+        for (int j = 0; j < GNW_MAXCOLS; ++j) {
+            const int c = t + 256 * j;
+            if (c < C) {
+                const double v = (double)xp[(long)r * ldx + c];
+                s[j] += v;
+                q[j] += v * v;
+            }
+        }
     }
-    __shared__ double ss[256], sq[256];
-    ss[threadIdx.x] = s; sq[threadIdx.x] = q;
+    __shared__ double cs[256 * GNW_MAXCOLS], cq[256 * GNW_MAXCOLS];
+#pragma unroll
+    for (int j = 0; j < GNW_MAXCOLS; ++j) {
+        const int c = t + 256 * j;
+        if (c < C) { cs[c] = s[j]; cq[c] = q[j]; }
+    }
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (threadIdx.x < w) { ss[threadIdx.x] += ss[threadIdx.x + w]; sq[threadIdx.x] += sq[threadIdx.x + w]; }
-        __syncthreads();
+    const int cpg = C / groups;
+    if (t < groups) {
+        double a = 0.0, b = 0.0;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { a += cs[c]; b += cq[c]; }
+        double* o = partial + 2 * (((long)inst * nchunk + chunk) * groups + t);
+        o[0] = a; o[1] = b;
     }
-    if (threadIdx.x == 0) {
-        const double mean = ss[0] / (double)total;
-        double var = sq[0] / (double)total - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stats[2 * ((long)inst * groups + g)] = (float)mean;
-        stats[2 * ((long)inst * groups + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ void __launch_bounds__(64)
+gn_wide_finish_kernel(const double* __restrict__ partial, float* __restrict__ stats, int rows, int C, int groups, int nchunk, int ninst, float eps) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= ninst * groups) return;
+    const int inst = idx / groups, g = idx - inst * groups;
+    double a = 0.0, b = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const double* o = partial + 2 * (((long)inst * nchunk + ch) * groups + g);
+        a += o[0]; b += o[1];
     }
+    const double n = (double)rows * (C / groups);
+    const double mean = a / n;
+    double var = b / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * idx] = (float)mean;
+    stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 __global__ void __launch_bounds__(256)
@@ -571,12 +598,25 @@ extern "C" int ds_split_f16(const void* x, int x_dtype, void* hi, void* lo, size
     return DS_OK;
 }
 
-extern "C" int ds_groupnorm_wide(const float* x, int ldx, const float* gamma, const float* beta, float* y, float* stats, int ninst,
+extern "C" size_t ds_groupnorm_wide_scratch_floats(int ninst, int rows_per_inst, int groups) {
+    if (ninst <= 0 || rows_per_inst <= 0 || groups <= 0) return 0;
+    const size_t nchunk = (size_t)ds_cdiv(rows_per_inst, GNW_CHUNK);
+    return (size_t)2 * ninst * groups + 2 + (size_t)4 * ninst * nchunk * groups;      // (mean, rstd) floats | 8-byte aligned fp64 partial sums
+}
+
+extern "C" int ds_groupnorm_wide(const float* x, int ldx, const float* gamma, const float* beta, float* y, float* scratch, int ninst,
                                  int rows_per_inst, int C, int groups, float eps, int silu, void* stream) {
-    DS_CHECK_ARG(x && gamma && beta && y && stats, "ds_groupnorm_wide: null argument");
-    DS_CHECK_ARG(ninst > 0 && rows_per_inst > 0 && C > 0 && groups > 0 && C % groups == 0 && ldx >= C, "ds_groupnorm_wide: bad sizes");
+    DS_CHECK_ARG(x && gamma && beta && y && scratch, "ds_groupnorm_wide: null argument");
+    DS_CHECK_ARG(ninst > 0 && ninst <= 65535 && rows_per_inst > 0 && C > 0 && groups > 0 && groups <= 256 && C % groups == 0 && ldx >= C && C <= 256 * GNW_MAXCOLS,
+                 "ds_groupnorm_wide: bad sizes (C <= %d, groups <= 256, ninst <= 65535)", 256 * GNW_MAXCOLS);
+    DS_CHECK_ARG((reinterpret_cast<uintptr_t>(scratch) & 7) == 0, "ds_groupnorm_wide: scratch must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    gn_wide_stats_kernel<<<dim3(groups, ninst), 256, 0, st>>>(x, ldx, stats, rows_per_inst, C, groups, eps);
+    const int nchunk = ds_cdiv(rows_per_inst, GNW_CHUNK);
+    float* stats = scratch;
+    double* partial = reinterpret_cast<double*>(scratch + (((size_t)2 * ninst * groups + 1) & ~(size_t)1));
+    gn_wide_partial_kernel<<<dim3(nchunk, ninst), 256, 0, st>>>(x, ldx, partial, rows_per_inst, C, groups, nchunk);
+    DS_CHECK_LAUNCH("ds_groupnorm_wide");
+    gn_wide_finish_kernel<<<ds_cdiv((long)ninst * groups, 64), 64, 0, st>>>(partial, stats, rows_per_inst, C, groups, nchunk, ninst, eps);
     DS_CHECK_LAUNCH("ds_groupnorm_wide");
     const long nrows = (long)ninst * rows_per_inst;
     gn_wide_apply_kernel<<<grid_for(nrows * C), 256, 0, st>>>(x, ldx, stats, gamma, beta, y, nrows, rows_per_inst, C, groups, silu);

@@ -731,7 +731,7 @@ def groupnorm_wide(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=
     lib = _lib.load()
     assert x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == Cch and x.stride(1) == 1
     y = torch.empty((x.shape[0], Cch), dtype=torch.float32, device=x.device)
-    stats = torch.empty((ninst * groups * 2,), dtype=torch.float32, device=x.device)
+    stats = torch.empty((lib.ds_groupnorm_wide_scratch_floats(ninst, rows_per_inst, groups),), dtype=torch.float32, device=x.device)
     check(lib.ds_groupnorm_wide(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), ninst,
                                 rows_per_inst, Cch, groups, float(eps), int(bool(silu)), _stream() if stream is None else stream),
           "ds_groupnorm_wide")

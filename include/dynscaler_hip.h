@@ -349,8 +349,10 @@ int ds_split_f16(const void* x, int x_dtype, void* hi, void* lo, size_t n, void*
 int ds_gemm_wide(const float* A, const void* W_hi, const void* W_lo, const float* bias, const float* residual, float* out,
                  const ds_gemm_desc* desc, void* stream);
 /* GroupNorm(groups) (+ SiLU) with fp32 input rows (stride ldx) and dense fp32 output; statistics in fp64, fixed order
- * (basics.py:76-86; openaimodel3d.py:275-292).  stats: caller scratch of 2 * ninst * groups floats. */
-int ds_groupnorm_wide(const float* x, int ldx, const float* gamma, const float* beta, float* y, float* stats, int ninst,
+ * (basics.py:76-86; openaimodel3d.py:275-292).  scratch: caller buffer of ds_groupnorm_wide_scratch_floats(...) floats, 8-byte aligned
+ * (per-chunk fp64 partial sums, then mean / rstd). */
+size_t ds_groupnorm_wide_scratch_floats(int ninst, int rows_per_inst, int groups);
+int ds_groupnorm_wide(const float* x, int ldx, const float* gamma, const float* beta, float* y, float* scratch, int ninst,
                       int rows_per_inst, int C, int groups, float eps, int silu, void* stream);
 /* nn.LayerNorm(C) over dense fp32 rows, fp32 out (attention.py:199-201). */
 int ds_layernorm_wide(const float* x, const float* gamma, const float* beta, float* y, long rows, int C, float eps, void* stream);

@@ -11,17 +11,20 @@ pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
-# fp16 activations / fp32 accumulation vs the reference's fp32 CPU path.  Every tolerance below is <= 2x the value
-# measured on MI355X in round 2 (gpurun_out/s2/gputest_verbose.log; DESIGN.md section 5 has the table and the error
-# budget that explains the numbers).  BASELINE.json's north_star asks for 1e-3 rel on fp16 LATENTS.
+# NORTH STAR (BASELINE.json): 1e-3 relative on the latents.  Asserted as such wherever a latent is compared with the reference on the
+# path the product runs (the default operand policy: wide evaluation on the steps whose update would carry the guided-eps error past
+# 1e-3, tests/test_gpu_fullsize.py, test_gpu_schedule50.py), and on eps itself in the wide mode below.
+NORTH_STAR = 1e-3
+# REGRESSION GUARDS of the single-fp16-operand modes (fp16 operands / fp32 accumulation vs the reference's fp32 CPU path): <= 2x the
+# values measured on MI355X (DESIGN.md section 5 has the table and the error budget that explains them).  Not parity claims.
 EPS_TOL_TINY = 4.4e-3   # toy UNet eps, measured 2.0e-3 .. 2.2e-3
 EPS_TOL = 2.2e-3        # full-size t2v / i2v UNet eps: measured 1.67e-3 / 1.70e-3 / 1.72e-3 in the fast mode, 1.23e-3 / 1.25e-3 in the default
-                        # ("outer") mode (<= 1.3x the fast mode's; the latent tolerance of the north star is asserted on x_prev)
-LATENT_TOL = 7.2e-4     # x_prev after CFG 7.5 + one DDIM update of the 50-step schedule (index 25), measured 3.6e-4
-PRED_X0_TOL = 8e-3      # pred_x0 of the same update, measured 3.9e-3: (x - sqrt(1-a) e_t)/sqrt(a) amplifies the CFG-combined
-                        # eps error by sqrt((1-a)/a); see DESIGN.md section 5 for why 1e-3 is out of reach of fp16 operands
+                        # ("outer") mode; in the wide mode 1.8e-6 (asserted at NORTH_STAR / 20 in the same tests)
+LATENT_TOL = 7.2e-4     # x_prev after CFG 7.5 + one DDIM update of the 50-step schedule (index 25), measured 3.6e-4 (inside the north star)
+PRED_X0_TOL = 8e-3      # pred_x0 of the same update on fp16 operands, measured 3.9e-3: (x - sqrt(1-a) e_t)/sqrt(a) amplifies the CFG-combined
+                        # eps error by sqrt((1-a)/a); an intermediate quantity at that index (only the last step's pred_x0 leaves a loop)
 PIPE_TOL = 9e-3         # toy pipelines end to end (4-6 DDIM steps, CFG 7.5, tiny UNet), fp16 or fp32 latents: measured
-PIPE_TOL_F16 = PIPE_TOL  # 3.7e-3 .. 4.4e-3
+PIPE_TOL_F16 = PIPE_TOL  # 3.7e-3 .. 4.4e-3 before the operand policy (rounds 2-4)
 VAE_TOL = 5.4e-3        # first stage: decode 1.4e-3 (toy) / 2.6e-3 (real config), encode moments 8.8e-4 / 1.0e-3
 
 
@@ -213,6 +216,12 @@ def test_unet_full_size_vs_reference_golden():
     l1, l2 = relerr(xp, rxp), relerr(x0, rx0)
     print(f"after CFG 7.5 + DDIM step {index}/50: x_prev rel err {l1:.3e}, pred_x0 rel err {l2:.3e}")
     assert l1 < LATENT_TOL and l2 < PRED_X0_TOL
+    # the same evaluation in the wide operand mode: eps itself, x_prev AND pred_x0 at the north star (with a factor 20 to spare)
+    epw = m(torch.cat([x, x]).to(d), torch.tensor([int(z["t"])] * 2, device=d), context=ctx.to(d), fps=int(z["fps"]), precision="wide")
+    w1, w2 = relerr(epw[:1], ec), relerr(epw[1:], eu)
+    xpw, x0w = ops.cfg_ddim(x.to(d), epw[:1].contiguous(), epw[1:].contiguous(), (1, 4, 16, 40, 64), 7.5, sched.step_coefficients(index))
+    print(f"wide mode: eps rel err {w1:.3e} / {w2:.3e}; x_prev {relerr(xpw, rxp):.3e}, pred_x0 {relerr(x0w, rx0):.3e}")
+    assert max(w1, w2, relerr(xpw, rxp), relerr(x0w, rx0)) < NORTH_STAR / 20
 
 
 def test_unet_full_size_i2v_vs_reference_golden():
@@ -229,6 +238,9 @@ def test_unet_full_size_i2v_vs_reference_golden():
     e = relerr(eps, T(z["eps"]))
     print(f"full i2v UNet eps rel err: {e:.3e}")
     assert eps.shape == (1, 4, 16, 40, 64) and e < EPS_TOL
+    epw = m(T(z["x"]).to(d), torch.tensor([int(z["t"])], device=d), context=T(z["ctx"]).to(d), fps=int(z["fps"]), precision="wide")
+    print(f"wide mode: eps rel err {relerr(epw, T(z['eps'])):.3e}")
+    assert relerr(epw, T(z["eps"])) < NORTH_STAR / 20
 
 
 def _host(params, seed, cond, uncond, device, temporal_length=4):
