@@ -250,11 +250,13 @@ int launch_wide(const WideArgs& ka, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ norms with fp32 outputs
-// GroupNorm statistics in two stages, fp64 accumulators, fixed summation order.  Stage 1: one workgroup per (256-row chunk, instance);
-// a thread owns columns t, t + 256, ... (coalesced row reads), sums its columns over the chunk's rows, the columns of a group are added
-// through LDS in column order -> partial[(inst * nchunk + chunk) * groups + g] = (sum, sum of squares).  Stage 2: one thread per
-// (instance, group) adds the chunks in order -> (mean, rstd).
-constexpr int GNW_CHUNK = 256, GNW_MAXCOLS = 12;     // rows per chunk; columns per thread (C <= 3072: the widest concat input is 2560)
+// GroupNorm statistics in two stages, fp64 accumulators, fixed summation order.  Stage 1: one workgroup per (32-row chunk, instance)
+// -- thousands of workgroups, so that the serial row walk of a thread hides behind the others' -- a thread owns columns t, t + 256, ...
+// (coalesced row reads), sums its columns over the chunk's rows, the columns of a group are added through LDS in column order ->
+// partial[(inst * nchunk + chunk) * groups + g] = (sum, sum of squares).  Stage 2: one wave per (instance, group): lane k adds chunks
+// k, k + 64, ... in order, then a fixed xor tree -> (mean, rstd).  (First form: one workgroup per (group, instance) reading its strided
+// columns, 210 us per launch; 256-row chunks: 274 us -- both latency-bound; profiles/r5_notes.md.)
+constexpr int GNW_CHUNK = 32, GNW_MAXCOLS = 12;     // rows per chunk; columns per thread (C <= 3072: the widest concat input is 2560)
 __global__ void __launch_bounds__(256)
 gn_wide_partial_kernel(const float* __restrict__ x, int ldx, double* __restrict__ partial, int rows, int C, int groups, int nchunk) {
     const int chunk = blockIdx.x, inst = blockIdx.y, t = threadIdx.x;
@@ -263,12 +265,13 @@ gn_wide_partial_kernel(const float* __restrict__ x, int ldx, double* __restrict_
     double s[GNW_MAXCOLS], q[GNW_MAXCOLS];
 #pragma unroll
     for (int j = 0; j < GNW_MAXCOLS; ++j) { s[j] = 0.0; q[j] = 0.0; }
+    const int ncol = (C - t + 255) / 256;         // columns this thread owns (<= GNW_MAXCOLS)
+#pragma unroll 4
     for (int r = 0; r < r1 - r0; ++r) {
 #pragma unroll
         for (int j = 0; j < GNW_MAXCOLS; ++j) {
-            const int c = t + 256 * j;
-            if (c < C) {
-                const double v = (double)xp[(long)r * ldx + c];
+            if (j < ncol) {
+                const double v = (double)xp[(long)r * ldx + t + 256 * j];
                 s[j] += v;
                 q[j] += v * v;
             }
@@ -291,21 +294,24 @@ gn_wide_partial_kernel(const float* __restrict__ x, int ldx, double* __restrict_
 }
 
 __global__ void __launch_bounds__(64)
-gn_wide_finish_kernel(const double* __restrict__ partial, float* __restrict__ stats, int rows, int C, int groups, int nchunk, int ninst, float eps) {
-    const int idx = blockIdx.x * 64 + threadIdx.x;
-    if (idx >= ninst * groups) return;
+gn_wide_finish_kernel(const double* __restrict__ partial, float* __restrict__ stats, int rows, int C, int groups, int nchunk, float eps) {
+    const int idx = blockIdx.x, lane = threadIdx.x;          // one wave per (instance, group)
     const int inst = idx / groups, g = idx - inst * groups;
     double a = 0.0, b = 0.0;
-    for (int ch = 0; ch < nchunk; ++ch) {
+    for (int ch = lane; ch < nchunk; ch += 64) {
         const double* o = partial + 2 * (((long)inst * nchunk + ch) * groups + g);
         a += o[0]; b += o[1];
     }
-    const double n = (double)rows * (C / groups);
-    const double mean = a / n;
-    double var = b / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[2 * idx] = (float)mean;
-    stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) { a += __shfl_xor(a, sh); b += __shfl_xor(b, sh); }
+    if (lane == 0) {
+        const double n = (double)rows * (C / groups);
+        const double mean = a / n;
+        double var = b / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * idx] = (float)mean;
+        stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -607,7 +613,7 @@ extern "C" size_t ds_groupnorm_wide_scratch_floats(int ninst, int rows_per_inst,
 extern "C" int ds_groupnorm_wide(const float* x, int ldx, const float* gamma, const float* beta, float* y, float* scratch, int ninst,
                                  int rows_per_inst, int C, int groups, float eps, int silu, void* stream) {
     DS_CHECK_ARG(x && gamma && beta && y && scratch, "ds_groupnorm_wide: null argument");
-    DS_CHECK_ARG(ninst > 0 && ninst <= 65535 && rows_per_inst > 0 && C > 0 && groups > 0 && groups <= 256 && C % groups == 0 && ldx >= C && C <= 256 * GNW_MAXCOLS,
+    DS_CHECK_ARG(ninst > 0 && ninst <= 65535 && (long)ninst * groups < (1L << 31) && rows_per_inst > 0 && C > 0 && groups > 0 && groups <= 256 && C % groups == 0 && ldx >= C && C <= 256 * GNW_MAXCOLS,
                  "ds_groupnorm_wide: bad sizes (C <= %d, groups <= 256, ninst <= 65535)", 256 * GNW_MAXCOLS);
     DS_CHECK_ARG((reinterpret_cast<uintptr_t>(scratch) & 7) == 0, "ds_groupnorm_wide: scratch must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -616,7 +622,7 @@ extern "C" int ds_groupnorm_wide(const float* x, int ldx, const float* gamma, co
     double* partial = reinterpret_cast<double*>(scratch + (((size_t)2 * ninst * groups + 1) & ~(size_t)1));
     gn_wide_partial_kernel<<<dim3(nchunk, ninst), 256, 0, st>>>(x, ldx, partial, rows_per_inst, C, groups, nchunk);
     DS_CHECK_LAUNCH("ds_groupnorm_wide");
-    gn_wide_finish_kernel<<<ds_cdiv((long)ninst * groups, 64), 64, 0, st>>>(partial, stats, rows_per_inst, C, groups, nchunk, ninst, eps);
+    gn_wide_finish_kernel<<<ninst * groups, 64, 0, st>>>(partial, stats, rows_per_inst, C, groups, nchunk, eps);
     DS_CHECK_LAUNCH("ds_groupnorm_wide");
     const long nrows = (long)ninst * rows_per_inst;
     gn_wide_apply_kernel<<<grid_for(nrows * C), 256, 0, st>>>(x, ldx, stats, gamma, beta, y, nrows, rows_per_inst, C, groups, silu);

@@ -254,7 +254,10 @@ class UNetModel(nn.Module):
             if not h:
                 return
             if self._handle_uses.get(h.value, 0) > 0:
-                self._handle_retired[h.value] = h      # destroyed by the last call that still uses it
+                # destroyed by the last call that still uses it -- TOGETHER with its packed buffer: the kernels such a call enqueues
+                # read the old packed weights asynchronously, so the buffer must outlive them (released after a device
+                # synchronisation in _done_with_handle), not just the host-side handle
+                self._handle_retired[h.value] = (h, getattr(self, "_packed_buf", None))
                 return
         _lib.load().ds_unet_destroy(h)
 
@@ -275,7 +278,11 @@ class UNetModel(nn.Module):
             self._handle_uses.pop(h.value, None)
             dead = self._handle_retired.pop(h.value, None)
         if dead is not None:
-            _lib.load().ds_unet_destroy(dead)
+            handle, buf = dead
+            if buf is not None and buf.is_cuda:
+                torch.cuda.synchronize(buf.device)     # the retired call's kernels (any stream) have read the old buffer
+            _lib.load().ds_unet_destroy(handle)
+            del buf
 
     def __del__(self):
         try:

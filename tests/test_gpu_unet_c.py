@@ -165,10 +165,12 @@ def test_c_program_full_size_vs_reference_golden_and_python_program():
     assert torch.equal(out["c"][0], out["python"][0])
 
 
-def test_cpp_host_example_equals_the_python_binding(tmp_path):
+@pytest.mark.parametrize("mode", ["default", "wide"])
+def test_cpp_host_example_equals_the_python_binding(tmp_path, mode):
     """examples/unet_host (C++: only dynscaler_hip.h + the HIP runtime) on the toy i2v UNet: weights, inputs and geometry handed
     over as raw files, eps.bin compared BIT FOR BIT with UNetModel's result (both run ds_unet_forward on identically packed
-    operands) and against the reference's golden eps."""
+    operands) and against the reference's golden eps.  "wide": the same host program with ds_unet_config.residual_f32 = 3 (the
+    packed buffer then holds the lo planes too): an fp32-level result from a plain C++ caller."""
     import subprocess
     from dynamicscaler_amd import build
     from dynamicscaler_amd.unet_spec import param_shapes
@@ -181,7 +183,8 @@ def test_cpp_host_example_equals_the_python_binding(tmp_path):
     sd = synth_state_dict(param_shapes(params), 5)
     x, t, ctx = T(z["x_0"]), T(z["t_0"]).to(torch.int64).reshape(-1), T(z["ctx_0"])
     B, _, Tn, H, W = x.shape
-    cfg = m._c_config()
+    cfg = (m.twin("wide") if mode == "wide" else m)._c_config()
+    assert cfg.residual_f32 == (3 if mode == "wide" else 2)
     fields = []
     for name, ctype in cfg._fields_:
         v = getattr(cfg, name)
@@ -199,6 +202,6 @@ def test_cpp_host_example_equals_the_python_binding(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     print(r.stdout.strip())
     eps_c = torch.from_numpy(np.fromfile(tmp_path / "eps.bin", dtype=np.float32).reshape(B, params["out_channels"], Tn, H, W))
-    eps_py = m(x.to(d), t.to(d), context=ctx.to(d), fps=int(z["fps_0"])).cpu()
+    eps_py = m(x.to(d), t.to(d), context=ctx.to(d), fps=int(z["fps_0"]), precision="wide" if mode == "wide" else None).cpu()
     assert torch.equal(eps_c, eps_py)
-    assert relerr(eps_c, T(z["eps_0"])) < EPS_TOL_TINY
+    assert relerr(eps_c, T(z["eps_0"])) < (2e-5 if mode == "wide" else EPS_TOL_TINY)
