@@ -70,9 +70,12 @@ def _worker(rank, world, port, steps, geom_name, out, with_units=False):
     pano = torch.randn((1, 4) + fhw)
     pano_x0 = torch.zeros_like(pano)
     modes = set()
+    from dynamicscaler_amd import parallel
+    prof = parallel.profile_begin()           # the per-rank account bench.py reports (per_rank)
     for step in rec["trace"][:steps]:
         modes.add(_run_step(pano, pano_x0, [tuple(w) for w in step["windows"]], fhw, rank, world, with_units))
-    out[rank] = (pano, pano_x0, sorted(modes))
+    parallel.profile_end()
+    out[rank] = (pano, pano_x0, sorted(modes), dict(prof), len(rec["trace"][0]["windows"]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -104,6 +107,17 @@ def test_ranks_equal_single_process(geom_name, steps, world, mode, with_units):
     for r in range(world):
         assert torch.equal(out[r][0], single[0][0]) and torch.equal(out[r][1], single[0][1])
         assert out[r][2] == [mode]
+    # the per-rank account: every tile (or evaluation unit) of every step is owned by exactly one rank; whole-column ownership has ONE
+    # exchange per step, a single process none
+    profs, ntiles = [out[r][3] for r in range(world)], out[0][4]
+    assert single[0][3]["tiles_owned"] == steps * ntiles and single[0][3]["exchanges"] == 0
+    if mode == "components":
+        assert sum(p["tiles_owned"] for p in profs) == steps * ntiles and all(p["exchanges"] == steps for p in profs)
+    elif mode == "levels":
+        assert sum(p["tiles_owned"] for p in profs) == steps * ntiles and all(p["exchanges"] >= steps for p in profs)
+    else:
+        assert sum(2 * p["tiles_owned"] + p["units_owned"] for p in profs) == 2 * steps * ntiles
+    assert all(p["exchange_s"] > 0 and p["exchange_bytes"] >= 0 for p in profs)
 
 
 def test_plan_components_and_owners():
