@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int BK = 64;          // halfs per K-step of a plane (128-byte LDS rows)
-constexpr int BM = 128, BN = 128;
+constexpr int BM = 256, BN = 128;          // 8 waves as 4 x 2, wave tile 64 x 64
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -32,18 +32,32 @@ __device__ __forceinline__ float silu_exact(float v) { return v / (1.0f + expf(-
 __device__ __forceinline__ float gelu_exact(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)); }
 
 // out[M,N] (fp32) = gatherA[M,K] (fp32 rows) * (Whi + Wlo / S)[N,K]^T, epilogue as ds_gemm_f16 (bias / per-item bias / fp32 residual /
-// SiLU / GEGLU).  128x128 tile, 4 waves as 2x2, wave tile 64x64 = 4x4 MFMA tiles of 16x16, two accumulator sets.
+// SiLU / GEGLU).  256x128 tile, 8 waves as 4x2 (two per SIMD: one wave's staging arithmetic under the other's MFMAs), wave tile
+// 64x64 = 4x4 MFMA tiles of 16x16, two accumulator sets.  The kernel is bound by operand delivery (fp32 A rows: 96 KB per K-step
+// and workgroup), which is why the tile is 256 rows tall: a 128x128 tile moved 64 KB per K-step for half the FLOPs.
+constexpr int WIDE_NT = 512;
+// LDS: A hi, A lo [BM rows] (one stage: split in registers on the way in) | two stages of W hi, W lo [BN rows] (the weight planes need
+// no arithmetic: LDS-DMA straight from memory, the next K-step's in flight under the MFMAs of this one): 64 + 2 x 32 = 128 KB
+constexpr size_t WIDE_LDS = (size_t)(2 * BM + 4 * BN) * BK * sizeof(f16);
+typedef __attribute__((address_space(3))) void wide_lds_void;
+// (a __device__ helper: with the builtin written inside the templated kernel clang's host pass drops the kernel's launch stub)
+__device__ __forceinline__ void wide_dma16(__amdgpu_buffer_rsrc_t rs, f16* dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (wide_lds_void*)dst, 16, voff, soff, 0, 0);
+}
 template <int AMODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(WIDE_NT)
 gemm_wide_kernel(WideArgs ka) {
-    __shared__ __attribute__((aligned(256))) f16 sm[4][BM * BK];     // planes: A hi, A lo, W hi, W lo (64 KB)
+    extern __shared__ __attribute__((aligned(256))) unsigned char wide_smem[];
+    f16* const smA[2] = {reinterpret_cast<f16*>(wide_smem), reinterpret_cast<f16*>(wide_smem) + BM * BK};
+    // W stage s: hi plane at smW(s, 0), lo plane at smW(s, 1)
+    auto smW = [&](int stage, int plane) { return reinterpret_cast<f16*>(wide_smem) + (2 * BM + (2 * stage + plane) * BN) * BK; };
     const ds_gemm_desc d = ka.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int tile_n = blockIdx.x % ka.tiles_n, tile_m = blockIdx.x / ka.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int ld_row = tid >> 3, ld_chunk = tid & 7;      // 32 rows x 8 chunks (8 elements each) per sweep, 4 sweeps per operand
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;      // 64 rows x 8 chunks (8 elements each) per sweep: 4 sweeps of A, 2 of W
 
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ka.A), 0, (int)ka.a_bytes, 0x00020000);
@@ -54,10 +68,10 @@ gemm_wide_kernel(WideArgs ka) {
     unsigned base[4];
     int ra_[4], rb_[4];
     bool valid[4];
-    unsigned b_off[4];
+    unsigned b_off[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ld_row + 32 * i;
+        const int m = m0 + ld_row + 64 * i;
         valid[i] = m < d.M;
         const int mm = valid[i] ? m : 0;
         if constexpr (AMODE == DS_A_CONV3) {
@@ -74,8 +88,13 @@ gemm_wide_kernel(WideArgs ka) {
             ra_[i] = rb_[i] = 0;
             base[i] = (unsigned)mm * (unsigned)d.lda * 4u;
         }
-        const int n = n0 + ld_row + 32 * i;
-        b_off[i] = n < d.N ? (unsigned)n * (unsigned)d.K * 2u + (unsigned)ld_chunk * 16u : OOB;
+        if (i < 2) {
+            // LDS-DMA: a wave instruction lands 8 rows x 128 B at a wave-uniform address (lane l at + 16 l), so the physical chunk is
+            // lane & 7 and the XOR swizzle moves to the SOURCE chunk; wave w stages rows 8 (w + 8 i) .. + 7 of each plane
+            const int row = 8 * (wave + 8 * i) + (lane >> 3);
+            const int n = n0 + row;
+            b_off[i] = n < d.N ? (unsigned)n * (unsigned)d.K * 2u + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u : OOB;
+        }
     }
     const int hl = d.upsample ? 2 * d.hin : d.hin, wl = d.upsample ? 2 * d.win : d.win;
     const int ups = d.upsample ? 1 : 0;
@@ -105,15 +124,17 @@ gemm_wide_kernel(WideArgs ka) {
     tap_offsets();
 
     f32x4 ga[4][2];
-    u32x4 gh[4], gl[4];
-    auto load_global = [&]() {
+    auto load_global = [&](int wstage) {
         const unsigned soff_a = (unsigned)cb * 4u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wide_dma16(rsH, smW(wstage, 0) + 8 * (wave + 8 * i) * BK, b_off[i], kbytes);
+            wide_dma16(rsL, smW(wstage, 1) + 8 * (wave + 8 * i) * BK, b_off[i], kbytes);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ga[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voff_a[i], soff_a, 0));
             ga[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voff_a[i] == OOB ? OOB : voff_a[i] + 16u, soff_a, 0));
-            gh[i] = __builtin_amdgcn_raw_buffer_load_b128(rsH, b_off[i], kbytes, 0);
-            gl[i] = __builtin_amdgcn_raw_buffer_load_b128(rsL, b_off[i], kbytes, 0);
         }
         kbytes += BK * 2;
         cb += BK;
@@ -126,7 +147,7 @@ gemm_wide_kernel(WideArgs ka) {
     auto store_lds = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = ld_row + 32 * i;
+            const int row = ld_row + 64 * i;
             const int o = row * BK + swz_chunk(row, ld_chunk) * 8;
             f16x8 hi, lo;
 #pragma unroll
@@ -136,10 +157,8 @@ gemm_wide_kernel(WideArgs ka) {
                 hi[j] = h;
                 lo[j] = (f16)((a - (float)h) * LO_SCALE);
             }
-            *reinterpret_cast<f16x8*>(&sm[0][o]) = hi;
-            *reinterpret_cast<f16x8*>(&sm[1][o]) = lo;
-            *reinterpret_cast<u32x4*>(&sm[2][o]) = gh[i];
-            *reinterpret_cast<u32x4*>(&sm[3][o]) = gl[i];
+            *reinterpret_cast<f16x8*>(smA[0] + o) = hi;
+            *reinterpret_cast<f16x8*>(smA[1] + o) = lo;
         }
     };
 
@@ -149,13 +168,19 @@ gemm_wide_kernel(WideArgs ka) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) { accM[a][b] = f32x4{0, 0, 0, 0}; accX[a][b] = f32x4{0, 0, 0, 0}; }
 
+    // every wave waits for ITS loads (A rows in registers, its share of the W planes by LDS-DMA), then the barrier makes all shares visible
+    auto landed = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     const int nk = d.K / BK;
-    load_global();
+    load_global(0);
+    landed();
     store_lds();
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) load_global();
+        const int ws = kt & 1;
+        if (more) load_global(ws ^ 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f16x8 wh[4], wl_[4];
@@ -163,15 +188,15 @@ gemm_wide_kernel(WideArgs ka) {
             for (int t = 0; t < 4; ++t) {
                 const int row = wn * 64 + t * 16 + l15;
                 const int o = row * BK + swz_chunk(row, 4 * ks + l4) * 8;
-                wh[t] = *reinterpret_cast<const f16x8*>(&sm[2][o]);
-                wl_[t] = *reinterpret_cast<const f16x8*>(&sm[3][o]);
+                wh[t] = *reinterpret_cast<const f16x8*>(smW(ws, 0) + o);
+                wl_[t] = *reinterpret_cast<const f16x8*>(smW(ws, 1) + o);
             }
 #pragma unroll
             for (int m16 = 0; m16 < 4; ++m16) {
                 const int row = wm * 64 + m16 * 16 + l15;
                 const int o = row * BK + swz_chunk(row, 4 * ks + l4) * 8;
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(&sm[0][o]);
-                const f16x8 al = *reinterpret_cast<const f16x8*>(&sm[1][o]);
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(smA[0] + o);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(smA[1] + o);
 #pragma unroll
                 for (int n16 = 0; n16 < 4; ++n16) {
                     accM[n16][m16] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[n16], ah, accM[n16][m16], 0, 0, 0);
@@ -180,8 +205,10 @@ gemm_wide_kernel(WideArgs ka) {
                 }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads are done before anyone overwrites the A planes
         __syncthreads();
         if (more) {
+            landed();
             store_lds();
             __syncthreads();
         }
@@ -244,7 +271,16 @@ gemm_wide_kernel(WideArgs ka) {
 
 template <int AMODE>
 int launch_wide(const WideArgs& ka, hipStream_t st) {
-    gemm_wide_kernel<AMODE><<<ka.tiles_m * ka.tiles_n, 256, 0, st>>>(ka);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS);
+        if (e != hipSuccess) {
+            ds_set_error("ds_gemm_wide: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DS_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    gemm_wide_kernel<AMODE><<<ka.tiles_m * ka.tiles_n, WIDE_NT, WIDE_LDS, st>>>(ka);
     DS_CHECK_LAUNCH("ds_gemm_wide");
     return DS_OK;
 }
@@ -432,6 +468,151 @@ attention_wide_kernel(const float* __restrict__ q, const float* __restrict__ k, 
         f32x4 r = f32x4{o[4 * d4] * inv, o[4 * d4 + 1] * inv, o[4 * d4 + 2] * inv, o[4 * d4 + 3] * inv};
         if (accumulate) r += *reinterpret_cast<const f32x4*>(op + 4 * d4);
         *reinterpret_cast<f32x4*>(op + 4 * d4) = r;
+    }
+}
+
+// The same on the fp32 matrix path: v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation; 157 TFLOP/s peak, the VALU form above
+// is bound by its broadcast LDS reads at ~7).  A workgroup = 4 waves x 16 queries; K / V tiles of 64 keys in LDS with row strides
+// (68 / 80 floats) that make the operand reads -- one float per lane: K[key = l % 16][d = 4 kk + l / 16], V[key = 4 kk + l / 16][d = l % 16]
+// -- conflict-free; S = Q K^T in the accumulator layout (lane: 4 queries x 1 key per 16-key tile), row maxima / sums by xor shuffles
+// over the 16 lanes of a query group, P back through a per-wave LDS strip (accumulator layout -> A-operand layout), O += P V.
+// A workgroup = AW_NW waves x 16 queries.
+constexpr int AW_KS = 68, AW_VS = 80, AW_PS = 68;
+constexpr int AW_NW = 8;                       // waves per workgroup: 128 queries share one staging of a K / V tile
+constexpr int AW_NT = 64 * AW_NW, AW_LD = 1024 / AW_NT;      // threads; float4 loads per thread and operand for a 64 x 64 tile
+constexpr size_t AW_LDS = (size_t)(64 * (AW_KS + AW_VS) + AW_NW * 16 * AW_PS) * sizeof(float);
+__global__ void __launch_bounds__(AW_NT)
+attention_wide_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
+                           int nq, int nk, int ldq, int ldk, int ldv, int ldo, int kvdiv, float scale, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float aw_smem[];      // Ks | Vs | one P strip per wave (AW_LDS bytes, dynamic: > 64 KB)
+    float* const Ks = aw_smem;
+    float* const Vs = aw_smem + 64 * AW_KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (16 * AW_NW) + wave * 16;
+    const long kvb = b / kvdiv;
+    // Q as the A operand of S = Q K^T: lane holds Q[q0 + l16][4 kk + lg], pre-multiplied by the scale
+    float qa[16];
+    {
+        const int qi = min(q0 + l16, nq - 1);
+        const float* qp = q + ((long)b * nq + qi) * ldq + h * 64 + lg;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) qa[kk] = qp[4 * kk] * scale;
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
+    float mrun[4], lrun[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.0f; }
+    float* const P = aw_smem + 64 * (AW_KS + AW_VS) + wave * 16 * AW_PS;
+    // K / V tiles travel memory -> registers -> LDS; the NEXT tile's loads are issued right after this tile has been published, so they
+    // are in flight under its 128 MFMAs
+    f32x4 gk[AW_LD], gv[AW_LD];
+    auto fetch = [&](int key0_) {
+#pragma unroll
+        for (int i = 0; i < AW_LD; ++i) {
+            const int idx = tid + AW_NT * i, key = idx >> 4, c4 = idx & 15;
+            const bool on = key0_ + key < nk;
+            const long row = kvb * nk + (on ? key0_ + key : 0);
+            gk[i] = on ? *reinterpret_cast<const f32x4*>(k + row * ldk + h * 64 + 4 * c4) : f32x4{0, 0, 0, 0};
+            gv[i] = on ? *reinterpret_cast<const f32x4*>(v + row * ldv + h * 64 + 4 * c4) : f32x4{0, 0, 0, 0};
+        }
+    };
+    fetch(0);
+    for (int key0 = 0; key0 < nk; key0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < AW_LD; ++i) {
+            const int idx = tid + AW_NT * i, key = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<f32x4*>(&Ks[key * AW_KS + 4 * c4]) = gk[i];
+            *reinterpret_cast<f32x4*>(&Vs[key * AW_VS + 4 * c4]) = gv[i];
+        }
+        __syncthreads();
+        if (key0 + 64 < nk) fetch(key0 + 64);
+        // S[kt]: queries 4 lg + r, key 16 kt + l16
+        f32x4 sacc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) sacc[kt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const float bk = Ks[(16 * kt + l16) * AW_KS + 4 * kk + lg];
+                sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[kk], bk, sacc[kt], 0, 0, 0);
+            }
+        }
+        float mt[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mt[r] = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const bool on = key0 + 16 * kt + l16 < nk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (!on) sacc[kt][r] = -INFINITY;
+                mt[r] = fmaxf(mt[r], sacc[kt][r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) mt[r] = fmaxf(mt[r], __shfl_xor(mt[r], sh));
+        }
+        float alpha[4], rs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mnew = fmaxf(mrun[r], mt[r]);        // finite: a tile holds at least one key
+            alpha[r] = expf(mrun[r] - mnew);                  // 0 on the first tile
+            mrun[r] = mnew;
+            rs[r] = 0.0f;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = expf(sacc[kt][r] - mrun[r]);   // 0 for masked keys
+                rs[r] += pv;
+                P[(4 * lg + r) * AW_PS + 16 * kt + l16] = pv;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) rs[r] += __shfl_xor(rs[r], sh);
+            lrun[r] = lrun[r] * alpha[r] + rs[r];
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own P strip: LDS operations of a wave complete in order
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float pa = P[l16 * AW_PS + 4 * kk + lg];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float bv = Vs[(4 * kk + lg) * AW_VS + 16 * dt + l16];
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, bv, o[dt], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // P is rewritten by the next tile
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + 4 * lg + r;
+        if (qi >= nq) continue;
+        const float inv = 1.0f / lrun[r];
+        float* op = out + ((long)b * nq + qi) * ldo + h * 64 + l16;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float val = o[dt][r] * inv;
+            if (accumulate) val += op[16 * dt];
+            op[16 * dt] = val;
+        }
     }
 }
 
@@ -644,8 +825,23 @@ extern "C" int ds_attention_wide(const float* q, const float* k, const float* v,
     DS_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "ds_attention_wide: row strides must be multiples of 4");
     DS_CHECK_ARG(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
                  "ds_attention_wide: operands must be 16-byte aligned");
-    attention_wide_kernel<<<dim3((nq + 63) / 64, heads, batch), 64, 0, (hipStream_t)stream>>>(q, k, v, out, nq, nk, ldq, ldk, ldv, ldo, kv_batch_div,
-                                                                                               scale, accumulate);
+    // the fp32 matrix-core form; DS_WIDE_ATTN_VALU=1 ("tune" variant) selects the VALU kernel it replaced
+    if (DS_TUNE_INT("DS_WIDE_ATTN_VALU", 0) != 0)
+        attention_wide_kernel<<<dim3((nq + 63) / 64, heads, batch), 64, 0, (hipStream_t)stream>>>(q, k, v, out, nq, nk, ldq, ldk, ldv, ldo, kv_batch_div,
+                                                                                                   scale, accumulate);
+    else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_wide_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AW_LDS);
+            if (e != hipSuccess) {
+                ds_set_error("ds_attention_wide: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return DS_ELAUNCH;
+            }
+            attr_set = true;
+        }
+        attention_wide_mfma_kernel<<<dim3((nq + 16 * AW_NW - 1) / (16 * AW_NW), heads, batch), AW_NT, AW_LDS, (hipStream_t)stream>>>(q, k, v, out, nq, nk, ldq, ldk, ldv, ldo,
+                                                                                                         kv_batch_div, scale, accumulate);
+    }
     DS_CHECK_LAUNCH("ds_attention_wide");
     return DS_OK;
 }
