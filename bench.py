@@ -300,7 +300,10 @@ def main():
         props = torch.cuda.get_device_properties(dev)
         pci = getattr(props, "pci_bus_id", None)
         if pci is not None:
-            pci = f"{getattr(props, 'pci_domain_id', 0):04x}:{pci:02x}:{getattr(props, 'pci_device_id', 0):02x}"
+            try:
+                pci = f"{int(getattr(props, 'pci_domain_id', 0)):04x}:{int(pci):02x}:{int(getattr(props, 'pci_device_id', 0)):02x}"
+            except (TypeError, ValueError):
+                pci = str(pci)
         mine = {"rank": rank, "device": dev_index, "name": torch.cuda.get_device_name(dev), "backend": dist.get_backend(),
                 "rccl": ver, "pci": pci, "uuid": str(getattr(props, "uuid", "")) or None}
         ranks_seen = [None] * world

@@ -3,11 +3,12 @@
 //     x = xh + xl / S,   xh = fp16(x),  xl = fp16((x - xh) * S),  S = 2^11        (the same for the weights, split at pack time)
 //     x . w = xh.wh + (xh.wl + xl.wh) / S  [+ xl.wl / S^2: dropped, 2^-22 relative]
 // three v_mfma_f32_16x16x32_f16 per fragment pair, the two cross terms in their own fp32 accumulator so that the 1/S is applied
-// once, after the K sum.  Products then carry ~22 mantissa bits and the evaluation is an fp32 one (eps within ~1e-5 of the
+// once, after the K sum.  Products then carry ~22 mantissa bits and the evaluation is an fp32 one (eps within 2e-6 of the
 // reference's fp32 CPU result instead of ~1e-3): what the highest-noise DDIM updates need, where sqrt((1 - a) / a) and the
 // guidance scale amplify the eps error past the 1e-3 budget on the latent (config 1's 999 -> 666 update: DESIGN.md section 5).
-// A precision mode for single steps, not the throughput path: plain register staging, one LDS stage, direct stores.
-// The other kernels of the mode (GroupNorm / LayerNorm with fp32 outputs, fp32 attention, fp32 glue) are below the GEMM.
+// A precision mode for single steps, not the throughput path: 3.7x the time of a default-mode evaluation (profiles/r5_notes.md section 1).
+// ds_gemm_wide is bound by the delivery of its fp32 A rows (96 KB per K-step and 256x128 tile through the L2 -> CU fabric); the other
+// kernels of the mode (GroupNorm / LayerNorm with fp32 outputs, attention on v_mfma_f32_16x16x4_f32, fp32 glue) are below the GEMM.
 #include <limits.h>
 #include "common.h"
 

@@ -562,10 +562,6 @@ class VC2_Pipeline_T2V:
         `use_skip_time` the schedule is cut (non-progressive) or the first frames get progressively lower noise levels;
         per step the panorama is merged with that resized latent re-noised to the step's level, densely or on the
         reference's sparse checkerboard (:445-468, `ds_residual_merge`)."""
-        if random_shuffle_init_frame_stride:
-            raise NotImplementedError("random_shuffle_init_frame_stride: the reference indexes the H axis with frame "
-                                      "indices there (t2v_normal_pipeline.py:337) and fails for panoramas lower than "
-                                      "their frame count; no driver uses it")
         unet_config = self.model_config["params"]["unet_config"]
         frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
         prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
@@ -582,7 +578,18 @@ class VC2_Pipeline_T2V:
         total_shape = (1, c_lat, frames * num_windows_f, lat_h * num_windows_h, lat_w * num_windows_w)
         resized, fm = None, True
         if init_panorama_latent is None:
-            init_panorama_latent = torch.randn(total_shape).to(self._execution_device)  # host draw, reference order; lives on the execution device like the reference's
+            init_panorama_latent = torch.randn(total_shape)                              # host draw, reference order
+            if random_shuffle_init_frame_stride > 0:
+                # t2v_normal_pipeline.py:328-337, literally: the reference shuffles slices of the init latent with Python's global
+                # `random` -- and indexes dim 3 (the H axis of [B, C, F, H, W]) with its FRAME indices; the same statements on the same
+                # host tensor reproduce it (and its shape error for panoramas lower than their frame count), repeatable under random.seed
+                import random
+                stride_ = int(random_shuffle_init_frame_stride)
+                for frame_index in range(frames, frames * num_windows_f, stride_):
+                    list_index = list(range(frame_index - frames, frame_index + stride_ - frames))
+                    random.shuffle(list_index)
+                    init_panorama_latent[:, :, :, frame_index:frame_index + stride_] = init_panorama_latent[:, :, :, list_index]
+            init_panorama_latent = init_panorama_latent.to(self._execution_device)     # lives on the execution device like the reference's
             if use_skip_time:
                 assert use_pre_denoise and pre_denoise_steps > 0, \
                     "[basic_sample_shift_multi_windows] skip ts should be used with pre denoise if init_panorama_latent is not provided "

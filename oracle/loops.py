@@ -242,7 +242,7 @@ def t2v_grid_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, *,
                     use_pre_denoise=False, pre_denoise_steps=None, skip_steps_after_pre_denoise=0,
                     clear_pre_denoised_latent=None, merge_predenoise_ratio_list=None, sparse_add_residual=True,
                     use_skip_time=False, skip_time_step_idx=None, progressive_skip=False,
-                    clear_pre_denoised_video_tensor=None, encode_first_stage=None, **grid_kw):
+                    clear_pre_denoised_video_tensor=None, encode_first_stage=None, random_shuffle_init_frame_stride=0, **grid_kw):
     """Returns (denoised, denoised) for output_type='latent' (t2v_normal_pipeline.py:561-568).  Includes the pre-denoise
     start (:345-412: a single tile denoised for a few steps or given, resized bicubically to the panorama, re-noised,
     optionally with a per-frame progressive noise level) and the per-step sparse / dense residual merge (:445-468)."""
@@ -265,6 +265,12 @@ def t2v_grid_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, *,
 
     if init_panorama_latent is None:
         pano = torch.randn(total_shape)
+        if random_shuffle_init_frame_stride > 0:                 # t2v_normal_pipeline.py:328-337 (dim 3 = H is what the reference indexes)
+            import random
+            for frame_index in range(frames, frames * num_windows_f, random_shuffle_init_frame_stride):
+                list_index = list(range(frame_index - frames, frame_index + random_shuffle_init_frame_stride - frames))
+                random.shuffle(list_index)
+                pano[:, :, :, frame_index:frame_index + random_shuffle_init_frame_stride] = pano[:, :, :, list_index]
         if use_skip_time:
             assert use_pre_denoise and pre_denoise_steps > 0 and skip_time_step_idx >= skip_steps_after_pre_denoise
         if use_pre_denoise and pre_denoise_steps > 0:

@@ -1124,6 +1124,32 @@ I2V_GRID_GEOMS = {    # VC2_Pipeline_I2V.basic_sample_shift_multi_windows (i2v_n
 }
 
 
+GRID_SHUFFLE_GEOM = dict(num_windows_w=4, num_windows_h=2, num_windows_f=2, loop_step=4, num_inference_steps=5,
+                         shift_jump_odd_w=True, shift_jump_odd_h=True, shift_jump_odd_f=True, random_shuffle_init_frame_stride=2)
+
+
+def g32_grid_random_shuffle():
+    """random_shuffle_init_frame_stride of the non-overlapping grid loop (pipeline/t2v_normal_pipeline.py:328-337): the init latent's
+    slices shuffled with Python's global `random` (seeded here; the reference indexes dim 3 with its frame indices).  Fake eps, fp32."""
+    import random
+    cond, uncond = synth_normal((1, 77, 64), 61), synth_normal((1, 77, 64), 62)
+    ld = FakeLatentDiffusion(FakeEps(), cond, uncond, temporal_length=4)
+    pipe = VC2_Pipeline_T2V(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": dict(TINY)}}})
+    torch.manual_seed(2333333)
+    random.seed(4242)
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=64, width=128, frames=4, fps=8, guidance_scale=7.5,
+                                                       output_type="latent", skip_time_step_idx=0, **GRID_SHUFFLE_GEOM)
+    torch.manual_seed(2333333)
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, plain = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=64, width=128, frames=4, fps=8, guidance_scale=7.5,
+                                                         output_type="latent", skip_time_step_idx=0,
+                                                         **dict(GRID_SHUFFLE_GEOM, random_shuffle_init_frame_stride=0))
+    assert not torch.equal(den, plain)
+    save_npz("loops_grid_shuffle.npz", cond=cond, uncond=uncond, denoised=den, random_seed=np.int64(4242),
+             geom_json=np.frombuffer(json.dumps(GRID_SHUFFLE_GEOM).encode(), dtype=np.uint8))
+
+
 def synth_image_embedder(dim, tokens=16, seed=77):
     """Deterministic stand-in for get_image_embeds (CLIP image encoder + Resampler are out of scope): a 4x4 average
     pool of the crop projected 3 -> dim by a fixed seeded matrix.  Same function in tests/helpers.py."""
@@ -1683,7 +1709,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale, "g22": g22_i2v_sphere_view_scale, "g24": g24_panorama_handlers, "g30": g30_panorama_handlers_uncalled}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale, "g22": g22_i2v_sphere_view_scale, "g24": g24_panorama_handlers, "g30": g30_panorama_handlers_uncalled, "g32": g32_grid_random_shuffle}
     if args.full:
         steps["g10"] = g10_unet_full
         steps["g10i"] = g10_unet_full_i2v

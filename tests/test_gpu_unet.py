@@ -661,6 +661,35 @@ def test_grid_pipeline_vs_reference_golden():
     assert e < PIPE_TOL
 
 
+def test_grid_pipeline_random_shuffle_init_vs_reference_golden():
+    """random_shuffle_init_frame_stride (pipeline/t2v_normal_pipeline.py:328-337; built in round 5): the init latent's slices shuffled
+    with Python's global `random`, the reference's statements literally (it indexes dim 3 with frame indices).  Under the same
+    random.seed the HIP pipeline reproduces the reference's panorama (make_golden.py g32), fake eps, bit-exact vs the oracle."""
+    import random
+    from oracle import loops as oloops, ddim as oddim
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V
+    d = dev()
+    z = np.load(os.path.join(G, "loops_grid_shuffle.npz"))
+    geom = json.loads(bytes(z["geom_json"]).decode())
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    ld = _fake_host(cond, uncond, d)
+    pipe = VC2_Pipeline_T2V(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": {"in_channels": 4}}}}).to(d, torch.float32)
+    torch.manual_seed(2333333)
+    random.seed(int(z["random_seed"]))
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=64, width=128, frames=4, fps=8, guidance_scale=7.5,
+                                                   output_type="latent", **geom)
+    torch.manual_seed(2333333)
+    random.seed(int(z["random_seed"]))
+    oref, _ = oloops.t2v_grid_sample(_oracle_fake, oddim.DiffusionTables(), cond, uncond, height=64, width=128, frames=4, guidance_scale=7.5, **geom)
+    assert torch.equal(den.cpu(), oref)
+    assert relerr(den, T(z["denoised"])) < 1e-4
+    # a panorama lower than its frame count fails like the reference does (its frame indices run off the H axis)
+    with pytest.raises((RuntimeError, IndexError)):
+        pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=16, width=128, frames=4, fps=8, guidance_scale=7.5, output_type="latent",
+                                              **dict(geom, num_windows_h=1, num_windows_f=4, random_shuffle_init_frame_stride=4))
+
+
 def test_grid_pipeline_pre_denoise_and_residual_merge():
     """R11's pre-denoise start / skip-time / progressive skip / given clear latent and the per-step sparse and dense
     residual merge (t2v_normal_pipeline.py:345-412, 445-468) on the HIP path, fake eps in fp32: the oracle on this host

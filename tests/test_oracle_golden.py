@@ -230,6 +230,19 @@ def test_g9_baseline_geometry_final_panorama_sha(name):
 
 
 # ------------------------------------------------------------------------------------------------ P4 / P3
+def test_g32_grid_loop_random_shuffle_init_bit_exact():
+    """random_shuffle_init_frame_stride (pipeline/t2v_normal_pipeline.py:328-337): the oracle's restatement against the reference's own run
+    under the same `random.seed` (make_golden.py g32) -- the shuffle of the init latent's slices, bug-for-bug on dim 3."""
+    import random
+    z = npz("loops_grid_shuffle.npz")
+    geom = json.loads(bytes(z["geom_json"]).decode())
+    cond, uncond = T(z["cond"]), T(z["uncond"])
+    torch.manual_seed(2333333)
+    random.seed(int(z["random_seed"]))
+    den, _ = oloops.t2v_grid_sample(_fake_eps, oddim.DiffusionTables(), cond, uncond, height=64, width=128, frames=4, guidance_scale=7.5, **geom)
+    assert torch.equal(den, T(z["denoised"]))
+
+
 def test_g11_grid_loop_fake_eps_bit_exact_and_traces():
     z = npz("loops_grid_i2v.npz")
     meta = json.load(open(os.path.join(G, "loops_grid_i2v_traces.json")))
