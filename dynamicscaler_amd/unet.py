@@ -141,6 +141,25 @@ class UNetModel(nn.Module):
         self._handle_uses = {}          # handle value -> calls in flight
         self._handle_retired = {}       # handle value -> handle, replaced while in use
 
+    # ------------------------------------------------------------------ copies / pickles never share a C handle
+    _RUNTIME_STATE = ("_handle", "_packed", "_packed_buf", "_twins", "_prepare_lock", "_handle_lock", "_handle_uses", "_handle_retired",
+                      "_ws_bytes", "_tap")
+
+    def __getstate__(self):
+        """copy.copy / copy.deepcopy / torch.save of the module: the C handle, the packed buffers, the twins and the locks belong to ONE
+        module object (two owners of a handle would destroy it twice); the copy repacks on its first forward."""
+        st = self.__dict__.copy()
+        for k in self._RUNTIME_STATE:
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._handle, self._packed, self._packed_buf, self._tap = None, None, None, None
+        self._twins, self._ws_bytes = {}, {}
+        self._prepare_lock, self._handle_lock = threading.Lock(), threading.Lock()
+        self._handle_uses, self._handle_retired = {}, {}
+
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, *a, **k):
         self.invalidate()
@@ -167,15 +186,8 @@ class UNetModel(nn.Module):
         tw = self._twins.get(operand_mode)
         if tw is None:
             import copy
-            tw = copy.copy(self)                 # shallow: _parameters / _modules (the parameter tree) are shared objects
-            tw._twins = {}
-            tw._packed = None
-            tw._handle = None
-            tw._tap = None
-            tw._generation = 0
-            tw._prepare_lock = threading.Lock()
-            tw._handle_lock = threading.Lock()
-            tw._handle_uses, tw._handle_retired = {}, {}
+            tw = copy.copy(self)                 # shallow: _parameters / _modules (the parameter tree) are shared objects; no handle,
+            tw._generation = 0                   # packed buffer, twin or lock travels with a copy (__getstate__ / __setstate__)
             tw.operand_mode = operand_mode
             tw.program = "c"
             tw.gn_from_producer = False

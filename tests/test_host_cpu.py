@@ -591,6 +591,87 @@ def test_bench_self_launches_ranks_without_touching_the_gpu():
     assert "WORLD_SIZE" not in r.stderr.split("Traceback")[0]
 
 
+def test_unet_twin_shares_parameters_and_copies_never_share_a_handle():
+    """UNetModel.twin("wide") evaluates the SAME parameter objects in the wide operand mode with its own handle / packed buffer;
+    copy.copy / deepcopy / torch.save of a module drop the C handle, the packed buffers, the twins and the locks (one owner per handle)."""
+    import copy
+    import io
+    from dynamicscaler_amd.unet import UNetModel
+    z = np.load(os.path.join(REPO, "tests", "golden", "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(z["params_json"]).decode())
+    m = UNetModel(**params)
+    tw = m.twin("wide")
+    assert tw is m.twin("wide") and tw.operand_mode == "wide" and m.operand_mode == "f16" and tw._handle is None and tw.program == "c"
+    assert all(a is b for a, b in zip(tw.parameters(), m.parameters()))
+    assert tw._c_config().residual_f32 == 3 and m._c_config().residual_f32 == 2
+    assert "_twins" not in [n for n, _ in m.named_modules()] and len(dict(m.named_parameters())) == len(dict(tw.named_parameters()))
+    # the wide launch program: same block structure, every tensor fp32 (epilogue flag 4 on every GEMM), no fold / cast launches
+    tr = tw.c_program_trace(2, 4, 8, 16, 77, 1)
+    assert not any(ln.startswith(("gemm_ln", "cast_rows", "layernorm_stats")) for ln in tr)
+    assert all(int(ln.split("epi=")[1].split()[0]) & 4 for ln in tr if ln.startswith("gemm "))
+    assert sum(ln.startswith("groupnorm_wide") for ln in tr) == sum(ln.startswith("groupnorm") for ln in m.c_program_trace(2, 4, 8, 16, 77, 1))
+    m._handle = object()          # pretend the module is prepared
+    for c in (copy.copy(m), copy.deepcopy(m)):
+        assert c._handle is None and c._packed is None and c._twins == {} and c._prepare_lock is not m._prepare_lock
+    m._handle = None
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)
+    assert r._handle is None and r._twins == {} and r.cfg == m.cfg
+    m.invalidate()
+    assert tw._packed is None
+
+
+def test_operand_policy_selects_the_steps_that_amplify_the_guided_eps_error():
+    """pipelines.operand_policy "auto": a DDIM step runs in the wide operand mode where scheduler.eps_amplification(index) x the residual
+    mode's guided-eps error at that noise level x guidance / 7.5 exceeds 1e-3 -- config 1's 4-step schedule: indices 3, 2, 1; the
+    50-step schedule of the headline metric: none in the default mode (host logic only; the measured side is tests/test_gpu_fullsize.py)."""
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V, GUIDED_EPS_ERR
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler, DiffusionTables
+
+    class U:                                   # what the policy reads of the HIP UNet
+        residual_dtype, residual_scope, operand_mode = torch.float32, "outer", "f16"
+
+        def twin(self, mode="wide"):
+            return self
+
+    class Host:
+        num_timesteps = 1000
+
+        def __init__(self):
+            for k, v in vars(DiffusionTables()).items():
+                setattr(self, k, v)
+            self.model = type("M", (), {"diffusion_model": U()})()
+
+    ld = Host()
+    sched = lvdm_DDIM_Scheduler(ld)
+    pipe = VC2_Pipeline_T2V(ld, sched, None)
+    assert pipe.operand_policy == "auto" and set(GUIDED_EPS_ERR) == {"f16", "f32outer", "f32"}
+    want = {4: [3, 2, 1], 10: [9, 8, 7, 6], 25: [24, 23, 22, 21], 40: [39], 50: []}
+    for n, idx in want.items():
+        sched.make_schedule(n, verbose=False)
+        assert pipe.wide_steps_of(n, 7.5) == idx, (n, pipe.wide_steps_of(n, 7.5))
+    sched.make_schedule(4, verbose=False)
+    a3, a0 = sched.eps_amplification(3), sched.eps_amplification(0)
+    assert 0.75 < a3 < 0.85 and a0 == 0.0 and abs(sched.eps_amplification(3, relative=False) - 3.79) < 0.02
+    sched.make_schedule(50, verbose=False)
+    assert abs(sched.eps_amplification(49) - 0.113) < 0.003
+    assert pipe.wide_steps_of(50, 12.0) == [49, 48, 47, 46]                     # stronger guidance amplifies more
+    ld.model.diffusion_model.residual_dtype = torch.float16                     # the fast mode has less margin: its first steps run wide
+    assert pipe.wide_steps_of(50, 7.5) == [49, 48]
+    ld.model.diffusion_model.residual_dtype = torch.float32
+    for pol, idx in (("f16", []), ("wide", list(range(49, -1, -1))), ({49, 3}, [49, 3])):
+        pipe.operand_policy = pol
+        assert pipe.wide_steps_of(50, 7.5) == idx
+    pipe.operand_policy = "sometimes"
+    with pytest.raises(ValueError, match="operand_policy"):
+        pipe.precision_for(49, 7.5)
+    pipe.operand_policy = "auto"
+    ld.model.diffusion_model = object()                                          # not the HIP UNet (fake eps models): never wide
+    assert pipe.wide_steps_of(50, 7.5) == [] and pipe.precision_for(49, 7.5) is None
+
+
 def test_bench_stalled_rank_makes_the_job_exit_nonzero():
     """Ranks that never arrive (fault injection: DS_BENCH_FAULT=stall:*; on this CPU-only container a healthy rank would stop at
     "needs an MI355X" before anyone could wait for it) must not hang `bench.py --gpus 2`: a stalled rank's watchdog says in which
