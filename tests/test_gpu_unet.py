@@ -23,8 +23,12 @@ EPS_TOL = 2.2e-3        # full-size t2v / i2v UNet eps: measured 1.67e-3 / 1.70e
 LATENT_TOL = 7.2e-4     # x_prev after CFG 7.5 + one DDIM update of the 50-step schedule (index 25), measured 3.6e-4 (inside the north star)
 PRED_X0_TOL = 8e-3      # pred_x0 of the same update on fp16 operands, measured 3.9e-3: (x - sqrt(1-a) e_t)/sqrt(a) amplifies the CFG-combined
                         # eps error by sqrt((1-a)/a); an intermediate quantity at that index (only the last step's pred_x0 leaves a loop)
-PIPE_TOL = 9e-3         # toy pipelines end to end (4-6 DDIM steps, CFG 7.5, tiny UNet), fp16 or fp32 latents: measured
-PIPE_TOL_F16 = PIPE_TOL  # 3.7e-3 .. 4.4e-3 before the operand policy (rounds 2-4)
+# The toy pipelines end to end (4-6 DDIM steps, CFG 7.5, tiny UNet; ring, grid, sphere, i2v, multi-prompt) against the reference's own
+# runs: AT THE NORTH STAR since round 5 -- the operand policy runs the steps of these short schedules that would amplify the guided-eps
+# error in the wide mode: measured 3e-6 .. 4e-6 with fp32 latents, 4.6e-4 .. 7.9e-4 with fp16 latents (the stored latent's own
+# rounding, 2^-11 per step); rounds 2-4, fp16 operands throughout: 3.7e-3 .. 4.4e-3 under a 9e-3 guard
+PIPE_TOL = NORTH_STAR
+PIPE_TOL_F16 = NORTH_STAR
 VAE_TOL = 5.4e-3        # first stage: decode 1.4e-3 (toy) / 2.6e-3 (real config), encode moments 8.8e-4 / 1.0e-3
 
 
@@ -729,10 +733,6 @@ def test_grid_pipeline_pre_denoise_and_residual_merge():
     e = relerr(den, T(z["gridpre_pre_sparse_tiny"]))
     print(f"grid pre_sparse tiny fp16: rel err {e:.3e}")
     assert e < PIPE_TOL
-    with pytest.raises(NotImplementedError):
-        pipe.basic_sample_shift_multi_windows(prompt="a", height=64, width=128, frames=4, num_windows_w=1, num_windows_h=1,
-                                              num_windows_f=2, loop_step=2, num_inference_steps=3, output_type="latent",
-                                              random_shuffle_init_frame_stride=2)
 
 
 def test_grid_pipeline_clear_video_tensor_start():

@@ -184,7 +184,7 @@ def test_cpp_host_example_equals_the_python_binding(tmp_path, mode):
     x, t, ctx = T(z["x_0"]), T(z["t_0"]).to(torch.int64).reshape(-1), T(z["ctx_0"])
     B, _, Tn, H, W = x.shape
     cfg = (m.twin("wide") if mode == "wide" else m)._c_config()
-    assert cfg.residual_f32 == (3 if mode == "wide" else 2)
+    assert cfg.residual_f32 == (3 if mode == "wide" else 0)          # (build_unet of this file puts the module in the fp16 residual mode)
     fields = []
     for name, ctype in cfg._fields_:
         v = getattr(cfg, name)
