@@ -48,6 +48,9 @@ class UNetConfig(C.Structure):
 
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 _pp = C.POINTER
+# ds_launch_hook / ds_block_tap (instrumentation of ds_unet_forward)
+LAUNCH_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p, C.c_double, C.POINTER(C.c_int32), C.c_int, C.c_void_p)
+BLOCK_TAP = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/dynscaler_hip.h one to one
 SIGNATURES = {
@@ -127,6 +130,8 @@ SIGNATURES = {
     "ds_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     "ds_unet_forward": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "ds_unet_trace": (C.c_long, [_vp, _i, _i, _i, _i, _i, _i, C.c_char_p, _sz]),
+    "ds_unet_set_hooks": (_i, [_vp, _vp, _vp, _vp]),
+    "ds_copy_rows": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
 }
 
 _lib = None

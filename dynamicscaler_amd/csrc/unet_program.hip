@@ -164,6 +164,9 @@ struct ds_unet {
     char* packed = nullptr;
     std::map<std::string, int> emb_off;
     int emb_total = 0, kpad_in = 0;
+    ds_launch_hook launch_hook = nullptr;     // instrumentation (ds_unet_set_hooks): per-launch callbacks, per-block taps
+    ds_block_tap block_tap = nullptr;
+    void* hook_user = nullptr;
     std::mutex peak_mu;
     std::map<std::array<int, 6>, size_t> peak_cache;   // (B, T, H, W, ctx_tokens, cfg_pairs) -> workspace peak of the dry run
 
@@ -737,6 +740,18 @@ struct Prog {
         log->push_back('\n');
     }
     void chk(int r) { if (r != DS_OK && rc == DS_OK) rc = r; }
+    // one kernel-family call of the program: nothing in a dry run; with a launch hook installed the host callback runs right before
+    // and right after the call enqueues its kernel(s) (per-launch HIP events, the tests' LDS / register poison launch)
+    template <typename F>
+    void launch(const char* kernel, double flops, std::initializer_list<int32_t> info, F&& call) {
+        if (!live()) return;
+        if (u->launch_hook) u->launch_hook(u->hook_user, 0, kernel, flops, info.begin(), (int)info.size(), st);
+        chk(call());
+        if (u->launch_hook) u->launch_hook(u->hook_user, 1, kernel, flops, info.begin(), (int)info.size(), st);
+    }
+    void tap(const std::string& block, const Ten& h, const Geo& geo) {
+        if (live() && u->block_tap) u->block_tap(u->hook_user, block.c_str(), ptr(h), h.rows, h.cols, h.ld, h.dt, geo.B, geo.T, geo.H, geo.W, st);
+    }
 
     // ---- kernels ----
     struct ConvGeo { int nimg = 0, hin = 0, win = 0, hout = 0, wout = 0, stride = 1, upsample = 0; };
@@ -768,12 +783,12 @@ struct Prog {
             chk(DS_EINVAL);
             return out;
         }
-        if (live()) {
+        launch("gemm", 2.0 * (double)M * N * K, {a_mode, (int32_t)M, N, K, epilogue, residual ? 1 : 0}, [&] {
             if (u->wide)       // the lo plane of a packed matrix follows its hi plane (Planner::w16)
-                chk(ds_gemm_wide((const float*)ptr(A), ptr(W), ptr(W) + (size_t)W.rows * W.ld * 2, bias, (const float*)ptr(residual), (float*)ptr(out), &d, st));
-            else if (cstats) chk(ds_gemm_f16_stats(ptr(A), ptr(W), bias, ptr(residual), ptr(out), (float*)ptr(cstats), cstats.ld / 2, &d, st));
-            else chk(ds_gemm_f16(ptr(A), ptr(W), bias, ptr(residual), ptr(out), &d, st));
-        }
+                return ds_gemm_wide((const float*)ptr(A), ptr(W), ptr(W) + (size_t)W.rows * W.ld * 2, bias, (const float*)ptr(residual), (float*)ptr(out), &d, st);
+            if (cstats) return ds_gemm_f16_stats(ptr(A), ptr(W), bias, ptr(residual), ptr(out), (float*)ptr(cstats), cstats.ld / 2, &d, st);
+            return ds_gemm_f16(ptr(A), ptr(W), bias, ptr(residual), ptr(out), &d, st);
+        });
         return out;
     }
     Ten gemm_ln(const Ten& x, const std::string& name, const Ten& stats, long M, int N, int K, int epilogue) {
@@ -784,9 +799,10 @@ struct Prog {
         d.M = (int)M; d.N = N; d.K = K; d.a_mode = DS_A_DENSE; d.cin = K; d.lda = x.ld; d.ldc = out.ld; d.ldr = 0;
         d.bias_rows = INT_MAX; d.ldbias = N; d.epilogue = epilogue;
         tr("gemm_ln M=%ld N=%d K=%d lda=%d ldc=%d epi=%d", M, N, K, d.lda, d.ldc, epilogue);
-        if (live())
-            chk(ds_gemm_f16_ln(ptr(x), u->P(name + ".wg"), (const float*)ptr(stats), (const float*)u->P(name + ".cs"), (const float*)u->P(name + ".cb"),
-                               ptr(out), &d, st));
+        launch("gemm", 2.0 * (double)M * N * K, {DS_A_DENSE, (int32_t)M, N, K, epilogue, 0}, [&] {
+            return ds_gemm_f16_ln(ptr(x), u->P(name + ".wg"), (const float*)ptr(stats), (const float*)u->P(name + ".cs"), (const float*)u->P(name + ".cb"),
+                                  ptr(out), &d, st);
+        });
         return out;
     }
     // GroupNorm statistics from the producer (ds_gemm_f16_stats -> ds_groupnorm_rows_colstats): where producer and norm are adjacent
@@ -799,9 +815,10 @@ struct Prog {
             Ten stt = raw(ds_groupnorm_wide_scratch_floats(ninst, rows_per, 32) * 4);
             Ten yw = make(x.rows, C, DS_F32);
             tr("groupnorm_wide ldx=%d ninst=%d rows=%d C=%d silu=%d eps=%g", x.ld, ninst, rows_per, C, silu, (double)eps);
-            if (live())
-                chk(ds_groupnorm_wide((const float*)ptr(x), x.ld, (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), (float*)ptr(yw),
-                                      (float*)ptr(stt), ninst, rows_per, C, 32, eps, silu, st));
+            launch("groupnorm", 0.0, {ninst, rows_per, C}, [&] {
+                return ds_groupnorm_wide((const float*)ptr(x), x.ld, (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), (float*)ptr(yw),
+                                         (float*)ptr(stt), ninst, rows_per, C, 32, eps, silu, st);
+            });
             if (raw16) *raw16 = x;        // the un-normalised operand is the fp32 tensor itself
             return yw;
         }
@@ -811,14 +828,13 @@ struct Prog {
         if (raw16) r = *raw16 = make(x.rows, C, DS_F16);
         tr("groupnorm xdt=%d ldx=%d ninst=%d rows=%d C=%d silu=%d raw=%d eps=%g stats=%d", x.dt, x.ld, ninst, rows_per, C, silu, raw16 ? 1 : 0, (double)eps,
            cstats ? cstats.ld / 2 : 0);
-        if (live()) {
+        launch("groupnorm", 0.0, {ninst, rows_per, C}, [&] {
             if (cstats)
-                chk(ds_groupnorm_rows_colstats(ptr(x), x.dt, x.ld, (const float*)ptr(cstats), cstats.ld / 2, (const float*)u->P(prefix + ".g"),
-                                               (const float*)u->P(prefix + ".be"), ptr(y), ptr(r), (float*)ptr(ws), ninst, rows_per, C, 32, eps, silu, st));
-            else
-                chk(ds_groupnorm_rows(ptr(x), x.dt, x.ld, (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), ptr(y), ptr(r),
-                                      (float*)ptr(ws), ninst, rows_per, C, 32, eps, silu, st));
-        }
+                return ds_groupnorm_rows_colstats(ptr(x), x.dt, x.ld, (const float*)ptr(cstats), cstats.ld / 2, (const float*)u->P(prefix + ".g"),
+                                                  (const float*)u->P(prefix + ".be"), ptr(y), ptr(r), (float*)ptr(ws), ninst, rows_per, C, 32, eps, silu, st);
+            return ds_groupnorm_rows(ptr(x), x.dt, x.ld, (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), ptr(y), ptr(r),
+                                     (float*)ptr(ws), ninst, rows_per, C, 32, eps, silu, st);
+        });
         return y;
     }
     Ten layernorm(const Ten& x, const std::string& prefix) {
@@ -826,40 +842,44 @@ struct Prog {
             Ten yw = make(x.rows, x.cols, DS_F32);
             tr("layernorm_wide rows=%ld C=%d", x.rows, x.cols);
             if (x.ld != x.cols) { ds_set_error("ds_unet_forward: layernorm_wide needs dense rows"); chk(DS_EINVAL); return yw; }
-            if (live()) chk(ds_layernorm_wide((const float*)ptr(x), (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), (float*)ptr(yw), x.rows, x.cols, 1e-5f, st));
+            launch("layernorm", 0.0, {(int32_t)x.rows, x.cols}, [&] {
+                return ds_layernorm_wide((const float*)ptr(x), (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), (float*)ptr(yw), x.rows, x.cols, 1e-5f, st);
+            });
             return yw;
         }
         Ten y = make(x.rows, x.cols, DS_F16);
         tr("layernorm xdt=%d rows=%ld C=%d", x.dt, x.rows, x.cols);
-        if (live()) chk(ds_layernorm_rows(ptr(x), x.dt, (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), ptr(y), (int)x.rows, x.cols, 1e-5f, st));
+        launch("layernorm", 0.0, {(int32_t)x.rows, x.cols}, [&] {
+            return ds_layernorm_rows(ptr(x), x.dt, (const float*)u->P(prefix + ".g"), (const float*)u->P(prefix + ".be"), ptr(y), (int)x.rows, x.cols, 1e-5f, st);
+        });
         return y;
     }
     Ten layernorm_stats(const Ten& x) {
         Ten s = make(x.rows, 2, DS_F32);
         tr("layernorm_stats rows=%ld C=%d", x.rows, x.cols);
-        if (live()) chk(ds_layernorm_stats(ptr(x), (float*)ptr(s), (int)x.rows, x.cols, 1e-5f, st));
+        launch("layernorm_stats", 0.0, {(int32_t)x.rows, x.cols}, [&] { return ds_layernorm_stats(ptr(x), (float*)ptr(s), (int)x.rows, x.cols, 1e-5f, st); });
         return s;
     }
     void attention(const Ten& q, const Ten& k, const Ten& v, const Ten& o, int batch, int heads, int nq, int nk, int kvdiv, float scale, int acc) {
         tr("attention batch=%d heads=%d nq=%d nk=%d ldq=%d ldk=%d ldv=%d ldo=%d kvdiv=%d acc=%d", batch, heads, nq, nk, q.ld, k.ld, v.ld, o.ld, kvdiv, acc);
-        if (u->wide) {
-            if (live()) chk(ds_attention_wide((const float*)ptr(q), (const float*)ptr(k), (const float*)ptr(v), (float*)ptr(o), batch, heads, nq, nk, q.ld, k.ld, v.ld, o.ld, kvdiv, scale, acc, st));
-            return;
-        }
-        if (live()) chk(ds_attention_f16(ptr(q), ptr(k), ptr(v), ptr(o), batch, heads, nq, nk, q.ld, k.ld, v.ld, o.ld, kvdiv, scale, acc, st));
+        launch("attention", 4.0 * batch * heads * (double)nq * nk * HEAD_DIM, {batch, heads, nq, nk}, [&] {
+            if (u->wide)
+                return ds_attention_wide((const float*)ptr(q), (const float*)ptr(k), (const float*)ptr(v), (float*)ptr(o), batch, heads, nq, nk, q.ld, k.ld, v.ld, o.ld, kvdiv, scale, acc, st);
+            return ds_attention_f16(ptr(q), ptr(k), ptr(v), ptr(o), batch, heads, nq, nk, q.ld, k.ld, v.ld, o.ld, kvdiv, scale, acc, st);
+        });
     }
     void tattention(const Ten& q, const Ten& k, const Ten& v, const Ten& o, int nb, int T, int hw, int heads, float scale) {
         tr("temporal_attention nb=%d T=%d hw=%d heads=%d ldq=%d ldk=%d ldv=%d ldo=%d", nb, T, hw, heads, q.ld, k.ld, v.ld, o.ld);
-        if (u->wide) {
-            if (live()) chk(ds_temporal_attention_wide((const float*)ptr(q), (const float*)ptr(k), (const float*)ptr(v), (float*)ptr(o), nb, T, hw, heads, q.ld, k.ld, v.ld, o.ld, scale, st));
-            return;
-        }
-        if (live()) chk(ds_temporal_attention_f16(ptr(q), ptr(k), ptr(v), ptr(o), nb, T, hw, heads, q.ld, k.ld, v.ld, o.ld, scale, st));
+        launch("temporal_attention", 4.0 * nb * hw * heads * (double)T * T * HEAD_DIM, {nb, T, hw, heads}, [&] {
+            if (u->wide)
+                return ds_temporal_attention_wide((const float*)ptr(q), (const float*)ptr(k), (const float*)ptr(v), (float*)ptr(o), nb, T, hw, heads, q.ld, k.ld, v.ld, o.ld, scale, st);
+            return ds_temporal_attention_f16(ptr(q), ptr(k), ptr(v), ptr(o), nb, T, hw, heads, q.ld, k.ld, v.ld, o.ld, scale, st);
+        });
     }
     Ten cast16(const Ten& x) {
         Ten y = make(x.rows, x.cols, DS_F16);
         tr("cast_rows rows=%ld C=%d ldx=%d", x.rows, x.cols, x.ld);
-        if (live()) chk(ds_cast_rows_f32_f16((const float*)ptr(x), x.ld, ptr(y), y.ld, x.rows, x.cols, st));
+        launch("cast_rows", 0.0, {(int32_t)x.rows, x.cols}, [&] { return ds_cast_rows_f32_f16((const float*)ptr(x), x.ld, ptr(y), y.ld, x.rows, x.cols, st); });
         return y;
     }
     Ten operand(const Ten& h) { return (h.is32() && !u->wide) ? cast16(h) : h; }
@@ -1013,7 +1033,7 @@ struct Prog {
         auto tstep = [&](const int64_t* t) {
             Ten e = make(B, mc, adt());
             tr("timestep_embedding n=%d dim=%d", B, mc);
-            if (live()) chk(u->wide ? ds_timestep_embedding_f32(t, (float*)ptr(e), B, mc, st) : ds_timestep_embedding(t, ptr(e), B, mc, st));
+            launch("timestep_embedding", 0.0, {B, mc}, [&] { return u->wide ? ds_timestep_embedding_f32(t, (float*)ptr(e), B, mc, st) : ds_timestep_embedding(t, ptr(e), B, mc, st); });
             return e;
         };
         Ten t_emb = tstep(timesteps);
@@ -1021,7 +1041,10 @@ struct Prog {
         Ten emb = linear(e1, "time_embed.2");
         if (c.fps_cond) {
             Ten fps_t = raw((size_t)B * 8);
-            if (live()) fill_i64_kernel<<<(B + 63) / 64, 64, 0, st>>>((int64_t*)ptr(fps_t), B, (int64_t)fps);
+            launch("fill", 0.0, {B}, [&] {
+                fill_i64_kernel<<<(B + 63) / 64, 64, 0, st>>>((int64_t*)ptr(fps_t), B, (int64_t)fps);
+                return hipGetLastError() == hipSuccess ? DS_OK : DS_ELAUNCH;
+            });
             Ten f_emb = tstep((const int64_t*)ptr(fps_t));
             Ten f1 = linear(f_emb, "fps_embedding.0", Ten(), DS_EPI_SILU);
             emb = linear(f1, "fps_embedding.2", emb);
@@ -1029,8 +1052,10 @@ struct Prog {
         t_emb = Ten(); e1 = Ten();
         Ten semb = make(emb.rows, emb.cols, adt());
         tr("silu n=%ld", emb.rows * emb.cols);
-        if (live()) chk(u->wide ? ds_silu_f32((const float*)ptr(emb), (float*)ptr(semb), (size_t)emb.rows * emb.cols, st)
-                                : ds_silu_f16(ptr(emb), ptr(semb), (size_t)emb.rows * emb.cols, st));
+        launch("silu", 0.0, {(int32_t)emb.rows, emb.cols}, [&] {
+            return u->wide ? ds_silu_f32((const float*)ptr(emb), (float*)ptr(semb), (size_t)emb.rows * emb.cols, st)
+                           : ds_silu_f16(ptr(emb), ptr(semb), (size_t)emb.rows * emb.cols, st);
+        });
         const int ted = 4 * mc;
         Ten emb_all = gemm(semb, wt("emb_all.w", u->emb_total, ted, DS_F16), (const float*)u->P("emb_all.b"), Ten(), B, u->emb_total, ted, DS_EPI_OUT_F32);
         emb = Ten(); semb = Ten();
@@ -1040,8 +1065,10 @@ struct Prog {
             const int D = c.context_dim;
             Ten c16 = make((long)B * L, D, adt());
             tr("cast n=%ld", (long)B * L * D);
-            if (live()) chk(u->wide ? ds_cast_to_f32(context, ctx_dtype, (float*)ptr(c16), (size_t)B * L * D, st)
-                                    : ds_cast_to_f16(context, ctx_dtype, ptr(c16), (size_t)B * L * D, st));
+            launch("cast", 0.0, {B, L, D}, [&] {
+                return u->wide ? ds_cast_to_f32(context, ctx_dtype, (float*)ptr(c16), (size_t)B * L * D, st)
+                               : ds_cast_to_f16(context, ctx_dtype, ptr(c16), (size_t)B * L * D, st);
+            });
             if (c.use_image_attention && L > 77) {
                 ctx.ltxt = 77; ctx.limg = L - 77;
                 ctx.text = make((long)B * 77, D, adt());
@@ -1067,8 +1094,10 @@ struct Prog {
                         const int nb = shared ? pairs : B;
                         Ten patches = make((long)nb * T * H * W, u->kpad_in, adt());
                         tr("im2col_in B=%d C=%d T=%d H=%d W=%d kpad=%d", nb, c.in_channels, T, H, W, u->kpad_in);
-                        if (live()) chk(u->wide ? ds_im2col_in_f32(x_in, x_dtype, (float*)ptr(patches), nb, c.in_channels, T, H, W, u->kpad_in, st)
-                                                : ds_im2col_in(x_in, x_dtype, ptr(patches), nb, c.in_channels, T, H, W, u->kpad_in, st));
+                        launch("im2col_in", 0.0, {nb, T, H, W}, [&] {
+                            return u->wide ? ds_im2col_in_f32(x_in, x_dtype, (float*)ptr(patches), nb, c.in_channels, T, H, W, u->kpad_in, st)
+                                           : ds_im2col_in(x_in, x_dtype, ptr(patches), nb, c.in_channels, T, H, W, u->kpad_in, st);
+                        });
                         h = gemm(patches, wt(b.prefix + ".w", b.cout, u->kpad_in, DS_F16), (const float*)u->P(b.prefix + ".b"), Ten(), patches.rows, b.cout, u->kpad_in,
                                  res_epi(), DS_A_DENSE, 0, nullptr, 0, 0, INT_MAX, 0, o);
                         break;
@@ -1092,6 +1121,7 @@ struct Prog {
                         break;
                     }
                 }
+                tap(b.prefix, h, geo);
             }
             return h;
         };
@@ -1130,7 +1160,10 @@ struct Prog {
             Ten cat = make((long)full.B * full.T * full.H * full.W, c_h + c_skip, rdt);
             Ten dst = shared_after ? Ten() : cols(cat, c_h, c_skip);
             h = run(group, h, geo, init_attn ? Ten() : dst);
-            if (init_attn) h = transformer(h, "init_attn.0", 8, c.transformer_depth, false, geo, ctx, false, dst);
+            if (init_attn) {
+                h = transformer(h, "init_attn.0", 8, c.transformer_depth, false, geo, ctx, false, dst);
+                tap("init_attn.0", h, geo);
+            }
             if (h.cols != c_skip) { ds_set_error("ds_unet_forward: skip tensor of %d channels where %d were planned", h.cols, c_skip); return DS_EINVAL; }
             if (shared_after) {       // one copy of the pair batch so far: both halves of the skip rows get it
                 const long half = h.rows;
@@ -1161,7 +1194,7 @@ struct Prog {
         h = Ten();
         Ten y = conv3(a, "out.2", B * T, H, W, mc, 1, 0, Ten(), nullptr, 0, 0, DS_EPI_OUT_F32, Ten(), nullptr, nullptr);
         tr("rows_to_ncthw ydt=%d ldy=%d B=%d C=%d T=%d H=%d W=%d", y.dt, y.ld, B, c.out_channels, T, H, W);
-        if (live()) chk(ds_rows_to_ncthw(ptr(y), y.dt, y.ld, eps, DS_F32, B, c.out_channels, T, H, W, st));
+        launch("rows_to_ncthw", 0.0, {B, T, H, W}, [&] { return ds_rows_to_ncthw(ptr(y), y.dt, y.ld, eps, DS_F32, B, c.out_channels, T, H, W, st); });
         if (arena.failed && rc == DS_OK) { ds_set_error("ds_unet_forward: workspace too small (ds_unet_workspace_bytes gives the size)"); rc = DS_EINVAL; }
         return rc;
     }
@@ -1210,6 +1243,23 @@ extern "C" int ds_unet_create(const ds_unet_config* cfg, ds_unet** out) {
         return DS_EINVAL;
     }
     *out = u.release();
+    return DS_OK;
+}
+
+extern "C" int ds_unet_set_hooks(ds_unet* u, ds_launch_hook launch, ds_block_tap tap, void* user) {
+    DS_CHECK_ARG(u, "ds_unet_set_hooks: null handle");
+    u->launch_hook = launch;
+    u->block_tap = tap;
+    u->hook_user = user;
+    return DS_OK;
+}
+
+extern "C" int ds_copy_rows(void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes, size_t row_bytes, size_t rows, void* stream) {
+    DS_CHECK_ARG(dst && src && row_bytes > 0 && rows > 0 && dst_pitch_bytes >= row_bytes && src_pitch_bytes >= row_bytes, "ds_copy_rows: bad argument");
+    if (hipMemcpy2DAsync(dst, dst_pitch_bytes, src, src_pitch_bytes, row_bytes, rows, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+        ds_set_error("ds_copy_rows: hipMemcpy2DAsync failed");
+        return DS_ELAUNCH;
+    }
     return DS_OK;
 }
 

@@ -132,7 +132,11 @@ class UNetModel(nn.Module):
             raise ValueError(f"DS_UNET_PROGRAM={prog!r}: expected c or python")
         self.program = prog
         self._handle = None
-        self._tap = None                     # optional callable(name, rows [M,C] fp16, (B,T,H,W)) after every block (tests)
+        # Instrumentation of the C launch program (ds_unet_set_hooks; diagnostics and measurement, eager launches only):
+        #   _tap(name, rows [M, C] tensor, (B, T, H, W))   after every block (a copy of the block's output rows)
+        #   launch_hook(phase, kernel, flops, info)        on the host right before (phase 0) / after (phase 1) every kernel-family call
+        self._tap = None
+        self.launch_hook = None
         self._generation = 0                 # bumped by every prepare(): identifies the packed buffers (hipGraph cache keys)
         self._prepare_lock = threading.Lock()
         # a repack (mode change, .to(), load_state_dict) may run while forwards on other host threads are still inside
@@ -553,7 +557,7 @@ class UNetModel(nn.Module):
             timesteps = timesteps.expand(B).contiguous()
         if pairs and (2 * pairs != B or not any(b.kind == "st" for g in self._inputs for b in g)):
             raise ValueError(f"cfg_pairs={pairs} needs a batch of {2 * pairs} (got {B}) and a SpatialTransformer in the input path")
-        if (self.program == "c" and not tracing and self._tap is None and ops._timing_hook is None and isinstance(fps, int)
+        if (self.program == "c" and not tracing and isinstance(fps, int)
                 and (self.fold_layernorm != "kernel" or self._wide()) and x.dtype in ops._DT):
             return self._forward_c(x, timesteps.contiguous(), context, fps, int(pairs or 0))
         if self._wide():
@@ -707,12 +711,49 @@ class UNetModel(nn.Module):
                     _lib.check(-1, "ds_unet_workspace_bytes")
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
             eps = torch.empty((B, self.cfg["out_channels"], T, H, W), dtype=torch.float32, device=dev)
-            _lib.check(lib.ds_unet_forward(h, x.data_ptr(), ops._DT[x.dtype], timesteps.data_ptr(), context.data_ptr(),
-                                           ops._DT[context.dtype], L, int(fps), B, T, H, W, pairs, ws.data_ptr(), nbytes, eps.data_ptr(),
-                                           torch.cuda.current_stream(dev).cuda_stream), "ds_unet_forward")
+            hooks = self._c_hooks(lib, dev)
+            if hooks is not None:
+                _lib.check(lib.ds_unet_set_hooks(h, hooks[0], hooks[1], None), "ds_unet_set_hooks")
+            try:
+                _lib.check(lib.ds_unet_forward(h, x.data_ptr(), ops._DT[x.dtype], timesteps.data_ptr(), context.data_ptr(),
+                                               ops._DT[context.dtype], L, int(fps), B, T, H, W, pairs, ws.data_ptr(), nbytes, eps.data_ptr(),
+                                               torch.cuda.current_stream(dev).cuda_stream), "ds_unet_forward")
+            finally:
+                if hooks is not None:
+                    lib.ds_unet_set_hooks(h, None, None, None)
+                    if hooks[2]:
+                        raise hooks[2][0]
         finally:
             self._done_with_handle(h)
         return eps
+
+    def _c_hooks(self, lib, dev):
+        """ctypes callbacks for ds_unet_set_hooks from `launch_hook` / `_tap` (None when neither is set).  An exception raised inside a
+        callback cannot cross the C frames: it is kept and re-raised after the forward."""
+        import ctypes as C
+        launch_py = self.launch_hook
+        tap_py = self._tap
+        if launch_py is None and tap_py is None:
+            return None
+        errors = []
+
+        def launch_cb(user, phase, kernel, flops, info, n_info, stream):
+            try:
+                launch_py(int(phase), kernel.decode(), float(flops), tuple(info[i] for i in range(n_info)))
+            except BaseException as e:      # noqa: BLE001
+                errors.append(e)
+
+        def tap_cb(user, block, rows, nrows, cols, ld, dtype, B, T, H, W, stream):
+            try:
+                dt = torch.float32 if dtype == _lib.DS_F32 else torch.float16
+                t = torch.empty((nrows, cols), dtype=dt, device=dev)
+                esz = t.element_size()
+                _lib.check(lib.ds_copy_rows(t.data_ptr(), cols * esz, rows, ld * esz, cols * esz, nrows, stream), "ds_copy_rows")
+                tap_py(block.decode(), t, (B, T, H, W))
+            except BaseException as e:      # noqa: BLE001
+                errors.append(e)
+
+        return (_lib.LAUNCH_HOOK(launch_cb) if launch_py is not None else None, _lib.BLOCK_TAP(tap_cb) if tap_py is not None else None, errors)
 
     def python_program_trace(self, B, T, H, W, ctx_tokens, cfg_pairs=0):
         """The launch sequence of the Python restatement for this geometry, in ds_unet_trace's line format (no GPU needed: the

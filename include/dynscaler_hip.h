@@ -466,6 +466,21 @@ size_t ds_unet_workspace_bytes(ds_unet* u, int B, int T, int H, int W, int ctx_t
 int ds_unet_forward(ds_unet* u, const void* x, int x_dtype, const int64_t* timesteps, const void* context, int ctx_dtype,
                     int ctx_tokens, int fps, int B, int T, int H, int W, int cfg_pairs, void* workspace, size_t workspace_bytes,
                     float* eps, void* stream);
+/* Instrumentation of ds_unet_forward (diagnostics and measurement; the model runs without).  launch hook: called on the HOST right
+ * before (phase 0) and right after (phase 1) the program enqueues one kernel-family call -- kernel = "gemm" | "attention" |
+ * "temporal_attention" | "groupnorm" | "layernorm" | "layernorm_stats" | "cast_rows" | "im2col_in" | ... ; flops = 2 M N K for a gemm,
+ * 4 B h nq nk 64 for attention, else 0; info = (a_mode, M, N, K, epilogue, has_residual) for a gemm, (batch, heads, nq, nk) for attention,
+ * a few sizes otherwise -- so that a host can bracket every launch with events on `stream` (bench.py's per-launch roofline) or put a
+ * launch of its own in front of each (the test suite's LDS / register poison run).  block tap: after every block of the program
+ * (reference names: "input_blocks.1.0", "init_attn.0", "middle_block.1", ...) with its output rows (device pointer, row stride ld in
+ * elements, dtype DS_F16 / DS_F32) and the geometry at that point; the rows are only valid until the next kernel is enqueued: copy
+ * them on `stream` (ds_copy_rows).  NULL clears a hook.  Not for use under stream capture. */
+typedef void (*ds_launch_hook)(void* user, int phase, const char* kernel, double flops, const int32_t* info, int n_info, void* stream);
+typedef void (*ds_block_tap)(void* user, const char* block, const void* rows, long nrows, int cols, int ld, int dtype, int B, int T, int H,
+                             int W, void* stream);
+int ds_unet_set_hooks(ds_unet* u, ds_launch_hook launch, ds_block_tap tap, void* user);
+/* dst row r = src row r (row_bytes each; pitches in bytes), device to device, async on `stream`. */
+int ds_copy_rows(void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes, size_t row_bytes, size_t rows, void* stream);
 /* The launch sequence of such a forward as text, one line per kernel call ("gemm M N K a_mode epilogue lda ldc ldr ..."), without
  * launching anything (no GPU needed): what tests compare with the Python restatement of the program.  Returns the number of
  * bytes written (excluding the terminator), or a negative DS_E* code; buf may be NULL to query the size. */
