@@ -669,7 +669,7 @@ def main():
                        "residual_stream": ("fp16 (matrix-core operands are fp16 in every mode)" if unet.residual_dtype == torch.float16 else
                                            "fp32 between the blocks, fp16 inside the transformers (DS_RESIDUAL_DTYPE=f32outer)"
                                            if unet.residual_scope == "outer" else "fp32 everywhere (strict precision mode, DS_RESIDUAL_DTYPE=f32)"),
-                       "unet_program": f"{unet.program} (ds_unet_forward: launch loop in C++)" if unet.program == "c" else "python (one ctypes call per kernel)",
+                       "unet_program": "ds_unet_forward (block program and launch loop in C++; one C call per evaluation)",
                        "bit_repeatable": "yes, in every mode (streams x hipGraph included): the cause of round 1's run-to-run "
                                          "differences under concurrent graph replays is fixed (profiles/r2_notes.md section 1)"},
             "sec_per_50_step_panorama": full_s if full_s is not None else 50 * elapsed / args.steps,

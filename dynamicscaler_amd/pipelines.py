@@ -210,7 +210,7 @@ class VC2_Pipeline_T2V:
         n = x.shape[0]
         ctx = torch.cat([c.to(x.device) for c in ctx_list], dim=0)
         model = self.pretrained_t2v.model
-        if cfg_pairs and self.share_cfg_prefix and hasattr(getattr(model, "diffusion_model", None), "_transformer_block"):
+        if cfg_pairs and self.share_cfg_prefix and hasattr(getattr(model, "diffusion_model", None), "c_program_trace"):      # the HIP UNet
             kwargs = dict(kwargs, cfg_pairs=int(cfg_pairs))
         if self._step_precision == "wide" and hasattr(getattr(model, "diffusion_model", None), "twin"):
             kwargs = dict(kwargs, precision="wide")

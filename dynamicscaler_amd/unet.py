@@ -4,8 +4,11 @@ Drop-in for `lvdm.modules.networks.openaimodel3d.UNetModel` (openaimodel3d.py:31
 keywords (the yaml `unet_config.params`), same `forward(x, timesteps, context, features_adapter, fps,
 timestep_cond, **kwargs)`, same state-dict keys.  The arithmetic is NOT torch: the parameters are repacked once
 into the layouts the HIP kernels want (fp16 [N][K] GEMM operands, fused QKV / KV / GEGLU-interleaved / all
-time-embedding projections in one matrix) and the forward is a flat program of C-ABI kernel launches on
-channel-contiguous "NTHWC" fp16 activations.  There is no CPU fallback.
+time-embedding projections in one matrix) and the forward is ONE C call -- ds_unet_forward (csrc/unet_program.hip):
+the block program, the scratch arena and the launch loop over the kernels live in C++, on channel-contiguous
+"NTHWC" activations.  This module owns the parameters, the packed buffers and the C handle(s).  There is no CPU
+fallback.  (Rounds 2-4 kept a Python restatement of the launch program next to the C one; round 5 removed it: its
+instrumentation -- per-launch hooks, per-block taps -- is offered by the C program itself, ds_unet_set_hooks.)
 
 Beyond the reference (which only runs batch 1): a batch of b independent evaluations
 (cond + uncond CFG branches, several tiles) shares one launch sequence; results per item are those of b
@@ -18,7 +21,6 @@ import torch
 import torch.nn as nn
 
 from . import ops, _lib
-from ._lib import DS_A_CONV3, DS_A_TCONV, DS_EPI_GEGLU, DS_EPI_SILU, DS_EPI_OUT_F32
 from .unet_spec import build_program, param_shapes
 
 HEAD_DIM = 64
@@ -51,7 +53,6 @@ class UNetModel(nn.Module):
                     ch = b.cout
             skip_ch.append(ch)
         self._cat_ch = [(group[0].cin - c, c) for group, c in zip(self._outputs, reversed(skip_ch))]
-        self.inplace_concat = os.environ.get("DS_INPLACE_CONCAT", "1") == "1"   # skip tensors produced inside the concat buffers
         cfg = self.cfg
         self.in_channels = cfg["in_channels"]
         self.model_channels = cfg["model_channels"]
@@ -79,14 +80,14 @@ class UNetModel(nn.Module):
             node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape), requires_grad=False))
         self._packed = None
         # LayerNorm folded into the projection it feeds (the normalised activation is never rounded to fp16 nor written to
-        # memory): False = LayerNorm kernel + plain GEMM; "stats" = ds_layernorm_stats + ds_gemm_f16_ln; "kernel" = ds_gemm_f16_lnk,
-        # the GEMM takes the rows' statistics from its own operand fragments (no other launch; measured slower at the bench's
-        # batch sizes).  DS_FOLD_LN = 0 | 1 (default) | 2; after changing the attribute call invalidate() (the packed projection
-        # weights differ).  profiles/r2_notes.md section 4.
+        # memory): True (default) = ds_layernorm_stats + ds_gemm_f16_ln; False = LayerNorm kernel + plain GEMM.  DS_FOLD_LN = 0 | 1;
+        # after changing the attribute call invalidate() (the packed projection weights differ).  profiles/r2_notes.md section 4.
+        # (ds_gemm_f16_lnk -- the statistics taken inside the GEMM -- stays a kernel of the library; measured slower at the bench's
+        # batch sizes, no launch program uses it.)
         fold = os.environ.get("DS_FOLD_LN", "1")
-        if fold not in ("0", "1", "2"):
-            raise ValueError(f"DS_FOLD_LN={fold!r}: expected 0 (LayerNorm kernels), 1 (folded, statistics launch) or 2 (folded, in-kernel statistics)")
-        self.fold_layernorm = {"0": False, "1": "stats", "2": "kernel"}[fold]
+        if fold not in ("0", "1"):
+            raise ValueError(f"DS_FOLD_LN={fold!r}: expected 0 (LayerNorm kernels) or 1 (folded into the consumer GEMM)")
+        self.fold_layernorm = fold == "1"
         # Storage type of the RESIDUAL STREAM (every "+ x" / "skip + h" output, conv_in, down / up-sample, proj_in; the skip
         # tensors).  The reference computes in fp32 throughout (openaimodel3d.py:657-708); the matrix-core operands are fp16 in
         # both modes.  torch.float16: everything fp16 (fastest).  torch.float32 ("strict"): the stream is stored, added and
@@ -124,13 +125,6 @@ class UNetModel(nn.Module):
         # keeps its own packed buffer (hi + lo planes) and C handle; the pipelines choose the steps (operand_policy).  C program only.
         self.operand_mode = "wide" if rd == "wide" else "f16"
         self._twins = {}                     # operand_mode -> twin module (shared parameters, own handle / packed buffer)
-        # Which launch program runs the forward: "c" = ds_unet_forward (csrc/unet_program.hip: one call, the launch loop in C++),
-        # "python" = the restatement below (one ctypes call per kernel: per-launch timing hooks, taps, DS_FOLD_LN=2).  The two
-        # issue the same launches on the same packed operands and are bit-identical (tests/test_gpu_unet_c.py).  DS_UNET_PROGRAM.
-        prog = os.environ.get("DS_UNET_PROGRAM", "c")
-        if prog not in ("c", "python"):
-            raise ValueError(f"DS_UNET_PROGRAM={prog!r}: expected c or python")
-        self.program = prog
         self._handle = None
         # Instrumentation of the C launch program (ds_unet_set_hooks; diagnostics and measurement, eager launches only):
         #   _tap(name, rows [M, C] tensor, (B, T, H, W))   after every block (a copy of the block's output rows)
@@ -193,7 +187,6 @@ class UNetModel(nn.Module):
             tw = copy.copy(self)                 # shallow: _parameters / _modules (the parameter tree) are shared objects; no handle,
             tw._generation = 0                   # packed buffer, twin or lock travels with a copy (__getstate__ / __setstate__)
             tw.operand_mode = operand_mode
-            tw.program = "c"
             tw.gn_from_producer = False
             self._twins[operand_mode] = tw
         return tw
@@ -229,10 +222,6 @@ class UNetModel(nn.Module):
 
     def _gn_fused(self):
         return bool(self.gn_from_producer and not self.batch_invariant and not self._wide())
-
-    def _fuse_gn(self, rows_per):
-        """This GroupNorm takes its statistics from its producer (instances of <= 256 rows keep the one-launch kernel)."""
-        return self._gn_fused() and rows_per % 32 == 0 and rows_per > 256
 
     def _mode(self):
         return (self._fold(), self.residual_dtype, self._inner32(), self._gn_fused(), self._wide())
@@ -310,8 +299,7 @@ class UNetModel(nn.Module):
         """The packing itself is ds_unet_pack (csrc/unet_program.hip): fp16 [N][K] GEMM operands (K = tap*Cin + c for convs),
         fused QKV / KV / image-KV matrices, the GEGLU projection interleaved in 32-row groups [x_g | gate_g], the
         time-embedding projections of all ResBlocks in one matrix (conv-1 bias folded in), LayerNorm folded into the projection
-        it feeds (fp16(gamma*W), column sums, beta.W + b).  Both launch programs -- the C one behind ds_unet_forward and the
-        Python one below -- read the same packed buffer; self._packed maps operand names to views of it."""
+        it feeds (fp16(gamma*W), column sums, beta.W + b).  self._packed maps operand names to views of the buffer (inspection, tests)."""
         import ctypes as C
         dev = device
         if dev.type != "cuda":
@@ -358,10 +346,6 @@ class UNetModel(nn.Module):
             else:
                 P[key.value.decode()] = raw.view(torch.float32)
         self._packed_buf = buf
-        self._emb_total = P["emb_all.w"].shape[0]
-        self._emb_off = {b.prefix: lib.ds_unet_emb_offset(h, b.prefix.encode())
-                         for g in list(self._inputs) + [self._middle] + list(self._outputs) for b in g if b.kind == "res"}
-        self._kpad_in = P["input_blocks.0.0.w"].shape[1]
         self._ws_bytes = {}
         self._device = dev
         self._generation += 1
@@ -369,155 +353,7 @@ class UNetModel(nn.Module):
         self._packed = P
         return self
 
-    # ------------------------------------------------------------------ forward program
-    def _gn(self, h, prefix, ninst, rows, C, eps, silu, raw_f16=False, colstats=None):
-        P = self._packed
-        return ops.groupnorm(h, P[prefix + ".g"], P[prefix + ".be"], ninst, rows, C, eps, silu, raw_f16=raw_f16, colstats=colstats)
-
-    def _res_epi(self, epilogue=0):
-        """Epilogue flags of a launch whose output belongs to the residual stream."""
-        return epilogue | (DS_EPI_OUT_F32 if self._strict() else 0)
-
-    def _operand(self, h):
-        """The fp16 matrix-core operand of a projection / convolution that reads the residual stream un-normalised."""
-        return ops.cast_rows_f16(h) if h.dtype == torch.float32 else h
-
-    def _linear(self, a, prefix, residual=None, epilogue=0, bias=True, out=None):
-        P = self._packed
-        w = P[prefix + ".w"]
-        return ops.gemm(a, w, P[prefix + ".b"] if bias else None, residual, M=a.shape[0], N=w.shape[0], K=w.shape[1],
-                        lda=a.stride(0), epilogue=epilogue, out=out)
-
-    def _conv3(self, a, prefix, dims, cin, stride=1, upsample=0, residual=None, bias=None, bias_rows=None, ldbias=None,
-               epilogue=0, out=None, colstats=None):
-        """dims = (nimg, hin, win) physical input; returns (out, (hout, wout))."""
-        P = self._packed
-        w = P[prefix + ".w"]
-        nimg, hin, win = dims
-        hl, wl = (2 * hin, 2 * win) if upsample else (hin, win)
-        hout = (hl - 1) // stride + 1
-        wout = (wl - 1) // stride + 1
-        M = nimg * hout * wout
-        out = ops.gemm(a, w, P[prefix + ".b"] if bias is None else bias, residual, M=M, N=w.shape[0], K=w.shape[1],
-                       a_mode=DS_A_CONV3, cin=cin, lda=a.stride(0), conv=(nimg, hin, win, hout, wout, stride, upsample),
-                       bias_rows=bias_rows, ldbias=ldbias, epilogue=epilogue, out=out, colstats=colstats)
-        return out, (hout, wout)
-
-    def _transformer_block(self, x, p, heads, spatial, geo, ctx, dup=None, last=False):
-        """x [M, inner].  spatial: attention over H*W per frame (+ cross-attention to ctx); else over T per pixel.
-        dup (spatial only): x holds ONE copy of a [cond | uncond] pair batch; attn1 (which does not see the context) runs
-        on it, then dup(x) doubles the batch for the cross-attention and everything after (see forward, cfg_pairs).
-        last: the block's output is only read by proj_out as a matrix-core operand, so it is stored in fp16 whatever the
-        residual-stream type (the one rounding the operand needs anyway)."""
-        P = self._packed
-        B, T, H, W = geo
-        M, inner = x.shape
-        scale = HEAD_DIM ** -0.5
-        fold = self._fold()
-        rs = DS_EPI_OUT_F32 if self._inner32() else 0       # the block's own stream (its three adds)
-
-        def ln_proj(xin, ln, name, N, epilogue=0):
-            """LayerNorm `ln` of xin followed by the projection `name`: the LayerNorm folded into the GEMM (row statistics +
-            ds_gemm_f16_ln on the raw activation), or the two separate kernels."""
-            Mx = xin.shape[0]
-            if fold:
-                st = ops.layernorm_stats(xin) if fold != "kernel" else None
-                return ops.gemm_ln(xin, P[name + ".wg"], st, P[name + ".cs"], P[name + ".cb"], M=Mx, N=N, K=inner, epilogue=epilogue)
-            n = ops.layernorm(xin, P[f"{p}.{ln}.g"], P[f"{p}.{ln}.be"])
-            return ops.gemm(n, P[name + ".w"], P.get(name + ".b"), None, M=Mx, N=N, K=inner, epilogue=epilogue)
-
-        def self_attn(name, xin):
-            qkv = ln_proj(xin, "norm1" if name == "attn1" else "norm2", f"{p}.{name}.qkv", 3 * inner)
-            o = torch.empty((M, inner), dtype=torch.float16, device=x.device)
-            ld = 3 * inner
-            if spatial:
-                ops.attention(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, batch=B * T, heads=heads, nq=H * W, nk=H * W,
-                              ldq=ld, ldk=ld, ldv=ld, ldo=inner, scale=scale)
-            else:
-                ops.temporal_attention(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, nseq_batches=B, T=T, hw=H * W,
-                                       heads=heads, ldq=ld, ldk=ld, ldv=ld, ldo=inner, scale=scale)
-            return self._linear(o, f"{p}.{name}.to_out.0", residual=xin, epilogue=rs)
-
-        x = self_attn("attn1", x)
-        if dup is not None:
-            x = dup(x)
-            B, M = 2 * B, 2 * M
-        if spatial:
-            q = ln_proj(x, "norm2", f"{p}.attn2.to_q", inner)
-            ctx_text, ctx_img, ltxt, limg = ctx
-            wkv = P[f"{p}.attn2.kv.w"]
-            kv = ops.gemm(ctx_text, wkv, None, None, M=ctx_text.shape[0], N=2 * inner, K=wkv.shape[1])
-            o = torch.empty((M, inner), dtype=torch.float16, device=x.device)
-            ops.attention(q, kv, kv[:, inner:], o, batch=B * T, heads=heads, nq=H * W, nk=ltxt, ldq=inner, ldk=2 * inner,
-                          ldv=2 * inner, ldo=inner, kv_batch_div=T, scale=scale)
-            if ctx_img is not None and f"{p}.attn2.kv_ip.w" in P:
-                wip = P[f"{p}.attn2.kv_ip.w"]
-                kvi = ops.gemm(ctx_img, wip, None, None, M=ctx_img.shape[0], N=2 * inner, K=wip.shape[1])
-                # out = out + 1.0 * out_ip (attention.py:117-124): second softmax over the image tokens, accumulated
-                ops.attention(q, kvi, kvi[:, inner:], o, batch=B * T, heads=heads, nq=H * W, nk=limg, ldq=inner,
-                              ldk=2 * inner, ldv=2 * inner, ldo=inner, kv_batch_div=T, scale=scale, accumulate=True)
-            x = self._linear(o, f"{p}.attn2.to_out.0", residual=x, epilogue=rs)
-        else:
-            x = self_attn("attn2", x)
-        g = ln_proj(x, "norm3", f"{p}.ff1", 8 * inner, epilogue=DS_EPI_GEGLU)      # GEGLU: 2 x (4 x inner) columns
-        return self._linear(g, f"{p}.ff.net.2", residual=x, epilogue=0 if last else rs)
-
-    def _transformer(self, h, prefix, heads, depth, spatial, geo, ctx, dup=None, out=None):
-        B, T, H, W = geo
-        C = h.shape[1]
-        if spatial:
-            a = self._gn(h, prefix + ".norm", B * T, H * W, C, 1e-6, False)
-        else:
-            a = self._gn(h, prefix + ".norm", B, T * H * W, C, 1e-6, False)
-        x = self._linear(a, prefix + ".proj_in", epilogue=DS_EPI_OUT_F32 if self._inner32() else 0)
-        for d in range(depth):
-            x = self._transformer_block(x, f"{prefix}.transformer_blocks.{d}", heads, spatial, geo, ctx,
-                                        dup=dup if d == 0 else None, last=d == depth - 1)
-            if dup is not None and d == 0:
-                h, geo = dup(h), (2 * B, T, H, W)
-        return self._linear(x, prefix + ".proj_out", residual=h, epilogue=self._res_epi(), out=out)
-
-    def _resblock(self, h, b, geo, emb_all, out=None):
-        P = self._packed
-        B, T, H, W = geo
-        p = b.prefix
-        rs = self._res_epi()
-        need_skip = b.cin != b.cout
-        h16 = h
-        if need_skip and h.dtype == torch.float32:     # the skip projection's fp16 operand comes out of the GroupNorm pass
-            a, h16 = self._gn(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5, True, raw_f16=True)
-        else:
-            a = self._gn(h, p + ".in_layers.0", B * T, H * W, b.cin, 1e-5, True)
-        off = self._emb_off[p]
-        # "full" strict mode: the intermediates that only a GroupNorm reads (this conv-1 output, temporal convs 1-3) stay fp32 too
-        # (6.0e-4 of the error budget's "mid" class, profiles/r3_notes.md section 2); matrix-core operands remain fp16
-        mid = DS_EPI_OUT_F32 if self._inner32() else 0
-        Mrows = B * T * H * W
-        table = lambda: ops.colstats_table(Mrows, b.cout, h.device)      # (sum, sumsq) per 32-row block and column, written by the producer
-        st1 = table() if self._fuse_gn(H * W) else None                  # conv-1 output -> out_layers GroupNorm (per frame)
-        h1, _ = self._conv3(a, p + ".in_layers.2", (B * T, H, W), b.cin, bias=emb_all[:, off:], bias_rows=T * H * W,
-                            ldbias=self._emb_total, epilogue=mid, colstats=st1)
-        a2 = self._gn(h1, p + ".out_layers.0", B * T, H * W, b.cout, 1e-5, True, colstats=st1)
-        skip = h if not need_skip else self._linear(h16, p + ".skip_connection", epilogue=rs)
-        stx = table() if (b.tconv and self._fuse_gn(T * H * W)) else None     # conv-2 output -> first temporal-conv GroupNorm (over T jointly)
-        h2, _ = self._conv3(a2, p + ".out_layers.3", (B * T, H, W), b.cout, residual=skip, epilogue=rs, out=None if b.tconv else out,
-                            colstats=stx)
-        if b.tconv:
-            x = h2
-            M = x.shape[0]
-            for i in (1, 2, 3, 4):
-                ci = 2 if i == 1 else 3
-                q = f"{p}.temopral_conv.conv{i}"
-                an = self._gn(x, q + ".0", B, T * H * W, b.cout, 1e-5, True, colstats=stx)
-                stx = table() if (i < 4 and self._fuse_gn(T * H * W)) else None     # temporal conv i -> GroupNorm of conv i + 1
-                w = P[f"{q}.{ci}.w"]
-                x = ops.gemm(an, w, P[f"{q}.{ci}.b"], h2 if i == 4 else None, M=M, N=w.shape[0], K=w.shape[1],
-                             a_mode=DS_A_TCONV, cin=b.cout, lda=an.stride(0), tconv=(T, H * W), epilogue=rs if i == 4 else mid,
-                             out=out if i == 4 else None, colstats=stx)
-            h2 = x
-        return h2
-
-    @torch.no_grad()
+    # ------------------------------------------------------------------ forward
     def forward(self, x, timesteps, context=None, features_adapter=None, fps=16, timestep_cond=None, **kwargs):
         """x [b,C,t,h,w] (fp16|fp32, HIP device), timesteps int64 [b], context [b,L,context_dim].
         Returns eps [b,C_out,t,h,w] fp32 (the reference UNet computes and returns fp32).
@@ -538,155 +374,29 @@ class UNetModel(nn.Module):
                                              timestep_cond=timestep_cond, **kwargs)
         if features_adapter is not None or timestep_cond is not None:
             raise NotImplementedError("features_adapter / timestep_cond are not used by the DynamicScaler pipelines")
-        tracing = x.device.type == "meta"          # python_program_trace: shapes only, ops replaced by recorders
-        if not x.is_cuda and not tracing:
+        if not x.is_cuda:
             raise RuntimeError("UNetModel.forward: input is on the CPU; this build has no CPU path (the HIP kernels are the product)")
-        if not tracing and self._gn_fused() and not _lib.load().ds_gemm_has_stats():
+        if self._gn_fused() and not _lib.load().ds_gemm_has_stats():
             raise RuntimeError("gn_from_producer / DS_GN_FROM_PRODUCER=1 needs a library built with DS_GEMM_STATS: "
                                "`python -m dynamicscaler_amd.build --variant gemmstats` and DS_HIP_LIBRARY=.../libdynscaler_hip_gemmstats.so")
-        if not tracing and (self._packed is None or self._device != x.device or self._packed_mode != self._mode()):
+        if self._packed is None or self._device != x.device or self._packed_mode != self._mode():
             self.prepare(x.device)
-        P = self._packed
-        cfg = self.cfg
-        mc = cfg["model_channels"]
-        B, Cin, T, H, W = x.shape
+        B = x.shape[0]
         dev = x.device
+        if x.dtype not in ops._DT:
+            x = x.float()
         x = x.contiguous()
         timesteps = timesteps.to(dev, torch.int64).reshape(-1)
         if timesteps.numel() == 1 and B > 1:
-            timesteps = timesteps.expand(B).contiguous()
+            timesteps = timesteps.expand(B)
         if pairs and (2 * pairs != B or not any(b.kind == "st" for g in self._inputs for b in g)):
             raise ValueError(f"cfg_pairs={pairs} needs a batch of {2 * pairs} (got {B}) and a SpatialTransformer in the input path")
-        if (self.program == "c" and not tracing and isinstance(fps, int)
-                and (self.fold_layernorm != "kernel" or self._wide()) and x.dtype in ops._DT):
-            return self._forward_c(x, timesteps.contiguous(), context, fps, int(pairs or 0))
-        if self._wide():
-            raise NotImplementedError("the wide operand mode runs through the C launch program only (program='c', an int fps, no taps / "
-                                      "timing hooks): csrc/unet_program.hip")
-        # ---- time (+fps) embedding -> per-ResBlock projections in one GEMM ----
-        t_emb = ops.timestep_embedding(timesteps, mc)
-        e1 = self._linear(t_emb, "time_embed.0", epilogue=DS_EPI_SILU)
-        emb = self._linear(e1, "time_embed.2")
-        if cfg["fps_cond"]:
-            if isinstance(fps, int):
-                fps_t = torch.full_like(timesteps, fps)
-            else:
-                fps_t = fps.to(dev, torch.int64).reshape(-1)
-                if fps_t.numel() == 1 and B > 1:
-                    fps_t = fps_t.expand(B).contiguous()
-            f_emb = ops.timestep_embedding(fps_t, mc)
-            f1 = self._linear(f_emb, "fps_embedding.0", epilogue=DS_EPI_SILU)
-            emb = self._linear(f1, "fps_embedding.2", residual=emb)
-        semb = ops.silu(emb)
-        w_all = P["emb_all.w"]
-        emb_all = ops.gemm(semb, w_all, P["emb_all.b"], None, M=B, N=w_all.shape[0], K=w_all.shape[1],
-                           epilogue=DS_EPI_OUT_F32)
-        # ---- context: text (+ image) tokens as 2-D fp16 matrices, NOT repeated over frames ----
-        context = context.to(dev)
-        L = context.shape[1]
-        if cfg["use_image_attention"] and L > 77:
-            ctx_text = context[:, :77].to(torch.float16).reshape(B * 77, -1).contiguous()
-            ctx_img = context[:, 77:].to(torch.float16).reshape(B * (L - 77), -1).contiguous()
-            ctx = (ctx_text, ctx_img, 77, L - 77)
-        else:
-            ctx = (context.to(torch.float16).reshape(B * L, -1).contiguous(), None, L, 0)
-
-        shared = bool(pairs)                      # still on the context-free prefix of a [cond | uncond] pair batch
-
-        def dup(t):
-            return torch.cat([t, t], 0)
-
-        def run(group, h, geo, out=None):
-            """`out`: where the group's LAST block writes its result ([rows, C] view, e.g. a column slice of a concat buffer)."""
-            nonlocal shared
-            for bi, b in enumerate(group):
-                o = out if bi == len(group) - 1 else None
-                Bq, Tq, Hq, Wq = geo
-                if b.kind == "conv_in":
-                    patches = ops.im2col_in(x[:pairs] if shared else x, self._kpad_in)
-                    w = P[b.prefix + ".w"]
-                    h = ops.gemm(patches, w, P[b.prefix + ".b"], None, M=patches.shape[0], N=w.shape[0], K=w.shape[1],
-                                 epilogue=self._res_epi(), out=o)
-                elif b.kind == "res":
-                    h = self._resblock(h, b, geo, emb_all, out=o)
-                elif b.kind == "st":
-                    h = self._transformer(h, b.prefix, b.heads, b.depth, True, geo, ctx, dup=dup if shared else None, out=o)
-                    if shared:
-                        shared, geo = False, (2 * Bq, Tq, Hq, Wq)
-                elif b.kind == "tt":
-                    h = self._transformer(h, b.prefix, b.heads, b.depth, False, geo, ctx, out=o)
-                elif b.kind == "down":
-                    h, (ho, wo) = self._conv3(self._operand(h), b.prefix + ".op", (Bq * Tq, Hq, Wq), b.cin, stride=2,
-                                              epilogue=self._res_epi(), out=o)
-                    geo = (Bq, Tq, ho, wo)
-                elif b.kind == "up":
-                    h, (ho, wo) = self._conv3(self._operand(h), b.prefix + ".conv", (Bq * Tq, Hq, Wq), b.cin, upsample=1,
-                                              epilogue=self._res_epi(), out=o)
-                    geo = (Bq, Tq, ho, wo)
-                if self._tap is not None:
-                    self._tap(b.prefix, h, geo)
-            return h, geo
-
-        def geo_after(group, geo):
-            Bq, Tq, Hq, Wq = geo
-            for b in group:
-                if b.kind == "down":
-                    Hq, Wq = (Hq - 1) // 2 + 1, (Wq - 1) // 2 + 1
-                elif b.kind == "up":
-                    Hq, Wq = 2 * Hq, 2 * Wq
-            return (Bq, Tq, Hq, Wq)
-
-        # torch.cat([h, hs.pop()], dim=1) (openaimodel3d.py:700-703) without the copy: every skip tensor is produced straight
-        # into the right-hand columns of the buffer its decoder block reads ([rows, C_h + C_skip]; the encoder side keeps
-        # reading it there through row strides), and the decoder-side h into the left-hand columns by whatever block ends the
-        # previous group.  Same kernels on the same numbers; only where the rows live changes.
-        geo = (pairs if shared else B, T, H, W)
-        h = None
-        hs = []                                  # (concat buffer | skip tensor, C_h, geometry)
-        n_in = len(self._inputs)
-        inplace = self.inplace_concat
-        for gi, group in enumerate(self._inputs):
-            c_h, c_skip = self._cat_ch[n_in - 1 - gi]
-            g_out = geo_after(group, geo)
-            init_attn = gi == 0 and cfg["addition_attention"]
-            shared_after = shared and not any(b.kind == "st" for b in group)
-            full = (B,) + g_out[1:]
-            cat = dst = None
-            if inplace:
-                cat = torch.empty((full[0] * full[1] * full[2] * full[3], c_h + c_skip), dtype=self.residual_dtype, device=dev)
-                dst = None if shared_after else cat[:, c_h:]
-            h, geo = run(group, h, geo, out=None if init_attn else dst)
-            if init_attn:
-                h = self._transformer(h, "init_attn.0", 8, cfg["transformer_depth"], False, geo, ctx, out=dst)
-                if self._tap is not None:
-                    self._tap("init_attn.0", h, geo)
-            assert h.shape[1] == c_skip
-            if not inplace:
-                hs.append((dup(h) if shared_after else h, c_h, full))
-                continue
-            if shared_after:                     # one copy of the pair batch so far: both halves of the skip rows get it
-                half = h.shape[0]
-                cat[:half, c_h:].copy_(h)
-                cat[half:, c_h:].copy_(h)
-            hs.append((cat, c_h, full))
-        assert geo_after(self._middle, geo) == hs[-1][2], \
-            f"skip connection geometry {hs[-1][2]} != {geo_after(self._middle, geo)} (tile h/w must be divisible by 8)"
-        h, geo = run(self._middle, h, geo, out=hs[-1][0][:, :hs[-1][1]] if inplace else None)
-        for group in self._outputs:
-            cat, c_h, sgeo = hs.pop()
-            assert sgeo == geo and h.shape[1] == c_h
-            if hs:
-                assert geo_after(group, geo) == hs[-1][2], \
-                    f"skip connection geometry {hs[-1][2]} != {geo_after(group, geo)} (tile h/w must be divisible by 8)"
-            if not inplace:
-                # the copy (DS_INPLACE_CONCAT=0: A/B and diagnostics)
-                cat = ops.concat_channels(h, cat) if h.dtype == torch.float16 else torch.cat([h, cat], 1)
-            h, geo = run(group, cat, geo, out=hs[-1][0][:, :hs[-1][1]] if (hs and inplace) else None)
-        a = self._gn(h, "out.0", B * T, H * W, mc, 1e-5, True)
-        y, _ = self._conv3(a, "out.2", (B * T, H, W), mc, epilogue=DS_EPI_OUT_F32)
-        return ops.rows_to_ncthw(y, (B, cfg["out_channels"], T, H, W), torch.float32)
-
-
+        if not isinstance(fps, int):             # the reference passes a python int or a [b] tensor of one value (ddpm3d.py:710)
+            f = torch.as_tensor(fps).reshape(-1)
+            if f.numel() == 0 or bool((f != f[0]).any()):
+                raise NotImplementedError("per-item fps values: the DynamicScaler pipelines condition every evaluation of a call on one fps")
+            fps = int(f[0])
+        return self._forward_c(x, timesteps.contiguous(), context, fps, int(pairs or 0))
 
     def _forward_c(self, x, timesteps, context, fps, pairs):
         """One ds_unet_forward call: the launch loop runs in C++ (csrc/unet_program.hip) on the caller's current stream, all scratch
@@ -754,12 +464,6 @@ class UNetModel(nn.Module):
                 errors.append(e)
 
         return (_lib.LAUNCH_HOOK(launch_cb) if launch_py is not None else None, _lib.BLOCK_TAP(tap_cb) if tap_py is not None else None, errors)
-
-    def python_program_trace(self, B, T, H, W, ctx_tokens, cfg_pairs=0):
-        """The launch sequence of the Python restatement for this geometry, in ds_unet_trace's line format (no GPU needed: the
-        forward runs on shape-only "meta" tensors with every op replaced by a recorder, trace.py)."""
-        from . import trace
-        return trace.python_program_trace(self, B, T, H, W, ctx_tokens, cfg_pairs)
 
     def c_program_trace(self, B, T, H, W, ctx_tokens, cfg_pairs=0):
         """The C program's launch sequence for this geometry as a list of text lines (ds_unet_trace; no GPU needed)."""

@@ -474,7 +474,8 @@ int ds_unet_forward(ds_unet* u, const void* x, int x_dtype, const int64_t* times
  * launch of its own in front of each (the test suite's LDS / register poison run).  block tap: after every block of the program
  * (reference names: "input_blocks.1.0", "init_attn.0", "middle_block.1", ...) with its output rows (device pointer, row stride ld in
  * elements, dtype DS_F16 / DS_F32) and the geometry at that point; the rows are only valid until the next kernel is enqueued: copy
- * them on `stream` (ds_copy_rows).  NULL clears a hook.  Not for use under stream capture. */
+ * them on `stream` (ds_copy_rows).  NULL clears a hook.  Under stream capture the callbacks run once, at capture time (a copy enqueued
+ * by a tap becomes a node of the graph and is refreshed by every replay). */
 typedef void (*ds_launch_hook)(void* user, int phase, const char* kernel, double flops, const int32_t* info, int n_info, void* stream);
 typedef void (*ds_block_tap)(void* user, const char* block, const void* rows, long nrows, int cols, int ld, int dtype, int B, int T, int H,
                              int W, void* stream);

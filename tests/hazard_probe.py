@@ -3,8 +3,8 @@
 (profiles/r1_notes.md "Withdrawn ..."): two hipGraphs of the UNet evaluation replaying concurrently on two streams once
 gave panoramas that differed in the last fp16 bit from process to process.
 
-    python tests/hazard_probe.py unet   [rounds]   two UNet graphs, every kernel output kept and compared
-    python tests/hazard_probe.py poison            every kernel preceded by the LDS / register poison launch
+    python tests/hazard_probe.py unet   [rounds]   two UNet graphs, every block's output kept (block taps) and compared
+    python tests/hazard_probe.py poison            every kernel preceded by the LDS / register poison launch (launch hook)
     python tests/hazard_probe.py pipe   [runs]     the toy ring pipeline (2 streams x graphs) repeated in this process
 
 DS_HIP_LIBRARY=dynamicscaler_amd/libdynscaler_hip_barebarrier.so selects the diagnostic build with round 1's bare K-step
@@ -30,50 +30,35 @@ from dynamicscaler_amd.unet import UNetModel  # noqa: E402
 from dynamicscaler_amd.unet_spec import param_shapes  # noqa: E402
 
 d = torch.device("cuda:0")
-OPS = ["gemm", "gemm_ln", "groupnorm", "layernorm", "layernorm_stats", "cast_rows_f16", "attention", "temporal_attention",
-       "concat_channels", "im2col_in", "rows_to_ncthw", "timestep_embedding", "silu"]
-
-
 def toy_unet():
     z = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
     params = json.loads(bytes(z["params_json"]).decode())
     m = UNetModel(**params)
     m.load_state_dict(synth_state_dict(param_shapes(params), 5), strict=True)
     m = m.to(d).eval()
-    m.program = "python"     # the probe interposes on single kernel calls
     m.prepare(d)
     return m, params
 
 
 class Recorder:
-    """Wraps the ops the UNet program calls; while `on`, every kernel's output tensor is appended to `log`."""
+    """Block taps of the C launch program (ds_unet_set_hooks through UNetModel._tap): while `on`, a copy of every block's output rows
+    is appended to `log` (under graph capture the copies become nodes of the graph: every replay refreshes them)."""
 
-    def __init__(self):
-        self.log, self.on, self.orig = [], False, {}
-        for name in OPS:
-            self.orig[name] = getattr(ops, name)
-            setattr(ops, name, self._wrap(name))
+    def __init__(self, model):
+        self.log, self.on, self.model = [], False, model
+        model._tap = self._tap
 
-    def _wrap(self, name):
-        def f(*a, **k):
-            out = self.orig[name](*a, **k)
-            if self.on:
-                info = ""
-                if name == "gemm":
-                    info = f" M{k.get('M')} N{k.get('N')} K{k.get('K')} mode{k.get('a_mode', 0)} epi{k.get('epilogue', 0)} " \
-                           f"bias{int(a[2] is not None) if len(a) > 2 else 0} res{int(a[3] is not None) if len(a) > 3 else 0}"
-                self.log.append((f"{len(self.log)}:{name}{info}", out))
-            return out
-        return f
+    def _tap(self, name, rows, geo):
+        if self.on:
+            self.log.append((f"{len(self.log)}:{name} {tuple(rows.shape)}", rows))
 
     def restore(self):
-        for name, fn in self.orig.items():
-            setattr(ops, name, fn)
+        self.model._tap = None
 
 
 def probe_unet(rounds):
     m, params = toy_unet()
-    rec = Recorder()
+    rec = Recorder(m)
     streams = [torch.cuda.Stream(d), torch.cuda.Stream(d)]
     n = 2   # tiles per batch: x = [tiles | tiles], cfg_pairs = n  (the multi-rank rehearsal's shape)
     findings = []
@@ -132,7 +117,7 @@ def probe_unet(rounds):
                                      "count": len(bad), "of": len(kept), "max_abs_diff": float(diff.max()),
                                      "frac_elems": float((diff > 0).float().mean())})
         print(json.dumps({"probe": "unet", "lib": os.path.basename(_lib.LIB_PATH), "keep_intermediates": keep,
-                          "rounds": rounds, "rounds_with_mismatch": nbad, "kernels_per_graph": len(graphs[0][1])}), flush=True)
+                          "rounds": rounds, "rounds_with_mismatch": nbad, "blocks_per_graph": len(graphs[0][1])}), flush=True)
     for f in findings[:12]:
         print(json.dumps(f), flush=True)
     rec.restore()
@@ -141,23 +126,11 @@ def probe_unet(rounds):
 
 def probe_poison():
     """Every launch of the UNet program preceded by ds_dbg_poison_cu_state: results must not change."""
-    lib = _lib.load()
+    diag = _lib.load_diag()          # the poison launch lives outside the product library (csrc/diag.hip)
 
-    class Poisoned:
-        def __init__(self, real):
-            self._real = real
-            self._diag = _lib.load_diag()          # the poison launch lives outside the product library (csrc/diag.hip)
-
-        def __getattr__(self, name):
-            fn = getattr(self._real, name)
-            if not name.startswith("ds_") or name in ("ds_last_error", "ds_abi_version", "ds_groupnorm_stats_workspace_floats"):
-                return fn
-
-            def call(*a):
-                rc = self._diag.ds_dbg_poison_cu_state(a[-1])
-                assert rc == 0
-                return fn(*a)
-            return call
+    def poison_in_front(phase, kernel, flops, info):
+        if phase == 0:
+            assert diag.ds_dbg_poison_cu_state(torch.cuda.current_stream().cuda_stream) == 0
 
     m, params = toy_unet()
     n = 2
@@ -165,21 +138,21 @@ def probe_poison():
     x = torch.cat([tiles, tiles], 0)
     ctx = torch.cat([synth_normal((1, 77, 64), 61)] * n + [synth_normal((1, 77, 64), 62)] * n, 0).to(d)
     ts = torch.full((2 * n,), 500, device=d, dtype=torch.long)
-    rec = Recorder()
+    rec = Recorder(m)
     rec.on, rec.log = True, []
     m(x, ts, context=ctx, fps=8, cfg_pairs=n)
     torch.cuda.synchronize()
     clean = [(nm, t.clone()) for nm, t in rec.log]
-    _lib._lib = Poisoned(lib)
+    m.launch_hook = poison_in_front
     rec.log = []
     m(x, ts, context=ctx, fps=8, cfg_pairs=n)
     torch.cuda.synchronize()
-    _lib._lib = lib
+    m.launch_hook = None
     rec.on = False
     bad = [(nm, float((t.float() - c.float()).abs().max()), bool(torch.isnan(t.float()).any()))
            for (nm, t), (_, c) in zip(rec.log, clean) if not torch.equal(t, c)]
-    print(json.dumps({"probe": "poison", "lib": os.path.basename(_lib.LIB_PATH), "kernels": len(clean),
-                      "kernels_changed_by_poison": len(bad), "first": bad[:5]}), flush=True)
+    print(json.dumps({"probe": "poison", "lib": os.path.basename(_lib.LIB_PATH), "blocks": len(clean),
+                      "blocks_changed_by_poison": len(bad), "first": bad[:5]}), flush=True)
     rec.restore()
     return len(bad)
 

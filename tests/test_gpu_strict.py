@@ -81,10 +81,6 @@ def test_unet_strict_batch_cfg_pairs_and_concat_invariants():
     plain = m(x2, t2, context=cs, fps=8)
     shared = m(x2, t2, context=cs, fps=8, cfg_pairs=1)
     assert torch.equal(plain, shared) and not torch.equal(plain[:1], plain[1:])
-    # in-place skip tensors vs the copy
-    m.inplace_concat = False
-    assert torch.equal(m(x2, t2, context=cs, fps=8), plain)
-    m.inplace_concat = True
     # attribute switch on a live model
     m16 = build_unet(params, 5, d, torch.float16)
     ref16 = m16(x2, t2, context=cs, fps=8)

@@ -23,20 +23,23 @@ from test_gpu_fullsize import dev, T, relerr, t2v_params      # noqa: E402
 from test_gpu_unet import EPS_TOL, EPS_TOL_TINY               # noqa: E402
 
 
-def build_unet(params, seed, device, residual_dtype=torch.float16, program="c"):
+def build_unet(params, seed, device, residual_dtype=torch.float16):
     from dynamicscaler_amd.unet import UNetModel
     from dynamicscaler_amd.unet_spec import param_shapes
     from dynamicscaler_amd.synth import synth_state_dict
     m = UNetModel(**params)
     m.load_state_dict(synth_state_dict(param_shapes(params), seed), strict=True)
     m.residual_dtype, m.residual_scope = residual_dtype, "full"
-    m.program = program
     return m.to(device).eval()
 
 
 @pytest.mark.parametrize("name", ["t2v", "i2v"])
 @pytest.mark.parametrize("residual_dtype", [torch.float16, torch.float32])
-def test_c_program_equals_python_program_bitwise(name, residual_dtype):
+def test_c_program_prefix_sharing_and_batch_invariance(name, residual_dtype):
+    """ds_unet_forward on the toy UNets: a [cond | uncond] pair batch with the shared context-free prefix equals the plain batch bit
+    for bit, a batch equals its separate forwards, fp16 and fp32 inputs agree where the input is fp16-representable, a wrong
+    cfg_pairs is refused.  (Rounds 3-4 also compared the C program bit for bit with a Python restatement of it; round 5 removed the
+    restatement -- the program is pinned by the reference goldens, tests below and tests/test_gpu_unet.py.)"""
     d = dev()
     from dynamicscaler_amd.synth import synth_normal
     z = np.load(os.path.join(G, f"unet_tiny_{name}.npz"))
@@ -44,26 +47,19 @@ def test_c_program_equals_python_program_bitwise(name, residual_dtype):
     m = build_unet(params, 5, d, residual_dtype)
     x0, c0 = T(z["x_0"]), T(z["ctx_0"])
     for n in (1, 3):
-        x = torch.cat([x0] + [synth_normal(x0.shape, 100 + k) for k in range(1, n)], 0)
+        x = torch.cat([x0] + [synth_normal(x0.shape, 100 + k) for k in range(1, n)], 0).half().float()
         ctx = torch.cat([synth_normal(c0.shape, 200 + k) for k in range(2 * n)], 0).to(d)
         t = torch.tensor([500] * (2 * n), device=d)
-        for xdt in (torch.float16, torch.float32):
-            x2 = torch.cat([x, x], 0).to(d, xdt)
-            for pairs in (None, n):
-                kw = {"cfg_pairs": pairs} if pairs else {}
-                m.program = "c"
-                a = m(x2, t, context=ctx, fps=8, **kw)
-                m.program = "python"
-                b = m(x2, t, context=ctx, fps=8, **kw)
-                assert a.dtype == torch.float32 and torch.equal(a, b), (name, residual_dtype, n, xdt, pairs)
-        # the shared prefix is bit-identical in the C program too, and a batch equals its separate forwards
-        m.program = "c"
         x2 = torch.cat([x, x], 0).to(d, torch.float16)
         plain, shared = m(x2, t, context=ctx, fps=8), m(x2, t, context=ctx, fps=8, cfg_pairs=n)
-        assert torch.equal(plain, shared)
+        assert plain.dtype == torch.float32 and torch.equal(plain, shared)
+        assert torch.equal(m(x2.float(), t, context=ctx, fps=8, cfg_pairs=n), shared)          # the input is rounded to the operand type once
         assert torch.equal(m(x2[:1], t[:1], context=ctx[:1], fps=8), plain[:1])
+        assert torch.equal(m(x2, t, context=ctx, fps=torch.tensor([8] * (2 * n))), plain)       # the reference's tensor-valued fps
     with pytest.raises(Exception):
         m(x2, t, context=ctx, fps=8, cfg_pairs=2 * n)
+    with pytest.raises(NotImplementedError):
+        m(x2, t, context=ctx, fps=torch.tensor([8, 16] * n))
 
 
 @pytest.mark.parametrize("name", ["t2v", "i2v"])
@@ -134,9 +130,9 @@ def test_raw_c_abi_flow_vs_reference_golden(name):
         lib.ds_unet_destroy(h)
 
 
-def test_c_program_full_size_vs_reference_golden_and_python_program():
-    """The real t2v UNet through ds_unet_forward: eps against the reference's fp32 CPU forward, bit-equal to the Python program,
-    and the host time of an eager forward (the launch loop in C++ instead of ~800 ctypes calls)."""
+def test_c_program_full_size_vs_reference_golden():
+    """The real t2v UNet through ds_unet_forward: eps against the reference's fp32 CPU forward, and the host time of an eager forward
+    (the launch loop in C++: one ctypes call per evaluation)."""
     import time
     from dynamicscaler_amd.synth import synth_normal
     d = dev()
@@ -146,23 +142,17 @@ def test_c_program_full_size_vs_reference_golden_and_python_program():
     ctx = torch.cat([synth_normal((1, 77, 1024), 1), synth_normal((1, 77, 1024), 2)]).to(d)
     x2 = torch.cat([x, x]).to(d, torch.float16)
     t = torch.tensor([int(z["t"])] * 2, device=d)
-    out = {}
-    for prog in ("c", "python"):
-        m.program = prog
+    eps = m(x2, t, context=ctx, fps=int(z["fps"]), cfg_pairs=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
         eps = m(x2, t, context=ctx, fps=int(z["fps"]), cfg_pairs=1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            eps = m(x2, t, context=ctx, fps=int(z["fps"]), cfg_pairs=1)
-        host = (time.perf_counter() - t0) / 3
-        torch.cuda.synchronize()
-        wall = (time.perf_counter() - t0) / 3
-        out[prog] = (eps, host, wall)
-    e1, e2 = relerr(out["c"][0][:1], T(z["eps_cond"])), relerr(out["c"][0][1:], T(z["eps_uncond"]))
-    print(f"C program, full UNet eps rel err: cond {e1:.3e} uncond {e2:.3e}; eager forward of one CFG pair: host {out['c'][1] * 1e3:.1f} ms "
-          f"(python program {out['python'][1] * 1e3:.1f} ms), wall {out['c'][2] * 1e3:.1f} ms (python program {out['python'][2] * 1e3:.1f} ms)")
-    assert e1 < EPS_TOL and e2 < EPS_TOL
-    assert torch.equal(out["c"][0], out["python"][0])
+    host = (time.perf_counter() - t0) / 3
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 3
+    e1, e2 = relerr(eps[:1], T(z["eps_cond"])), relerr(eps[1:], T(z["eps_uncond"]))
+    print(f"C program, full UNet eps rel err: cond {e1:.3e} uncond {e2:.3e}; eager forward of one CFG pair: host {host * 1e3:.1f} ms, wall {wall * 1e3:.1f} ms")
+    assert e1 < EPS_TOL and e2 < EPS_TOL and host < 0.5 * wall
 
 
 @pytest.mark.parametrize("mode", ["default", "wide"])

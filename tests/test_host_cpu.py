@@ -165,31 +165,55 @@ def test_c_unet_program_parameter_table_equals_the_reference_state_dict_keys():
     assert lib.ds_unet_create(C.byref(bad), C.byref(h)) != 0
 
 
+def _kernel_lines(lines):
+    return [ln for ln in lines if not ln.startswith(("copy ", "cast n="))]
+
+
 @pytest.mark.parametrize("gn_fused", [False, True])
-@pytest.mark.parametrize("strict", [False, True, "outer"])
-def test_c_unet_program_issues_the_same_launches_as_the_python_program(strict, gn_fused):
-    """The C launch program (ds_unet_trace: csrc/unet_program.hip run dry) and the Python restatement (UNetModel.forward on
-    shape-only tensors with recording ops, dynamicscaler_amd/trace.py) issue the same kernel calls with the same descriptors
-    -- toy and both real configs, plain and shared-CFG-prefix batches, T = 16 and 24, fp16 and fp32 residual stream."""
+@pytest.mark.parametrize("strict", [False, True, "outer", "wide"])
+def test_c_unet_program_launch_sequence_follows_the_block_structure(strict, gn_fused):
+    """The C launch program run dry (ds_unet_trace, csrc/unet_program.hip) against the block structure derived independently on the host
+    (unet_spec.build_program, the mirror of openaimodel3d.py:441-649): per-kind launch counts -- toy and both real configs, plain and
+    shared-CFG-prefix batches, T = 16 and 24, every residual mode and the wide operand mode.  (Rounds 2-4 compared the trace with a
+    Python restatement of the program; round 5 removed the restatement.)"""
     import torch
-    from dynamicscaler_amd import trace
     from dynamicscaler_amd.unet import UNetModel
+    if strict == "wide" and gn_fused:
+        pytest.skip("gn_from_producer is not available in the wide mode")
     for name, params in _unet_configs().items():
         m = UNetModel(**params)
         m.residual_dtype = torch.float32 if strict else torch.float16
         m.residual_scope = "outer" if strict == "outer" else "full"
+        m.operand_mode = "wide" if strict == "wide" else "f16"
         m.gn_from_producer = gn_fused          # GroupNorm statistics from the producer's epilogue (opt-in, DS_GN_FROM_PRODUCER)
-        L = 93 if params.get("use_image_attention") else 77
+        img = bool(params.get("use_image_attention"))
+        L = 93 if img else 77
+        blocks = [b for g in list(m._inputs) + [m._middle] + list(m._outputs) for b in g]
+        n_res = sum(b.kind == "res" for b in blocks)
+        n_st = sum(b.depth for b in blocks if b.kind == "st")
+        n_tt = sum(b.depth for b in blocks if b.kind == "tt") + (m.cfg["transformer_depth"] if m.cfg["addition_attention"] else 0)
+        tconv = bool(m.cfg["temporal_conv"])
         geoms = [(2, 4, 8, 8, 0), (2, 4, 8, 8, 1), (6, 4, 16, 8, 3)] if name.startswith("tiny") else [(2, 16, 40, 64, 1), (2, 24, 40, 64, 0)]
         for (B, T, H, W, pairs) in geoms:
             c_lines = m.c_program_trace(B, T, H, W, L, pairs)
-            a, b = trace.kernel_lines(c_lines), trace.kernel_lines(m.python_program_trace(B, T, H, W, L, pairs))
-            assert len(a) > 100 and a == b, (name, (B, T, H, W, pairs), next((x, y) for x, y in zip(a, b) if x != y))
-            assert any(ln.startswith("gemm_ln ") for ln in a) == (strict is not True)      # the fold is off only with an fp32 INNER stream
-            assert any(ln.startswith("cast_rows ") for ln in a) == bool(strict)
+            a = _kernel_lines(c_lines)
+            assert len(a) > 100
+            kinds = {}
+            for ln in a:
+                kinds[ln.split()[0]] = kinds.get(ln.split()[0], 0) + 1
+            assert kinds.get("attention", 0) == n_st * (3 if img else 2), (name, kinds)                 # self + text cross (+ image cross)
+            assert kinds.get("temporal_attention", 0) == 2 * n_tt, (name, kinds)
+            gn = kinds.get("groupnorm", 0) + kinds.get("groupnorm_wide", 0)
+            n_tr = sum(b.kind in ("st", "tt") for b in blocks) + (1 if m.cfg["addition_attention"] else 0)
+            assert gn == n_res * (6 if tconv else 2) + n_tr + 1, (name, kinds)                            # + out.0
+            assert kinds.get("rows_to_ncthw") == 1 and kinds.get("im2col_in") == 1 and kinds.get("timestep_embedding") == (2 if m.cfg["fps_cond"] else 1)
+            assert any(ln.startswith("gemm_ln ") for ln in a) == (strict in (False, "outer"))             # the fold needs an fp16 INNER stream
+            assert any(ln.startswith("cast_rows ") for ln in a) == (strict in (True, "outer"))            # (the wide mode never casts down)
             fused = [ln for ln in a if ln.startswith("groupnorm ") and not ln.endswith("stats=0")]
             assert (not fused) if not gn_fused else (bool(fused) or name.startswith("tiny")), (name, len(fused))   # instances of <= 256 rows keep the one-launch norm
             assert sum(ln.startswith("gemm ") and not ln.endswith("stats=0") for ln in a) == len(fused)
+            if strict == "wide":
+                assert all(int(ln.split("epi=")[1].split()[0]) & 4 for ln in a if ln.startswith("gemm "))
             if pairs:
                 assert sum(ln.startswith("copy ") for ln in c_lines) >= 4       # the duplicated prefix: x, h and the skip halves
 
@@ -601,7 +625,7 @@ def test_unet_twin_shares_parameters_and_copies_never_share_a_handle():
     params = json.loads(bytes(z["params_json"]).decode())
     m = UNetModel(**params)
     tw = m.twin("wide")
-    assert tw is m.twin("wide") and tw.operand_mode == "wide" and m.operand_mode == "f16" and tw._handle is None and tw.program == "c"
+    assert tw is m.twin("wide") and tw.operand_mode == "wide" and m.operand_mode == "f16" and tw._handle is None
     assert all(a is b for a, b in zip(tw.parameters(), m.parameters()))
     assert tw._c_config().residual_f32 == 3 and m._c_config().residual_f32 == 2
     assert "_twins" not in [n for n, _ in m.named_modules()] and len(dict(m.named_parameters())) == len(dict(tw.named_parameters()))
