@@ -165,6 +165,43 @@ class _SubsampledGather:
         self.read_set[sub[sub >= 0]] = True
 
 
+class _UpsampledScatter:
+    """Scatter maps of a view that is resized up by s with 'nearest' before set_view_tensor_no_interpolation
+    (view_set_scale_factor, t2v_sphere_panorama_pipeline.py:268-275): pixel (y, x) of the tile is pixel (s y + dy, s x + dx) of the
+    scaled view for every (dy, dx) -- s * s scatter maps of the tile's size, one per offset.  The winners of duplicated targets are
+    resolved on the scaled view (`big`: the last source in ITS row-major order, what the reference's scatter does on one thread),
+    so the s * s scatters hit disjoint targets and commute."""
+
+    def __init__(self, big, s, height, width):
+        m = big.scatter.view(height, s, width, s)
+        self.subs = [m[:, dy, :, dx].reshape(-1).contiguous() for dy in range(s) for dx in range(s)]
+        self.write_set = big.write_set
+
+
+def _set_maps(cache, sub_cache, fov, theta, phi, width, height, W, H, s):
+    """what a view's scatters need: a ViewMaps at the tile size (s = 1; .subs = [its scatter map]) or an _UpsampledScatter."""
+    if s == 1:
+        m = cache.get(fov, theta, phi, width, height, W, H)
+        if not hasattr(m, "subs"):
+            m.subs = [m.scatter]
+        return m
+    key = ("set", fov, theta, phi, s)
+    r = sub_cache.get(key)
+    if r is None:
+        r = sub_cache[key] = _UpsampledScatter(cache.get(fov, theta, phi, width * s, height * s, W, H), s, height, width)
+    return r
+
+
+def _downsample_outputs(final_latents, denoised, factor):
+    """t2v_sphere_panorama_pipeline.py:298-305 / i2v_sphere_panorama_pipeline.py:481-488: both outputs resized with 'nearest' to
+    (H // factor, W // factor) before the decode."""
+    if factor is None:
+        return final_latents, denoised
+    H, W = denoised.shape[-2:]
+    th, tw = int(H // factor), int(W // factor)
+    return ops.resize_latent(final_latents, th, tw, "nearest"), ops.resize_latent(denoised, th, tw, "nearest")
+
+
 class ViewMapCache:
     def __init__(self, device):
         self.device = device
@@ -276,15 +313,15 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
         """[sic] name kept from the reference.  Views are perspective crops of the 2:1 equirect latent; they are
         processed with the reference's sequential semantics (levels of views with disjoint footprints are batched).
         Returns (final_latents, denoised) for output_type='latent' (:307-312)."""
-        if view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
-            raise NotImplementedError("view_set_scale_factor / downsample_factor_before_vae_decode other than 1 (gen_pano_360.py "
-                                      "uses 1).  With view_set_scale_factor > 1 the reference itself is not repeatable: its "
-                                      "scatter then has several sources per target and torch's CPU index_put_ resolves "
-                                      "duplicates that straddle a thread's chunk by timing (tests/golden/make_golden.py g21)")
         if use_skip_time:
             raise NotImplementedError  # like the reference (:146-148)
-        gsf = int(view_get_scale_factor)
+        gsf, ssf = int(view_get_scale_factor), int(view_set_scale_factor)
         assert gsf >= 1 and gsf == view_get_scale_factor, "view_get_scale_factor must be a positive integer"
+        # view_set_scale_factor s (:268-275): x_prev / pred_x0 / the mask's ones are resized up by s with 'nearest' and scattered
+        # through the map of the (s h) x (s w) view.  Several neighbouring sources then share a target; the last one in row-major
+        # order stays, which is what the reference's index_put_ does on one thread (with more threads its own result depends on
+        # timing at the thread chunks' boundaries: tests/golden/make_golden.py g33 is generated with torch.set_num_threads(1))
+        assert ssf >= 1 and ssf == view_set_scale_factor, "view_set_scale_factor must be a positive integer"
         unet_config = self.model_config["params"]["unet_config"]
         frames = self.pretrained_t2v.temporal_length if frames < 0 else frames
         prompt, text_emb, uc_emb = self._encode(prompt, prompt_embeds, guidance_scale)
@@ -309,7 +346,7 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
         device = st.device
         mask = torch.zeros((H * W,), dtype=torch.uint8, device=device)
         cache = ViewMapCache(device)
-        prompt_cache = {}
+        prompt_cache, sc_cache = {}, {}
         sched = self.scheduler
         scattered = 0
         P = lat_h * lat_w
@@ -336,7 +373,8 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
             lat_maps = [cache.get(view_fov, th, ph, lat_w, lat_h, W, H) if gsf == 1 else
                         _SubsampledGather(cache.get(view_fov, th, ph, lat_w * gsf, lat_h * gsf, W, H), gsf, lat_h, lat_w, H * W)
                         for (ph, th, fv) in views]
-            set_maps = [cache.get(fv, th, ph, lat_w, lat_h, W, H) for (ph, th, fv) in views]          # mask gather + scatters: curr_fov
+            set_maps = [cache.get(fv, th, ph, lat_w, lat_h, W, H) for (ph, th, fv) in views]          # mask gather: curr_fov
+            sc_maps = [_set_maps(cache, sc_cache, fv, th, ph, lat_w, lat_h, W, H, ssf) for (ph, th, fv) in views]   # scatters: curr_fov
             renoise = st.ratio is not None and i < total_steps - 1
             coef = sched.step_coefficients(total_steps - i - 1)
             self._begin_step(i, total_steps - i - 1, st.guidance_scale)
@@ -351,7 +389,7 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
             if renoise:
                 c_rn, s_rn = sched.renoise_coefficients(total_steps - i - 2, total_steps - i - 1)
             reads = [lat_maps[j].read_set | set_maps[j].read_set for j in range(len(views))]
-            writes = [set_maps[j].write_set for j in range(len(views))]
+            writes = [sc_maps[j].write_set for j in range(len(views))]
             for level in plan_levels_sets(reads, writes):
                 mine = parallel.rank_share(level, st.rank, st.world)
                 xp_parts, x0_parts = [], []
@@ -388,13 +426,13 @@ class VC2_Pipeline_T2V_SpherePano(_RingPipe):
                     order = level
                 else:
                     xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
-                s_idx = torch.stack([set_maps[j].scatter for j in order])
-                ops.map_scatter3(st.pano, st.pano_x0, mask, xp_all.contiguous(), x0_all.contiguous(), s_idx)
+                xp_all, x0_all = xp_all.contiguous(), x0_all.contiguous()
+                for k in range(ssf * ssf):
+                    ops.map_scatter3(st.pano, st.pano_x0, mask, xp_all, x0_all, torch.stack([sc_maps[j].subs[k] for j in order]))
             scattered += len(views)
             if step_callback is not None:
                 step_callback(i, int(t), views, st.pano, st.pano_x0)
-        denoised = st.pano_x0.clone()
-        final_latents = st.pano.clone()
+        final_latents, denoised = _downsample_outputs(st.pano.clone(), st.pano_x0.clone(), downsample_factor_before_vae_decode)
         if output_type == "latent":
             return final_latents, denoised
         return self.pretrained_t2v.decode_first_stage_2DAE(denoised), denoised
@@ -440,13 +478,9 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
         `static_frame_latent` [1,C,1,H,W] = a VAE-encoded panorama image to reuse for paste_on_static; without it the tiled
         VAE encode runs every step like the reference's (:247, fresh posterior noise each time).
         Returns (final_latents, denoised) for output_type='latent' (:476-495)."""
-        if view_set_scale_factor != 1 or downsample_factor_before_vae_decode not in (None, 1):
-            raise NotImplementedError("view_set_scale_factor / downsample_factor_before_vae_decode other than 1 (gen_pano_360.py "
-                                      "uses 1).  With view_set_scale_factor > 1 the reference itself is not repeatable: its "
-                                      "scatter then has adjacent duplicate targets, which torch's CPU index_put_ resolves by "
-                                      "thread timing (tests/golden/make_golden.py, g21)")
-        gsf = int(view_get_scale_factor)
+        gsf, ssf = int(view_get_scale_factor), int(view_set_scale_factor)
         assert gsf >= 1 and gsf == view_get_scale_factor, "view_get_scale_factor must be a positive integer"
+        assert ssf >= 1 and ssf == view_set_scale_factor, "view_set_scale_factor must be a positive integer"   # (see the t2v loop)
         has_vae = getattr(self.pretrained_t2v, "first_stage_model", None) is not None
         if (use_skip_time and init_sphere_latent is None) or (paste_on_static and static_frame_latent is None):
             if not has_vae:
@@ -524,12 +558,17 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                                                             lat_h, lat_w, H * W)
             return r
 
+        def set_map(ph, th):
+            """scatter maps of a view: at the tile size, or through the (s h) x (s w) view with view_set_scale_factor s (:421-428)"""
+            return _set_maps(cache, sub_cache, view_fov, th, ph, lat_w, lat_h, W, H, ssf)
+
         def pix_conflict(ka, kb):
             r = conflict_cache.get((ka, kb))
             if r is None:
                 a, b = cache.get(view_fov, ka[1], ka[0], lat_w, lat_h, W, H), cache.get(view_fov, kb[1], kb[0], lat_w, lat_h, W, H)
                 ra, rb = a.read_set | lat_map(ka[0], ka[1]).read_set, b.read_set | lat_map(kb[0], kb[1]).read_set
-                r = conflict_cache[(ka, kb)] = bool((a.write_set & (rb | b.write_set)).any() or (ra & b.write_set).any())
+                wa, wb = set_map(ka[0], ka[1]).write_set, set_map(kb[0], kb[1]).write_set
+                r = conflict_cache[(ka, kb)] = bool((wa & (rb | wb)).any() or (ra & wb).any())
             return r
 
         for i in range(len(timesteps)):
@@ -564,6 +603,10 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
             lat_maps = [lat_map(ph, th) for (_, _, ph, th) in items]
             renoise = st.ratio is not None and live
             merge_prev = merge_prev_denoised_ratio_list[i] if (merge_prev_denoised_ratio_list is not None and live) else None
+            if merge_prev is not None and ssf != 1:                # the reference mixes the scaled x_prev with the unscaled view (:430-436)
+                raise RuntimeError(f"merge_prev_denoised_ratio_list with view_set_scale_factor {ssf}: the size of tensor a "
+                                   f"({lat_w * ssf}) must match the size of tensor b ({lat_w}) (the reference raises here, "
+                                   "i2v_sphere_panorama_pipeline.py:430-436)")
             coef = sched.step_coefficients(total_steps - i - 1)
             self._begin_step(i, total_steps - i - 1, st.guidance_scale)
             noises = []                                            # host noise in the reference's item order
@@ -617,18 +660,19 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                     order = level
                 else:
                     xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
-                s_idx = torch.stack([maps[j].scatter for j in order])
+                sc = [set_map(items[j][2], items[j][3]) for j in order]
                 f0 = torch.tensor([items[j][0] for j in order], dtype=torch.int32, device=device)
                 xp_all, x0_all = xp_all.contiguous(), x0_all.contiguous()
-                ops.map_scatter3_frames(st.pano, st.pano_x0, mask, xp_all, x0_all, s_idx, f0, frames)
-                if temp is not None:                               # :446-454
-                    ops.map_scatter3_frames(temp, None, None, xp_all, None, s_idx, f0, frames)
+                for k in range(ssf * ssf):
+                    s_idx = torch.stack([m.subs[k] for m in sc])
+                    ops.map_scatter3_frames(st.pano, st.pano_x0, mask, xp_all, x0_all, s_idx, f0, frames)
+                    if temp is not None:                           # :446-454
+                        ops.map_scatter3_frames(temp, None, None, xp_all, None, s_idx, f0, frames)
             if temp is not None:                                   # :473-474
                 st.pano = temp
             if step_callback is not None:
                 step_callback(i, int(t), items, st.pano, st.pano_x0)
-        denoised = st.pano_x0.clone()
-        final_latents = st.pano.clone()
+        final_latents, denoised = _downsample_outputs(st.pano.clone(), st.pano_x0.clone(), downsample_factor_before_vae_decode)
         if output_type == "latent":
             return final_latents, denoised
         return self.pretrained_t2v.decode_first_stage_2DAE(denoised), denoised

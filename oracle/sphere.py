@@ -139,9 +139,10 @@ def t2v_sphere_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, 
                       guidance_scale=7.5, equirect_width, equirect_height, phi_theta_dict, view_fov, loop_step_theta,
                       merge_renoised_overlap_latent_ratio=None, phi_fov_dict=None, denoise_to_step=None,
                       num_inference_steps=4, init_sphere_latent=None, in_channels=4, trace=None,
-                      view_get_scale_factor=1, view_set_scale_factor=1):
+                      view_get_scale_factor=1, view_set_scale_factor=1, downsample_factor_before_vae_decode=None):
     """basic_sample_shift_shpere_panorama, output_type='latent' (t2v_sphere_panorama_pipeline.py:23-312).  Returns
-    (final_latents, denoised) (:307-312).  view_get_scale_factor g: the view is gathered at g x the tile size and resized
+    (final_latents, denoised) (:307-312), both resized down with 'nearest' when downsample_factor_before_vae_decode is given
+    (:298-305).  view_get_scale_factor g: the view is gathered at g x the tile size and resized
     back with 'nearest' (:194-203); view_set_scale_factor s: x_prev / pred_x0 are resized up by s with 'nearest' before the
     scatter (:268-275), and so is the ones-tensor that marks the mask."""
     from .loops import resize_video_latent
@@ -192,7 +193,17 @@ def t2v_sphere_sample(eps_model, tables: DiffusionTables, cond_ctx, uncond_ctx, 
                 sphere_scatter_fast(mask, ones, cfov, cth, cphi)
         if trace is not None:
             trace.append((i, int(t), views))
-    return pano.clone(), pano_x0.clone()
+    return _downsampled(pano.clone(), pano_x0.clone(), downsample_factor_before_vae_decode)
+
+
+def _downsampled(final, denoised, factor):
+    """t2v_sphere_panorama_pipeline.py:298-305 / i2v_sphere_panorama_pipeline.py:481-488."""
+    from .loops import resize_video_latent
+    if factor is None:
+        return final, denoised
+    H, W = denoised.shape[-2:]
+    th, tw = int(H // factor), int(W // factor)
+    return resize_video_latent(final.clone(), th, tw, "nearest"), resize_video_latent(denoised.clone(), th, tw, "nearest")
 
 
 @torch.no_grad()
@@ -201,9 +212,12 @@ def i2v_sphere_sample(eps_model, image_embedder, tables: DiffusionTables, text_c
                       loop_step_frame=None, equirect_width, equirect_height, phi_theta_dict, view_fov, loop_step_theta,
                       merge_renoised_overlap_latent_ratio=None, merge_prev_denoised_ratio_list=None,
                       denoise_to_step=None, paste_on_static=None, static_frame_latent=None, num_inference_steps=4,
-                      init_sphere_latent=None, in_channels=4, trace=None, view_get_scale_factor=1):
-    """basic_sample_shift_shpere_panorama of the i2v pipeline (i2v_sphere_panorama_pipeline.py:31-495), set scale factor 1,
-    output_type='latent'; returns (final_latents, denoised) (:476-495).  view_get_scale_factor g: the latent view is
+                      init_sphere_latent=None, in_channels=4, trace=None, view_get_scale_factor=1, view_set_scale_factor=1,
+                      downsample_factor_before_vae_decode=None):
+    """basic_sample_shift_shpere_panorama of the i2v pipeline (i2v_sphere_panorama_pipeline.py:31-495),
+    output_type='latent'; returns (final_latents, denoised) (:476-495).  view_set_scale_factor s: x_prev / pred_x0 (and the ones
+    that mark the mask) are resized up by s with 'nearest' before the scatters (:421-428); with a merge_prev ratio the reference
+    then mixes tensors of two sizes and raises -- so does mix_latents_with_mask here.  view_get_scale_factor g: the latent view is
     gathered at g x the tile size and resized back with 'nearest' (:330-341; the mask view is not, :345-352).
     `image_embedder(crop [1,3,height,width]) -> [1,L,D]` stands for get_image_embeds, `pano_image` [3,H_img,W_img] for
     the loaded panorama image, `static_frame_latent` [1,C,1,H,W] for tiled_vae_encode_image's result (VAE: SURVEY 8-f N2);
@@ -257,6 +271,9 @@ def i2v_sphere_sample(eps_model, image_embedder, tables: DiffusionTables, text_c
                     e_c = eps_model(view, ts, ctx)
                     e = cfg_combine(e_c, eps_model(view, ts, uncond_ctx), guidance_scale) if guidance_scale != 1.0 else e_c
                     x_prev, x0 = ddim_step(sched, view, e, [total_steps - i - 1] * view.shape[2])
+                    if view_set_scale_factor != 1:
+                        sh, sw = lh * view_set_scale_factor, lw * view_set_scale_factor
+                        x_prev, x0 = resize_video_latent(x_prev, sh, sw, "nearest"), resize_video_latent(x0, sh, sw, "nearest")
                     if merge_prev_denoised_ratio_list is not None and i < total_steps - 1:
                         x_prev = mix_latents_with_mask(x_prev, prev, vmask, merge_prev_denoised_ratio_list[i])
                     for dst, src in ((pano, x_prev), (temp, x_prev), (pano_x0, x0), (mask, torch.ones_like(x_prev))):
@@ -269,7 +286,7 @@ def i2v_sphere_sample(eps_model, image_embedder, tables: DiffusionTables, text_c
             pano = temp
         if trace is not None:
             trace.append((i, int(t), views))
-    return pano.clone(), pano_x0.clone()
+    return _downsampled(pano.clone(), pano_x0.clone(), downsample_factor_before_vae_decode)
 
 
 def sphere_splat_bilinear(pano, view, fov, theta, phi):

@@ -1487,6 +1487,93 @@ def g22_i2v_sphere_view_scale():
     print("wrote sphere_i2v_scale.json")
 
 
+SPHERE_SET_SCALE_GEOMS = {
+    # view_set_scale_factor s: x_prev / pred_x0 resized up by s with 'nearest' before the scatter -- s x s neighbouring sources per
+    # target.  Generated with ONE torch thread (see SPHERE_SCALE_GEOMS): the reference's index_put_ is then a sequential loop and
+    # the last source in row-major order of the scaled view wins.
+    "set2": dict(height=64, width=128, frames=4, equirect_width=512, equirect_height=256, view_fov=120, loop_step_theta=4,
+                 phi_theta_dict={"60": [0, 180], "0": [0, 120, 240], "-60": [90, 270]}, merge_renoised_overlap_latent_ratio=1,
+                 num_inference_steps=4, view_set_scale_factor=2),
+    "set3_get2_fov_down2": dict(height=64, width=128, frames=4, equirect_width=512, equirect_height=256, view_fov=120, loop_step_theta=3,
+                                phi_theta_dict={"45": [0, 120, 240], "-45": [60, 180, 300]}, phi_fov_dict={"45": 100},
+                                merge_renoised_overlap_latent_ratio=0.6, num_inference_steps=3, view_get_scale_factor=2,
+                                view_set_scale_factor=3, downsample_factor_before_vae_decode=2),
+}
+
+
+def g33_sphere_view_set_scale():
+    """view_set_scale_factor and downsample_factor_before_vae_decode of both sphere loops (t2v_sphere_panorama_pipeline.py:268-275,
+    298-305; i2v_sphere_panorama_pipeline.py:421-428, 481-488), fake eps, fp32, torch.set_num_threads(1) (the reference's scatter
+    resolves duplicated targets by thread timing otherwise).  i2v: g13's inputs and stubs, merge-prev off (the reference mixes a
+    scaled with an unscaled tensor there and raises)."""
+    import pipeline.i2v_sphere_panorama_pipeline as mod
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        cond, uncond = synth_normal((1, 77, 64), 61), synth_normal((1, 77, 64), 62)
+        arrays = {"cond": cond, "uncond": uncond}
+        ld = FakeLatentDiffusion(FakeEps(), cond, uncond, temporal_length=4)
+        for gname, geom in SPHERE_SET_SCALE_GEOMS.items():
+            g = dict(geom)
+            g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+            if "phi_fov_dict" in g:
+                g["phi_fov_dict"] = {int(k): v for k, v in g["phi_fov_dict"].items()}
+            pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": dict(TINY)}}})
+            torch.manual_seed(2333333)
+            with contextlib.redirect_stdout(io.StringIO()):
+                final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent", **g)
+            arrays[f"sphere_{gname}_final"], arrays[f"sphere_{gname}_denoised"] = final, den
+        # i2v
+        pano_img = synth_normal((3, 256, 512), 89).clamp(-1, 1)
+        static_latent = synth_normal((1, 4, 1, 32, 64), 90)
+        p_i2v = dict(TINY)
+        p_i2v["use_image_attention"] = True
+        embed = synth_image_embedder(64)
+        cases = {"long_s2": dict(I2V_SPHERE_GEOMS["long"], view_set_scale_factor=2, merge_prev_denoised_ratio_list=None),
+                 "static_s2_g2_down2": dict(I2V_SPHERE_GEOMS["static"], view_set_scale_factor=2, view_get_scale_factor=2,
+                                            merge_prev_denoised_ratio_list=None, downsample_factor_before_vae_decode=2)}
+        orig_loader = mod.load_image_tensor_from_path
+        mod.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: pano_img   # I/O stub (cv2 absent)
+        try:
+            ld = FakeLatentDiffusion(FakeEps(), cond, uncond, temporal_length=4)
+            ld.get_image_embeds = embed
+            ld.embedder = object()
+            for name, geom in cases.items():
+                g = dict(geom)
+                g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+                pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": p_i2v}}})
+                pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+                pipe.tiled_vae_encode_image = lambda image_path, image_size: static_latent.clone()      # VAE stub (N2)
+                torch.manual_seed(2333333)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", img_cond_path="unused.png", fps=8,
+                                                                         guidance_scale=7.5, pano_image_path="unused.png",
+                                                                         output_type="latent", **g)
+                arrays[f"i2v_{name}_final"] = final
+                arrays[f"i2v_{name}_denoised"] = den
+            # merge-prev with a set scale factor: what the reference raises
+            g = dict(I2V_SPHERE_GEOMS["base"], view_set_scale_factor=2)
+            g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+            pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": p_i2v}}})
+            pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+            raised = None
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", img_cond_path="unused.png", fps=8, guidance_scale=7.5,
+                                                            pano_image_path="unused.png", output_type="latent", **g)
+            except Exception as e:      # noqa: BLE001 -- recorded, whatever it is
+                raised = type(e).__name__
+        finally:
+            mod.load_image_tensor_from_path = orig_loader
+    finally:
+        torch.set_num_threads(nthreads)
+    save_npz("sphere_set_scale.npz", **arrays)
+    with open(os.path.join(HERE, "sphere_set_scale.json"), "w") as f:
+        json.dump({"geoms": SPHERE_SET_SCALE_GEOMS, "i2v_cases": cases, "merge_prev_with_set_scale_raises": raised}, f)
+    print("wrote sphere_set_scale.json; merge-prev + set scale raised:", raised)
+
+
 VAE_TINY = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2], num_res_blocks=1,
                 attn_resolutions=[], dropout=0.0)
 VAE_FULL = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
@@ -1709,7 +1796,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     steps = {"g1": g1_segments, "g2": g2_ring, "g3": g3_mix, "g4": g4_scheduler, "g8": g8_unet_tiny,
-             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale, "g22": g22_i2v_sphere_view_scale, "g24": g24_panorama_handlers, "g30": g30_panorama_handlers_uncalled, "g32": g32_grid_random_shuffle}
+             "g9": g9_loops_small, "g9t": g9_traces, "g11": g11_grid_and_i2v, "g12": g12_sphere, "g13": g13_i2v_sphere, "g14": g14_vae_decode, "g15": g15_vae_encode, "g16": g16_encoders, "g19": g19_multi_prompt, "g20": g20_cfg4_geometry, "g21": g21_sphere_view_scale, "g22": g22_i2v_sphere_view_scale, "g24": g24_panorama_handlers, "g30": g30_panorama_handlers_uncalled, "g32": g32_grid_random_shuffle, "g33": g33_sphere_view_set_scale}
     if args.full:
         steps["g10"] = g10_unet_full
         steps["g10i"] = g10_unet_full_i2v

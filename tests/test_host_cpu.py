@@ -833,3 +833,32 @@ def test_tap_and_round_scatter_maps_reproduce_the_oracle_on_cpu():
                 sel = (m.idx[b] >= 0).nonzero().view(-1)
                 out[b][:, m.idx[b][sel].long()] = view[b].reshape(3, -1)[:, sel]
             assert torch.equal(out.view(B, 3, H, W), osphere.sphere_round_scatter(pano, view, fov, th, ph)), (fov, B)
+
+
+def test_upsampled_scatter_maps_equal_the_scatter_of_the_scaled_view():
+    """view_set_scale_factor s (sphere._UpsampledScatter): the s * s sub-sampled scatter maps of the tile, applied in any order, write
+    what the oracle's scatter of the 'nearest'-resized view writes (duplicates resolved on the scaled view) -- and nothing else."""
+    import torch
+    from oracle import sphere as S
+    from oracle.loops import resize_video_latent
+    from dynamicscaler_amd.sphere import ViewMapCache, _set_maps
+    H, W, h, w = 32, 64, 8, 16
+    for s, (fov, th, ph) in ((2, (120, 30, 60)), (3, (100, 200, -45)), (1, (120, 0, 0))):
+        torch.manual_seed(s)
+        pano = torch.randn(1, 2, 3, H, W)
+        view = torch.randn(1, 2, 3, h, w)
+        ref = pano.clone()
+        S.sphere_scatter_fast(ref, resize_video_latent(view, h * s, w * s, "nearest") if s > 1 else view, fov, th, ph)
+        m = _set_maps(ViewMapCache("cpu"), {}, fov, th, ph, w, h, W, H, s)
+        assert len(m.subs) == s * s
+        got = pano.clone().view(1, 2, 3, H * W)
+        src = view.reshape(1, 2, 3, h * w)
+        hit = torch.zeros(H * W, dtype=torch.int32)
+        for k in reversed(range(s * s)):
+            idx = m.subs[k].long()
+            on = idx >= 0
+            got[..., idx[on]] = src[..., on]
+            hit[idx[on]] += 1
+        assert int(hit.max()) == 1                                   # disjoint targets: the sub-scatters commute
+        assert torch.equal(got.view(pano.shape), ref)
+        assert torch.equal(torch.from_numpy(m.write_set), hit.bool())

@@ -472,6 +472,43 @@ def test_g22_i2v_sphere_loop_view_get_scale_factor_bit_exact():
         assert torch.equal(den, T(zs[f"{name}_denoised"])), name
 
 
+def test_g33_sphere_loops_view_set_scale_factor_bit_exact():
+    """view_set_scale_factor 2 / 3 (x_prev, pred_x0 and the mask's ones resized up with 'nearest' before the scatter: several
+    neighbouring sources per target, the last one in row-major order wins) and downsample_factor_before_vae_decode of both sphere
+    loops, also combined with a get scale factor, a per-phi fov, frame windows + docking and paste_on_static -- bit-exact against
+    the reference run with one torch thread (with more, its own scatter is not repeatable).  merge-prev with a set scale factor
+    mixes tensors of two sizes: the reference raises, and so does the oracle."""
+    from oracle import sphere as S
+    from helpers import synth_image_embedder
+    zs = npz("sphere_set_scale.npz")
+    meta = json.load(open(os.path.join(G, "sphere_set_scale.json")))
+    cond, uncond = T(zs["cond"]), T(zs["uncond"])
+    assert len(meta["geoms"]) == 2 and len(meta["i2v_cases"]) == 2
+    for gname, geom in meta["geoms"].items():
+        torch.manual_seed(2333333)
+        final, den = S.t2v_sphere_sample(_fake_eps, oddim.DiffusionTables(), cond, uncond, guidance_scale=7.5, **_sphere_geom(geom))
+        assert torch.equal(final, T(zs[f"sphere_{gname}_final"])) and torch.equal(den, T(zs[f"sphere_{gname}_denoised"])), gname
+    z = np.load(os.path.join(G, "sphere_i2v.npz"))
+    pano_img = T(z["pano_img"])
+    embed = synth_image_embedder(64)
+    uc = torch.cat([uncond, embed(torch.zeros(1, 3, 8, 16))], dim=1)
+    fake = lambda x, ts, ctx: 0.1 * x + 0.01 * ctx.mean()
+    for name, geom in meta["i2v_cases"].items():
+        g = dict(geom)
+        g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+        dock = g.pop("dock_at_f", None)
+        torch.manual_seed(2333333)
+        final, den = S.i2v_sphere_sample(fake, embed, oddim.DiffusionTables(), cond, uc, pano_img, guidance_scale=7.5, dock_at_f=dock,
+                                         static_frame_latent=T(z["static_latent"]), **g)
+        assert torch.equal(final, T(zs[f"i2v_{name}_final"])), name
+        assert torch.equal(den, T(zs[f"i2v_{name}_denoised"])), name
+    assert meta["merge_prev_with_set_scale_raises"] == "RuntimeError"
+    base = dict(json.load(open(os.path.join(G, "sphere_i2v_traces.json")))["geoms"]["base"], view_set_scale_factor=2)
+    base["phi_theta_dict"] = {int(k): v for k, v in base["phi_theta_dict"].items()}
+    with pytest.raises(RuntimeError):
+        S.i2v_sphere_sample(fake, embed, oddim.DiffusionTables(), cond, uc, pano_img, guidance_scale=7.5, **base)
+
+
 def test_g13_i2v_sphere_loop_tiny_unet():
     from oracle.sphere import i2v_sphere_sample
     from helpers import synth_image_embedder
