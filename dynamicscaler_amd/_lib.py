@@ -117,6 +117,8 @@ SIGNATURES = {
     "ds_silu_f32": (_i, [_vp, _vp, _sz, _vp]),
     "ds_cast_to_f32": (_i, [_vp, _i, _vp, _sz, _vp]),
     "ds_im2col_in_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ds_im2col_in_affine_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp]),
+    "ds_softmax_rows_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ds_unet_create": (_i, [_pp(UNetConfig), _pp(_vp)]),
     "ds_unet_destroy": (_i, [_vp]),
     "ds_unet_num_weights": (_i, [_vp]),

@@ -725,6 +725,69 @@ im2col_in_f32_kernel(const T* __restrict__ x, float* __restrict__ patches, int B
     }
 }
 
+// first-stage decoder input in the wide mode: im2col_in_affine_kernel (misc.hip) with fp32 patches
+template <typename T>
+__global__ void __launch_bounds__(256)
+im2col_in_affine_f32_kernel(const T* __restrict__ x, float* __restrict__ patches, int B, int C, int Tn, int H, int W, int kpad,
+                            const float* __restrict__ wmat, const float* __restrict__ bvec, float in_scale) {
+    const long total = (long)B * Tn * H * W * kpad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / kpad;
+        const int col = (int)(idx - m * kpad);
+        float v = 0.0f;
+        if (col < 9 * C) {
+            const int tap = col / C, c = col - tap * C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            long r = m;
+            const int xx = (int)(r % W); r /= W;
+            const int yy = (int)(r % H); r /= H;
+            const int t = (int)(r % Tn);
+            const int b = (int)(r / Tn);
+            const int iy = yy + ky - 1, ix = xx + kx - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                v = bvec[c];
+                for (int ci = 0; ci < C; ++ci)
+                    v += wmat[c * C + ci] * ((float)x[((((long)b * C + ci) * Tn + t) * H + iy) * W + ix] * in_scale);
+            }
+        }
+        patches[idx] = v;
+    }
+}
+
+// Row softmax with fp32 probabilities (the first-stage AttnBlock in the wide mode, ae_modules.py:62-64): softmax_rows_kernel (misc.hip)
+// with expf instead of the hardware exp2 and an fp32 store; one wave per row.
+__global__ void __launch_bounds__(256)
+softmax_rows_f32_kernel(const float* __restrict__ s, float* __restrict__ p, int rows, int cols, int lds, int ldp, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float* sr = s + row * lds;
+    float* pr = p + row * ldp;
+    float m = -1e30f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sr + c);
+        m = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) m = fmaxf(m, __shfl_xor(m, sh));
+    float l = 0.0f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sr + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l += expf((v[j] - m) * scale);
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) l += __shfl_xor(l, sh);
+    const float inv = 1.0f / l;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sr + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = expf((v[j] - m) * scale) * inv;
+        *reinterpret_cast<f32x4*>(pr + c) = o;
+    }
+}
+
 inline int grid_for(long work) {
     long g = (work + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -890,5 +953,31 @@ extern "C" int ds_im2col_in_f32(const void* x, int x_dtype, float* patches, int 
     else if (x_dtype == DS_F32) im2col_in_f32_kernel<float><<<grid_for(work), 256, 0, (hipStream_t)stream>>>((const float*)x, patches, B, C, T, H, W, kpad);
     else DS_CHECK_ARG(false, "ds_im2col_in_f32: bad dtype %d", x_dtype);
     DS_CHECK_LAUNCH("ds_im2col_in_f32");
+    return DS_OK;
+}
+
+extern "C" int ds_im2col_in_affine_f32(const void* x, int x_dtype, float* patches, int B, int C, int T, int H, int W, int kpad,
+                                       const float* wmat, const float* bvec, float in_scale, void* stream) {
+    DS_CHECK_ARG(x && patches && wmat && bvec, "ds_im2col_in_affine_f32: null argument");
+    DS_CHECK_ARG(B > 0 && C > 0 && C <= 8 && T > 0 && H > 0 && W > 0, "ds_im2col_in_affine_f32: sizes must be positive, C <= 8");
+    DS_CHECK_ARG(kpad >= 9 * C && kpad % 64 == 0, "ds_im2col_in_affine_f32: kpad=%d must be >= 9*C and a multiple of 64", kpad);
+    const long work = (long)B * T * H * W * kpad;
+    if (x_dtype == DS_F16)
+        im2col_in_affine_f32_kernel<f16><<<grid_for(work), 256, 0, (hipStream_t)stream>>>((const f16*)x, patches, B, C, T, H, W, kpad, wmat, bvec, in_scale);
+    else if (x_dtype == DS_F32)
+        im2col_in_affine_f32_kernel<float><<<grid_for(work), 256, 0, (hipStream_t)stream>>>((const float*)x, patches, B, C, T, H, W, kpad, wmat, bvec, in_scale);
+    else
+        DS_CHECK_ARG(false, "ds_im2col_in_affine_f32: bad dtype %d", x_dtype);
+    DS_CHECK_LAUNCH("ds_im2col_in_affine_f32");
+    return DS_OK;
+}
+
+extern "C" int ds_softmax_rows_f32(const float* s, float* p, int rows, int cols, int lds, int ldp, float scale, void* stream) {
+    DS_CHECK_ARG(s && p, "ds_softmax_rows_f32: null argument");
+    DS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && lds % 4 == 0 && ldp % 4 == 0 && lds >= cols && ldp >= cols,
+                 "ds_softmax_rows_f32: cols / strides must be positive multiples of 4");
+    DS_CHECK_ARG(((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(p)) & 15) == 0, "ds_softmax_rows_f32: 16-byte aligned rows");
+    softmax_rows_f32_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(s, p, rows, cols, lds, ldp, scale);
+    DS_CHECK_LAUNCH("ds_softmax_rows_f32");
     return DS_OK;
 }

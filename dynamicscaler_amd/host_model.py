@@ -69,7 +69,7 @@ class SyntheticConditioner:
 class LatentDiffusionHost(nn.Module):
     def __init__(self, unet_config, timesteps=1000, linear_start=0.00085, linear_end=0.012, uncond_type="empty_seq",
                  use_scale=False, channels=4, conditioner=None, first_stage_config=None, scale_factor=1.0,
-                 cond_stage_config=None, cond_img_config=None, finegrained=False, **_ignored):
+                 cond_stage_config=None, cond_img_config=None, finegrained=False, first_stage_operands="f16", **_ignored):
         super().__init__()
         params = unet_config["params"] if "params" in unet_config else unet_config
         self.model = DiffusionWrapper(UNetModel(**params), "crossattn")
@@ -88,6 +88,8 @@ class LatentDiffusionHost(nn.Module):
             from .vae import AutoencoderKL
             fp = first_stage_config.get("params", first_stage_config)
             self.first_stage_model = AutoencoderKL(fp["ddconfig"], fp.get("embed_dim", 4))
+            # "wide": the first stage on fp32 activations and split-fp16 products (vae.py; ~4x the decode time, inside 1e-3)
+            self.first_stage_model.operand_mode = first_stage_operands
         self.cond_stage_model = None
         if cond_stage_config is not None:                                    # ddpm3d.py:427-444 (frozen, eval)
             self.cond_stage_model = self._instantiate_encoder(cond_stage_config)

@@ -547,34 +547,44 @@ def concat_channels(a, b, stream=None):
     return dst
 
 
-def im2col_in(x, kpad, stream=None):
+def im2col_in(x, kpad, stream=None, out_dtype=torch.float16):
+    """3x3 patches [B*T*H*W, kpad] of a [B, C, T, H, W] input (conv_in as a dense GEMM); fp32 patches: ds_im2col_in_f32."""
     lib = _lib.load()
     st = _stream() if stream is None else stream
     B, Cc, T, H, W = x.shape
-    patches = torch.empty((B * T * H * W, kpad), dtype=torch.float16, device=x.device)
+    patches = torch.empty((B * T * H * W, kpad), dtype=out_dtype, device=x.device)
+    if out_dtype == torch.float32:
+        check(lib.ds_im2col_in_f32(x.data_ptr(), _DT[x.dtype], patches.data_ptr(), B, Cc, T, H, W, kpad, st), "ds_im2col_in_f32")
+        return patches
     check(lib.ds_im2col_in(x.data_ptr(), _DT[x.dtype], patches.data_ptr(), B, Cc, T, H, W, kpad, st), "ds_im2col_in")
     return patches
 
 
-def im2col_in_affine(x, kpad, wmat, bvec, in_scale, stream=None):
-    """conv_in patches of post_quant_conv(x * in_scale) (first-stage decoder); wmat fp32 [C,C], bvec fp32 [C] on the device."""
+def im2col_in_affine(x, kpad, wmat, bvec, in_scale, stream=None, out_dtype=torch.float16):
+    """conv_in patches of post_quant_conv(x * in_scale) (first-stage decoder); wmat fp32 [C,C], bvec fp32 [C] on the device.
+    out_dtype fp32: the patches of the wide operand mode (ds_im2col_in_affine_f32)."""
     lib = _lib.load()
     st = _stream() if stream is None else stream
     B, Cc, T, H, W = x.shape
-    patches = torch.empty((B * T * H * W, kpad), dtype=torch.float16, device=x.device)
-    check(lib.ds_im2col_in_affine(x.data_ptr(), _DT[x.dtype], patches.data_ptr(), B, Cc, T, H, W, kpad, wmat.data_ptr(),
-                                  bvec.data_ptr(), float(in_scale), st), "ds_im2col_in_affine")
+    patches = torch.empty((B * T * H * W, kpad), dtype=out_dtype, device=x.device)
+    fn, name = (lib.ds_im2col_in_affine, "ds_im2col_in_affine") if out_dtype == torch.float16 else \
+        (lib.ds_im2col_in_affine_f32, "ds_im2col_in_affine_f32")
+    check(fn(x.data_ptr(), _DT[x.dtype], patches.data_ptr(), B, Cc, T, H, W, kpad, wmat.data_ptr(), bvec.data_ptr(), float(in_scale), st), name)
     return patches
 
 
 def softmax_rows(s, scale, out=None, stream=None):
-    """fp32 scores [rows, cols] -> fp16 softmax(s * scale) over the columns."""
+    """fp32 scores [rows, cols] -> softmax(s * scale) over the columns: fp16, or fp32 into an fp32 `out` (ds_softmax_rows_f32)."""
     lib = _lib.load()
     st = _stream() if stream is None else stream
     rows, cols = s.shape
     if out is None:
         out = torch.empty((rows, cols), dtype=torch.float16, device=s.device)
     assert out.shape[0] == rows and out.shape[1] >= cols
+    if out.dtype == torch.float32:
+        check(lib.ds_softmax_rows_f32(s.data_ptr(), out.data_ptr(), rows, cols, s.stride(0), out.stride(0), float(scale), st),
+              "ds_softmax_rows_f32")
+        return out
     check(lib.ds_softmax_rows(s.data_ptr(), out.data_ptr(), rows, cols, s.stride(0), out.stride(0), float(scale), st),
           "ds_softmax_rows")
     return out

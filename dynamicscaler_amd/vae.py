@@ -11,6 +11,12 @@ head_dim-64 flash kernel: per image, scores = Q K^T go through memory as fp32 (d
 ds_softmax_rows, then P V as a GEMM against V^T (produced directly as Wv X^T, so nothing is transposed); v's bias
 moves into proj_out's (softmax rows sum to 1).  post_quant_conv and the 1/scale_factor are applied while conv_in's
 patches are gathered (ds_im2col_in_affine).  Frames are decoded in chunks of `frames_per_chunk` images.
+
+`operand_mode = "wide"` (round 5): the same program on the wide operand kernels of the UNet (csrc/wide.hip) -- activations are fp32
+rows, every product is the three-MFMA split-fp16 form (ds_gemm_wide; weights as hi / lo planes), GroupNorm, the softmax and the
+patch gathers have fp32 forms -- for a decode / encode inside the 1e-3 north star of the latents (fp16 operands: 2.6e-3 on the
+decoded pixels of the real config).  One operand of a launch is limited to 2 GiB there (ds_gemm_wide: a 512 x 4096 frame at 128
+channels is 1.07 GB), frames go one at a time.
 """
 import torch
 import torch.nn as nn
@@ -32,8 +38,9 @@ class AutoencoderKLDecoder(nn.Module):
         self._params = nn.ParameterDict()
         for key, shape in self._shapes.items():
             self._params[key.replace(".", "/")] = nn.Parameter(torch.zeros(shape), requires_grad=False)
-        self._packed, self._device = None, None
+        self._packed, self._device, self._packed_mode = None, None, None
         self.frames_per_chunk = 8
+        self.operand_mode = "f16"           # "f16" | "wide" (fp32 activations, split-fp16 products: see the module docstring)
 
     # ---- reference-keyed state dict ----
     def state_dict(self, *a, **k):
@@ -55,17 +62,30 @@ class AutoencoderKLDecoder(nn.Module):
         self._packed = None
         return missing, unexpected
 
+    @property
+    def _wide(self):
+        if self.operand_mode not in ("f16", "wide"):
+            raise ValueError(f"AutoencoderKL.operand_mode {self.operand_mode!r}: 'f16' or 'wide'")
+        return self.operand_mode == "wide"
+
     def prepare(self, device):
-        """Repack to the kernels' layouts (fp16 [N][K], K = tap*Cin + c), once per device."""
+        """Repack to the kernels' layouts (fp16 [N][K], K = tap*Cin + c; the wide mode: (hi, lo) fp16 planes of the fp32 matrix), once
+        per device and operand mode."""
         sd = self.state_dict()
         dev = torch.device(device)
         P = {}
+        wide = self._wide
 
         def w16(t):
+            if wide:
+                return ops.split_f16(t.to(dev, torch.float32).contiguous())
             return t.to(dev, torch.float16).contiguous()
 
         def f32(t):
             return t.to(dev, torch.float32).contiguous()
+
+        def a16(t):         # a weight that is the A (left) operand of its launch: fp16, or plain fp32 in the wide mode
+            return f32(t) if wide else t.to(dev, torch.float16).contiguous()
 
         def conv_w(w):      # [O,I,3,3] -> [O][9*I] with k = (ky*3+kx)*I + i
             return w16(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
@@ -89,7 +109,7 @@ class AutoencoderKLDecoder(nn.Module):
                 P[p + ".norm.g"], P[p + ".norm.be"] = f32(sd[p + ".norm.weight"]), f32(sd[p + ".norm.bias"])
                 for n in ("q", "k"):
                     P[f"{p}.{n}.w"], P[f"{p}.{n}.b"] = w16(sd[f"{p}.{n}.weight"].reshape(cin, cin)), f32(sd[f"{p}.{n}.bias"])
-                P[p + ".v.w"] = w16(sd[p + ".v.weight"].reshape(cin, cin))
+                P[p + ".v.w"] = a16(sd[p + ".v.weight"].reshape(cin, cin))
                 wp = sd[p + ".proj_out.weight"].reshape(cin, cin).double()
                 P[p + ".proj.w"] = w16(wp.float())
                 # softmax rows sum to 1: P (V + 1 b_v^T) = P V + b_v, so b_v rides on proj_out's bias
@@ -120,7 +140,7 @@ class AutoencoderKLDecoder(nn.Module):
                     P[p + ".norm.g"], P[p + ".norm.be"] = f32(sd[p + ".norm.weight"]), f32(sd[p + ".norm.bias"])
                     for n in ("q", "k"):
                         P[f"{p}.{n}.w"], P[f"{p}.{n}.b"] = w16(sd[f"{p}.{n}.weight"].reshape(cin, cin)), f32(sd[f"{p}.{n}.bias"])
-                    P[p + ".v.w"] = w16(sd[p + ".v.weight"].reshape(cin, cin))
+                    P[p + ".v.w"] = a16(sd[p + ".v.weight"].reshape(cin, cin))
                     wpj = sd[p + ".proj_out.weight"].reshape(cin, cin).double()
                     P[p + ".proj.w"] = w16(wpj.float())
                     P[p + ".proj.b"] = f32((sd[p + ".proj_out.bias"].double() + wpj @ sd[p + ".v.bias"].double()).float())
@@ -136,8 +156,22 @@ class AutoencoderKLDecoder(nn.Module):
                     P[p + ".b"] = f32((wq @ sd[p + ".bias"].double() + sd["quant_conv.bias"].double()).float())
         P["pq.w"] = f32(sd["post_quant_conv.weight"].reshape(self.dd["z_channels"], self.embed_dim))
         P["pq.b"] = f32(sd["post_quant_conv.bias"])
-        self._packed, self._device = P, dev
+        self._packed, self._device, self._packed_mode = P, dev, self.operand_mode
         return self
+
+    def _ready(self, device):
+        if self._packed is None or self._device != device or self._packed_mode != self.operand_mode:
+            self.prepare(device)
+        return self._packed
+
+    def _gemm(self, a, w, b, residual, **kw):
+        """ds_gemm_f16, or ds_gemm_wide on the (hi, lo) planes of w"""
+        if self._wide:
+            return ops.gemm_wide(a, w[0], w[1], b, residual, **kw)
+        return ops.gemm(a, w, b, residual, **kw)
+
+    def _gn(self, x, g, be, ninst, rows, C, silu):
+        return (ops.groupnorm_wide if self._wide else ops.groupnorm)(x, g, be, ninst, rows, C, 1e-6, silu)
 
     # ---- ops ----
     def _conv3(self, a, w, b, nimg, hin, win, cin, upsample=0, residual=None, epilogue=0, down=False):
@@ -145,16 +179,17 @@ class AutoencoderKLDecoder(nn.Module):
         if down:       # Downsample: F.pad(x, (0,1,0,1)) + 3x3 stride-2 conv without padding (ae_modules.py:102-106)
             hl, wl = (hin - 2) // 2 + 1, (win - 2) // 2 + 1
         M = nimg * hl * wl
-        out = ops.gemm(a, w, b, residual, M=M, N=w.shape[0], K=w.shape[1], a_mode=DS_A_CONV3, cin=cin, lda=a.stride(0),
-                       conv=(nimg, hin, win, hl, wl, 2 if down else 1, upsample, 1 if down else 0), epilogue=epilogue)
+        N, K = (w[0] if self._wide else w).shape
+        out = self._gemm(a, w, b, residual, M=M, N=N, K=K, a_mode=DS_A_CONV3, cin=cin, lda=a.stride(0),
+                         conv=(nimg, hin, win, hl, wl, 2 if down else 1, upsample, 1 if down else 0), epilogue=epilogue)
         return out, hl, wl
 
     def _res(self, x, p, nimg, H, W, cin, cout):
         P = self._packed
-        a = ops.groupnorm(x, P[p + ".norm1.g"], P[p + ".norm1.be"], nimg, H * W, cin, 1e-6, True)
+        a = self._gn(x, P[p + ".norm1.g"], P[p + ".norm1.be"], nimg, H * W, cin, True)
         h1, _, _ = self._conv3(a, P[p + ".conv1.w"], P[p + ".conv1.b"], nimg, H, W, cin)
-        a2 = ops.groupnorm(h1, P[p + ".norm2.g"], P[p + ".norm2.be"], nimg, H * W, cout, 1e-6, True)
-        skip = x if cin == cout else ops.gemm(x, P[p + ".nin.w"], P[p + ".nin.b"], None, M=x.shape[0], N=cout, K=cin)
+        a2 = self._gn(h1, P[p + ".norm2.g"], P[p + ".norm2.be"], nimg, H * W, cout, True)
+        skip = x if cin == cout else self._gemm(x, P[p + ".nin.w"], P[p + ".nin.b"], None, M=x.shape[0], N=cout, K=cin)
         out, _, _ = self._conv3(a2, P[p + ".conv2.w"], P[p + ".conv2.b"], nimg, H, W, cout, residual=skip)
         return out
 
@@ -164,18 +199,17 @@ class AutoencoderKLDecoder(nn.Module):
         AutoencoderKL.encode's posterior (quant_conv(Encoder(x)), autoencoder.py:97-101), every (b, t) one image."""
         if not x.is_cuda:
             raise RuntimeError("AutoencoderKL.encode: input is on the CPU; this build has no CPU path")
-        if self._packed is None or self._device != x.device:
-            self.prepare(x.device)
         if not self._has_encoder:
             raise RuntimeError("AutoencoderKL.encode: the loaded state dict had no encoder / quant_conv weights")
-        P = self._packed
+        P = self._ready(x.device)
+        act = torch.float32 if self._wide else torch.float16
         B, Cin, T, H, W = x.shape
         nimg = B * T
         h = None
         for kind, p, cin, cout in encoder_blocks(self.dd):
             if kind == "conv_in":
-                patches = ops.im2col_in(x.contiguous(), self._kpad_enc)
-                h = ops.gemm(patches, P[p + ".w"], P[p + ".b"], None, M=patches.shape[0], N=cout, K=self._kpad_enc)
+                patches = ops.im2col_in(x.contiguous(), self._kpad_enc, out_dtype=act)
+                h = self._gemm(patches, P[p + ".w"], P[p + ".b"], None, M=patches.shape[0], N=cout, K=self._kpad_enc)
             elif kind == "res":
                 h = self._res(h, p, nimg, H, W, cin, cout)
             elif kind == "attn":
@@ -183,49 +217,56 @@ class AutoencoderKLDecoder(nn.Module):
             elif kind == "down":
                 h, H, W = self._conv3(h, P[p + ".w"], P[p + ".b"], nimg, H, W, cin, down=True)
             elif kind == "norm_out":
-                h = ops.groupnorm(h, P[p + ".g"], P[p + ".be"], nimg, H * W, cin, 1e-6, True)
+                h = self._gn(h, P[p + ".g"], P[p + ".be"], nimg, H * W, cin, True)
             elif kind == "conv_out":
                 h, _, _ = self._conv3(h, P[p + ".w"], P[p + ".b"], nimg, H, W, cin, epilogue=DS_EPI_OUT_F32)
         return h, (H, W)
 
     def _attn(self, x, p, nimg, hw, C):
         P = self._packed
-        h = ops.groupnorm(x, P[p + ".norm.g"], P[p + ".norm.be"], nimg, hw, C, 1e-6, False)
+        wide = self._wide
+        act = torch.float32 if wide else torch.float16
+        h = self._gn(x, P[p + ".norm.g"], P[p + ".norm.be"], nimg, hw, C, False)
         M = nimg * hw
-        q = ops.gemm(h, P[p + ".q.w"], P[p + ".q.b"], None, M=M, N=C, K=C)
-        k = ops.gemm(h, P[p + ".k.w"], P[p + ".k.b"], None, M=M, N=C, K=C)
-        o = torch.empty((M, C), dtype=torch.float16, device=x.device)
+        q = self._gemm(h, P[p + ".q.w"], P[p + ".q.b"], None, M=M, N=C, K=C)
+        k = self._gemm(h, P[p + ".k.w"], P[p + ".k.b"], None, M=M, N=C, K=C)
+        o = torch.empty((M, C), dtype=act, device=x.device)
         hwp = (hw + 63) // 64 * 64        # the P V contraction runs over the tokens: padded to the GEMM's K granule
         s = torch.empty((hw, hw), dtype=torch.float32, device=x.device)
-        pr = torch.zeros((hw, hwp), dtype=torch.float16, device=x.device)      # pad columns stay 0
-        vt = torch.zeros((C, hwp), dtype=torch.float16, device=x.device)
+        pr = torch.zeros((hw, hwp), dtype=act, device=x.device)      # pad columns stay 0
+        vt = torch.zeros((C, hwp), dtype=act, device=x.device)
+
+        def right(t):       # an activation as the right-hand ([N][K]) operand of a launch: itself, or its (hi, lo) planes
+            return ops.split_f16(t) if wide else t
+
         for i in range(nimg):
             rows = slice(i * hw, (i + 1) * hw)
-            ops.gemm(q[rows], k[rows], None, None, M=hw, N=hw, K=C, out=s, epilogue=DS_EPI_OUT_F32)     # q k^T
+            self._gemm(q[rows], right(k[rows]), None, None, M=hw, N=hw, K=C, out=s, epilogue=DS_EPI_OUT_F32)   # q k^T
             ops.softmax_rows(s, int(C) ** (-0.5), out=pr)
-            ops.gemm(P[p + ".v.w"], h[rows], None, None, M=C, N=hw, K=C, out=vt)                      # V^T = Wv X^T
-            ops.gemm(pr, vt, None, None, M=hw, N=C, K=hwp, out=o[rows])                               # P V
-        return ops.gemm(o, P[p + ".proj.w"], P[p + ".proj.b"], x, M=M, N=C, K=C)
+            self._gemm(P[p + ".v.w"], right(h[rows]), None, None, M=C, N=hw, K=C, out=vt)                     # V^T = Wv X^T
+            self._gemm(pr, right(vt), None, None, M=hw, N=C, K=hwp, out=o[rows])                              # P V
+        return self._gemm(o, P[p + ".proj.w"], P[p + ".proj.b"], x, M=M, N=C, K=C)
 
     @torch.no_grad()
     def decode_frames(self, z, in_scale=1.0):
         """z [B, z_channels, T, h, w] (HIP device, fp16/fp32) -> [B, out_ch, T, H, W] fp32; every (b, t) is one image."""
         if not z.is_cuda:
             raise RuntimeError("AutoencoderKLDecoder: input is on the CPU; this build has no CPU path")
-        if self._packed is None or self._device != z.device:
-            self.prepare(z.device)
-        P = self._packed
+        P = self._ready(z.device)
+        wide = self._wide
         B, Cz, T, hh, ww = z.shape
         outs = []
-        for t0 in range(0, T, self.frames_per_chunk):
-            zc = z[:, :, t0:t0 + self.frames_per_chunk].contiguous()
+        chunk = 1 if wide else self.frames_per_chunk       # (fp32 rows: one frame keeps every operand of a launch under 2 GiB)
+        for t0 in range(0, T, chunk):
+            zc = z[:, :, t0:t0 + chunk].contiguous()
             Tn = zc.shape[2]
             nimg, H, W = B * Tn, hh, ww
             x = None
             for kind, p, cin, cout in decoder_blocks(self.dd):
                 if kind == "conv_in":
-                    patches = ops.im2col_in_affine(zc, self._kpad_in, P["pq.w"], P["pq.b"], in_scale)
-                    x = ops.gemm(patches, P[p + ".w"], P[p + ".b"], None, M=patches.shape[0], N=cout, K=self._kpad_in)
+                    patches = ops.im2col_in_affine(zc, self._kpad_in, P["pq.w"], P["pq.b"], in_scale,
+                                                   out_dtype=torch.float32 if wide else torch.float16)
+                    x = self._gemm(patches, P[p + ".w"], P[p + ".b"], None, M=patches.shape[0], N=cout, K=self._kpad_in)
                 elif kind == "res":
                     x = self._res(x, p, nimg, H, W, cin, cout)
                 elif kind == "attn":
@@ -233,7 +274,7 @@ class AutoencoderKLDecoder(nn.Module):
                 elif kind == "up":
                     x, H, W = self._conv3(x, P[p + ".w"], P[p + ".b"], nimg, H, W, cin, upsample=1)
                 elif kind == "norm_out":
-                    x = ops.groupnorm(x, P[p + ".g"], P[p + ".be"], nimg, H * W, cin, 1e-6, True)
+                    x = self._gn(x, P[p + ".g"], P[p + ".be"], nimg, H * W, cin, True)
                 elif kind == "conv_out":
                     y, _, _ = self._conv3(x, P[p + ".w"], P[p + ".b"], nimg, H, W, cin, epilogue=DS_EPI_OUT_F32)
                     outs.append(ops.rows_to_ncthw(y, (B, cout, Tn, H, W), torch.float32))

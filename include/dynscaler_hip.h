@@ -367,6 +367,11 @@ int ds_timestep_embedding_f32(const int64_t* t, float* out, int n, int dim, void
 int ds_silu_f32(const float* x, float* y, size_t n, void* stream);
 int ds_cast_to_f32(const void* x, int x_dtype, float* y, size_t n, void* stream);
 int ds_im2col_in_f32(const void* x, int x_dtype, float* patches, int B, int C, int T, int H, int W, int kpad, void* stream);
+/* fp32 forms of the first-stage (AutoencoderKL) glue, for a decode / encode on wide operands: ds_im2col_in_affine with fp32 patches
+ * (autoencoder.py:103-107) and ds_softmax_rows with fp32 probabilities (the 512-wide single-head AttnBlock, ae_modules.py:62-64). */
+int ds_im2col_in_affine_f32(const void* x, int x_dtype, float* patches, int B, int C, int T, int H, int W, int kpad,
+                            const float* wmat, const float* bvec, float in_scale, void* stream);
+int ds_softmax_rows_f32(const float* s, float* p, int rows, int cols, int lds, int ldp, float scale, void* stream);
 
 /* ---- conditioning producers: OpenCLIP ViT-H/14 towers and the IP-Adapter Resampler ---- */
 /* softmax(q k^T * scale [+ causal mask]) v for head_dim 64 (text tower, open_clip Transformer behind
