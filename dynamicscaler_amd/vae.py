@@ -15,8 +15,10 @@ patches are gathered (ds_im2col_in_affine).  Frames are decoded in chunks of `fr
 `operand_mode = "wide"` (round 5): the same program on the wide operand kernels of the UNet (csrc/wide.hip) -- activations are fp32
 rows, every product is the three-MFMA split-fp16 form (ds_gemm_wide; weights as hi / lo planes), GroupNorm, the softmax and the
 patch gathers have fp32 forms -- for a decode / encode inside the 1e-3 north star of the latents (fp16 operands: 2.6e-3 on the
-decoded pixels of the real config).  One operand of a launch is limited to 2 GiB there (ds_gemm_wide: a 512 x 4096 frame at 128
-channels is 1.07 GB), frames go one at a time.
+decoded pixels of the real config); frames go one at a time there.
+
+An activation operand of 2 GiB or more (32-bit buffer addressing in the GEMM kernels: a 1024 x 8192 frame at 128 fp16 channels is
+exactly 2 GiB) is evaluated in bands / row chunks / query blocks (`operand_limit`, _conv3_banded), bit-identically.
 """
 import torch
 import torch.nn as nn
@@ -41,6 +43,10 @@ class AutoencoderKLDecoder(nn.Module):
         self._packed, self._device, self._packed_mode = None, None, None
         self.frames_per_chunk = 8
         self.operand_mode = "f16"           # "f16" | "wide" (fp32 activations, split-fp16 products: see the module docstring)
+        # the GEMM kernels address an operand through a 32-bit buffer descriptor (< 2 GiB).  A launch whose activation operand would
+        # reach this many bytes is evaluated image by image, and a single image in bands of output rows with a one-row halo (_conv3) /
+        # in row chunks (1x1): a 1024 x 8192 frame at 128 fp16 channels is exactly 2 GiB.  Banding does not change a single bit.
+        self.operand_limit = 3 << 29        # 1.5 GiB
 
     # ---- reference-keyed state dict ----
     def state_dict(self, *a, **k):
@@ -174,12 +180,57 @@ class AutoencoderKLDecoder(nn.Module):
         return (ops.groupnorm_wide if self._wide else ops.groupnorm)(x, g, be, ninst, rows, C, 1e-6, silu)
 
     # ---- ops ----
-    def _conv3(self, a, w, b, nimg, hin, win, cin, upsample=0, residual=None, epilogue=0, down=False):
+    def _dense(self, a, w, b, residual, M, N, K):
+        """1x1 conv / linear over the rows of a, in row chunks when a is too large for one launch"""
+        nbytes = a.shape[0] * a.stride(0) * a.element_size()
+        if nbytes < self.operand_limit:
+            return self._gemm(a, w, b, residual, M=M, N=N, K=K)
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+        step = max(256, (M * self.operand_limit // nbytes) // 256 * 256)
+        for m0 in range(0, M, step):
+            m1 = min(M, m0 + step)
+            self._gemm(a[m0:m1], w, b, None if residual is None else residual[m0:m1], M=m1 - m0, N=N, K=K, out=out[m0:m1])
+        return out
+
+    def _conv3_banded(self, a, w, b, nimg, hin, win, cin, upsample, residual, epilogue):
+        """_conv3 (stride 1) of an operand too large for one launch: image by image, an image in bands of input rows [i0, i1) with a
+        one-row halo on each inner side -- the band's sub-image [i0 - 1, i1 + 1) is convolved as an image of its own (zero padding
+        at ITS borders) and the output rows of the halo, the only ones that padding reaches, are dropped.  Same taps, same order:
+        bit-identical to the single launch."""
+        f = 2 if upsample else 1
+        hl, wl = f * hin, f * win
+        N = (w[0] if self._wide else w).shape[0]
+        odt = torch.float32 if (self._wide or (epilogue & DS_EPI_OUT_F32)) else torch.float16
+        out = torch.empty((nimg * hl * wl, N), dtype=odt, device=a.device)
+        row_bytes = win * a.stride(0) * a.element_size()
+        band = max(1, int(self.operand_limit // row_bytes) - 2)
+        # ds_gemm_f16 picks the K order of a stride-1 3x3 conv from the instance's size (taps innermost from 2048 pixels on): a band
+        # must stay on the image's side of that rule or its sums are formed in another order.  Every image that really needs bands is
+        # far above it; an artificially small limit is rounded up to bands of >= 2048 pixels (a short last band joins its neighbour).
+        if hin * win >= 2048:
+            band = max(band, -(-2048 // win))
+        starts = list(range(0, hin, band))
+        if len(starts) > 1 and (hin - starts[-1] + 1) * win < 2048 <= hin * win:
+            starts.pop()
+        for img in range(nimg):
+            for j, i0 in enumerate(starts):
+                i1 = starts[j + 1] if j + 1 < len(starts) else hin
+                s0, s1 = max(i0 - 1, 0), min(i1 + 1, hin)
+                sub = a[(img * hin + s0) * win:(img * hin + s1) * win]
+                res = None if residual is None else residual[(img * hl + f * s0) * wl:(img * hl + f * s1) * wl]
+                part, _, _ = self._conv3(sub, w, b, 1, s1 - s0, win, cin, upsample=upsample, residual=res, epilogue=epilogue, banded=True)
+                o0 = (img * hl + f * i0) * wl
+                out[o0:o0 + f * (i1 - i0) * wl] = part[f * (i0 - s0) * wl:f * (i1 - s0) * wl]
+        return out, hl, wl
+
+    def _conv3(self, a, w, b, nimg, hin, win, cin, upsample=0, residual=None, epilogue=0, down=False, banded=False):
         hl, wl = (2 * hin, 2 * win) if upsample else (hin, win)
         if down:       # Downsample: F.pad(x, (0,1,0,1)) + 3x3 stride-2 conv without padding (ae_modules.py:102-106)
             hl, wl = (hin - 2) // 2 + 1, (win - 2) // 2 + 1
         M = nimg * hl * wl
         N, K = (w[0] if self._wide else w).shape
+        if not banded and not down and a.shape[0] * a.stride(0) * a.element_size() >= self.operand_limit:
+            return self._conv3_banded(a, w, b, nimg, hin, win, cin, upsample, residual, epilogue)
         out = self._gemm(a, w, b, residual, M=M, N=N, K=K, a_mode=DS_A_CONV3, cin=cin, lda=a.stride(0),
                          conv=(nimg, hin, win, hl, wl, 2 if down else 1, upsample, 1 if down else 0), epilogue=epilogue)
         return out, hl, wl
@@ -189,7 +240,7 @@ class AutoencoderKLDecoder(nn.Module):
         a = self._gn(x, P[p + ".norm1.g"], P[p + ".norm1.be"], nimg, H * W, cin, True)
         h1, _, _ = self._conv3(a, P[p + ".conv1.w"], P[p + ".conv1.b"], nimg, H, W, cin)
         a2 = self._gn(h1, P[p + ".norm2.g"], P[p + ".norm2.be"], nimg, H * W, cout, True)
-        skip = x if cin == cout else self._gemm(x, P[p + ".nin.w"], P[p + ".nin.b"], None, M=x.shape[0], N=cout, K=cin)
+        skip = x if cin == cout else self._dense(x, P[p + ".nin.w"], P[p + ".nin.b"], None, x.shape[0], cout, cin)
         out, _, _ = self._conv3(a2, P[p + ".conv2.w"], P[p + ".conv2.b"], nimg, H, W, cout, residual=skip)
         return out
 
@@ -232,8 +283,11 @@ class AutoencoderKLDecoder(nn.Module):
         k = self._gemm(h, P[p + ".k.w"], P[p + ".k.b"], None, M=M, N=C, K=C)
         o = torch.empty((M, C), dtype=act, device=x.device)
         hwp = (hw + 63) // 64 * 64        # the P V contraction runs over the tokens: padded to the GEMM's K granule
-        s = torch.empty((hw, hw), dtype=torch.float32, device=x.device)
-        pr = torch.zeros((hw, hwp), dtype=act, device=x.device)      # pad columns stay 0
+        # queries in blocks: the score rows of a block stay under the operand limit (a 128 x 1024 latent has 131 072 tokens: its
+        # whole score matrix would be 69 GB); a query's row does not depend on the block it is in
+        qb = min(hw, max(64, int(self.operand_limit // (4 * hwp)) // 64 * 64))
+        s = torch.empty((qb, hw), dtype=torch.float32, device=x.device)
+        pr = torch.zeros((qb, hwp), dtype=act, device=x.device)      # pad columns stay 0
         vt = torch.zeros((C, hwp), dtype=act, device=x.device)
 
         def right(t):       # an activation as the right-hand ([N][K]) operand of a launch: itself, or its (hi, lo) planes
@@ -241,10 +295,14 @@ class AutoencoderKLDecoder(nn.Module):
 
         for i in range(nimg):
             rows = slice(i * hw, (i + 1) * hw)
-            self._gemm(q[rows], right(k[rows]), None, None, M=hw, N=hw, K=C, out=s, epilogue=DS_EPI_OUT_F32)   # q k^T
-            ops.softmax_rows(s, int(C) ** (-0.5), out=pr)
+            kr = right(k[rows])
             self._gemm(P[p + ".v.w"], right(h[rows]), None, None, M=C, N=hw, K=C, out=vt)                     # V^T = Wv X^T
-            self._gemm(pr, right(vt), None, None, M=hw, N=C, K=hwp, out=o[rows])                              # P V
+            vr = right(vt)
+            for q0 in range(0, hw, qb):
+                n = min(qb, hw - q0)
+                self._gemm(q[i * hw + q0:i * hw + q0 + n], kr, None, None, M=n, N=hw, K=C, out=s[:n], epilogue=DS_EPI_OUT_F32)   # q k^T
+                ops.softmax_rows(s[:n], int(C) ** (-0.5), out=pr[:n])
+                self._gemm(pr[:n], vr, None, None, M=n, N=C, K=hwp, out=o[i * hw + q0:i * hw + q0 + n])                         # P V
         return self._gemm(o, P[p + ".proj.w"], P[p + ".proj.b"], x, M=M, N=C, K=C)
 
     @torch.no_grad()

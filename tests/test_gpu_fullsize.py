@@ -689,3 +689,29 @@ def test_ring_loop_real_unet_mid_schedule_on_the_headline_window_grid_vs_referen
     # step's pred-x0 leaves the loop: asserted at 1e-3 by the "last six steps" test above); reported, with a regression guard
     assert len(errs) == 4 and all(e < RING50_TOL for k, e in errs.items() if k != "x0"), r
     assert errs["x0"] < 2.3e-3, r          # 1.25 x measured (1.83e-3)
+
+
+def test_vae_decodes_a_cfg5_frame():
+    """N2 at the largest configuration's size: one 128 x 1024 latent frame -> 1024 x 8192 pixels through the real first-stage config.
+    The last level's activations are exactly 2 GiB at 128 fp16 channels (4.3 GB at 256 fp32 ones), the mid-block attention has 131 072
+    tokens: bands / row chunks / query blocks (vae.py operand_limit).  No reference output exists at this size (a 69 GB score
+    matrix on the reference's side); the two operand modes run on independent GEMM, GroupNorm and softmax kernels with different
+    band counts, and must agree to fp16-operand accuracy (measured 1.7e-3; the fp16 decode is 2.6e-3 from the reference at 40 x 64)."""
+    from dynamicscaler_amd.vae import AutoencoderKLDecoder
+    from dynamicscaler_amd.vae_spec import decoder_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict, synth_normal
+    d = torch.device("cuda:0")
+    zf = np.load(os.path.join(G, "vae_full.npz"))
+    dd = json.loads(bytes(zf["full_dd_json"]).decode())
+    m = AutoencoderKLDecoder(dd, 4)
+    m.load_state_dict(synth_state_dict(decoder_param_shapes(dd, 4), seed=22))
+    z = synth_normal((1, 4, 1, 128, 1024), 5).to(d)
+    out = m.decode_frames(z, in_scale=1.0 / 0.18215)
+    assert out.shape == (1, 3, 1, 1024, 8192) and bool(torch.isfinite(out).all())
+    m.operand_mode = "wide"
+    wide = m.decode_frames(z, in_scale=1.0 / 0.18215)
+    e = float((out.double() - wide.double()).norm() / wide.double().norm())
+    print(f"cfg5 frame decode, fp16 vs wide operands: rel-L2 {e:.3e}")
+    assert e < 3.5e-3
+    del out, wide
+    torch.cuda.empty_cache()

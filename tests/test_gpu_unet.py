@@ -1121,6 +1121,38 @@ def test_vae_decode_vs_reference_golden(operands):
     assert out.shape == (1, 3, 320, 512) and e3 < tol
 
 
+@pytest.mark.parametrize("operands", ["f16", "wide"])
+def test_vae_decode_in_bands_is_bit_identical(operands):
+    """An activation operand of 2 GiB or more cannot go through one launch (32-bit buffer addressing): AutoencoderKL then evaluates a
+    3x3 conv image by image and an image in bands of rows with a one-row halo, a 1x1 conv in row chunks, and the mid-block attention
+    in blocks of queries (vae.py operand_limit; a 1024 x 8192 frame at 128 fp16 channels is exactly 2 GiB).  Forced here on the real
+    config at 40 x 64 and on three toy frames by a tiny limit: the decode must not change by a bit, in either operand mode (bands keep
+    an image of >= 2048 pixels on the taps-innermost side of ds_gemm_f16's K-order rule: _conv3_banded)."""
+    from dynamicscaler_amd.vae import AutoencoderKLDecoder
+    from dynamicscaler_amd.vae_spec import decoder_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    d = dev()
+    zf = np.load(os.path.join(G, "vae_full.npz"))
+    ddf = json.loads(bytes(zf["full_dd_json"]).decode())
+    mf = AutoencoderKLDecoder(ddf, 4)
+    mf.operand_mode = operands
+    mf.load_state_dict(synth_state_dict(decoder_param_shapes(ddf, 4), seed=22))
+    zz = T(zf["full_z"]).to(d)
+    ref = mf.decode(zz)
+    for limit in (3_000_000, 1_000_000, 200_000):
+        mf.operand_limit = limit * (2 if operands == "wide" else 1)
+        assert torch.equal(mf.decode(zz), ref), limit
+    z = np.load(os.path.join(G, "vae_tiny.npz"))
+    dd = json.loads(bytes(z["tiny_dd_json"]).decode())
+    m = AutoencoderKLDecoder(dd, 4)
+    m.operand_mode = operands
+    m.load_state_dict(synth_state_dict(decoder_param_shapes(dd, 4), seed=21))
+    zt = T(z["tiny_z"]).to(d)
+    ref = m.decode_frames(zt, in_scale=1.0 / 0.18215)
+    m.operand_limit = 40_000          # several images per chunk, each cut into bands; attention in query blocks of 64
+    assert torch.equal(m.decode_frames(zt, in_scale=1.0 / 0.18215), ref)
+
+
 def test_decode_tail_seam_safe_with_vae():
     """P6: output_type != 'latent' runs the seam-padded per-frame decode (t2v_sphere_panorama_pipeline.py:638-655) through
     the HIP first-stage decoder; checked against the oracle's decoder on the same padded latent."""
