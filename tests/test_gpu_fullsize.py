@@ -715,3 +715,47 @@ def test_vae_decodes_a_cfg5_frame():
     assert e < 3.5e-3
     del out, wide
     torch.cuda.empty_cache()
+
+
+def test_decode_tail_at_cfg3_and_cfg5_sizes():
+    """P6 at full size: the seam-safe decode tail (t2v_sphere_panorama_pipeline.py:638-655: W padded with the wrapped outer 1/16
+    chunks, one decode per frame, the padding cropped) on a cfg3 panorama latent [1, 4, 16, 64, 512] -> [1, 3, 16, 512, 4096] and on
+    one frame of cfg5's [.., 128, 1024] (padded to 1152 columns: 2.4 GB operands, decoded in bands), real first-stage config with
+    synthetic weights.  Checked against a direct decode of the padded frame on wide operands (independent kernels, fp16-operand
+    accuracy) and for the crop's geometry."""
+    import types
+    from dynamicscaler_amd.host_model import LatentDiffusionHost
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    from dynamicscaler_amd.vae_spec import decoder_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict, synth_normal
+    import time
+    d = torch.device("cuda:0")
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    dd = json.loads(bytes(np.load(os.path.join(G, "vae_full.npz"))["full_dd_json"]).decode())
+    ld = LatentDiffusionHost({"params": params}, conditioner=lambda p: None, first_stage_config={"params": {"ddconfig": dd, "embed_dim": 4}},
+                             scale_factor=0.18215)
+    ld.first_stage_model.load_state_dict(synth_state_dict(decoder_param_shapes(dd, 4), seed=22))
+    ld = ld.to(d).eval()
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+    for name, shape, frames in (("cfg3", (1, 4, 16, 64, 512), 16), ("cfg5, one frame", (1, 4, 1, 128, 1024), 1)):
+        lat = (synth_normal(shape, 9) * 0.18215).to(d)
+        st = types.SimpleNamespace(pano=lat, pano_x0=lat, in_device=torch.device("cpu"))
+        torch.cuda.synchronize()
+        t0 = time.time()
+        videos, padded = pipe._finish(st, "tensor", frames, True)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        H, W = shape[3] * 8, shape[4] * 8
+        assert videos.shape == (1, 3, frames, H, W) and padded.shape[-1] == shape[4] * 18 // 16 and bool(torch.isfinite(videos).all())
+        assert torch.equal(padded[..., shape[4] // 16:-(shape[4] // 16)], lat.cpu())
+        ld.first_stage_model.operand_mode = "wide"
+        ref = ld.decode_first_stage_2DAE(padded[:, :, [0]].to(d))
+        ld.first_stage_model.operand_mode = "f16"
+        ref = ref[..., W // 16:-(W // 16)]
+        e = float((videos[:, :, [0]].double() - ref.double()).norm() / ref.double().norm())
+        print(f"decode tail {name}: {frames} frame(s) {H}x{W} in {dt:.2f} s; frame 0 vs the wide-operand decode {e:.3e}")
+        assert e < 3.5e-3
+        del videos, ref, st, lat
+        torch.cuda.empty_cache()
