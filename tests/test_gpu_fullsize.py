@@ -759,3 +759,39 @@ def test_decode_tail_at_cfg3_and_cfg5_sizes():
         assert e < 3.5e-3
         del videos, ref, st, lat
         torch.cuda.empty_cache()
+
+
+def test_tiled_vae_encode_at_cfg4_size():
+    """N2 encode side at full size: tiled_vae_encode_image (i2v_sphere_panorama_pipeline.py:498-562) of a 512 x 4096 panorama image
+    (cfg4's; 4 x 4 tiles with 256-pixel margins) through the real first-stage config -> [1, 4, 1, 64, 512]; fp16 against wide
+    operands (same seeded posterior noise; the encoder's moments are 1.04e-3 / 1.3e-6 from the reference at 320 x 512 in the two
+    modes)."""
+    import time
+    from dynamicscaler_amd.host_model import LatentDiffusionHost
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano
+    from dynamicscaler_amd.vae_spec import vae_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict, synth_normal
+    d = torch.device("cuda:0")
+    zt = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(zt["params_json"]).decode())
+    dd = json.loads(bytes(np.load(os.path.join(G, "vae_enc_full.npz"))["full_dd_json"]).decode())
+    ld = LatentDiffusionHost({"params": params}, conditioner=lambda p: None, first_stage_config={"params": {"ddconfig": dd, "embed_dim": 4}},
+                             scale_factor=0.18215)
+    ld.first_stage_model.load_state_dict(synth_state_dict(vae_param_shapes(dd, 4), seed=24))
+    ld = ld.to(d).eval()
+    pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+    img = synth_normal((3, 512, 4096), 31).clamp(-1, 1)
+    outs = {}
+    for mode in ("f16", "wide"):
+        ld.first_stage_model.operand_mode = mode
+        torch.manual_seed(81)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        outs[mode] = pipe.tiled_vae_encode_image(image_tensor=img)
+        torch.cuda.synchronize()
+        print(f"tiled encode 512x4096 [{mode}]: {time.time() - t0:.2f} s")
+    assert outs["f16"].shape == (1, 4, 1, 64, 512) and bool(torch.isfinite(outs["f16"]).all())
+    e = float((outs["f16"].double() - outs["wide"].double()).norm() / outs["wide"].double().norm())
+    print(f"tiled encode, fp16 vs wide operands: rel-L2 {e:.3e}")
+    assert e < 2.5e-3
