@@ -37,14 +37,21 @@ def view_uv(fov, theta, phi, width, height, W, H, dtype=torch.float32):
 
 
 class ViewMaps:
-    """gather / scatter index maps of one view, host (numpy) and device (int32)."""
+    """gather / scatter index maps of one view, host (numpy) and device (int32).  gather_only: the gather map alone (the i2v loops'
+    crops of the panorama IMAGE: a 512 x 320 view of a 2048 x 1024 image -- the scatter side's winner resolution and footprints
+    walk arrays of the panorama's size and cost 80 ms per view there, 3.5 s per step of gen_pano_360's 44 views)."""
 
-    def __init__(self, fov, theta, phi, width, height, W, H, device):
+    def __init__(self, fov, theta, phi, width, height, W, H, device, gather_only=False):
         u, v = view_uv(fov, theta, phi, width, height, W, H)
         fu, fv = torch.floor(u).long(), torch.floor(v).long()
         g = (torch.clamp(fv, 0, H - 1) * W + fu % W)
         gvalid = (u >= 0) & (u < W) & (v >= 0) & (v < H)                       # :197-200
         g = torch.where(gvalid, g, torch.full_like(g, -1)).view(-1)
+        if gather_only:
+            self.gather_np = g.numpy().astype(np.int32)
+            self.gather = torch.from_numpy(self.gather_np).to(device)
+            self.gather_valid_mask = gvalid.to(torch.float32)
+            return
         s = fv * W + fu
         svalid = ((fu >= 0) & (fu < W) & (fv >= 0) & (fv < H)).view(-1)        # :166
         s = s.view(-1).numpy()
@@ -203,16 +210,56 @@ def _downsample_outputs(final_latents, denoised, factor):
 
 
 class ViewMapCache:
+    """ViewMaps per (fov, theta, phi, view size, panorama size).  prefetch(): the maps of the NEXT step's views are computed on a
+    worker thread while the GPU runs the current step (the theta offsets walk deterministically, so the keys are known): gen_pano_360's
+    44 views cost 1.6 s of host time per step otherwise -- as much as the step's UNet evaluations -- for the first loop_step_theta
+    steps.  The worker only computes host tensors (its uploads would queue behind the step's kernels on the stream); get() uploads."""
+
     def __init__(self, device):
         self.device = device
         self._maps = {}
+        self._host = {}            # prefetched on the host, not uploaded yet
+        self._pool, self._pending = None, None
 
-    def get(self, fov, theta, phi, width, height, W, H):
+    def get(self, fov, theta, phi, width, height, W, H, gather_only=False):
         key = (fov, theta, phi, width, height, W, H)
         m = self._maps.get(key)
-        if m is None:
-            m = self._maps[key] = ViewMaps(fov, theta, phi, width, height, W, H, self.device)
+        if m is None or (not gather_only and not hasattr(m, "scatter")):
+            m = self._host.pop(key, None)
+            if m is not None and (gather_only or hasattr(m, "scatter")):
+                m.gather = m.gather.to(self.device)
+                if hasattr(m, "scatter"):
+                    m.scatter = m.scatter.to(self.device)
+                self._maps[key] = m
+            else:
+                m = self._maps[key] = ViewMaps(fov, theta, phi, width, height, W, H, self.device, gather_only=gather_only)
         return m
+
+    def prefetch(self, requests):
+        """requests: [(fov, theta, phi, width, height, W, H, gather_only)] -- computed on the worker thread, picked up by get() after
+        wait().  Same op sequence on the same host: the maps are those get() would have built."""
+        todo = [r for r in requests if r[:7] not in self._maps and r[:7] not in self._host]
+        if not todo:
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(1)
+
+        def work():
+            for (fov, theta, phi, width, height, W, H, gather_only) in todo:
+                self._host[(fov, theta, phi, width, height, W, H)] = ViewMaps(fov, theta, phi, width, height, W, H, "cpu", gather_only=gather_only)
+        self._pending = self._pool.submit(work)
+
+    def wait(self):
+        if self._pending is not None:
+            self._pending.result()
+            self._pending = None
+
+    def close(self):
+        self.wait()
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
 
 
 class PanoramaLatentProxy:
@@ -571,9 +618,26 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                 r = conflict_cache[(ka, kb)] = bool((wa & (rb | wb)).any() or (ra & wb).any())
             return r
 
+        def step_views(i):
+            off = (i % loop_step_theta) * (view_fov // loop_step_theta)
+            return [(ph, th + off) for ph in list(phi_theta_dict.keys()) for th in phi_theta_dict[ph]]
+
+        def prefetch_maps(i):
+            """the index maps step i needs (latent views at the tile / get / set sizes, image crops), on the worker thread"""
+            lat, img = [], []
+            for (ph, th) in step_views(i):
+                for g in sorted({1, gsf, ssf}):
+                    lat.append((view_fov, th, ph, lat_w * g, lat_h * g, W, H, False))
+                if (ph, th) not in emb_cache:
+                    img.append((view_fov, th, ph, width, height, Wimg, Himg, True))
+            cache.prefetch(lat)
+            img_cache.prefetch(img)
+
         for i in range(len(timesteps)):
             t = timesteps[i]
             theta_offset = (i % loop_step_theta) * (view_fov // loop_step_theta)
+            cache.wait()
+            img_cache.wait()
             mask.zero_()                                           # reset mask record (:242)
             live = i < total_steps - 1
             temp = None
@@ -594,13 +658,15 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                                 prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(device)
                             cur_text = prompt_cache[cur]
                         if (cphi, cth) not in emb_cache:           # the same view recurs every loop_step_theta steps
-                            im = img_cache.get(view_fov, cth, cphi, width, height, Wimg, Himg)
+                            im = img_cache.get(view_fov, cth, cphi, width, height, Wimg, Himg, gather_only=True)
                             crop = ops.map_gather(image5, im.gather[None]).reshape(1, 3, height, width)
                             emb_cache[(cphi, cth)] = self.pretrained_t2v.get_image_embeds(
                                 batch_imgs=crop.to(self.pretrained_t2v.device)).to(device)
                         ctxs.append(torch.cat([cur_text, emb_cache[(cphi, cth)].to(cur_text.dtype)], dim=1))
             maps = [cache.get(view_fov, th, ph, lat_w, lat_h, W, H) for (_, _, ph, th) in items]
             lat_maps = [lat_map(ph, th) for (_, _, ph, th) in items]
+            if i + 1 < len(timesteps):
+                prefetch_maps(i + 1)                               # host work of the next step, under this step's evaluations
             renoise = st.ratio is not None and live
             merge_prev = merge_prev_denoised_ratio_list[i] if (merge_prev_denoised_ratio_list is not None and live) else None
             if merge_prev is not None and ssf != 1:                # the reference mixes the scaled x_prev with the unscaled view (:430-436)
@@ -620,16 +686,31 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
             if renoise:
                 c_rn, s_rn = sched.renoise_coefficients(total_steps - i - 2, total_steps - i - 1)
             fsets = [frozenset(f % total_f for f in range(fb, fe)) for (fb, fe, _, _) in items]
+            tb = max(1, min(self.max_tile_batch, self.wide_tile_batch)) if self._step_precision == "wide" else self.max_tile_batch
+            # the step's batches, and the first frames of all of them in ONE upload (a host -> device copy per batch is ordered behind
+            # the kernels already queued: it would stop the host from running ahead of the GPU 30 times a step)
+            plan, flat = [], []
             for level in plan_levels_items(fsets, [(ph, th) for (_, _, ph, th) in items], pix_conflict):
                 mine = parallel.rank_share(level, st.rank, st.world)
+                batches = [mine[s0:s0 + tb] for s0 in range(0, len(mine), tb)]
+                order = level if st.world > 1 else mine
+                plan.append((level, batches, order))
+                for grp in batches + [order]:
+                    flat += [items[j][0] for j in grp]
+            f0_all = torch.tensor(flat, dtype=torch.int32, device=device) if flat else None
+            f0_pos = [0]
+
+            def first_frames(n):
+                f0_pos[0] += n
+                return f0_all[f0_pos[0] - n:f0_pos[0]]
+
+            for level, batches, order in plan:
                 xp_parts, x0_parts = [], []
-                tb = max(1, min(self.max_tile_batch, self.wide_tile_batch)) if self._step_precision == "wide" else self.max_tile_batch
-                for s0 in range(0, len(mine), tb):
-                    ids = mine[s0:s0 + tb]
+                for ids in batches:
                     n = len(ids)
                     g_idx = torch.stack([maps[j].gather for j in ids])
                     l_idx = g_idx if gsf == 1 else torch.stack([lat_maps[j].gather for j in ids])
-                    f0 = torch.tensor([items[j][0] for j in ids], dtype=torch.int32, device=device)
+                    f0 = first_frames(n)
                     tiles = ops.map_gather_frames(st.pano, l_idx, f0, frames).reshape((n,) + st.tile_shape[1:])
                     prev = tiles.clone() if merge_prev is not None else None
                     mt = ops.map_gather_frames(mask, g_idx, f0, frames).reshape(n, frames, lat_h, lat_w)
@@ -657,11 +738,10 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                     empty = torch.empty((0,) + st.tile_shape[1:], dtype=st.pano.dtype, device=device)
                     xp_all, x0_all = parallel.exchange_level(torch.cat(xp_parts, 0) if xp_parts else empty,
                                                              torch.cat(x0_parts, 0) if x0_parts else empty, len(level))
-                    order = level
                 else:
-                    xp_all, x0_all, order = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0), mine
+                    xp_all, x0_all = torch.cat(xp_parts, 0), torch.cat(x0_parts, 0)
                 sc = [set_map(items[j][2], items[j][3]) for j in order]
-                f0 = torch.tensor([items[j][0] for j in order], dtype=torch.int32, device=device)
+                f0 = first_frames(len(order))
                 xp_all, x0_all = xp_all.contiguous(), x0_all.contiguous()
                 for k in range(ssf * ssf):
                     s_idx = torch.stack([m.subs[k] for m in sc])
@@ -672,6 +752,8 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                 st.pano = temp
             if step_callback is not None:
                 step_callback(i, int(t), items, st.pano, st.pano_x0)
+        cache.close()
+        img_cache.close()
         final_latents, denoised = _downsample_outputs(st.pano.clone(), st.pano_x0.clone(), downsample_factor_before_vae_decode)
         if output_type == "latent":
             return final_latents, denoised
