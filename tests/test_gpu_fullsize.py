@@ -795,3 +795,63 @@ def test_tiled_vae_encode_at_cfg4_size():
     e = float((outs["f16"].double() - outs["wide"].double()).norm() / outs["wide"].double().norm())
     print(f"tiled encode, fp16 vs wide operands: rel-L2 {e:.3e}")
     assert e < 2.5e-3
+
+
+def test_i2v_end_to_end_at_cfg4_size_image_to_frames():
+    """Everything between a panorama image and decoded frames at config 4's size, in one call: the tiled first-stage encode of the
+    4096 x 512 image (use_skip_time without an init latent, i2v_sphere_panorama_pipeline.py:704-722), its re-noising to the resumed
+    schedule position, two ring-loop steps of the real i2v UNet over the 8 x 2 shifted windows with per-window image tokens
+    (:777-970), and the decode of the 16 frames (:972-996) -- real first-stage and UNet configs, synthetic weights.  A run-through at
+    size (none of these pieces had met at this size): shapes, finiteness, that the loop moved the latent, and that a second call
+    with the same seed repeats bit for bit."""
+    import time
+    import yaml
+    from helpers import synth_image_embedder
+    from dynamicscaler_amd.host_model import LatentDiffusionHost, SyntheticConditioner
+    from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.vae import AutoencoderKL
+    from dynamicscaler_amd.vae_spec import vae_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict, synth_normal
+    d = dev()
+    if "i2v" not in _HOST:
+        params = yaml.safe_load(open(os.path.join(REPO, "dynamicscaler_amd", "configs", "i2v_512_v1_unet.yaml")))
+        ld = LatentDiffusionHost({"params": params}, conditioner=SyntheticConditioner(77, params["context_dim"], cond_seed=11, uncond_seed=12))
+        ld.model.diffusion_model.load_state_dict(synth_state_dict(param_shapes(params), 3), strict=True)
+        ld.get_image_embeds = synth_image_embedder(params["context_dim"])
+        ld.embedder = object()
+        ld = ld.to(d)
+        _HOST["i2v"] = (ld, params)
+    ld, params = _HOST["i2v"]
+    dd = json.loads(bytes(np.load(os.path.join(G, "vae_enc_full.npz"))["full_dd_json"]).decode())
+    vae = AutoencoderKL(dd, 4)
+    vae.load_state_dict(synth_state_dict(vae_param_shapes(dd, 4), seed=24))
+    ld.first_stage_model, ld.scale_factor = vae, 0.18215
+    geom = dict(height=320, width=512, frames=16, total_w=4096, total_h=512, num_windows_w=8, num_windows_h=2, num_windows_f=1, loop_step=8,
+                num_inference_steps=4, overlap_ratio_list_f=[0.0] * 4)
+    img = synth_normal((3, 512, 4096), 77).clamp(-1, 1)
+    outs = []
+    try:
+        for rep in range(2):
+            pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="reference"),
+                                               {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+            steps = []
+            torch.manual_seed(2333333)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            videos, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="tensor",
+                                                                pano_image_tensor=img, use_skip_time=True, skip_time_step_idx=2,
+                                                                step_callback=lambda i, t, w, p, p0: steps.append((i, int(t), len(w))), **geom)
+            torch.cuda.synchronize()
+            print(f"i2v image -> frames at cfg4's size, run {rep}: {time.time() - t0:.1f} s, steps {steps}")
+            assert [s[2] for s in steps] == [16, 16] and [s[1] for s in steps] == [333, 0]
+            # (the second return value is the W-PADDED latent in the seam-safe decode branch, like the reference's: 512 + 2 x 32 columns)
+            assert videos.shape == (1, 3, 16, 512, 4096) and den.shape == (1, 4, 16, 64, 576)
+            assert bool(torch.isfinite(videos).all()) and bool(torch.isfinite(den).all())
+            outs.append((videos.cpu(), den.cpu()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert float(outs[0][1].std()) > 0.05
+    finally:
+        ld.first_stage_model = None
+        ld.scale_factor = 1.0
