@@ -855,3 +855,77 @@ def test_i2v_end_to_end_at_cfg4_size_image_to_frames():
     finally:
         ld.first_stage_model = None
         ld.scale_factor = 1.0
+
+
+def test_grid_loop_with_pre_denoise_at_full_size():
+    """P4 at full size: VC2_Pipeline_T2V.basic_sample_shift_multi_windows (pipeline/t2v_normal_pipeline.py:213-568) on an 8 x 2 grid of
+    512 x 320 x 16f tiles (4096 x 640) with the real t2v UNet: a pre-denoised tile (2 steps) resized bicubically to the panorama and
+    re-noised (:345-412), then the shifted-grid steps with the per-step sparse residual merge (:445-468), 4-step schedule.  A
+    run-through at size (shapes, finiteness, the windows of every step, bit-repeatable); parity of each piece is pinned at the toy
+    size against the reference (tests/test_gpu_unet.py)."""
+    import time
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    d = dev()
+    ld, params, _ = full_host(d)
+    ld = ld.to(d)
+    kw = dict(num_windows_w=8, num_windows_h=2, num_windows_f=1, loop_step=4, num_inference_steps=4, use_pre_denoise=True, pre_denoise_steps=2,
+              merge_predenoise_ratio_list=[0.5, 0.6, 0.7, 0.8], sparse_add_residual=True)
+    outs = []
+    for rep in range(2):
+        pipe = VC2_Pipeline_T2V(ld, lvdm_DDIM_Scheduler(ld, rng_mode="reference"), {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+        trace = []
+        torch.manual_seed(2333333)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=320, width=512, frames=16, fps=8, guidance_scale=7.5,
+                                                       output_type="latent", step_callback=lambda i, t, w, p, p0: trace.append((i, int(t), len(w))),
+                                                       **kw)
+        torch.cuda.synchronize()
+        print(f"grid loop 4096x640x16f with pre-denoise, run {rep}: {time.time() - t0:.1f} s, steps {trace}")
+        assert den.shape == (1, 4, 16, 80, 512) and bool(torch.isfinite(den).all())
+        assert len(trace) >= 2 and all(n == 16 for _, _, n in trace)
+        outs.append(den.cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_t2v_end_to_end_at_cfg5_size_latent_to_frames():
+    """Config 5 through to pixels: two ring-loop steps of the real t2v UNet at T = 24 over the 16 x 4 shifted windows of an
+    8192 x 1024 x 24f panorama (64 tiles per step) and the seam-safe decode of the 24 frames -- each a 1024 x 9216 padded image whose
+    last decoder level is 2.4 GB per operand, i.e. decoded in bands (vae.py operand_limit).  A run-through at size: shapes,
+    finiteness, timing."""
+    import time
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.vae import AutoencoderKL
+    from dynamicscaler_amd.vae_spec import decoder_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict
+    d = dev()
+    ld, params, _ = full_host(d)
+    ld = ld.to(d)
+    dd = json.loads(bytes(np.load(os.path.join(G, "vae_full.npz"))["full_dd_json"]).decode())
+    vae = AutoencoderKL(dd, 4)
+    vae.load_state_dict(synth_state_dict(decoder_param_shapes(dd, 4), seed=22))
+    old = (ld.first_stage_model, ld.scale_factor, ld.temporal_length)
+    ld.first_stage_model, ld.scale_factor = vae.to(d), 0.18215
+    geom = dict(height=320, width=512, frames=24, total_w=8192, total_h=1024, num_windows_w=16, num_windows_h=4, num_windows_f=1, loop_step=8,
+                num_inference_steps=2)
+    try:
+        pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="device"), {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+        steps = []
+        torch.manual_seed(2333333)
+        torch.cuda.synchronize()
+        t0 = time.time()
+
+        def cb(i, t, w, p, p0):
+            torch.cuda.synchronize()
+            steps.append((i, int(t), len(w), round(time.time() - t0, 1)))
+        videos, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="tensor", step_callback=cb, **geom)
+        torch.cuda.synchronize()
+        print(f"t2v cfg5 latent -> frames: {time.time() - t0:.1f} s in all, steps (i, t, windows, s since start) {steps}")
+        assert [s[2] for s in steps] == [64, 64]
+        assert videos.shape == (1, 3, 24, 1024, 8192) and den.shape == (1, 4, 24, 128, 1152)
+        assert bool(torch.isfinite(videos).all()) and bool(torch.isfinite(den).all())
+    finally:
+        ld.first_stage_model, ld.scale_factor, ld.temporal_length = old
+        torch.cuda.empty_cache()
