@@ -219,7 +219,7 @@ class ViewMapCache:
         self.device = device
         self._maps = {}
         self._host = {}            # prefetched on the host, not uploaded yet
-        self._pool, self._pending = None, None
+        self._pending, self._error = None, None
 
     def get(self, fov, theta, phi, width, height, W, H, gather_only=False):
         key = (fov, theta, phi, width, height, W, H)
@@ -241,25 +241,26 @@ class ViewMapCache:
         todo = [r for r in requests if r[:7] not in self._maps and r[:7] not in self._host]
         if not todo:
             return
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(1)
+        import threading
+        self.wait()
 
         def work():
-            for (fov, theta, phi, width, height, W, H, gather_only) in todo:
-                self._host[(fov, theta, phi, width, height, W, H)] = ViewMaps(fov, theta, phi, width, height, W, H, "cpu", gather_only=gather_only)
-        self._pending = self._pool.submit(work)
+            try:
+                for (fov, theta, phi, width, height, W, H, gather_only) in todo:
+                    self._host[(fov, theta, phi, width, height, W, H)] = ViewMaps(fov, theta, phi, width, height, W, H, "cpu",
+                                                                                  gather_only=gather_only)
+            except BaseException as e:      # noqa: BLE001 -- handed to the thread that waits
+                self._error = e
+        self._pending = threading.Thread(target=work, name="ds-view-maps", daemon=True)
+        self._pending.start()
 
     def wait(self):
         if self._pending is not None:
-            self._pending.result()
+            self._pending.join()
             self._pending = None
-
-    def close(self):
-        self.wait()
-        if self._pool is not None:
-            self._pool.shutdown()
-            self._pool = None
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise e
 
 
 class PanoramaLatentProxy:
@@ -752,8 +753,8 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                 st.pano = temp
             if step_callback is not None:
                 step_callback(i, int(t), items, st.pano, st.pano_x0)
-        cache.close()
-        img_cache.close()
+        cache.wait()
+        img_cache.wait()
         final_latents, denoised = _downsample_outputs(st.pano.clone(), st.pano_x0.clone(), downsample_factor_before_vae_decode)
         if output_type == "latent":
             return final_latents, denoised

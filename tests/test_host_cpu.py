@@ -862,3 +862,28 @@ def test_upsampled_scatter_maps_equal_the_scatter_of_the_scaled_view():
         assert int(hit.max()) == 1                                   # disjoint targets: the sub-scatters commute
         assert torch.equal(got.view(pano.shape), ref)
         assert torch.equal(torch.from_numpy(m.write_set), hit.bool())
+
+
+def test_view_map_prefetch_equals_direct_build():
+    """ViewMapCache.prefetch (the next sphere step's index maps on a worker thread, host tensors only) hands get() the maps a direct
+    build gives; gather-only maps carry no scatter side and are rebuilt in full when a caller needs it; a worker error surfaces in wait()."""
+    import torch
+    from dynamicscaler_amd.sphere import ViewMapCache, ViewMaps
+    reqs = [(120, 30 * k, ph, 16, 8, 64, 32, False) for k in range(4) for ph in (60, 0, -45)] + [(120, 12, 0, 64, 40, 256, 128, True)]
+    c = ViewMapCache("cpu")
+    c.prefetch(reqs)
+    c.wait()
+    assert len(c._host) == len(reqs) and not c._maps
+    for (fov, th, ph, w, h, W, H, go) in reqs:
+        m = c.get(fov, th, ph, w, h, W, H, gather_only=go)
+        ref = ViewMaps(fov, th, ph, w, h, W, H, "cpu", gather_only=go)
+        assert torch.equal(m.gather, ref.gather) and hasattr(m, "scatter") == (not go)
+        if not go:
+            assert torch.equal(m.scatter, ref.scatter) and (m.write_set == ref.write_set).all() and (m.read_set == ref.read_set).all()
+    assert not c._host
+    full = c.get(120, 12, 0, 64, 40, 256, 128)                   # the gather-only entry is replaced by a full one on demand
+    assert hasattr(full, "scatter") and torch.equal(full.gather, ViewMaps(120, 12, 0, 64, 40, 256, 128, "cpu").gather)
+    c.prefetch([(120, 0, 0, 16, 8, 64, 33, False), ("wide", 0, 0, 16, 8, 64, 32, False)])     # not an angle: the worker's error
+    with pytest.raises((TypeError, ValueError)):
+        c.wait()
+    c.wait()                                                     # ... is raised once
