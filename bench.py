@@ -628,6 +628,46 @@ def main():
                                    "result_sha256": _hl.sha256(so.pano.float().cpu().numpy().tobytes()).hexdigest()[:16]}
             del pp, so, begin_o
             torch.cuda.empty_cache()
+        # what gen_pano_360.py runs FIRST is not a ring loop but the i2v sphere loop (gen_pano_360.py:227-260, 400-478): 44 perspective
+        # views of 512 x 320 x 16f per step on a 2048 x 1024 equirect (fov 120, theta offset walking over 10 steps), per-view image tokens,
+        # paste_on_static, merge-prev, the 48-step schedule.  1 warm-up + 2 timed steps, device-synchronised after every step.
+        phase[0] = "other configuration sphere_stage1"
+        try:
+            from dynamicscaler_amd.sphere import VC2_Pipeline_I2V_SpherePano as SpherePipe
+            t_setup = time.perf_counter()
+            ld_s, params_s, _ = host_for("i2v")
+            sp = SpherePipe(ld_s, lvdm_DDIM_Scheduler(ld_s, rng_mode="device"), {"params": {"unet_config": {"params": params_s}}})
+            sp.to(dev, lat_dt)
+            sp.max_tile_batch, sp.use_graph = args.tile_batch, bool(args.graph)
+            ring_ = [360 * t // 6 for t in range(6)]
+            stamps = []
+
+            def sphere_cb(i, t, views, p, p0):
+                torch.cuda.synchronize()
+                stamps.append((time.perf_counter(), len(views)))
+            t_s0 = time.perf_counter()
+            fin_s, _den_s = sp.basic_sample_shift_shpere_panorama(
+                prompt="a synthetic prompt", fps=8, guidance_scale=7.5, output_type="latent", height=320, width=512, frames=16, total_f=16,
+                equirect_width=2048, equirect_height=1024, view_fov=120, loop_step_theta=10, num_inference_steps=48, denoise_to_step=3,
+                phi_theta_dict={90: [0], -90: [0], 75: ring_, -75: ring_, 60: ring_, -60: ring_, 45: ring_, -45: ring_, 0: ring_},
+                merge_renoised_overlap_latent_ratio=1, overlap_ratio_list_f=[0.75] * 24 + [0.5] * 24, loop_step_frame=8, paste_on_static=True,
+                merge_prev_denoised_ratio_list=[0.5 * (1 - t / 10) for t in range(10)] + [0] * 38,
+                init_sphere_latent=synth_normal((1, 4, 16, 128, 256), 2333333), pano_image_tensor=synth_normal((3, 1024, 2048), 77).clamp(-1, 1),
+                static_frame_latent=synth_normal((1, 4, 1, 128, 256), 78), step_callback=sphere_cb)
+            t_timed = stamps[2][0] - stamps[0][0]
+            assert bool(torch.isfinite(fin_s.float()).all()), "sphere_stage1"
+            other_configs["sphere_stage1"] = {
+                "workload": "gen_pano_360.py stage 1: i2v sphere loop, 2048x1024 equirect, 44 views of 512x320x16f per step (fov 120), per-view "
+                            "image tokens, paste_on_static, merge-prev, CFG 7.5, 48-step schedule",
+                "ms_per_step": round(1e3 * t_timed / 2, 2), "value": round(2 / t_timed, 4), "unit": "denoising-steps/sec", "steps": 2, "warmup": 1,
+                "views_per_step": stamps[0][1], "unet_evals_per_step": 2 * stamps[0][1], "first_step_ms": round(1e3 * (stamps[0][0] - t_s0), 1),
+                "residual_mode": timed_mode, "setup_s": round(t_s0 - t_setup, 1),
+                "note": "the views of a step overlap: 31 dependency levels of 1-2 views, so an evaluation runs at the small-batch rate",
+                "result_sha256": _hl.sha256(fin_s.float().cpu().numpy().tobytes()).hexdigest()[:16]}
+            del sp, fin_s, _den_s
+            torch.cuda.empty_cache()
+        except Exception as e:      # noqa: BLE001 -- a diagnostic entry must not cost the headline line
+            other_configs["sphere_stage1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- CPU baseline: the oracle on this host, bounded sample ----
     cpu_baseline = None

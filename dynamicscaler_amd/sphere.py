@@ -656,6 +656,14 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                 cur_static = static if static is not None else encode_static().to(device=device, dtype=st.pano.dtype)
                 temp = sched.re_noise(cur_static.expand(1, shape[1], total_f, H, W).contiguous(), 0, total_steps - i - 1)
             items, ctxs = [], []
+            # the crops of this step's views that are not embedded yet (a view recurs every loop_step_theta steps), through the image
+            # tower in ONE pass (the reference embeds view by view, :356-366; the towers' kernels give a row the same bits in any batch)
+            new = [k for k in dict.fromkeys(step_views(i)) if k not in emb_cache]
+            if new:
+                idx = torch.stack([img_cache.get(view_fov, th, ph, width, height, Wimg, Himg, gather_only=True).gather for (ph, th) in new])
+                crops = ops.map_gather(image5, idx).reshape(len(new), 3, height, width)
+                embs = self.pretrained_t2v.get_image_embeds(batch_imgs=crops.to(self.pretrained_t2v.device)).to(device)
+                emb_cache.update({k: embs[j:j + 1] for j, k in enumerate(new)})
             for (fb, fe) in i2v_frame_windows(i, frames=frames, total_f=total_f, overlap_ratio_f=overlap_ratio_list_f[i],
                                               loop_step_frame=loop_step_frame, dock_at_f=dock_at_f):
                 for phi_angle in list(phi_theta_dict.keys()):
@@ -668,11 +676,6 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                             if cur not in prompt_cache:
                                 prompt_cache[cur] = self.pretrained_t2v.get_learned_conditioning([cur]).to(device)
                             cur_text = prompt_cache[cur]
-                        if (cphi, cth) not in emb_cache:           # the same view recurs every loop_step_theta steps
-                            im = img_cache.get(view_fov, cth, cphi, width, height, Wimg, Himg, gather_only=True)
-                            crop = ops.map_gather(image5, im.gather[None]).reshape(1, 3, height, width)
-                            emb_cache[(cphi, cth)] = self.pretrained_t2v.get_image_embeds(
-                                batch_imgs=crop.to(self.pretrained_t2v.device)).to(device)
                         ctxs.append(torch.cat([cur_text, emb_cache[(cphi, cth)].to(cur_text.dtype)], dim=1))
             maps = [cache.get(view_fov, th, ph, lat_w, lat_h, W, H) for (_, _, ph, th) in items]
             lat_maps = [lat_map(ph, th) for (_, _, ph, th) in items]
