@@ -1383,12 +1383,19 @@ def test_gen_pano_360_stage_chain_runs():
         overlap_ratio_list_f=[0.0] * N, loop_step_frame=2, equirect_width=512, equirect_height=256, view_fov=120,
         loop_step_theta=2, phi_theta_dict={0: [0, 120, 240], -60: [0, 180], 60: [0, 180]}, merge_renoised_overlap_latent_ratio=1,
         merge_prev_denoised_ratio_list=[0.3] * N, denoise_to_step=stop, paste_on_static=True, num_inference_steps=N,
-        output_type="latent")
+        output_type="latent",
+        # ... and the rest of what gen_pano_360.py:227-268 passes by name, values as there (several are swallowed by **kwargs in the
+        # reference too and travel on to the UNet call, which ignores them)
+        img_cond_path=["unused.png"], init_panorama_latent=None, use_skip_time=False, skip_time_step_idx=0, progressive_skip=False,
+        loop_step=4, pano_image_path=None, dock_at_f=None, phi_prompt_dict=None, view_get_scale_factor=1, view_set_scale_factor=1,
+        downsample_factor_before_vae_decode=1, latents=None, num_videos_per_prompt=1, generator_seed=1)
     assert sphere_lat.shape == (1, 4, 4, 32, 64) and bool(torch.isfinite(sphere_lat.float()).all())
     lat1 = resize_video_latent(sphere_lat.clone(), target_height=32, target_width=64, mode="nearest")
     ring_args = dict(prompt="a prompt", height=64, width=128, frames=4, fps=8, guidance_scale=7.5, num_windows_f=1, loop_step=4,
                      total_f=4, overlap_ratio_list_f=[0.0] * N, loop_step_frame=2, merge_prev_denoised_ratio_list=[0.3] * N,
-                     num_inference_steps=N, use_skip_time=True, skip_time_step_idx=stop, progressive_skip=False)
+                     num_inference_steps=N, use_skip_time=True, skip_time_step_idx=stop, progressive_skip=False,
+                     # gen_pano_360.py:291-322 / 355-384 also pass:
+                     img_cond_path=["unused.png"], pano_image_path=None, dock_at_f=None, latents=None, num_videos_per_prompt=1, generator_seed=1)
     _, lat2 = pipe.basic_sample_shift_multi_windows(init_panorama_latent=lat1, total_h=256, total_w=512, num_windows_h=2 + 3,
                                                     num_windows_w=5, pano_image_tensor=pano_img, output_type="latent", **ring_args)
     assert lat2.shape == lat1.shape and bool(torch.isfinite(lat2.float()).all())
