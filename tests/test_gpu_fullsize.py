@@ -929,3 +929,84 @@ def test_t2v_end_to_end_at_cfg5_size_latent_to_frames():
     finally:
         ld.first_stage_model, ld.scale_factor, ld.temporal_length = old
         torch.cuda.empty_cache()
+
+
+def test_gen_pano_360_stage_chain_at_full_size():
+    """gen_pano_360.py's three stages (main(): 227-384) at its own sizes, real i2v UNet + real first-stage configs, synthetic weights and
+    panorama image, a 4-step schedule cut to two steps per stage: (1) the i2v sphere loop on the 2048 x 1024 equirect -- 44 views a step,
+    paste_on_static with the tiled VAE encode of the panorama image at every step, merge-prev, denoise_to_step; (2) nearest resize to
+    1024 x 512 and the i2v ring loop resumed with use_skip_time (2 x 2 windows); (3) bicubic x2, re_noise, the ring loop at 2048 x 1024
+    (4 x 4 windows) and the seam-safe decode of its 16 frames.  A run-through of the hand-offs at size (shapes, finiteness, timing);
+    fp16 operands throughout (the operand policy would run a 4-step schedule's first steps wide: config 1's tests cover that)."""
+    import time
+    import yaml
+    from helpers import synth_image_embedder
+    from dynamicscaler_amd.host_model import LatentDiffusionHost, SyntheticConditioner
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.sphere import VC2_Pipeline_I2V_SpherePano
+    from dynamicscaler_amd.tensor_utils import resize_video_latent
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.vae import AutoencoderKL
+    from dynamicscaler_amd.vae_spec import vae_param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict, synth_normal
+    d = dev()
+    if "i2v" not in _HOST:
+        params = yaml.safe_load(open(os.path.join(REPO, "dynamicscaler_amd", "configs", "i2v_512_v1_unet.yaml")))
+        ld = LatentDiffusionHost({"params": params}, conditioner=SyntheticConditioner(77, params["context_dim"], cond_seed=11, uncond_seed=12))
+        ld.model.diffusion_model.load_state_dict(synth_state_dict(param_shapes(params), 3), strict=True)
+        ld.get_image_embeds = synth_image_embedder(params["context_dim"])
+        ld.embedder = object()
+        ld = ld.to(d)
+        _HOST["i2v"] = (ld, params)
+    ld, params = _HOST["i2v"]
+    dd = json.loads(bytes(np.load(os.path.join(G, "vae_enc_full.npz"))["full_dd_json"]).decode())
+    vae = AutoencoderKL(dd, 4)
+    vae.load_state_dict(synth_state_dict(vae_param_shapes(dd, 4), seed=24))
+    ld.first_stage_model, ld.scale_factor = vae.to(d), 0.18215
+    N, stop = 4, 2
+    ring6 = [360 * t // 6 for t in range(6)]
+    try:
+        pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="device"), {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+        pipe.operand_policy = "f16"
+        pipe.use_graph = True
+        img1 = synth_normal((3, 1024, 2048), 89).clamp(-1, 1)
+        t0 = time.time()
+        sphere_lat, _ = pipe.basic_sample_shift_shpere_panorama(
+            prompt="a prompt", img_cond_path=["unused.png"], height=320, width=512, frames=16, fps=8, guidance_scale=7.5, init_panorama_latent=None,
+            use_skip_time=False, skip_time_step_idx=0, progressive_skip=False, loop_step=8, pano_image_path=None, pano_image_tensor=img1,
+            total_f=16, dock_at_f=False, overlap_ratio_list_f=[0.75, 0.75, 0.5, 0.5], loop_step_frame=8, equirect_width=2048, equirect_height=1024,
+            phi_theta_dict={90: [0], -90: [0], 75: ring6, -75: ring6, 60: ring6, -60: ring6, 45: ring6, -45: ring6, 0: ring6},
+            phi_prompt_dict=None, view_fov=120, loop_step_theta=10, merge_renoised_overlap_latent_ratio=1, paste_on_static=True,
+            view_get_scale_factor=1, view_set_scale_factor=1, denoise_to_step=stop, merge_prev_denoised_ratio_list=[0.5, 0.25, 0, 0],
+            downsample_factor_before_vae_decode=1, latents=None, num_inference_steps=N, num_videos_per_prompt=1, generator_seed=1,
+            output_type="latent")
+        torch.cuda.synchronize()
+        t1 = time.time()
+        assert sphere_lat.shape == (1, 4, 16, 128, 256) and bool(torch.isfinite(sphere_lat.float()).all())
+        lat1 = resize_video_latent(sphere_lat.clone(), target_height=64, target_width=128, mode="nearest")
+        ring_args = dict(prompt="a prompt", img_cond_path=["unused.png"], height=320, width=512, frames=16, fps=8, guidance_scale=7.5,
+                         use_skip_time=True, skip_time_step_idx=stop, progressive_skip=False, num_windows_f=1, loop_step=8, pano_image_path=None,
+                         total_f=16, dock_at_f=False, loop_step_frame=8, merge_prev_denoised_ratio_list=[0.5, 0.25, 0, 0], latents=None,
+                         num_inference_steps=N, num_videos_per_prompt=1, generator_seed=1)
+        img2 = synth_normal((3, 512, 1024), 90).clamp(-1, 1)
+        _, lat2 = pipe.basic_sample_shift_multi_windows(init_panorama_latent=lat1, total_h=512, total_w=1024, num_windows_h=2, num_windows_w=2,
+                                                        overlap_ratio_list_f=[0.75, 0.75, 0.5, 0.5], pano_image_tensor=img2, output_type="latent",
+                                                        **ring_args)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        assert lat2.shape == (1, 4, 16, 64, 128) and bool(torch.isfinite(lat2.float()).all())
+        up = resize_video_latent(lat2.clone(), target_height=128, target_width=256, mode="bicubic")
+        pipe.scheduler.make_schedule(N)
+        mixed = pipe.scheduler.re_noise(up, 0, N - stop)
+        videos, lat3 = pipe.basic_sample_shift_multi_windows(init_panorama_latent=mixed, total_h=1024, total_w=2048, num_windows_h=4, num_windows_w=4,
+                                                             overlap_ratio_list_f=[0.75, 0.75, 0.5, 0.5], pano_image_tensor=img1, output_type="tensor",
+                                                             **ring_args)
+        torch.cuda.synchronize()
+        t3 = time.time()
+        print(f"gen_pano_360 chain at size: sphere stage (2 steps) {t1 - t0:.1f} s, 1x plane (2 steps) {t2 - t1:.1f} s, 2x plane (2 steps) + decode {t3 - t2:.1f} s")
+        assert lat3.shape == (1, 4, 16, 128, 288) and videos.shape == (1, 3, 16, 1024, 2048)
+        assert bool(torch.isfinite(videos).all()) and bool(torch.isfinite(lat3.float()).all())
+    finally:
+        ld.first_stage_model = None
+        ld.scale_factor = 1.0
+        torch.cuda.empty_cache()
