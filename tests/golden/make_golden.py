@@ -37,6 +37,11 @@ so parity is pinned by what this script captures from the imported reference cod
   G28 ring_real_unet_50step.npz      (--full) the t2v ring loop, REAL UNet, on the metric's 50-step schedule: first and last 6 steps (96 forwards)
   G29 i2v_ring_real_unet_50step.npz  (--full) the same for the i2v ring loop with the REAL i2v UNet (96 forwards)
 
+  G31 ring_real_unet_50step_mid.npz  (--full) the t2v ring loop, REAL UNet, steps 20..25 of 50 on cfg3's window grid cut to 2 x 2 (48 forwards)
+  G32 loops_grid_shuffle.npz         random_shuffle_init_frame_stride of the grid loop, bug for bug (fake eps)
+  G33 sphere_set_scale.npz           view_set_scale_factor 2 / 3 and downsample_factor_before_vae_decode of both sphere loops (fake eps, one torch thread)
+  G34 i2v_ring_real_unet_50step_mid.npz  (--full) the i2v ring loop, REAL i2v UNet, steps 20..25 of 50 (48 forwards)
+
   G16 encoders_{toy,full}.npz  Resampler (the reference's module, ip_resampler.py) and the CLIP ViT-H/14 text / image
                              towers -- open_clip is absent, so the tower vectors come from transformers' CLIP
                              implementation carrying the same synthetic weights (independent anchor, not the reference)
@@ -941,6 +946,62 @@ def g29_i2v_ring_real_unet_50step():
         json.dump({"geoms": geoms, "traces": traces}, f)
 
 
+def g34_i2v_ring_real_unet_50step_mid():
+    """P3 in the MIDDLE of the 50-step schedule (the i2v counterpart of g31): the reference's i2v ring loop
+    (pipeline/i2v_sphere_panorama_pipeline.py:777-970) with the REAL i2v UNet -- 77 text + 16 image tokens per window, merge-prev --
+    on g29's 1024 x 512 x 16f panorama with loop_step = 8, entered through use_skip_time (:673-675) at step 20: six steps at schedule
+    indices 29..24 from a latent at index 29's noise level, stopped at the start of the seventh.  Panorama latent after steps 0 / 2 / 5
+    and the pred-x0 panorama after step 5; 48 forwards of the reference on CPU."""
+    import utils.shift_window_utils as swu
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_i2v_512_v1.0.yaml")))["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"
+    if dry:
+        params = dict(TINY, use_image_attention=True)
+    unet = build_reference_unet(params, seed=3)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 11), synth_normal((1, 77, cd), 12)
+    embed = synth_image_embedder(cd)
+    pano_img = synth_normal((3, 512, 1024), 189).clamp(-1, 1)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    ld.get_image_embeds = embed
+    ld.embedder = object()
+    shape = (1, 4, 16, 64, 128)
+    sched = lvdm_DDIM_Scheduler(ld)
+    sched.make_schedule(50)
+    first_index = 49 - RING50_MID_SKIP
+    init = _late_latent(sched, shape, first_index, 2333351)
+    n = 50 - RING50_MID_SKIP
+    geom = dict(I2V_RING_REAL, num_inference_steps=50, loop_step=8, overlap_ratio_list_f=[0.0] * n,
+                merge_prev_denoised_ratio_list=[0.4, 0.4, 0.3, 0.3, 0.2, 0.2] + [0.0] * (n - 6))
+    orig_loader = swu.load_image_tensor_from_path
+    swu.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: pano_img   # I/O stub (cv2 absent)
+    try:
+        pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+        pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+        kw = dict(prompt="a prompt", img_cond_path="unused.png", fps=16, guidance_scale=7.5, pano_image_path="unused.png",
+                  output_type="latent", init_panorama_latent=init.clone(), use_skip_time=True, skip_time_step_idx=RING50_MID_SKIP, **geom)
+        torch.manual_seed(2333333)
+        snaps, trace, out = _record_ring_run(lambda: pipe.basic_sample_shift_multi_windows(**kw), RING50_STEPS)
+    finally:
+        swu.load_image_tensor_from_path = orig_loader
+    assert len(snaps) == RING50_STEPS and out is None
+    A = {"fps": np.int64(16), "guidance": np.float32(7.5), "steps": np.int64(RING50_STEPS), "skip": np.int64(RING50_MID_SKIP),
+         "first_index": np.int64(first_index), "pano_img_seed": np.int64(189), "init": init.numpy().astype(np.float16)}
+    assert np.array_equal(A["init"].astype(np.float32), init.numpy())
+    for k, (x, x0) in enumerate(snaps):
+        if k in RING50_LAST_KEPT:
+            A[f"pano_{k}"] = _trim16(x)
+    A[f"x0_{RING50_STEPS - 1}"] = _trim16(snaps[-1][1])
+    if dry:
+        print("dry run ok", [float(np.std(A[f"pano_{k}"])) for k in RING50_LAST_KEPT], trace[:RING50_STEPS][-1])
+        return
+    save_npz("i2v_ring_real_unet_50step_mid.npz", **A)
+    with open(os.path.join(HERE, "i2v_ring_real_unet_50step_mid_trace.json"), "w") as f:
+        json.dump({"geom": geom, "trace": trace[:RING50_STEPS]}, f)
+
+
 def g18_unet_t24(full=False):
     """BASELINE config 5 runs the UNet at T = 24 (`frames=24`, t2v_sphere_panorama_pipeline.py:411 -> UNetModel.forward with
     a 24-frame tile, openaimodel3d.py:657-708): one forward of the reference at T = 24, toy config and (--full) the real
@@ -1809,6 +1870,7 @@ if __name__ == "__main__":
         steps["g28"] = g28_ring_real_unet_50step
         steps["g29"] = g29_i2v_ring_real_unet_50step
         steps["g31"] = g31_ring_real_unet_50step_mid
+        steps["g34"] = g34_i2v_ring_real_unet_50step_mid
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)

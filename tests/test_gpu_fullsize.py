@@ -691,6 +691,52 @@ def test_ring_loop_real_unet_mid_schedule_on_the_headline_window_grid_vs_referen
     assert errs["x0"] < 2.3e-3, r          # 1.25 x measured (1.83e-3)
 
 
+def test_i2v_ring_loop_real_unet_mid_schedule_vs_reference():
+    """The i2v counterpart of the mid-schedule test (make_golden.py g34): the reference's i2v ring loop with the REAL i2v UNet -- 77 text
+    + 16 image tokens per window from the crop of the panorama image under it, merge-prev ratios 0.4 .. 0.2 -- on a 1024 x 512 x 16f
+    panorama, 2 x 2 shifted windows, loop_step = 8, entered through use_skip_time at step 20 of 50 (schedule indices 29..24).  Panorama
+    latent after steps 0 / 2 / 5: 1e-3 in the library default mode; the intermediate pred-x0 panorama after step 5 is reported."""
+    from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.synth import synth_normal
+    path = os.path.join(G, "i2v_ring_real_unet_50step_mid.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/i2v_ring_real_unet_50step_mid.npz not generated (make_golden.py --full --only g34)")
+    d = dev()
+    z = np.load(path)
+    rec = json.load(open(os.path.join(G, "i2v_ring_real_unet_50step_mid_trace.json")))
+    nrec, skip = int(z["steps"]), int(z["skip"])
+    ld, params = _i2v_host(d)
+    unet = ld.model.diffusion_model
+    _reset_mode(unet)                    # the library default
+    pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="reference"), {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+    snaps, trace = [], []
+
+    def cb(i, t, wins, pano, pano_x0):
+        trace.append((i, int(t), [list(x) for x in wins]))
+        snaps.append((pano.float().cpu().clone(), pano_x0.float().cpu().clone()))
+        if len(snaps) == nrec:
+            raise _Stop()
+
+    torch.manual_seed(2333333)
+    try:
+        pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=int(z["fps"]), guidance_scale=float(z["guidance"]), output_type="latent",
+                                              init_panorama_latent=T(z["init"]).float(), step_callback=cb, use_skip_time=True, skip_time_step_idx=skip,
+                                              pano_image_tensor=synth_normal((3, 512, 1024), int(z["pano_img_seed"])).clamp(-1, 1), **rec["geom"])
+    except _Stop:
+        pass
+    assert len(snaps) == nrec and pipe.wide_steps_run == []
+    for (i, t, wins), ref in zip(trace, rec["trace"]):
+        assert i == ref["i"] and t == ref["t"] and wins == ref["windows"], (i, t, wins, ref)
+    errs = {k: relerr(snaps[k][0], T(z[f"pano_{k}"])) for k in range(nrec) if f"pano_{k}" in z.files}
+    errs["x0"] = relerr(snaps[-1][1], T(z[f"x0_{nrec - 1}"]))
+    r = dict(test="i2v_ring50_mid_real_unet", residual="outer", errs={str(k): v for k, v in errs.items()})
+    print(r)
+    record(**r)
+    assert len(errs) == 4 and all(e < RING50_TOL for k, e in errs.items() if k != "x0"), r      # the latent panorama: north star
+    assert errs["x0"] < 2.5e-3, r          # intermediate pred-x0 (never leaves the loop at this t): regression guard, like the t2v test's
+
+
 def test_vae_decodes_a_cfg5_frame():
     """N2 at the largest configuration's size: one 128 x 1024 latent frame -> 1024 x 8192 pixels through the real first-stage config.
     The last level's activations are exactly 2 GiB at 128 fp16 channels (4.3 GB at 256 fp32 ones), the mid-block attention has 131 072
