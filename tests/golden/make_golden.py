@@ -41,6 +41,7 @@ so parity is pinned by what this script captures from the imported reference cod
   G32 loops_grid_shuffle.npz         random_shuffle_init_frame_stride of the grid loop, bug for bug (fake eps)
   G33 sphere_set_scale.npz           view_set_scale_factor 2 / 3 and downsample_factor_before_vae_decode of both sphere loops (fake eps, one torch thread)
   G34 i2v_ring_real_unet_50step_mid.npz  (--full) the i2v ring loop, REAL i2v UNet, steps 20..25 of 50 (48 forwards)
+  G35 cfg3_real_unet_two_steps.npz   (--full) BASELINE config 3's own geometry (4096x512x16f, 8x2 windows), REAL t2v UNet, steps 24..25 of 50 (64 forwards)
 
   G16 encoders_{toy,full}.npz  Resampler (the reference's module, ip_resampler.py) and the CLIP ViT-H/14 text / image
                              towers -- open_clip is absent, so the tower vectors come from transformers' CLIP
@@ -944,6 +945,52 @@ def g29_i2v_ring_real_unet_50step():
     save_npz("i2v_ring_real_unet_50step.npz", **A)
     with open(os.path.join(HERE, "i2v_ring_real_unet_50step_trace.json"), "w") as f:
         json.dump({"geoms": geoms, "traces": traces}, f)
+
+
+CFG3_REAL_SKIP, CFG3_REAL_STEPS = 24, 2
+
+
+def g35_cfg3_real_unet_two_steps():
+    """The HEADLINE geometry itself with the real UNet: the reference's t2v ring loop (pipeline/t2v_sphere_panorama_pipeline.py:481-634) on
+    BASELINE config 3 -- 4096 x 512 x 16f, 8 x 2 shifted windows of 512 x 320, loop_step 8, CFG 7.5, the 50-step schedule -- entered
+    through use_skip_time at step 24 (schedule indices 25, 24): two whole steps, 16 windows each (the second one shifted by 1/8 window,
+    its last column wrapping across the W seam), from a latent at index 25's noise level; stopped at the start of the third.  Panorama
+    latent and pred-x0 panorama after the second step (and the latent after the first); 64 forwards of the reference on CPU (~55 min)."""
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"
+    if dry:
+        params = dict(TINY)
+    unet = build_reference_unet(params, seed=0)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 1), synth_normal((1, 77, cd), 2)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    geom = dict(height=320, width=512, frames=16, total_w=4096, total_h=512, num_windows_w=8, num_windows_h=2, num_windows_f=1, loop_step=8,
+                num_inference_steps=50)
+    shape = (1, 4, 16, geom["total_h"] // 8, geom["total_w"] // 8)
+    sched = lvdm_DDIM_Scheduler(ld)
+    sched.make_schedule(50)
+    first_index = 49 - CFG3_REAL_SKIP
+    init = _late_latent(sched, shape, first_index, 2333360)
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+    kw = dict(prompt="a prompt", output_type="latent", fps=8, guidance_scale=7.5, init_panorama_latent=init.clone(),
+              use_skip_time=True, skip_time_step_idx=CFG3_REAL_SKIP, **geom)
+    torch.manual_seed(2333333)
+    snaps, trace, out = _record_ring_run(lambda: pipe.basic_sample_shift_multi_windows(**kw), CFG3_REAL_STEPS)
+    assert len(snaps) == CFG3_REAL_STEPS and out is None
+    A = {"fps": np.int64(8), "guidance": np.float32(7.5), "steps": np.int64(CFG3_REAL_STEPS), "skip": np.int64(CFG3_REAL_SKIP),
+         "first_index": np.int64(first_index), "init": init.numpy().astype(np.float16)}
+    assert np.array_equal(A["init"].astype(np.float32), init.numpy())
+    for k, (x, x0) in enumerate(snaps):
+        A[f"pano_{k}"] = _trim16(x)
+    A[f"x0_{CFG3_REAL_STEPS - 1}"] = _trim16(snaps[-1][1])
+    if dry:
+        print("dry run ok", [float(np.std(A[f"pano_{k}"])) for k in range(CFG3_REAL_STEPS)], len(trace[0]["windows"]), trace[1]["windows"][-1])
+        return
+    save_npz("cfg3_real_unet_two_steps.npz", **A)
+    with open(os.path.join(HERE, "cfg3_real_unet_two_steps_trace.json"), "w") as f:
+        json.dump({"geom": geom, "trace": trace[:CFG3_REAL_STEPS]}, f)
 
 
 def g34_i2v_ring_real_unet_50step_mid():
@@ -1871,6 +1918,7 @@ if __name__ == "__main__":
         steps["g29"] = g29_i2v_ring_real_unet_50step
         steps["g31"] = g31_ring_real_unet_50step_mid
         steps["g34"] = g34_i2v_ring_real_unet_50step_mid
+        steps["g35"] = g35_cfg3_real_unet_two_steps
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)

@@ -691,6 +691,64 @@ def test_ring_loop_real_unet_mid_schedule_on_the_headline_window_grid_vs_referen
     assert errs["x0"] < 2.3e-3, r          # 1.25 x measured (1.83e-3)
 
 
+def test_cfg3_headline_geometry_two_steps_with_the_real_unet_vs_reference():
+    """BASELINE config 3 itself against the reference with the real UNet (make_golden.py g35): 4096 x 512 x 16f, 8 x 2 shifted windows of
+    512 x 320, loop_step 8, CFG 7.5, the 50-step schedule entered at step 24 (schedule indices 25, 24) -- two whole steps of 16 windows
+    each, the second shifted by 1/8 window with its last column wrapping across the W seam; 64 forwards of the reference on the CPU.
+    The HIP ring loop in bench.py's execution mode (tile batch 8, two streams, hipGraph replay, shared CFG prefix), library default
+    operand / residual modes: the panorama latent after each step at the north star's 1e-3; the intermediate pred-x0 panorama is
+    reported with a regression guard (it multiplies the guided-eps error by sqrt(1 - a) / sqrt(a) and is overwritten by every later step)."""
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    path = os.path.join(G, "cfg3_real_unet_two_steps.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/cfg3_real_unet_two_steps.npz not generated (make_golden.py --full --only g35)")
+    d = dev()
+    z = np.load(path)
+    rec = json.load(open(os.path.join(G, "cfg3_real_unet_two_steps_trace.json")))
+    nrec, skip = int(z["steps"]), int(z["skip"])
+    assert rec["geom"]["total_w"] == 4096 and rec["geom"]["num_windows_w"] == 8 and rec["geom"]["num_windows_h"] == 2
+    ld, params, _ = full_host(d)
+    unet = ld.model.diffusion_model
+    _reset_mode(unet)                    # the library default
+    out = {}
+    for mode in ("bench", "plain"):
+        pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="reference"), {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+        if mode == "bench":
+            pipe.max_tile_batch, pipe.num_streams, pipe.use_graph = 8, 2, True
+        snaps, trace = [], []
+
+        def cb(i, t, wins, pano, pano_x0):
+            trace.append((i, int(t), [list(x) for x in wins]))
+            snaps.append((pano.float().cpu().clone(), pano_x0.float().cpu().clone()))
+            if len(snaps) == nrec:
+                raise _Stop()
+
+        torch.manual_seed(2333333)
+        try:
+            pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=int(z["fps"]), guidance_scale=float(z["guidance"]), output_type="latent",
+                                                  init_panorama_latent=T(z["init"]).float(), step_callback=cb, use_skip_time=True,
+                                                  skip_time_step_idx=skip, **rec["geom"])
+        except _Stop:
+            pass
+        assert len(snaps) == nrec and pipe.wide_steps_run == []
+        for (i, t, wins), ref in zip(trace, rec["trace"]):
+            assert i == ref["i"] and t == ref["t"] and wins == ref["windows"] and len(wins) == 16, (i, t, wins, ref)
+        out[mode] = snaps
+    W = rec["geom"]["total_w"] // 8
+    assert any(w[1] > W for w in trace[1][2]), "no window of the second step crosses the W seam"
+    for k in range(nrec):                 # the execution mode does not change a bit of the panorama
+        assert torch.equal(out["bench"][k][0], out["plain"][k][0]) and torch.equal(out["bench"][k][1], out["plain"][k][1]), k
+    snaps = out["bench"]
+    errs = {k: relerr(snaps[k][0], T(z[f"pano_{k}"])) for k in range(nrec)}
+    errs["x0"] = relerr(snaps[-1][1], T(z[f"x0_{nrec - 1}"]))
+    r = dict(test="cfg3_real_unet_two_steps", residual="outer", errs={str(k): v for k, v in errs.items()})
+    print(r)
+    record(**r)
+    assert all(e < NORTH_STAR for k, e in errs.items() if k != "x0"), r
+    assert errs["x0"] < 2.5e-3, r
+
+
 def test_i2v_ring_loop_real_unet_mid_schedule_vs_reference():
     """The i2v counterpart of the mid-schedule test (make_golden.py g34): the reference's i2v ring loop with the REAL i2v UNet -- 77 text
     + 16 image tokens per window from the crop of the panorama image under it, merge-prev ratios 0.4 .. 0.2 -- on a 1024 x 512 x 16f
