@@ -41,6 +41,7 @@ so parity is pinned by what this script captures from the imported reference cod
   G32 loops_grid_shuffle.npz         random_shuffle_init_frame_stride of the grid loop, bug for bug (fake eps)
   G33 sphere_set_scale.npz           view_set_scale_factor 2 / 3 and downsample_factor_before_vae_decode of both sphere loops (fake eps, one torch thread)
   G34 i2v_ring_real_unet_50step_mid.npz  (--full) the i2v ring loop, REAL i2v UNet, steps 20..25 of 50 (48 forwards)
+  G36 cfg4_real_unet_one_step.npz    (--full) BASELINE config 4's geometry (i2v, 4096x512x16f, 8x2 windows), REAL i2v UNet, step 24 of 50 (32 forwards)
   G35 cfg3_real_unet_two_steps.npz   (--full) BASELINE config 3's own geometry (4096x512x16f, 8x2 windows), REAL t2v UNet, steps 24..25 of 50 (64 forwards)
 
   G16 encoders_{toy,full}.npz  Resampler (the reference's module, ip_resampler.py) and the CLIP ViT-H/14 text / image
@@ -993,6 +994,58 @@ def g35_cfg3_real_unet_two_steps():
         json.dump({"geom": geom, "trace": trace[:CFG3_REAL_STEPS]}, f)
 
 
+def g36_cfg4_real_unet_one_step():
+    """BASELINE config 4's geometry with the real i2v UNet: the reference's i2v ring loop (pipeline/i2v_sphere_panorama_pipeline.py:777-970)
+    on 4096 x 512 x 16f, 8 x 2 shifted windows, per-window 16 image tokens from the crop of a (synthetic) 4096 x 512 panorama image under
+    each window, merge-prev 0.4, CFG 7.5, the 50-step schedule entered through use_skip_time at step 24 (schedule index 25): ONE whole step
+    of 16 windows from a latent at that noise level; stopped at the start of the second.  32 forwards of the reference on CPU (~27 min)."""
+    import utils.shift_window_utils as swu
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_i2v_512_v1.0.yaml")))["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"
+    if dry:
+        params = dict(TINY, use_image_attention=True)
+    unet = build_reference_unet(params, seed=3)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 11), synth_normal((1, 77, cd), 12)
+    embed = synth_image_embedder(cd)
+    pano_img = synth_normal((3, 512, 4096), 190).clamp(-1, 1)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    ld.get_image_embeds = embed
+    ld.embedder = object()
+    shape = (1, 4, 16, 64, 512)
+    sched = lvdm_DDIM_Scheduler(ld)
+    sched.make_schedule(50)
+    first_index = 49 - CFG3_REAL_SKIP
+    init = _late_latent(sched, shape, first_index, 2333370)
+    n = 50 - CFG3_REAL_SKIP
+    geom = dict(height=320, width=512, frames=16, total_w=4096, total_h=512, total_f=16, num_windows_w=8, num_windows_h=2, num_windows_f=1,
+                loop_step=8, num_inference_steps=50, overlap_ratio_list_f=[0.0] * n, merge_prev_denoised_ratio_list=[0.4] + [0.0] * (n - 1))
+    orig_loader = swu.load_image_tensor_from_path
+    swu.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: pano_img   # I/O stub (cv2 absent)
+    try:
+        pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+        pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+        kw = dict(prompt="a prompt", img_cond_path="unused.png", fps=16, guidance_scale=7.5, pano_image_path="unused.png",
+                  output_type="latent", init_panorama_latent=init.clone(), use_skip_time=True, skip_time_step_idx=CFG3_REAL_SKIP, **geom)
+        torch.manual_seed(2333333)
+        snaps, trace, out = _record_ring_run(lambda: pipe.basic_sample_shift_multi_windows(**kw), 1)
+    finally:
+        swu.load_image_tensor_from_path = orig_loader
+    assert len(snaps) == 1 and out is None
+    A = {"fps": np.int64(16), "guidance": np.float32(7.5), "steps": np.int64(1), "skip": np.int64(CFG3_REAL_SKIP),
+         "first_index": np.int64(first_index), "pano_img_seed": np.int64(190), "init": init.numpy().astype(np.float16),
+         "pano_0": _trim16(snaps[0][0]), "x0_0": _trim16(snaps[0][1])}
+    assert np.array_equal(A["init"].astype(np.float32), init.numpy())
+    if dry:
+        print("dry run ok", float(np.std(A["pano_0"])), len(trace[0]["windows"]))
+        return
+    save_npz("cfg4_real_unet_one_step.npz", **A)
+    with open(os.path.join(HERE, "cfg4_real_unet_one_step_trace.json"), "w") as f:
+        json.dump({"geom": geom, "trace": trace[:1]}, f)
+
+
 def g34_i2v_ring_real_unet_50step_mid():
     """P3 in the MIDDLE of the 50-step schedule (the i2v counterpart of g31): the reference's i2v ring loop
     (pipeline/i2v_sphere_panorama_pipeline.py:777-970) with the REAL i2v UNet -- 77 text + 16 image tokens per window, merge-prev --
@@ -1919,6 +1972,7 @@ if __name__ == "__main__":
         steps["g31"] = g31_ring_real_unet_50step_mid
         steps["g34"] = g34_i2v_ring_real_unet_50step_mid
         steps["g35"] = g35_cfg3_real_unet_two_steps
+        steps["g36"] = g36_cfg4_real_unet_one_step
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)

@@ -752,6 +752,58 @@ def test_cfg3_headline_geometry_two_steps_with_the_real_unet_vs_reference():
     assert errs["x0"] < 3.2e-3, r
 
 
+def test_cfg4_geometry_one_step_with_the_real_i2v_unet_vs_reference():
+    """BASELINE config 4's geometry against the reference with the real i2v UNet (make_golden.py g36): 4096 x 512 x 16f, 8 x 2 shifted
+    windows, 77 text + 16 image tokens per window from the crop of a 4096 x 512 panorama image under it, merge-prev, CFG 7.5, one whole
+    step (16 windows, 32 CPU forwards of the reference) at step 24 of the 50-step schedule.  bench.py's execution mode (tile batch 8, two
+    streams, hipGraph, shared CFG prefix) = the plain run bit for bit; panorama latent after the step: the north star's 1e-3."""
+    from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V_SpherePano
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.synth import synth_normal
+    path = os.path.join(G, "cfg4_real_unet_one_step.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/cfg4_real_unet_one_step.npz not generated (make_golden.py --full --only g36)")
+    d = dev()
+    z = np.load(path)
+    rec = json.load(open(os.path.join(G, "cfg4_real_unet_one_step_trace.json")))
+    skip = int(z["skip"])
+    assert rec["geom"]["total_w"] == 4096 and rec["geom"]["num_windows_w"] == 8 and rec["geom"]["num_windows_h"] == 2
+    ld, params = _i2v_host(d)
+    unet = ld.model.diffusion_model
+    _reset_mode(unet)
+    img = synth_normal((3, 512, 4096), int(z["pano_img_seed"])).clamp(-1, 1)
+    out = {}
+    for mode in ("bench", "plain"):
+        pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="reference"), {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+        if mode == "bench":
+            pipe.max_tile_batch, pipe.num_streams, pipe.use_graph = 8, 2, True
+        snaps, trace = [], []
+
+        def cb(i, t, wins, pano, pano_x0):
+            trace.append((i, int(t), [list(x) for x in wins]))
+            snaps.append((pano.float().cpu().clone(), pano_x0.float().cpu().clone()))
+            raise _Stop()
+
+        torch.manual_seed(2333333)
+        try:
+            pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=int(z["fps"]), guidance_scale=float(z["guidance"]), output_type="latent",
+                                                  init_panorama_latent=T(z["init"]).float(), step_callback=cb, use_skip_time=True,
+                                                  skip_time_step_idx=skip, pano_image_tensor=img, **rec["geom"])
+        except _Stop:
+            pass
+        assert len(snaps) == 1 and pipe.wide_steps_run == []
+        (i, t, wins), ref = trace[0], rec["trace"][0]
+        assert i == ref["i"] and t == ref["t"] and wins == ref["windows"] and len(wins) == 16, (i, t, wins, ref)
+        out[mode] = snaps[0]
+    assert torch.equal(out["bench"][0], out["plain"][0]) and torch.equal(out["bench"][1], out["plain"][1])
+    errs = {"0": relerr(out["bench"][0], T(z["pano_0"])), "x0": relerr(out["bench"][1], T(z["x0_0"]))}
+    r = dict(test="cfg4_real_unet_one_step", residual="outer", errs=errs)
+    print(r)
+    record(**r)
+    assert errs["0"] < NORTH_STAR, r
+    assert errs["x0"] < 3.2e-3, r          # intermediate pred-x0 at schedule index 25: reported (see the config 3 test)
+
+
 def test_i2v_ring_loop_real_unet_mid_schedule_vs_reference():
     """The i2v counterpart of the mid-schedule test (make_golden.py g34): the reference's i2v ring loop with the REAL i2v UNet -- 77 text
     + 16 image tokens per window from the crop of the panorama image under it, merge-prev ratios 0.4 .. 0.2 -- on a 1024 x 512 x 16f
