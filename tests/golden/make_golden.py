@@ -41,6 +41,7 @@ so parity is pinned by what this script captures from the imported reference cod
   G32 loops_grid_shuffle.npz         random_shuffle_init_frame_stride of the grid loop, bug for bug (fake eps)
   G33 sphere_set_scale.npz           view_set_scale_factor 2 / 3 and downsample_factor_before_vae_decode of both sphere loops (fake eps, one torch thread)
   G34 i2v_ring_real_unet_50step_mid.npz  (--full) the i2v ring loop, REAL i2v UNet, steps 20..25 of 50 (48 forwards)
+  G37 sphere_real_unet.npz           (--full) the t2v SPHERE loop with the REAL UNet: 1024x512 equirect, 5 views a step, first 2 of 50 steps (20 forwards)
   G36 cfg4_real_unet_one_step.npz    (--full) BASELINE config 4's geometry (i2v, 4096x512x16f, 8x2 windows), REAL i2v UNet, step 24 of 50 (32 forwards)
   G35 cfg3_real_unet_two_steps.npz   (--full) BASELINE config 3's own geometry (4096x512x16f, 8x2 windows), REAL t2v UNet, steps 24..25 of 50 (64 forwards)
 
@@ -1046,6 +1047,46 @@ def g36_cfg4_real_unet_one_step():
         json.dump({"geom": geom, "trace": trace[:1]}, f)
 
 
+SPHERE_REAL_GEOM = dict(height=320, width=512, frames=16, equirect_width=1024, equirect_height=512, view_fov=120, loop_step_theta=4,
+                        phi_theta_dict={"0": [0, 90, 180, 270], "60": [45]}, merge_renoised_overlap_latent_ratio=None,
+                        num_inference_steps=50, denoise_to_step=2)
+
+
+def g37_sphere_real_unet():
+    """P5 with the REAL UNet: the reference's t2v sphere loop (pipeline/t2v_sphere_panorama_pipeline.py:23-312) on a 1024 x 512 equirect
+    (latent 64 x 128), five overlapping perspective views of 512 x 320 x 16f per step (fov 120; phi 0: theta 0 / 90 / 180 / 270, phi 60:
+    theta 45), theta offset walking (loop_step_theta 4), CFG 7.5, the first two steps of the 50-step schedule (denoise_to_step = 2) from a
+    given init latent.  merge_renoised_overlap_latent_ratio = None: no re-noise draw in the loop (the reference's randn_like on a strided
+    view takes a host-dependent path), so the panoramas can be compared across hosts.  20 forwards of the reference on CPU."""
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"
+    if dry:
+        params = dict(TINY)
+    unet = build_reference_unet(params, seed=0)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 1), synth_normal((1, 77, cd), 2)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    g = dict(SPHERE_REAL_GEOM)
+    g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+    init = synth_normal((1, 4, 16, 64, 128), 2333380).half().float()
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+    torch.manual_seed(2333333)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", fps=8, guidance_scale=7.5, output_type="latent",
+                                                             init_sphere_latent=init.clone(), **g)
+    A = {"fps": np.int64(8), "guidance": np.float32(7.5), "init": init.numpy().astype(np.float16), "final": _trim16(final), "denoised": _trim16(den)}
+    assert np.array_equal(A["init"].astype(np.float32), init.numpy())
+    if dry:
+        print("dry run ok", float(final.std()), float(den.std()), float((den == 0).float().mean()))
+        return
+    save_npz("sphere_real_unet.npz", **A)
+    with open(os.path.join(HERE, "sphere_real_unet.json"), "w") as f:
+        json.dump({"geom": SPHERE_REAL_GEOM}, f)
+
+
 def g34_i2v_ring_real_unet_50step_mid():
     """P3 in the MIDDLE of the 50-step schedule (the i2v counterpart of g31): the reference's i2v ring loop
     (pipeline/i2v_sphere_panorama_pipeline.py:777-970) with the REAL i2v UNet -- 77 text + 16 image tokens per window, merge-prev --
@@ -1973,6 +2014,7 @@ if __name__ == "__main__":
         steps["g34"] = g34_i2v_ring_real_unet_50step_mid
         steps["g35"] = g35_cfg3_real_unet_two_steps
         steps["g36"] = g36_cfg4_real_unet_one_step
+        steps["g37"] = g37_sphere_real_unet
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)
