@@ -41,6 +41,8 @@ so parity is pinned by what this script captures from the imported reference cod
   G32 loops_grid_shuffle.npz         random_shuffle_init_frame_stride of the grid loop, bug for bug (fake eps)
   G33 sphere_set_scale.npz           view_set_scale_factor 2 / 3 and downsample_factor_before_vae_decode of both sphere loops (fake eps, one torch thread)
   G34 i2v_ring_real_unet_50step_mid.npz  (--full) the i2v ring loop, REAL i2v UNet, steps 20..25 of 50 (48 forwards)
+  G39 sphere_i2v_real_unet.npz       (--full) the i2v SPHERE loop with the REAL i2v UNet: image tokens per view, re-noise, merge-prev, 2 steps (20 forwards)
+  G38 grid_real_unet.npz             (--full) the non-overlapping shifted GRID loop with the REAL t2v UNet: 2 x 1 tiles, 4 steps (16 forwards)
   G37 sphere_real_unet.npz           (--full) the t2v SPHERE loop with the REAL UNet: 1024x512 equirect, 5 views a step, first 2 of 50 steps (20 forwards)
   G36 cfg4_real_unet_one_step.npz    (--full) BASELINE config 4's geometry (i2v, 4096x512x16f, 8x2 windows), REAL i2v UNet, step 24 of 50 (32 forwards)
   G35 cfg3_real_unet_two_steps.npz   (--full) BASELINE config 3's own geometry (4096x512x16f, 8x2 windows), REAL t2v UNet, steps 24..25 of 50 (64 forwards)
@@ -1087,6 +1089,90 @@ def g37_sphere_real_unet():
         json.dump({"geom": SPHERE_REAL_GEOM}, f)
 
 
+GRID_REAL_GEOM = dict(num_windows_w=2, num_windows_h=1, num_windows_f=1, loop_step=4, num_inference_steps=4,
+                      skip_time_step_idx=0)        # (printed unconditionally by the reference, t2v_normal_pipeline.py:306)
+I2V_SPHERE_REAL_GEOM = dict(height=320, width=512, frames=16, total_f=16, equirect_width=1024, equirect_height=512, view_fov=120, loop_step_theta=4,
+                            phi_theta_dict={"0": [0, 90, 180, 270], "60": [45]}, merge_renoised_overlap_latent_ratio=1,
+                            merge_prev_denoised_ratio_list=[0.3, 0.2] + [0.0] * 48, overlap_ratio_list_f=[0.0] * 50, loop_step_frame=8,
+                            num_inference_steps=50, denoise_to_step=2)
+
+
+def g38_grid_real_unet():
+    """P4 with the REAL UNet: the reference's non-overlapping shifted grid loop (pipeline/t2v_normal_pipeline.py:213-568) on a 2 x 1 grid of
+    512 x 320 x 16f tiles (1024 x 320), loop_step 4 (the grid moves a quarter tile per step, wrapping in W, H and F), CFG 7.5, config 1's
+    4-step schedule, from a given init latent; 16 forwards of the reference on CPU."""
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"
+    if dry:
+        params = dict(TINY)
+    unet = build_reference_unet(params, seed=0)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 1), synth_normal((1, 77, cd), 2)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    init = synth_normal((1, 4, 16, 40, 128), 2333390).half().float()
+    pipe = VC2_Pipeline_T2V(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+    torch.manual_seed(2333333)
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", height=320, width=512, frames=16, fps=8, guidance_scale=7.5,
+                                                       output_type="latent", init_panorama_latent=init.clone(), **GRID_REAL_GEOM)
+    A = {"fps": np.int64(8), "guidance": np.float32(7.5), "init": init.numpy().astype(np.float16), "denoised": _trim16(den)}
+    assert np.array_equal(A["init"].astype(np.float32), init.numpy())
+    if dry:
+        print("dry run ok", tuple(den.shape), float(den.std()))
+        return
+    save_npz("grid_real_unet.npz", **A)
+    with open(os.path.join(HERE, "grid_real_unet.json"), "w") as f:
+        json.dump({"geom": GRID_REAL_GEOM}, f)
+
+
+def g39_i2v_sphere_real_unet():
+    """P5 (i2v) with the REAL i2v UNet: the reference's i2v sphere loop (pipeline/i2v_sphere_panorama_pipeline.py:31-495) on a 1024 x 512
+    equirect, five overlapping 512 x 320 x 16f views a step, 16 image tokens per view from its perspective crop of a (synthetic) panorama
+    image, overlap re-noise at ratio 1 (a contiguous view here: torch's plain randn stream), merge-prev 0.3 / 0.2, CFG 7.5, the first two
+    steps of the 50-step schedule; 20 forwards of the reference on CPU."""
+    import pipeline.i2v_sphere_panorama_pipeline as mod
+    from pipeline.i2v_sphere_panorama_pipeline import VC2_Pipeline_I2V_SpherePano
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_i2v_512_v1.0.yaml")))["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"
+    if dry:
+        params = dict(TINY, use_image_attention=True)
+    unet = build_reference_unet(params, seed=3)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 11), synth_normal((1, 77, cd), 12)
+    embed = synth_image_embedder(cd)
+    pano_img = synth_normal((3, 512, 1024), 191).clamp(-1, 1)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    ld.get_image_embeds = embed
+    ld.embedder = object()
+    g = dict(I2V_SPHERE_REAL_GEOM)
+    g["phi_theta_dict"] = {int(k): v for k, v in g["phi_theta_dict"].items()}
+    init = synth_normal((1, 4, 16, 64, 128), 2333395).half().float()
+    orig_loader = mod.load_image_tensor_from_path
+    mod.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: pano_img   # I/O stub (cv2 absent)
+    try:
+        pipe = VC2_Pipeline_I2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+        pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: pano_img[None, :, :height, :width]
+        torch.manual_seed(2333333)
+        with contextlib.redirect_stdout(io.StringIO()):
+            final, den = pipe.basic_sample_shift_shpere_panorama(prompt="a prompt", img_cond_path="unused.png", fps=8, guidance_scale=7.5,
+                                                                 pano_image_path="unused.png", output_type="latent",
+                                                                 init_sphere_latent=init.clone(), **g)
+    finally:
+        mod.load_image_tensor_from_path = orig_loader
+    A = {"fps": np.int64(8), "guidance": np.float32(7.5), "pano_img_seed": np.int64(191), "init": init.numpy().astype(np.float16),
+         "final": _trim16(final), "denoised": _trim16(den)}
+    assert np.array_equal(A["init"].astype(np.float32), init.numpy())
+    if dry:
+        print("dry run ok", float(final.std()), float(den.std()))
+        return
+    save_npz("sphere_i2v_real_unet.npz", **A)
+    with open(os.path.join(HERE, "sphere_i2v_real_unet.json"), "w") as f:
+        json.dump({"geom": I2V_SPHERE_REAL_GEOM}, f)
+
+
 def g34_i2v_ring_real_unet_50step_mid():
     """P3 in the MIDDLE of the 50-step schedule (the i2v counterpart of g31): the reference's i2v ring loop
     (pipeline/i2v_sphere_panorama_pipeline.py:777-970) with the REAL i2v UNet -- 77 text + 16 image tokens per window, merge-prev --
@@ -2015,6 +2101,8 @@ if __name__ == "__main__":
         steps["g35"] = g35_cfg3_real_unet_two_steps
         steps["g36"] = g36_cfg4_real_unet_one_step
         steps["g37"] = g37_sphere_real_unet
+        steps["g38"] = g38_grid_real_unet
+        steps["g39"] = g39_i2v_sphere_real_unet
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)
