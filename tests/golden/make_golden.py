@@ -41,6 +41,7 @@ so parity is pinned by what this script captures from the imported reference cod
   G32 loops_grid_shuffle.npz         random_shuffle_init_frame_stride of the grid loop, bug for bug (fake eps)
   G33 sphere_set_scale.npz           view_set_scale_factor 2 / 3 and downsample_factor_before_vae_decode of both sphere loops (fake eps, one torch thread)
   G34 i2v_ring_real_unet_50step_mid.npz  (--full) the i2v ring loop, REAL i2v UNet, steps 20..25 of 50 (48 forwards)
+  G40 grid_i2v_real_unet.npz         (--full) the i2v GRID loop (i2v_normal_pipeline) with the REAL i2v UNet: 2 x 1 tiles, 4 steps (16 forwards)
   G39 sphere_i2v_real_unet.npz       (--full) the i2v SPHERE loop with the REAL i2v UNet: image tokens per view, re-noise, merge-prev, 2 steps (20 forwards)
   G38 grid_real_unet.npz             (--full) the non-overlapping shifted GRID loop with the REAL t2v UNet: 2 x 1 tiles, 4 steps (16 forwards)
   G37 sphere_real_unet.npz           (--full) the t2v SPHERE loop with the REAL UNet: 1024x512 equirect, 5 views a step, first 2 of 50 steps (20 forwards)
@@ -1173,6 +1174,53 @@ def g39_i2v_sphere_real_unet():
         json.dump({"geom": I2V_SPHERE_REAL_GEOM}, f)
 
 
+I2V_GRID_REAL_GEOM = dict(height=320, width=512, frames=16, num_windows_w=2, num_windows_h=1, num_windows_f=1, loop_step=4, num_inference_steps=4)
+
+
+def g40_i2v_grid_real_unet():
+    """P4 (i2v) with the REAL i2v UNet: the reference's non-overlapping shifted grid loop of the i2v base class
+    (pipeline/i2v_normal_pipeline.py:68-425) on 2 x 1 tiles of 512 x 320 x 16f (1024 x 320), loop_step 4, per-window image tokens from the
+    crop of the (synthetic) panorama image under the shifted window, 0/1-mask re-noise, CFG 7.5, 4-step schedule, given init latent;
+    16 forwards of the reference on CPU."""
+    import utils.shift_window_utils as swu
+    from pipeline.i2v_normal_pipeline import VC2_Pipeline_I2V as RefI2V
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_i2v_512_v1.0.yaml")))["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"
+    if dry:
+        params = dict(TINY, use_image_attention=True)
+    unet = build_reference_unet(params, seed=3)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 11), synth_normal((1, 77, cd), 12)
+    embed = synth_image_embedder(cd)
+    grid_img = synth_normal((3, 320, 1024), 192).clamp(-1, 1)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=16)
+    ld.get_image_embeds = embed
+    ld.embedder = object()
+    init = synth_normal((1, 4, 16, 40, 128), 2333398).half().float()
+    orig_loader = swu.load_image_tensor_from_path
+    swu.load_image_tensor_from_path = lambda image_path, height, width, norm_to_1=True: grid_img
+    try:
+        pipe = RefI2V(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+        pipe._load_imgs_from_paths = lambda img_path_list, height=320, width=512: grid_img[None, :, :height, :width]
+        torch.manual_seed(2333333)
+        with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+            _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", img_cond_path="unused.png", fps=8, guidance_scale=7.5,
+                                                           pano_image_path="unused.png", output_type="latent",
+                                                           init_panorama_latent=init.clone(), **I2V_GRID_REAL_GEOM)
+    finally:
+        swu.load_image_tensor_from_path = orig_loader
+    A = {"fps": np.int64(8), "guidance": np.float32(7.5), "grid_img_seed": np.int64(192), "init": init.numpy().astype(np.float16),
+         "denoised": _trim16(den)}
+    assert np.array_equal(A["init"].astype(np.float32), init.numpy())
+    if dry:
+        print("dry run ok", tuple(den.shape), float(den.std()))
+        return
+    save_npz("grid_i2v_real_unet.npz", **A)
+    with open(os.path.join(HERE, "grid_i2v_real_unet.json"), "w") as f:
+        json.dump({"geom": I2V_GRID_REAL_GEOM}, f)
+
+
 def g34_i2v_ring_real_unet_50step_mid():
     """P3 in the MIDDLE of the 50-step schedule (the i2v counterpart of g31): the reference's i2v ring loop
     (pipeline/i2v_sphere_panorama_pipeline.py:777-970) with the REAL i2v UNet -- 77 text + 16 image tokens per window, merge-prev --
@@ -2103,6 +2151,7 @@ if __name__ == "__main__":
         steps["g37"] = g37_sphere_real_unet
         steps["g38"] = g38_grid_real_unet
         steps["g39"] = g39_i2v_sphere_real_unet
+        steps["g40"] = g40_i2v_grid_real_unet
         steps["g14"] = lambda: g14_vae_decode(full=True)
         steps["g15"] = lambda: g15_vae_encode(full=True)
         steps["g16"] = lambda: g16_encoders(full=True)

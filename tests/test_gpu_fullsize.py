@@ -868,6 +868,37 @@ def test_grid_loop_with_the_real_unet_vs_reference():
     assert tuple(den.shape) == tuple(z["denoised"].shape) and e < NORTH_STAR, r
 
 
+def test_i2v_grid_loop_with_the_real_unet_vs_reference():
+    """P4 (i2v) with the REAL i2v UNet (make_golden.py g40): the reference's non-overlapping shifted grid loop of the i2v base class
+    (pipeline/i2v_normal_pipeline.py:68-425) on 2 x 1 tiles of 512 x 320 x 16f, loop_step 4, image tokens from the crop of the panorama image
+    under each shifted window, 0/1-mask re-noise, CFG 7.5, 4-step schedule; 16 CPU forwards of the reference.  Under the pipelines' operand
+    policy (first three updates on wide operands): the final pred-x0 panorama at 1e-3."""
+    from dynamicscaler_amd.pipelines_i2v import VC2_Pipeline_I2V
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.synth import synth_normal
+    path = os.path.join(G, "grid_i2v_real_unet.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/grid_i2v_real_unet.npz not generated (make_golden.py --full --only g40)")
+    d = dev()
+    z = np.load(path)
+    geom = json.load(open(os.path.join(G, "grid_i2v_real_unet.json")))["geom"]
+    ld, params = _i2v_host(d)
+    _reset_mode(ld.model.diffusion_model)
+    pipe = VC2_Pipeline_I2V(ld, lvdm_DDIM_Scheduler(ld, rng_mode="reference"), {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+    steps = []
+    torch.manual_seed(2333333)
+    _, den = pipe.basic_sample_shift_multi_windows(prompt="a prompt", fps=int(z["fps"]), guidance_scale=float(z["guidance"]), output_type="latent",
+                                                   init_panorama_latent=T(z["init"]).float(),
+                                                   pano_image_tensor=synth_normal((3, 320, 1024), int(z["grid_img_seed"])).clamp(-1, 1),
+                                                   step_callback=lambda i, t, w, p, p0: steps.append((i, int(t), len(w))), **geom)
+    assert [s[1:] for s in steps] == [(999, 2), (666, 2), (333, 2), (0, 2)] and pipe.wide_steps_run == [(0, 3), (1, 2), (2, 1)]
+    e = relerr(den, T(z["denoised"]))
+    r = dict(test="grid_i2v_real_unet", policy="auto", denoised=e)
+    print(r)
+    record(**r)
+    assert tuple(den.shape) == tuple(z["denoised"].shape) and e < NORTH_STAR, r
+
+
 def test_i2v_sphere_loop_with_the_real_unet_vs_reference():
     """P5 (i2v) with the REAL i2v UNet (make_golden.py g39): the reference's i2v sphere loop on a 1024 x 512 equirect, five overlapping
     512 x 320 x 16f views a step with 16 image tokens each from the view's perspective crop of the panorama image, mask-gated overlap
