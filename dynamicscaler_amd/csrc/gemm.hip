@@ -143,7 +143,12 @@ struct TileCfg {
     static constexpr int LROWS = NT / 8;                      // rows staged per sweep (8 lanes x 16 B per 128-B row)
     static constexpr int AR = BM / LROWS, BR = BN / LROWS;    // staged rows per thread
     static constexpr size_t STAGE1 = (size_t)(BM + BN) * BK * sizeof(f16);   // one stage: [BM rows of A | BN rows of W], 128 B each
-    static constexpr size_t STAGE = (size_t)NS * STAGE1;
+    // NS == 1 selects the SPLIT-RING form (round 6): TWO A stages and ONE W stage -- [A stage 0 | A stage 1 | W] -- so that a 4-wave
+    // workgroup with LDS-DMA staging fits in half a CU's LDS and two of them share a CU: they run out of step, and one's prologue /
+    // epilogue (memory- and vector-bound) proceeds under the other's K loop.  W (L2-resident) is re-loaded between two barriers at the
+    // end of every K-step; the A rows of K-step k+2 go out at the same point (one step ahead of their use).
+    static constexpr bool SW = NS == 1;
+    static constexpr size_t STAGE = SW ? (size_t)(2 * BM + BN) * BK * sizeof(f16) : (size_t)NS * STAGE1;
     // epilogue: every wave transposes its own accumulators through a private LDS strip of 32 rows x NG MFMA tiles
     // (fp32, +4 floats of padding per row) -- no workgroup barrier after the main loop
     static constexpr int NG0 = TN <= 4 ? TN : (TN + (TN + 3) / 4 - 1) / ((TN + 3) / 4);   // tiles per column group
@@ -164,7 +169,8 @@ struct TileCfg {
     // one workgroup per CU: operands go global -> LDS by LDS-DMA (no VGPR staging, no ds_write phase in which all
     // eight waves would leave the matrix pipe idle together); two per CU: register staging (the partner workgroup's
     // MFMAs cover the store phase)
-    static constexpr bool DMA = WG_PER_CU == 1;
+    static constexpr bool DMA = WG_PER_CU == 1 || SW;
+    static_assert(!SW || WG_PER_CU == 2, "the split-ring form exists for two workgroups per CU");
     static_assert(BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0 && BM % LROWS == 0 && BN % LROWS == 0, "tile shape");
     static_assert(LDS <= 163840, "LDS budget");
 };
@@ -216,8 +222,8 @@ gemm_f16_kernel(GemmArgs) {
     const int ld_stats = kp->ld_stats;
     const int m_base = kp->m_base, m_total = kp->m_total;
     // stage-major: stage s = [BM rows of A | BN rows of W] at smem + s * STAGE1
-    auto stA = [&](int buf) { return reinterpret_cast<f16*>(smem) + (size_t)buf * (BM + BN) * BK; };
-    auto stB = [&](int buf) { return reinterpret_cast<f16*>(smem) + ((size_t)buf * (BM + BN) + BM) * BK; };
+    auto stA = [&](int buf) { return reinterpret_cast<f16*>(smem) + (size_t)buf * (Cfg::SW ? BM : BM + BN) * BK; };
+    auto stB = [&](int buf) { return reinterpret_cast<f16*>(smem) + (Cfg::SW ? (size_t)2 * BM : (size_t)buf * (BM + BN) + BM) * BK; };
 
     // ---- XCD-aware block remap (bijective for any grid size) ----
     const int nwg = tiles_m * tiles_n;
@@ -404,6 +410,18 @@ gemm_f16_kernel(GemmArgs) {
         }
         next_k();
     };
+    // split-ring form: the A rows of the cursor's K-step into A stage `buf` (cursor moves on); the W rows of K-step kw into the W stage
+    // (dense / temporal / tap-major conv: K-step kw of a W row starts at byte kw * 2 BK)
+    auto load_a_only = [&](int buf) {
+        const unsigned soff_a = (unsigned)cb * 2u;
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PER_THREAD; ++i) dma16(rsA, stA(buf) + (LROWS * i + 8 * wave) * BK, voff_a[i], soff_a);
+        next_k();
+    };
+    auto load_w_only = [&](int kw) {
+#pragma unroll
+        for (int i = 0; i < B_ROWS_PER_THREAD; ++i) dma16(rsW, stB(0) + (LROWS * i + 8 * wave) * BK, b_off[i], (unsigned)kw * (BK * 2));
+    };
     auto store_lds = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ROWS_PER_THREAD; ++i) {
@@ -431,7 +449,10 @@ gemm_f16_kernel(GemmArgs) {
     // cursor moves one K-step on.
     DS_STAMP(0);
     if (first_tile) {
-        if constexpr (Cfg::DMA) {
+        if constexpr (Cfg::SW) {
+            load_global(0);                                  // A(0), W(0)
+            if (d.K / BK > 1) load_a_only(1);                // A(1)
+        } else if constexpr (Cfg::DMA) {
             for (int s0 = 0; s0 < NS - 1 && s0 < d.K / BK; ++s0) load_global(s0);   // NS-1 K-steps in flight
         } else {
             load_global(0);
@@ -584,11 +605,11 @@ gemm_f16_kernel(GemmArgs) {
 
     auto kstep = [&](int kt, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;   // K-step kt+NS-1 exists: stage it while computing this one
-        const int buf = kt % NS;
-        const int nbuf = (kt + NS - 1) % NS;               // its LDS stage (read last in step kt-1)
+        const int buf = Cfg::SW ? (kt & 1) : kt % NS;
+        const int nbuf = Cfg::SW ? buf : (kt + NS - 1) % NS;   // its LDS stage (read last in step kt-1; split-ring: A(kt+2) follows A(kt))
         if constexpr (!Cfg::DMA) {
             if (MORE) load_global(nbuf);
-        } else if constexpr (Cfg::HOIST_ALL) {
+        } else if constexpr (Cfg::HOIST_ALL && !Cfg::SW) {
             if (MORE) load_global(nbuf);                   // small wave tiles: the pieces go out in front of the reads
         }
         const f16* a_base = stA(buf) + wm * WM * BK;
@@ -672,7 +693,7 @@ gemm_f16_kernel(GemmArgs) {
                     if (n16 == 0) kstats(a_op, m16);
                     const int slot = f * S + si;
                     // piece j goes out behind MFMA slot ((j + 1) * PSPAN) / NPIECE - 1
-                    if (Cfg::DMA && MORE) {
+                    if (Cfg::DMA && !Cfg::SW && MORE) {
 #pragma unroll
                         for (int j = 0; j < NPIECE; ++j)
                             if (slot == ((j + 1) * PSPAN) / NPIECE - 1) {
@@ -684,7 +705,7 @@ gemm_f16_kernel(GemmArgs) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (Cfg::DMA) {
+            if constexpr (Cfg::DMA && !Cfg::SW) {
                 if (MORE) advance_k();
             }
         }
@@ -762,7 +783,28 @@ gemm_f16_kernel(GemmArgs) {
             }
         }
 #endif
-        stage_sync(nbuf, MORE);
+        if constexpr (Cfg::SW) {
+            // split ring: every wave is done with A(kt) and W(kt) -> W(kt+1) into the W stage, A(kt+2) into A(kt)'s stage; the counted
+            // wait leaves only the newest A pieces in flight (W(kt+1) and the older A(kt+1) have landed); second barrier: for every wave
+            if (kt + 1 < nk) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                load_w_only(kt + 1);
+                if (kt + 2 < nk) {
+                    load_a_only(buf);
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_ROWS_PER_THREAD) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            } else {
+                stage_sync(nbuf, false);
+            }
+        } else {
+            stage_sync(nbuf, MORE);
+        }
     };
 #ifdef DS_SETPRIO_HI       // A/B (build variant "setprio"): static priority for the second-dispatched half of an 8-wave workgroup
     if constexpr (WGM * WGN == 8) {
@@ -771,7 +813,9 @@ gemm_f16_kernel(GemmArgs) {
 #endif
     {
         int kt = 0;
-        for (; kt + NS - 1 < nk; ++kt) kstep(kt, std::true_type{});
+        if constexpr (!Cfg::SW) {
+            for (; kt + NS - 1 < nk; ++kt) kstep(kt, std::true_type{});
+        }
         for (; kt < nk; ++kt) kstep(kt, std::false_type{});
     }
 
@@ -1208,12 +1252,12 @@ gemm_f16_kernel(GemmArgs) {
     using R32 = std::integral_constant<int, 2>;
     if constexpr (ln_fold) {         // ds_gemm_f16_ln: no residual, no per-item bias (checked on the host)
         if (geglu) {
-            if constexpr (TN % 2 == 0) epilogue(std::true_type{}, R0{}, std::false_type{});
+            if constexpr (TN % 2 == 0 && BN % 320 != 0) epilogue(std::true_type{}, R0{}, std::false_type{});
         } else {
             epilogue(std::false_type{}, R0{}, std::false_type{});
         }
     } else if (geglu) {
-        if constexpr (TN % 2 == 0) {
+        if constexpr (TN % 2 == 0 && BN % 320 != 0) {
             if (residual) epilogue(std::true_type{}, R16{}, std::false_type{});     // fp16 residual only (checked on the host)
             else epilogue(std::true_type{}, R0{}, std::false_type{});
         }
@@ -1298,7 +1342,8 @@ int launch(const void* A, const void* W, const float* bias, const void* residual
 // Tile choice.  256-row tiles halve the operand bytes a CU pulls through its vector-memory path and LDS per MFMA
 // (profiles/r1_notes.md: on 128x128 tiles each of the three -- loads, LDS, MFMA -- is near its limit), but need one
 // workgroup per CU to have work: they are used when the grid still fills the chip.
-enum { TILE_128x64 = 0, TILE_128x128 = 1, TILE_256x256 = 2, TILE_256x320 = 3, TILE_128x128_DEEP = 4, TILE_128x64_DEEP = 5 };
+enum { TILE_128x64 = 0, TILE_128x128 = 1, TILE_256x256 = 2, TILE_256x320 = 3, TILE_128x128_DEEP = 4, TILE_128x64_DEEP = 5,
+       TILE_128x320_SW = 6, TILE_128x256_SW = 7 };   // split-ring forms, two workgroups per CU (TileCfg::SW)
 
 int choose_tile(const ds_gemm_desc& d) {
     const int forced = (int)DS_TUNE_INT("DS_GEMM_TILE", -1);
@@ -1319,7 +1364,10 @@ int choose_tile(const ds_gemm_desc& d) {
         else if (small == TILE_128x128 && nblk128 <= 256) small_or_deep = TILE_128x128_DEEP;
     }
     if (forced == TILE_128x128_DEEP || (forced == TILE_128x64_DEEP && !geglu)) return forced;
+    if (forced == TILE_128x320_SW && d.N % 320 == 0 && !geglu) return forced;
+    if (forced == TILE_128x256_SW && d.N % 256 == 0) return forced;
     if (big < 0) return small_or_deep;
+    if (forced == TILE_256x320 && d.N % 320 == 0 && !geglu) return TILE_256x320;      // (N = 1280 k: both big tiles apply)
     if (forced == TILE_256x256 || forced == TILE_256x320) return big;
     const long nblk = tiles_m256 * (d.N / (big == TILE_256x256 ? 256 : 320));
     const long big_min = DS_TUNE_INT("DS_GEMM_BIG_MIN", 160);
@@ -1330,6 +1378,14 @@ template <int AMODE>
 int dispatch(int tile, const void* A, const void* W, const float* bias, const void* residual, void* out,
              const ds_gemm_desc& d, hipStream_t st, const float* ln_stats = nullptr, const float* ln_colsum = nullptr, float ln_eps = 0.0f,
              StatOut so = StatOut()) {
+    // the split-ring forms stage W by K-step index: not for the taps-innermost K order; deep-K 3x3 convolutions keep the big tiles
+    if constexpr (AMODE == A_CONV3_TI || AMODE == DS_A_CONV3) {
+        if (tile == TILE_128x320_SW) tile = TILE_256x320;
+        if (tile == TILE_128x256_SW) tile = TILE_256x256;
+    } else {
+        if (tile == TILE_128x320_SW) return launch<128, 320, 4, 1, AMODE, 1>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
+        if (tile == TILE_128x256_SW) return launch<128, 256, 2, 2, AMODE, 1>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
+    }
     switch (tile) {
         case TILE_256x256: return launch<256, 256, 2, 4, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
         case TILE_256x320: return launch<256, 320, 4, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);

@@ -14,6 +14,8 @@
 
 namespace {
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int MAX_C = 4096;
 // Rows per partial-sum chunk: the unit of the statistics' summation order, so a function of the instance's SHAPE only (never of
 // the launch's instance count: a batch must equal its separate forwards bit for bit).  ~160 KB of fp16 per chunk -- 256 rows at
@@ -381,6 +383,200 @@ gn_small_kernel(const XT* __restrict__ x, const float* __restrict__ gamma, const
     }
 }
 
+// Mid-size instances (round 6): statistics and normalisation in ONE launch with the instance read ONCE.  A 512-thread workgroup owns
+// (instance, slab of `gslab` whole groups) for ALL rows of the instance and keeps its slab -- up to NCH rows x 16 bytes per thread,
+// ~410 KB per CU -- in REGISTERS between the statistics and the normalisation: 6 instead of 10 bytes of traffic per fp32 element (4
+// instead of 6 for fp16 rows), one launch instead of two.  Thread (col, rlane) owns one 16-byte column chunk of the slab and rows
+// rlane, rlane + rl, ...; per-thread sums in fp32 in row order, the (row lane x channel) partial sums of a group are added in fp64 by
+// one wave per group in a fixed order (strided lanes, xor butterfly): bitwise repeatable, and a function of the instance's shape
+// only.  The slabs of one instance sit on one XCD (consecutive dispatch slots there), so the 128-byte lines they share are fetched
+// into that L2 once and their narrow row pieces of the output meet in it before they are written back.
+template <typename XT> struct Chunk16;
+// (plain, not non-temporal accesses: the slabs of an instance share cache lines, read and written)
+template <> struct Chunk16<float> {
+    static constexpr int EPC = 4;
+    static __device__ __forceinline__ float get(const f32x4& v, int j) { return v[j]; }
+    // statistics units: 4 per chunk -- a channel each
+    static __device__ __forceinline__ void accum(const f32x4& v, float (&s)[4], float (&q)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += v[j]; q[j] = fmaf(v[j], v[j], q[j]); }
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, unsigned off, const float (&o)[4]) {
+        const f16x4 h = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, h), rs, off, 0, 0);
+    }
+};
+template <> struct Chunk16<f16> {
+    static constexpr int EPC = 8;
+    static __device__ __forceinline__ float get(const f32x4& v, int j) { return (float)__builtin_bit_cast(f16x8, v)[j]; }
+    // statistics units: 4 per chunk -- a PAIR of adjacent channels each (channels per group are even), summed by v_dot2_f32_f16
+    // (exact fp16 products, fp32 accumulate): no fp32 copy of the chunk is ever formed in the statistics pass
+    static __device__ __forceinline__ void accum(const f32x4& v, float (&s)[4], float (&q)[4]) {
+        const f16x8 h = __builtin_bit_cast(f16x8, v);
+        const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16x2 p = {h[2 * j], h[2 * j + 1]};
+            s[j] = __builtin_amdgcn_fdot2(p, one2, s[j], false);
+            q[j] = __builtin_amdgcn_fdot2(p, p, q[j], false);
+        }
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, unsigned off, const float (&o)[8]) {
+        const f16x8 h = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3], (f16)o[4], (f16)o[5], (f16)o[6], (f16)o[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, h), rs, off, 0, 0);
+    }
+};
+constexpr int GN_RES_NT = 512;
+constexpr int GN_RES_NCH_MAX = 52;
+typedef __attribute__((address_space(3))) void gn_lds_void;
+// LDS-DMA, 16 bytes per lane: lane l of the wave-instruction lands at dst + 16 l (dst wave-uniform); an out-of-range offset zero-fills
+__device__ __forceinline__ void gn_dma16(__amdgpu_buffer_rsrc_t rs, void* dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (gn_lds_void*)dst, 16, voff, 0, 0, 0);
+}
+
+// NCH chunks per thread, the LAST NL of them parked in LDS (fetched by LDS-DMA: no register ever holds them before the statistics pass
+// reads them back), the first NCH - NL in registers.  Every global access is a raw BUFFER access whose offset is out of range for rows
+// past the instance's end / idle threads (loads return zeros, stores are dropped): straight-line code, all loads in flight at once.
+template <typename XT, int NCH, int NL, bool SILU>
+__global__ void __launch_bounds__(GN_RES_NT)
+gn_resident_kernel(const XT* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, f16* __restrict__ y,
+                   f16* __restrict__ xraw, int rows, int C, int groups, float eps, int ldx, int gslab, int nslab, int ninst) {
+    typedef Chunk16<XT> CK;
+    constexpr int EPC = CK::EPC, NR = NCH - NL;
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) float red[GN_RES_NT * 4];
+    __shared__ float smean[8], srstd[8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char gn_park[];     // [NL][GN_RES_NT] chunks of 16 bytes
+    int inst, slab;
+    if ((ninst & 7) == 0) {            // blockIdx % 8 names the XCD: the slabs of an instance share one
+        const int r = blockIdx.x >> 3;
+        slab = r % nslab;
+        inst = (r / nslab) * 8 + (blockIdx.x & 7);
+    } else {
+        slab = blockIdx.x % nslab;
+        inst = blockIdx.x / nslab;
+    }
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cpg = C / groups, slab_ch = gslab * cpg, nch_row = slab_ch / EPC, rl = GN_RES_NT / nch_row;
+    const bool on = tid < rl * nch_row;
+    const int col = tid % nch_row, rlane = tid / nch_row;
+    const int c0 = slab * slab_ch + col * EPC;
+    const XT* pinst = x + (long)inst * rows * ldx;
+    const unsigned row_bytes = (unsigned)ldx * (unsigned)sizeof(XT), step_bytes = (unsigned)rl * row_bytes;
+    const unsigned off0 = (unsigned)rlane * row_bytes + (unsigned)c0 * (unsigned)sizeof(XT);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<XT*>(pinst), 0, (int)((unsigned)rows * row_bytes), 0x00020000);
+    // rows this thread holds: k < nk_mine (rlane + k rl < rows); idle threads none
+    const int nk_mine = on ? (rows - rlane + rl - 1) / rl : 0;
+    if constexpr (NL > 0) {
+#pragma unroll
+        for (int k = NR; k < NCH; ++k)
+            gn_dma16(rsx, gn_park + ((size_t)(k - NR) * GN_RES_NT + wave * 64) * 16, k < nk_mine ? off0 + (unsigned)k * step_bytes : OOB);
+    }
+    f32x4 v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+        v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, k < nk_mine ? off0 + (unsigned)k * step_bytes : OOB, 0, 0));
+    // statistics: 4 units per chunk (a channel for fp32 rows, a pair of channels for fp16 rows), upg units per group
+    constexpr int UPE = EPC / 4;                       // channels per unit
+    const int upg = cpg / UPE, slab_units = slab_ch / UPE;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < NR; ++k) CK::accum(v[k], s, q);
+    const f32x4* mine = reinterpret_cast<const f32x4*>(gn_park) + tid;     // this lane's parked chunks: written by its own DMA lane
+    if constexpr (NL > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < NL; ++k) CK::accum(mine[k * GN_RES_NT], s, q);
+    }
+    // (row lane x unit) partial sums -> one wave per group adds its rl x upg values in fp64, strided lanes then an xor butterfly: a
+    // fixed order.  Sums first, then squares through the same array (8 KB: the parked chunks take the rest of the LDS).
+    const int g_red = tid >> 6, lane_red = tid & 63;
+    double S = 0.0, Q = 0.0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (on) *reinterpret_cast<f32x4*>(red + rlane * slab_units + col * 4) = pass ? f32x4{q[0], q[1], q[2], q[3]} : f32x4{s[0], s[1], s[2], s[3]};
+        __syncthreads();
+        if (g_red < gslab) {
+            double acc = 0.0;
+            const int n = rl * upg;
+            for (int i = lane_red; i < n; i += 64) {
+                const int l = i / upg, j = i - l * upg;
+                acc += (double)red[l * slab_units + g_red * upg + j];
+            }
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) acc += __shfl_xor(acc, sh);
+            if (pass) Q = acc; else S = acc;
+        }
+        __syncthreads();
+    }
+    if (g_red < gslab && lane_red == 0) {
+        const double count = (double)rows * cpg;
+        const double m = S / count;
+        double var = Q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        smean[g_red] = (float)m;
+        srstd[g_red] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    float a[EPC], b[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+        const int cc = on ? c0 + j : 0;
+        const int g = on ? (col * EPC + j) / cpg : 0;
+        a[j] = srstd[g] * gamma[cc];
+        b[j] = beta[cc] - smean[g] * a[j];
+    }
+    // dense fp16 outputs [rows][C]: byte offset of this thread's chunk in row rlane, and the step between its rows
+    const unsigned out_row = (unsigned)C * 2u, out_step = (unsigned)rl * out_row;
+    const unsigned oo0 = (unsigned)rlane * out_row + (unsigned)c0 * 2u;
+    const unsigned out_bytes = (unsigned)rows * out_row;
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(y + (long)inst * rows * C, 0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(xraw ? xraw + (long)inst * rows * C : y, 0, xraw ? (int)out_bytes : 0, 0x00020000);
+    auto emit = [&](const f32x4& t, int k) {
+        const unsigned off = k < nk_mine ? oo0 + (unsigned)k * out_step : OOB;
+        float o[EPC], raw[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            const float f = CK::get(t, j);
+            float u = fmaf(f, a[j], b[j]);
+            if (SILU) u = fast_silu(u);
+            o[j] = u;
+            raw[j] = f;
+        }
+        CK::store(rsy, off, o);
+        if (xraw) CK::store(rsr, off, raw);
+    };
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        asm volatile("" : "+v"(v[k]));          // the raw chunk, not a converted copy kept from the statistics pass, is what stays live
+        emit(v[k], k);
+        if (EPC == 8 || (k & 1)) __builtin_amdgcn_sched_barrier(0);     // bounded interleaving: 8 values in flight hide the SiLU's latency, all chunks' would spill
+    }
+    if constexpr (NL > 0) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            emit(mine[k * GN_RES_NT], NR + k);
+            if (EPC == 8 || (k & 1)) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// groups per slab for the resident form, 0 = not applicable: whole groups, 16-byte column chunks, at most 8 groups (one reducing
+// wave each), the widest slab whose rows fit NCH_MAX x row lanes -- a function of (rows, C, groups, element size) only
+static inline int gn_resident_gslab(int rows, int C, int groups, int elt) {
+    const int cpg = C / groups, epc = 16 / elt;
+    int best = 0;
+    for (int g = 1; g <= 8 && g <= groups; g *= 2) {
+        if (groups % g || (g * cpg) % epc || (elt == 2 && (cpg & 1))) continue;     // (fp16 rows: the statistics add channel PAIRS)
+        const int nch_row = g * cpg / epc;
+        if (nch_row > GN_RES_NT) break;
+        const int rl = GN_RES_NT / nch_row;
+        if ((rows + rl - 1) / rl <= GN_RES_NCH_MAX) best = g;
+    }
+    return best;
+}
+
 // LayerNorm: one wave per row, NV 8-channel vectors per lane (C <= 512*NV), RW rows per wave with all their loads issued
 // before the first reduction (bytes in flight: the 320-channel rows of the first UNet level are only 640 B each).
 template <int NV, int RW, typename XT>
@@ -575,6 +771,36 @@ int groupnorm_rows(const XT* x, int ldx, const float* gamma, const float* beta, 
 #endif
         gn_small_kernel<XT><<<ninst, GN_SMALL_NT, 0, st>>>(x, gamma, beta, y, rows_per_inst, C, groups, silu, eps, ldx, x_f16);
         DS_CHECK_LAUNCH("ds_groupnorm(small)");
+        return DS_OK;
+    }
+    // mid-size instances (per-frame norms of levels 1-2, the joint-T norms of levels 3-4): one launch, the instance read once
+    const int gslab = DS_TUNE_INT("DS_GN_RESIDENT", 1) != 0 ? gn_resident_gslab(rows_per_inst, C, groups, (int)sizeof(XT)) : 0;
+    if (gslab > 0) {
+        const int cpg = C / groups, nch_row = gslab * cpg / (16 / (int)sizeof(XT)), rl = GN_RES_NT / nch_row;
+        const int rpt = (rows_per_inst + rl - 1) / rl, nslab = groups / gslab;
+        const long nwg = (long)ninst * nslab;
+        // rows per thread: 13 / 26 in registers; up to 52 as 36 in registers + 16 parked in LDS (128 KB)
+        auto go = [&](auto kern, size_t dyn) -> int {
+            if (dyn > 0) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+                        ds_set_error("ds_groupnorm(resident): hipFuncSetAttribute failed");
+                        return DS_ELAUNCH;
+                    }
+                    attr_set = true;
+                }
+            }
+            kern<<<nwg, GN_RES_NT, dyn, st>>>(x, gamma, beta, y, x_f16, rows_per_inst, C, groups, eps, ldx, gslab, nslab, ninst);
+            return DS_OK;
+        };
+        constexpr size_t PARK = (size_t)16 * GN_RES_NT * 16;
+        int rc;
+        if (rpt <= 13) rc = silu ? go(&gn_resident_kernel<XT, 13, 0, true>, 0) : go(&gn_resident_kernel<XT, 13, 0, false>, 0);
+        else if (rpt <= 26) rc = silu ? go(&gn_resident_kernel<XT, 26, 0, true>, 0) : go(&gn_resident_kernel<XT, 26, 0, false>, 0);
+        else rc = silu ? go(&gn_resident_kernel<XT, GN_RES_NCH_MAX, 16, true>, PARK) : go(&gn_resident_kernel<XT, GN_RES_NCH_MAX, 16, false>, PARK);
+        if (rc) return rc;
+        DS_CHECK_LAUNCH("ds_groupnorm(resident)");
         return DS_OK;
     }
     const int chunk_rows = gn_chunk_rows(rows_per_inst, C);

@@ -172,10 +172,12 @@ def all_gather_tiles(x_prev_local, x0_local, counts, group=None):
     rank = dist.get_rank(group)
     cmax = max(counts)
     tile_shape = tuple(x_prev_local.shape[1:])
-    send = torch.zeros((2, cmax) + tile_shape, dtype=x_prev_local.dtype, device=x_prev_local.device)
+    nt = 1 if x0_local is None else 2          # x0_local None: only the x_prev tiles travel (run_step need_x0=False)
+    send = torch.zeros((nt, cmax) + tile_shape, dtype=x_prev_local.dtype, device=x_prev_local.device)
     if counts[rank]:
         send[0, :counts[rank]] = x_prev_local
-        send[1, :counts[rank]] = x0_local
+        if nt == 2:
+            send[1, :counts[rank]] = x0_local
     recv = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
     if _HOST_STAGED and send.is_cuda:
         recv_h = torch.empty(recv.shape, dtype=recv.dtype)
@@ -184,7 +186,7 @@ def all_gather_tiles(x_prev_local, x0_local, counts, group=None):
     else:
         dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view((world,) + tuple(send.shape))
-    return [(x_prev_local, x0_local) if r == rank else (recv[r, 0, :counts[r]], recv[r, 1, :counts[r]]) for r in range(world)]
+    return [(x_prev_local, x0_local) if r == rank else (recv[r, 0, :counts[r]], recv[r, 1, :counts[r]] if nt == 2 else None) for r in range(world)]
 
 
 class EvalUnits:
@@ -230,7 +232,17 @@ def exchange_units(local, n_units, group=None):
     return out
 
 
-def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, group=None, units=None):
+def windows_cover(windows, pano_fhw):
+    """True when the union of the windows (left, right, top, down, f_begin, f_end; wrapped on the ring) is the whole panorama."""
+    import numpy as np
+    F, H, W = pano_fhw
+    seen = np.zeros((F, H, W), dtype=bool)
+    for (l, r, t, d, f0, f1) in windows:
+        seen[np.ix_(np.arange(f0, f1) % F, np.arange(t, d) % H, np.arange(l, r) % W)] = True
+    return bool(seen.all())
+
+
+def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, group=None, units=None, need_x0=True):
     """One DDIM step over `windows` (reference order), shared over `world` ranks -- the scheduling both the HIP pipelines
     (pipelines._denoise_windows) and the CPU rehearsal (tests/test_parallel_gloo.py) run.
       process(ids) -> (x_prev, x0) tiles [len(ids), ...] of the windows `ids` (pairwise disjoint, in the given order)
@@ -238,6 +250,9 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
                                      scatter has no order among its windows)
       empty_tiles()                  -> a [0, ...] tile tensor (dtype / device of the tiles)
       units                          EvalUnits or None: lets a level with fewer tiles than ranks be shared out by evaluation
+      need_x0                        False: the other ranks' pred-x0 tiles are neither exchanged nor scattered (scatter gets x0 = None for
+                                     them) -- the pred-x0 panorama is only read when a loop ends, so a loop whose LAST step's
+                                     windows cover the panorama (windows_cover) exchanges it on that step only: half the bytes per step
     Returns the mode used: "single", "components", "levels" or "units" (at least one level shared out by evaluation)."""
     levels = plan_levels(windows, pano_fhw)
     if world <= 1:
@@ -262,6 +277,8 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
         counts = [sum(len(ids) for ids in by_level[r]) for r in range(world)]
         xp_l = torch.cat(mine_xp, 0) if mine_xp else empty_tiles()
         x0_l = torch.cat(mine_x0, 0) if mine_x0 else empty_tiles()
+        if not need_x0:
+            x0_l = None
         parts = _exchange(lambda: all_gather_tiles(xp_l, x0_l, counts, group), xp_l, x0_l)    # the step's ONE exchange
         # the other ranks' tiles go into this replica LEVEL BY LEVEL: one scatter call only ever holds pairwise-disjoint
         # windows (a component's later level overwrites part of its earlier one, and a batched scatter has no order)
@@ -274,9 +291,10 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
                 n = len(by_level[r][li])
                 ids += by_level[r][li]
                 xs.append(parts[r][0][off:off + n])
-                x0s.append(parts[r][1][off:off + n])
+                if need_x0:
+                    x0s.append(parts[r][1][off:off + n])
             if ids:
-                scatter(ids, torch.cat(xs, 0), torch.cat(x0s, 0))
+                scatter(ids, torch.cat(xs, 0), torch.cat(x0s, 0) if need_x0 else None)
         return "components"
     mode = "levels"
     for level in levels:
@@ -295,6 +313,8 @@ def run_step(windows, pano_fhw, rank, world, process, scatter, empty_tiles, grou
         ids = rank_share(level, rank, world)
         _account("tiles_owned", len(ids))
         xp, x0 = process(ids) if ids else (empty_tiles(), empty_tiles())
+        if not need_x0:
+            x0 = None
         xp_all, x0_all = _exchange(lambda: exchange_level(xp, x0, len(level), group), xp, x0)
         scatter(level, xp_all, x0_all)
     return mode
@@ -311,11 +331,13 @@ def exchange_level(x_prev_local, x0_local, n_items, group=None, force=False):
     counts = share_counts(n_items, world)
     cmax = max(counts)
     tile_shape = tuple(x_prev_local.shape[1:])
-    send = torch.zeros((2, cmax) + tile_shape, dtype=x_prev_local.dtype, device=x_prev_local.device)
+    nt = 1 if x0_local is None else 2          # x0_local None: x_prev tiles only (returns x0_all = None)
+    send = torch.zeros((nt, cmax) + tile_shape, dtype=x_prev_local.dtype, device=x_prev_local.device)
     n_local = counts[rank]
     if n_local:
         send[0, :n_local] = x_prev_local
-        send[1, :n_local] = x0_local
+        if nt == 2:
+            send[1, :n_local] = x0_local
     # output = concatenation along dim 0 (the form both RCCL and gloo accept), viewed back as [world, 2, cmax, ...]
     recv = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
     if _HOST_STAGED and send.is_cuda:
@@ -326,11 +348,12 @@ def exchange_level(x_prev_local, x0_local, n_items, group=None, force=False):
         dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view((world,) + tuple(send.shape))
     x_prev_all = torch.empty((n_items,) + tile_shape, dtype=send.dtype, device=send.device)
-    x0_all = torch.empty_like(x_prev_all)
+    x0_all = torch.empty_like(x_prev_all) if nt == 2 else None
     for r in range(world):
         if counts[r]:
             x_prev_all[r::world] = recv[r, 0, :counts[r]]
-            x0_all[r::world] = recv[r, 1, :counts[r]]
+            if nt == 2:
+                x0_all[r::world] = recv[r, 1, :counts[r]]
     return x_prev_all, x0_all
 
 

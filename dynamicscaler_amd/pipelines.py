@@ -107,6 +107,9 @@ class VC2_Pipeline_T2V:
         # A wide step costs several times an fp16-mode step (3 MFMAs per product on a plain register-staged kernel, fp32 attention
         # and norms); its windows are evaluated `wide_tile_batch` at a time (fp32 operands: 32-bit buffer addressing bounds a
         # launch's A operand).
+        # several ranks: "last" = pred-x0 tiles are exchanged on the loop's last step only (when that step's windows cover the
+        # panorama); "every" = on every step (a step callback that reads the pred-x0 panorama needs this; the loops set it then)
+        self.exchange_x0 = os.environ.get("DS_EXCHANGE_X0", "last")
         self.operand_policy = os.environ.get("DS_OPERAND_POLICY", "auto")
         self.operand_budget = 1e-3
         self.wide_tile_batch = 1
@@ -478,16 +481,21 @@ class VC2_Pipeline_T2V:
             for s in range(0, len(ids), ops.DS_MAX_WINDOWS):
                 part = ids[s:s + ops.DS_MAX_WINDOWS]
                 origins = [(wins[j][4], wins[j][2], wins[j][0]) for j in part]
-                ops.ring_scatter3(pano, st.pano_x0, mask, xp[s:s + len(part)].contiguous(), x0[s:s + len(part)].contiguous(),
-                                  origins)
+                # x0 None: another rank's tiles on a step that does not exchange pred-x0 (see need_x0 below)
+                ops.ring_scatter3(pano, st.pano_x0 if x0 is not None else None, mask, xp[s:s + len(part)].contiguous(),
+                                  None if x0 is None else x0[s:s + len(part)].contiguous(), origins)
 
         def empty_tiles():
             return torch.empty((0,) + st.tile_shape[1:], dtype=pano.dtype, device=device)
 
         # levels of pairwise-disjoint windows; over several ranks whole components (columns) per rank with one exchange
         # per step, or a strided share of every level (parallel.run_step)
+        # The pred-x0 panorama is read when the loop ends (or by a step callback), never by the next step: where the loop's LAST step
+        # covers the whole panorama (st.x0_last_only, set by the ring loops from their window grid) only that step exchanges pred-x0
+        # tiles -- until then a rank's pred-x0 replica is complete only over the tiles it computed itself.
+        need_x0 = not (st.world > 1 and getattr(st, "x0_last_only", False) and i < st.total_steps - 1)
         st.share_mode = self.last_share_mode = parallel.run_step(wins, st.pano_fhw, st.rank, st.world, process, scatter, empty_tiles,
-                                                                      units=units)
+                                                                      units=units, need_x0=need_x0)
 
     def _new_state(self, init_panorama_latent, total_shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale,
                    text_emb, uc_emb, ratio, kwargs):
@@ -685,6 +693,8 @@ class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
                              merge_renoised_overlap_latent_ratio=merge_renoised_overlap_latent_ratio,
                              window_multi_prompt_dict=window_multi_prompt_dict, use_skip_time=use_skip_time,
                              skip_time_step_idx=skip_time_step_idx, progressive_skip=progressive_skip, **kwargs)
+        if step_callback is not None:
+            st.x0_last_only = False          # the callback sees the pred-x0 panorama of every step: exchange it on every step
         with self.progress_bar(total=len(st.timesteps)) as bar:
             for i in range(len(st.timesteps)):
                 wins = self.ring_step(st, i)
@@ -744,6 +754,12 @@ class VC2_Pipeline_T2V_SpherePano(VC2_Pipeline_T2V):
                                 total_latent_h=st.total_lat_h, step_w=st.step_w, step_h=st.step_h, off_w=st.off_w,
                                 off_h=st.off_h, step_f=st.step_f, num_windows_w=st.nw, num_windows_h=st.nh,
                                 num_windows_f=st.nf, loop_step=st.loop_step, dock_at_h=st.dock_at_h)
+        if st.world > 1 and not hasattr(st, "x0_last_only"):
+            last = t2v_ring_windows(st.total_steps - 1, latent_h=st.lat_h, latent_w=st.lat_w, frames=st.frames,
+                                    total_latent_h=st.total_lat_h, step_w=st.step_w, step_h=st.step_h, off_w=st.off_w,
+                                    off_h=st.off_h, step_f=st.step_f, num_windows_w=st.nw, num_windows_h=st.nh,
+                                    num_windows_f=st.nf, loop_step=st.loop_step, dock_at_h=st.dock_at_h)
+            st.x0_last_only = self.exchange_x0 == "last" and parallel.windows_cover(last, st.pano_fhw)
         renoise = st.ratio is not None and i < st.total_steps - 1
         # per-window prompt (R13): embeddings cached per distinct prompt instead of re-running CLIP per tile
         ctxs = []

@@ -197,6 +197,8 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
                              window_multi_prompt_dict=window_multi_prompt_dict, use_skip_time=use_skip_time,
                              skip_time_step_idx=skip_time_step_idx, progressive_skip=progressive_skip,
                              pano_image_tensor=pano_image_tensor, **kwargs)
+        if step_callback is not None:
+            st.x0_last_only = False          # the callback sees the pred-x0 panorama of every step: exchange it on every step
         with self.progress_bar(total=st.total_steps) as bar:
             for i in range(st.total_steps):
                 wins = self.ring_step(st, i)
@@ -282,6 +284,11 @@ class VC2_Pipeline_I2V_SpherePano(VC2_Pipeline_I2V):
         vs = self.vae_scale_factor
         st.mask.zero_()  # reset denoised mask record (:810)
         wins = i2v_ring_windows(i, overlap_ratio_f=st.overlap_ratio_list_f[i], **st.win_args)
+        if st.world > 1 and not hasattr(st, "x0_last_only"):
+            from . import parallel
+            last_i = st.total_steps - 1
+            st.x0_last_only = self.exchange_x0 == "last" and parallel.windows_cover(
+                i2v_ring_windows(last_i, overlap_ratio_f=st.overlap_ratio_list_f[last_i], **st.win_args), st.pano_fhw)
         ctxs = []
         new = [k for k in dict.fromkeys((w[0], w[2]) for w in wins) if k not in st.img_cache]   # crops not embedded yet: one tower pass
         if new:

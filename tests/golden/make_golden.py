@@ -998,6 +998,55 @@ def g35_cfg3_real_unet_two_steps():
         json.dump({"geom": geom, "trace": trace[:CFG3_REAL_STEPS]}, f)
 
 
+CFG5_CHAIN_SKIP, CFG5_CHAIN_STEPS = 24, 2
+
+
+def g41_cfg5_chain_real_unet():
+    """Config 5's DEPENDENCY SHAPE with the real UNet: the reference's t2v ring loop (pipeline/t2v_sphere_panorama_pipeline.py:437-476,
+    481-634) on BASELINE config 5's window grid cut to two columns -- 1024 x 1024 x 24f, 2 x 4 shifted windows of 512 x 320 x 24 frames
+    (num_windows_h = 4: chains of FOUR vertically overlapping, dependent tiles per column; the UNet runs at T = 24,
+    lvdm/modules/networks/openaimodel3d.py:657-708), loop_step 8, CFG 7.5, the 50-step schedule -- entered through use_skip_time at
+    step 24 (schedule indices 25, 24): two whole steps of 8 windows; the loop's own counter restarts at 0, so the first step has no
+    offset and the second is shifted by 1/8 window step in W and H: its bottom row (top 3 + 3 x 29 = 90, 40 rows of a 128-row latent)
+    wraps across the H seam.  Panorama latent after each step and the pred-x0 panorama after the second; 32 forwards of the reference
+    at T = 24 on CPU."""
+    params = yaml.safe_load(open(os.path.join(REFERENCE_ROOT, "configs/inference_t2v_512_v2.0.yaml")))
+    params = params["model"]["params"]["unet_config"]["params"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+    dry = os.environ.get("GOLDEN_DRY") == "1"
+    if dry:
+        params = dict(TINY)
+    unet = build_reference_unet(params, seed=0)
+    cd = params["context_dim"]
+    cond, uncond = synth_normal((1, 77, cd), 1), synth_normal((1, 77, cd), 2)
+    ld = FakeLatentDiffusion(WrappedUNet(unet), cond, uncond, temporal_length=24)
+    geom = dict(height=320, width=512, frames=24, total_w=1024, total_h=1024, num_windows_w=2, num_windows_h=4, num_windows_f=1, loop_step=8,
+                num_inference_steps=50)
+    shape = (1, 4, 24, geom["total_h"] // 8, geom["total_w"] // 8)
+    sched = lvdm_DDIM_Scheduler(ld)
+    sched.make_schedule(50)
+    first_index = 49 - CFG5_CHAIN_SKIP
+    init = _late_latent(sched, shape, first_index, 2333370)
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld), {"params": {"unet_config": {"params": params}}})
+    kw = dict(prompt="a prompt", output_type="latent", fps=8, guidance_scale=7.5, init_panorama_latent=init.clone(),
+              use_skip_time=True, skip_time_step_idx=CFG5_CHAIN_SKIP, **geom)
+    torch.manual_seed(2333333)
+    snaps, trace, out = _record_ring_run(lambda: pipe.basic_sample_shift_multi_windows(**kw), CFG5_CHAIN_STEPS)
+    assert len(snaps) == CFG5_CHAIN_STEPS and out is None
+    A = {"fps": np.int64(8), "guidance": np.float32(7.5), "steps": np.int64(CFG5_CHAIN_STEPS), "skip": np.int64(CFG5_CHAIN_SKIP),
+         "first_index": np.int64(first_index), "init": init.numpy().astype(np.float16)}
+    assert np.array_equal(A["init"].astype(np.float32), init.numpy())
+    for k, (x, x0) in enumerate(snaps):
+        A[f"pano_{k}"] = _trim16(x)
+    A[f"x0_{CFG5_CHAIN_STEPS - 1}"] = _trim16(snaps[-1][1])
+    if dry:
+        print("dry run ok", [float(np.std(A[f"pano_{k}"])) for k in range(CFG5_CHAIN_STEPS)], len(trace[0]["windows"]), trace[1]["windows"])
+        return
+    save_npz("cfg5_chain_real_unet.npz", **A)
+    with open(os.path.join(HERE, "cfg5_chain_real_unet_trace.json"), "w") as f:
+        json.dump({"geom": geom, "trace": trace[:CFG5_CHAIN_STEPS]}, f)
+
+
 def g36_cfg4_real_unet_one_step():
     """BASELINE config 4's geometry with the real i2v UNet: the reference's i2v ring loop (pipeline/i2v_sphere_panorama_pipeline.py:777-970)
     on 4096 x 512 x 16f, 8 x 2 shifted windows, per-window 16 image tokens from the crop of a (synthetic) 4096 x 512 panorama image under
@@ -2148,6 +2197,7 @@ if __name__ == "__main__":
         steps["g34"] = g34_i2v_ring_real_unet_50step_mid
         steps["g35"] = g35_cfg3_real_unet_two_steps
         steps["g36"] = g36_cfg4_real_unet_one_step
+        steps["g41"] = g41_cfg5_chain_real_unet
         steps["g37"] = g37_sphere_real_unet
         steps["g38"] = g38_grid_real_unet
         steps["g39"] = g39_i2v_sphere_real_unet

@@ -455,7 +455,10 @@ def test_temporal_attention(T):
 
 
 # ------------------------------------------------------------------------------------------------ norms / misc
-@pytest.mark.parametrize("ninst,rows,C", [(6, 80, 320), (2, 4 * 80, 64), (3, 40, 2560), (2, 700, 1920), (5, 33, 128)])
+# (from (8, 2560, 320) on: the one-launch register-resident form of round 6 -- 52 / 26 / 13 rows per thread, instance counts that are and
+#  are not multiples of 8 (the XCD-aware slab placement), the joint-T shape of level 3)
+@pytest.mark.parametrize("ninst,rows,C", [(6, 80, 320), (2, 4 * 80, 64), (3, 40, 2560), (2, 700, 1920), (5, 33, 128),
+                                          (8, 2560, 320), (3, 2560, 320), (16, 640, 640), (5, 640, 1280), (4, 2560, 1280), (16, 300, 640), (2, 2551, 640)])
 @pytest.mark.parametrize("silu", [False, True])
 def test_groupnorm(ninst, rows, C, silu):
     from dynamicscaler_amd import ops
@@ -554,7 +557,9 @@ def test_gemm_fp32_residual_rejects_unsupported():
         ops.gemm(A, W[:64].contiguous(), torch.zeros((2, 64), device=d), R, M=64, N=64, K=64, bias_rows=32, ldbias=64)
 
 
-@pytest.mark.parametrize("ninst,rows,C", [(6, 80, 320), (2, 4 * 80, 64), (3, 40, 2560), (2, 700, 1920), (70, 33, 128), (64, 160, 1280)])
+@pytest.mark.parametrize("ninst,rows,C", [(6, 80, 320), (2, 4 * 80, 64), (3, 40, 2560), (2, 700, 1920), (70, 33, 128), (64, 160, 1280),
+                                          (8, 2560, 320), (3, 2560, 320), (16, 640, 640), (5, 640, 1280), (4, 2560, 1280), (16, 300, 640), (2, 2551, 640),
+                                          (3, 640, 2560), (2, 640, 1920)])
 @pytest.mark.parametrize("silu", [False, True])
 def test_groupnorm_fp32_input(ninst, rows, C, silu):
     """ds_groupnorm_rows with DS_F32 rows (the fp32 residual stream): statistics and normalisation from the unrounded values,

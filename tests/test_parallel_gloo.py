@@ -17,7 +17,7 @@ def _update(tile, j):
     return tile * 0.5 + (j + 1), tile * 0.25 - (j + 1)
 
 
-def _run_step(pano, pano_x0, wins, pano_fhw, rank, world, with_units=False):
+def _run_step(pano, pano_x0, wins, pano_fhw, rank, world, with_units=False, need_x0=True):
     """parallel.run_step -- the scheduling the HIP pipelines run -- with a CPU stand-in for the tile compute.
     with_units: also hand over the per-evaluation stages (parallel.EvalUnits), the stand-in's two "branches" being the two
     halves of _update -- what lets a level with fewer tiles than ranks be shared out by evaluation (the CFG split)."""
@@ -54,12 +54,13 @@ def _run_step(pano, pano_x0, wins, pano_fhw, rank, world, with_units=False):
         for n, j in reversed(list(enumerate(ids))):          # ... so any order within a call gives the same panorama
             l, r, t, d, fb, fe = wins[j]
             oring.ring_scatter(pano, xp[n:n + 1], l, r, t, d, fb, fe)
-            oring.ring_scatter(pano_x0, x0[n:n + 1], l, r, t, d, fb, fe)
+            if x0 is not None:                                # None: another rank's tiles on a step that does not exchange pred-x0
+                oring.ring_scatter(pano_x0, x0[n:n + 1], l, r, t, d, fb, fe)
 
-    return parallel.run_step(wins, pano_fhw, rank, world, process, scatter, lambda: torch.empty(shape), units=units)
+    return parallel.run_step(wins, pano_fhw, rank, world, process, scatter, lambda: torch.empty(shape), units=units, need_x0=need_x0)
 
 
-def _worker(rank, world, port, steps, geom_name, out, with_units=False):
+def _worker(rank, world, port, steps, geom_name, out, with_units=False, x0_last_only=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -72,8 +73,12 @@ def _worker(rank, world, port, steps, geom_name, out, with_units=False):
     modes = set()
     from dynamicscaler_amd import parallel
     prof = parallel.profile_begin()           # the per-rank account bench.py reports (per_rank)
-    for step in rec["trace"][:steps]:
-        modes.add(_run_step(pano, pano_x0, [tuple(w) for w in step["windows"]], fhw, rank, world, with_units))
+    for k, step in enumerate(rec["trace"][:steps]):
+        wins = [tuple(w) for w in step["windows"]]
+        need_x0 = True
+        if x0_last_only and parallel.windows_cover([tuple(w) for w in rec["trace"][steps - 1]["windows"]], fhw):
+            need_x0 = k == steps - 1           # the pipelines' rule: pred-x0 tiles travel on the last step only, if that step covers the panorama
+        modes.add(_run_step(pano, pano_x0, wins, fhw, rank, world, with_units, need_x0=need_x0))
     parallel.profile_end()
     out[rank] = (pano, pano_x0, sorted(modes), dict(prof), len(rec["trace"][0]["windows"]))
     if world > 1:
@@ -118,6 +123,37 @@ def test_ranks_equal_single_process(geom_name, steps, world, mode, with_units):
     else:
         assert sum(2 * p["tiles_owned"] + p["units_owned"] for p in profs) == 2 * steps * ntiles
     assert all(p["exchange_s"] > 0 and p["exchange_bytes"] >= 0 for p in profs)
+
+
+@pytest.mark.parametrize("geom_name,steps,world,with_units", [("cfg3_4096x512", 3, 2, False), ("cfg3_overlap_nw10", 3, 2, False), ("cfg2_2048x512", 3, 5, True)])
+def test_pred_x0_exchanged_on_the_last_step_only(geom_name, steps, world, with_units):
+    """need_x0=False on every step but the last (parallel.run_step; SURVEY 8-e: P_denoised is only needed when the loop ends): after the last
+    step every rank's pred-x0 AND latent replicas equal the single-process panoramas, with fewer bytes exchanged than with x0 on every step."""
+    mgr = mp.Manager()
+    single = mgr.dict()
+    _worker(0, 1, 0, steps, geom_name, single)
+    every, last = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), steps, geom_name, every, with_units, False), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, geom_name, last, with_units, True), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.equal(last[r][0], single[0][0]) and torch.equal(last[r][1], single[0][1]), r
+    b_every, b_last = sum(every[r][3]["exchange_bytes"] for r in range(world)), sum(last[r][3]["exchange_bytes"] for r in range(world))
+    from dynamicscaler_amd import parallel
+    rec = json.load(open(os.path.join(G, "loop_traces.json")))[geom_name]
+    g = rec["geom"]
+    covered = parallel.windows_cover([tuple(w) for w in rec["trace"][steps - 1]["windows"]], (g["frames"], g["total_h"] // 8, g["total_w"] // 8))
+    assert covered == (geom_name != "cfg3_overlap_nw10")      # that grid leaves rows of the panorama untouched: pred-x0 travels on every step there
+    if covered and "units" not in every[0][2]:   # (a level shared out by evaluation exchanges eps tensors, not tiles: nothing to save there)
+        assert b_last < b_every, (b_last, b_every)
+    elif not covered:
+        assert b_last == b_every
+
+
+def test_windows_cover():
+    from dynamicscaler_amd import parallel
+    assert parallel.windows_cover([(0, 8, 0, 4, 0, 2), (8, 16, 0, 4, 0, 2)], (2, 4, 16))
+    assert parallel.windows_cover([(12, 20, 2, 6, 0, 2), (4, 12, 2, 6, 0, 2)], (2, 4, 16))          # wrapped in W and H
+    assert not parallel.windows_cover([(0, 8, 0, 4, 0, 2), (8, 15, 0, 4, 0, 2)], (2, 4, 16))
 
 
 def test_plan_components_and_owners():

@@ -3,7 +3,7 @@ default choose_tile pick against each tile id that applies.  Uses the "tune" bui
 process: one child process per tile id):   python tools/bench_tile_choice.py [evals=2]"""
 import hashlib, json, os, subprocess, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TILES = {-1: "default", -2: "default(2)", 0: "128x64", 1: "128x128", 2: "256x256", 3: "256x320", 4: "128x128deep", 5: "128x64deep"}
+TILES = {-1: "default", -2: "default(2)", 0: "128x64", 1: "128x128", 2: "256x256", 3: "256x320", 4: "128x128deep", 5: "128x64deep", 6: "128x320sw", 7: "128x256sw"}
 if "--child" not in sys.argv:
     E = sys.argv[1] if len(sys.argv) > 1 else "2"
     table = {}
