@@ -283,6 +283,14 @@ def main():
     sched = pipe.scheduler
     st = begin_state()
     wide_steps_of_schedule = pipe.wide_steps_of(GEOM["num_inference_steps"], 7.5)
+    strict_steps_of_schedule = pipe.strict_steps_of(GEOM["num_inference_steps"], 7.5)
+    # The operand policy (calibrated on this UNet by ring_begin) may put the schedule's FIRST steps on another rung (strict: +12 %, wide:
+    # 3.7x).  The timed region measures the own-mode steps -- the other 48-50 of the schedule -- and starts behind them; the complete
+    # 50-step panorama below is timed with every step in the mode the policy gives it, and one step per rung is timed separately.
+    NSTEPS_ = GEOM["num_inference_steps"]
+    lead_steps = 0
+    while lead_steps < NSTEPS_ - 1 and pipe.precision_for(NSTEPS_ - 1 - lead_steps, 7.5) is not None:
+        lead_steps += 1
 
     def barrier():
         if world > 1:
@@ -343,9 +351,10 @@ def main():
 
     nsched = GEOM["num_inference_steps"] - 1      # steps 0..48 re-noise the overlaps; the last step of a schedule does not,
     phase[0] = "warm-up + timed steps"            # so a run longer than one panorama wraps around before it
-    elapsed, step_idx = timed_steps(pipe, st, 0, args.warmup, args.steps, nsched)
+    elapsed, step_idx = timed_steps(pipe, st, lead_steps, args.warmup, args.steps, nsched)
     assert bool(torch.isfinite(st.pano.float()).all()), "non-finite latent after the timed steps"
-    assert pipe.wide_steps_run == [] or pipe.operand_policy != "auto", pipe.wide_steps_run
+    if pipe.operand_policy == "auto":         # every warm-up / timed step ran in the model's own mode
+        assert all(pipe.precision_for(NSTEPS_ - 1 - (k % nsched), 7.5) is None for k in range(lead_steps, step_idx)), (lead_steps, step_idx)
     # what the job computed, so that runs can be compared: the panorama latent after warmup + timed steps is a function of
     # (config, warmup, steps, latents, residual mode) only -- not of --gpus, --tile-batch, --streams or --graph (rank sharding
     # and batching are bit-exact: tests/test_gpu_fullsize.py, test_gpu_multirank.py)
@@ -583,25 +592,28 @@ def main():
 
     # ---- one step of the same panorama in the WIDE operand mode (outside the reported region): what a step costs where the operand
     #      policy selects it -- none of the 50-step schedule at CFG 7.5 (config.wide_steps_of_schedule), config 1's first three ----
-    wide_step_ms = None
+    wide_step_ms, strict_step_ms, own_step_eager_ms = None, None, None
     if (args.wide_step > 0 or (args.wide_step < 0 and world == 1 and not profiled)) and args.config != "cfg5":
-        phase[0] = "wide-mode step"
         pipe.num_streams, pipe.use_graph = args.streams, False
         pol = pipe.operand_policy
-        pipe.operand_policy = "wide"
-        try:
-            stw = begin_state()
-            pipe.ring_step(stw, 0)             # packs the twin's hi + lo planes, loads the kernels
-            barrier()
-            t_ = time.perf_counter()
-            pipe.ring_step(stw, 1)
-            barrier()
-            wide_step_ms = round(1e3 * max_over_ranks(time.perf_counter() - t_), 1)
-            assert bool(torch.isfinite(stw.pano.float()).all())
-            del stw
-        finally:
-            pipe.operand_policy = pol
-        unet._twins.clear()                    # the twin's 5.3 GB of planes are not needed any more
+        rung_ms = {}
+        for rung in ("f16", "strict", "wide"):      # eager launches for all three, so that the ratios compare like with like
+            phase[0] = f"{rung}-rung step"
+            pipe.operand_policy = rung
+            try:
+                stw = begin_state()
+                pipe.ring_step(stw, 0)             # packs the twin's image (strict: a second fp16 image; wide: hi + lo planes), loads the kernels
+                barrier()
+                t_ = time.perf_counter()
+                pipe.ring_step(stw, 1)
+                barrier()
+                rung_ms[rung] = round(1e3 * max_over_ranks(time.perf_counter() - t_), 1)
+                assert bool(torch.isfinite(stw.pano.float()).all())
+                del stw
+            finally:
+                pipe.operand_policy = pol
+        own_step_eager_ms, strict_step_ms, wide_step_ms = rung_ms["f16"], rung_ms["strict"], rung_ms["wide"]
+        unet._twins.clear()                    # the twins' packed images (2.6 + 5.3 GB) are not needed any more
         torch.cuda.empty_cache()
 
     # ---- the other BASELINE configurations one GPU can run (cfg2 / cfg4 / cfg5): W = 1 + K = 2 steps each, same bracketing, so
@@ -787,6 +799,24 @@ def main():
             "sec_per_step": round(t_step, 1),
         }
 
+    # what the operand policy decided, on which (calibrated) figures; and what a 25- / 40-step schedule costs with the strict rung tried
+    # before the wide one against round 5's wide-only ladder (from the three eager single-step figures above)
+    operand_report = pipe.operand_report(NSTEPS_, 7.5)
+    short_schedule_cost = None
+    if wide_step_ms is not None:
+        short_schedule_cost = {}
+        keep_rungs = pipe.operand_rungs
+        for n_ in (25, 40):
+            sched.make_schedule(n_, verbose=False)
+            row = {}
+            for name_, rungs_ in (("strict_first", ("strict", "wide")), ("wide_only", ("wide",))):
+                pipe.operand_rungs = rungs_
+                ns_, nw_ = len(pipe.strict_steps_of(n_, 7.5)), len(pipe.wide_steps_of(n_, 7.5))
+                row[name_] = {"strict_steps": ns_, "wide_steps": nw_,
+                              "sec_per_panorama": round(1e-3 * (ns_ * strict_step_ms + nw_ * wide_step_ms + (n_ - ns_ - nw_) * own_step_eager_ms), 2)}
+            short_schedule_cost[f"{n_}_steps"] = row
+        pipe.operand_rungs = keep_rungs
+        sched.make_schedule(NSTEPS_, verbose=False)
     if rank == 0:
         line = {
             "metric": f"denoising-steps/sec (whole node), {cfg['size']} panorama", "value": steps_per_s,
@@ -804,10 +834,15 @@ def main():
                        # which steps of the schedule the operand policy evaluates in the wide mode (fp32 storage, split-fp16 products:
                        # csrc/wide.hip) -- by schedule index, per DDIM step; [] = every step on single fp16 operands -- and what one
                        # such step of this panorama costs (measured outside the reported region)
-                       "operand_policy": pipe.operand_policy, "wide_steps_of_schedule": wide_steps_of_schedule,
-                       "operand_mode_per_step": "f16 operands at every step of the 50-step schedule" if not wide_steps_of_schedule else
-                                                f"wide at schedule indices {wide_steps_of_schedule}, f16 operands elsewhere",
-                       "wide_step_ms": wide_step_ms,
+                       "operand_policy": operand_report, "wide_steps_of_schedule": wide_steps_of_schedule,
+                       "strict_steps_of_schedule": strict_steps_of_schedule,
+                       "operand_mode_per_step": (f"strict rung (fp32 residual stream, fp16 operands) at schedule indices {strict_steps_of_schedule}, "
+                                                 if strict_steps_of_schedule else "") +
+                                                (f"wide at schedule indices {wide_steps_of_schedule}, " if wide_steps_of_schedule else "") +
+                                                "the model's own mode (fp16 operands) at every other step of the 50-step schedule",
+                       "timed_region_starts_at_step": lead_steps,
+                       "wide_step_ms": wide_step_ms, "strict_step_ms": strict_step_ms, "own_mode_step_eager_ms": own_step_eager_ms,
+                       "short_schedule_cost": short_schedule_cost,
                        "residual_stream": ("fp16 (matrix-core operands are fp16 in every mode)" if unet.residual_dtype == torch.float16 else
                                            "fp32 between the blocks, fp16 inside the transformers (DS_RESIDUAL_DTYPE=f32outer)"
                                            if unet.residual_scope == "outer" else "fp32 everywhere (strict precision mode, DS_RESIDUAL_DTYPE=f32)"),

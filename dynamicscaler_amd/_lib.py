@@ -85,6 +85,8 @@ SIGNATURES = {
     "ds_gemm_has_stats": (_i, []),
     "ds_set_launch_share": (_i, [_i]),
     "ds_gemm_f16_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _pp(GemmDesc), _vp]),
+    "ds_groupnorm_onepass_applies": (_i, [_i, _i, _i, _i]),
+    "ds_groupnorm_rows_onepass": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "ds_groupnorm_rows_colstats": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "ds_gemm_f16_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),
     "ds_gemm_f16_lnk": (_i, [_vp, _vp, _f, _vp, _vp, _vp, C.POINTER(GemmDesc), _vp]),

@@ -54,6 +54,8 @@ VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"],
             "now4": ["-DDS_EXP_NO_W4=1"],
             # with ds_gemm_f16_stats (GroupNorm statistics from the producer's epilogue: opt-in feature, profiles/r4_notes.md section 3)
             "gemmstats": ["-DDS_GEMM_STATS=1", "-DDS_PERSIST=0"],   # (with the persistent tile loop one of its kernels spills)
+            # round 6: GEMM kernels held to fewer registers than two waves per SIMD allow (room for co-resident waves of other kernels)
+            "regcap208": ["-DDS_GEMM_VGPR_CAP=208", "-DDS_TUNING_ENV=1"], "regcap192": ["-DDS_GEMM_VGPR_CAP=192", "-DDS_TUNING_ENV=1"],
             "m16p1": ["-DDS_M16_PSPAN4=1"], "m16p3": ["-DDS_M16_PSPAN4=3"], "m16p4": ["-DDS_M16_PSPAN4=4"], "m16a3": ["-DDS_M16_AHEAD=3"], "m16a1": ["-DDS_M16_AHEAD=1"]}
 
 

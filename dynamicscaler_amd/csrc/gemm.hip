@@ -192,8 +192,15 @@ struct GemmArgs {
 };
 typedef const GemmArgs __attribute__((address_space(4)))* GemmArgsPtr;
 
+// DS_GEMM_VGPR_CAP (A/B builds only): a register budget below what two waves per SIMD allow, so that waves of ANOTHER kernel (the
+// memory-bound norms on the second stream) can be resident on a CU next to a persistent GEMM workgroup
+#ifdef DS_GEMM_VGPR_CAP
+#define DS_GEMM_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(DS_GEMM_VGPR_CAP)))
+#else
+#define DS_GEMM_KERNEL_ATTR
+#endif
 template <int BM, int BN, int WGM, int WGN, int AMODE, int NS>
-__global__ void __launch_bounds__((TileCfg<BM, BN, WGM, WGN, NS>::NT), (TileCfg<BM, BN, WGM, WGN, NS>::WG_PER_CU))
+__global__ void __launch_bounds__((TileCfg<BM, BN, WGM, WGN, NS>::NT), (TileCfg<BM, BN, WGM, WGN, NS>::WG_PER_CU)) DS_GEMM_KERNEL_ATTR
 gemm_f16_kernel(GemmArgs) {
     using Cfg = TileCfg<BM, BN, WGM, WGN, NS>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
@@ -1355,6 +1362,14 @@ int choose_tile(const ds_gemm_desc& d) {
     int big = -1;
     if (d.N % 256 == 0) big = TILE_256x256;
     else if (d.N % 320 == 0 && !geglu) big = TILE_256x320;
+    // N a multiple of both (1280, 3840): the 320-wide tile where it takes FEWER rounds of one tile per CU -- 40960 x 1280: 640 tiles (3
+    // rounds) against 800 (4); 10240 x 3840: 480 (2) against 600 (3); measured -3 ... -9 % on the level-3 convolutions, -13 ... -29 % on
+    // the level-3/4 QKV projections of small batches, and slower where the round counts tie (profiles/r6_notes.md section 3).  Every tile
+    // sums K in the same order: same bits.
+    if (big == TILE_256x256 && d.N % 320 == 0 && !geglu && DS_TUNE_INT("DS_GEMM_PREF320", 1) != 0) {
+        const long ncu = launch_cus();
+        if (ds_cdiv(tiles_m256 * (d.N / 320), ncu) < ds_cdiv(tiles_m256 * (d.N / 256), ncu)) big = TILE_256x320;
+    }
     // a grid that leaves every CU with at most one 128x128 workgroup: 4-stage LDS-DMA pipeline instead of relying on a
     // partner workgroup to hide the load latency
     const long nblk128 = (long)ds_cdiv(d.M, 128) * ds_cdiv(d.N, 128);
@@ -1368,6 +1383,7 @@ int choose_tile(const ds_gemm_desc& d) {
     if (forced == TILE_128x256_SW && d.N % 256 == 0) return forced;
     if (big < 0) return small_or_deep;
     if (forced == TILE_256x320 && d.N % 320 == 0 && !geglu) return TILE_256x320;      // (N = 1280 k: both big tiles apply)
+    if (forced == TILE_256x256 && d.N % 256 == 0) return TILE_256x256;
     if (forced == TILE_256x256 || forced == TILE_256x320) return big;
     const long nblk = tiles_m256 * (d.N / (big == TILE_256x256 ? 256 : 320));
     const long big_min = DS_TUNE_INT("DS_GEMM_BIG_MIN", 160);
@@ -1379,6 +1395,10 @@ int dispatch(int tile, const void* A, const void* W, const float* bias, const vo
              const ds_gemm_desc& d, hipStream_t st, const float* ln_stats = nullptr, const float* ln_colsum = nullptr, float ln_eps = 0.0f,
              StatOut so = StatOut()) {
     // the split-ring forms stage W by K-step index: not for the taps-innermost K order; deep-K 3x3 convolutions keep the big tiles
+    // They are measured-and-not-adopted forms (profiles/r6_notes.md section 2: no gain on any short-K shape at 16 evaluations, the short-K
+    // family is bound by the memory system's rate for its access pattern, not by a per-CU serial chain): instantiated in the "tune"
+    // build only (choose_tile returns them only when forced there).
+#ifdef DS_TUNING_ENV
     if constexpr (AMODE == A_CONV3_TI || AMODE == DS_A_CONV3) {
         if (tile == TILE_128x320_SW) tile = TILE_256x320;
         if (tile == TILE_128x256_SW) tile = TILE_256x256;
@@ -1386,6 +1406,7 @@ int dispatch(int tile, const void* A, const void* W, const float* bias, const vo
         if (tile == TILE_128x320_SW) return launch<128, 320, 4, 1, AMODE, 1>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
         if (tile == TILE_128x256_SW) return launch<128, 256, 2, 2, AMODE, 1>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
     }
+#endif
     switch (tile) {
         case TILE_256x256: return launch<256, 256, 2, 4, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);
         case TILE_256x320: return launch<256, 320, 4, 2, AMODE>(A, W, bias, residual, out, d, st, ln_stats, ln_colsum, ln_eps, so);

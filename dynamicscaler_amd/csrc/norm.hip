@@ -759,7 +759,7 @@ int groupnorm_rows_colstats(const XT* x, int ldx, const float2* colstats, int ld
 
 template <typename XT>
 int groupnorm_rows(const XT* x, int ldx, const float* gamma, const float* beta, f16* y, f16* x_f16, float* workspace, int ninst,
-                   int rows_per_inst, int C, int groups, float eps, int silu, hipStream_t st) {
+                   int rows_per_inst, int C, int groups, float eps, int silu, hipStream_t st, bool onepass = false) {
     // The path depends on the instance's shape only, never on how many instances a launch holds: the two forms sum in different
     // orders, and a batch must equal its separate forwards bit for bit (what keeps rank-sharded runs identical to the
     // single-process panorama).  Until round 3 a `ninst >= 64` condition sat here: a batch of 2 evaluations (an 8-GPU rank's
@@ -773,8 +773,16 @@ int groupnorm_rows(const XT* x, int ldx, const float* gamma, const float* beta, 
         DS_CHECK_LAUNCH("ds_groupnorm(small)");
         return DS_OK;
     }
-    // mid-size instances (per-frame norms of levels 1-2, the joint-T norms of levels 3-4): one launch, the instance read once
-    const int gslab = DS_TUNE_INT("DS_GN_RESIDENT", 1) != 0 ? gn_resident_gslab(rows_per_inst, C, groups, (int)sizeof(XT)) : 0;
+    // mid-size instances (per-frame norms of levels 1-2, the joint-T norms of levels 3-4) in ONE launch with the instance read once
+    // (gn_resident_kernel): OPT-IN (ds_groupnorm_rows_onepass; DS_GN_RESIDENT=1 in the "tune" build).  Measured on MI355X
+    // (profiles/r6_notes.md section 4): per launch 0.6-1.0x of the two-launch form, but in the step it does not pay -- cfg3 -0.2 %, the
+    // sphere stage +5 % (a 512-thread, 233-register, 144 KB workgroup needs a whole CU to itself: unlike the small workgroups of the
+    // two-launch form it cannot start in the tail of the kernel before it) -- and its sums follow another order (other last bits).
+    const int gslab = (onepass || DS_TUNE_INT("DS_GN_RESIDENT", 0) != 0) ? gn_resident_gslab(rows_per_inst, C, groups, (int)sizeof(XT)) : 0;
+    if (onepass && gslab == 0) {
+        ds_set_error("ds_groupnorm_rows_onepass: no one-pass form for rows_per_inst=%d C=%d groups=%d (ds_groupnorm_onepass_applies)", rows_per_inst, C, groups);
+        return DS_EINVAL;
+    }
     if (gslab > 0) {
         const int cpg = C / groups, nch_row = gslab * cpg / (16 / (int)sizeof(XT)), rl = GN_RES_NT / nch_row;
         const int rpt = (rows_per_inst + rl - 1) / rl, nslab = groups / gslab;
@@ -845,6 +853,27 @@ extern "C" int ds_groupnorm_rows(const void* x, int x_dtype, int ldx, const floa
     if (x_dtype == DS_F32)
         return groupnorm_rows<float>((const float*)x, ldx, gamma, beta, (f16*)y, (f16*)x_f16, workspace, ninst, rows_per_inst, C, groups, eps, silu, st);
     return groupnorm_rows<f16>((const f16*)x, ldx, gamma, beta, (f16*)y, nullptr, workspace, ninst, rows_per_inst, C, groups, eps, silu, st);
+}
+
+// The one-launch, read-once form (gn_resident_kernel) for the instance shapes it exists for (ds_groupnorm_onepass_applies != 0): same
+// arguments and result tolerance as ds_groupnorm_rows, statistics summed in another order.  Opt-in: see groupnorm_rows.
+extern "C" int ds_groupnorm_onepass_applies(int rows_per_inst, int C, int groups, int x_dtype) {
+    if (rows_per_inst <= GN_SMALL_ROWS || C <= 0 || groups <= 0 || C % groups || C % 8) return 0;
+    return gn_resident_gslab(rows_per_inst, C, groups, x_dtype == DS_F32 ? 4 : 2) > 0;
+}
+
+extern "C" int ds_groupnorm_rows_onepass(const void* x, int x_dtype, int ldx, const float* gamma, const float* beta, void* y, void* x_f16,
+                                         int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream) {
+    DS_CHECK_ARG(x && gamma && beta && y, "ds_groupnorm_rows_onepass: null argument");
+    DS_CHECK_ARG(x_dtype == DS_F16 || x_dtype == DS_F32, "ds_groupnorm_rows_onepass: x_dtype must be DS_F16 or DS_F32");
+    DS_CHECK_ARG(ninst > 0 && rows_per_inst > GN_SMALL_ROWS, "ds_groupnorm_rows_onepass: ninst must be positive, rows_per_inst > %d", GN_SMALL_ROWS);
+    DS_CHECK_ARG(C % 8 == 0 && C <= MAX_C && groups > 0 && groups <= 256 && C % groups == 0, "ds_groupnorm_rows_onepass: C=%d groups=%d unsupported", C, groups);
+    DS_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "ds_groupnorm_rows_onepass: ldx=%d (>= C, multiple of 8, x 16-byte aligned)", ldx);
+    DS_CHECK_ARG(!x_f16 || x_dtype == DS_F32, "ds_groupnorm_rows_onepass: the fp16 copy of x is only produced from fp32 input");
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == DS_F32)
+        return groupnorm_rows<float>((const float*)x, ldx, gamma, beta, (f16*)y, (f16*)x_f16, nullptr, ninst, rows_per_inst, C, groups, eps, silu, st, true);
+    return groupnorm_rows<f16>((const f16*)x, ldx, gamma, beta, (f16*)y, nullptr, nullptr, ninst, rows_per_inst, C, groups, eps, silu, st, true);
 }
 
 // GroupNorm whose statistics come from the producing GEMM (ds_gemm_f16_stats): colstats[(row / 32) * ld_stats + column] = (sum,

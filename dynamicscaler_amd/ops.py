@@ -406,7 +406,11 @@ def gemm(A, W, bias=None, residual=None, *, M, N, K, out=None, a_mode=DS_A_DENSE
     return out
 
 
-def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None, raw_f16=False, colstats=None):
+def groupnorm_onepass_applies(rows_per_inst, Cch, dtype, groups=32):
+    return bool(_lib.load().ds_groupnorm_onepass_applies(rows_per_inst, Cch, groups, _DT[dtype]))
+
+
+def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, stream=None, raw_f16=False, colstats=None, onepass=False):
     """x [ninst*rows_per_inst, Cch] fp16 or fp32, rows contiguous or a column slice of a wider row-major buffer (row stride
     x.stride(0)); returns a dense fp16 [rows, Cch] tensor.  raw_f16 (fp32 x only): also returns fp16(x) as a dense tensor,
     written in the same pass -> (y, x16).  colstats: the producer's partial-statistics view for x's columns (gemm(..., colstats=)):
@@ -418,6 +422,10 @@ def groupnorm(x, gamma, beta, ninst, rows_per_inst, Cch, eps, silu, groups=32, s
                      device=x.device)
     y = torch.empty((x.shape[0], Cch), dtype=torch.float16, device=x.device)
     x16 = torch.empty((x.shape[0], Cch), dtype=torch.float16, device=x.device) if raw_f16 else None
+    if onepass:       # the one-launch read-once form (ds_groupnorm_rows_onepass; opt-in, see include/dynscaler_hip.h)
+        check(lib.ds_groupnorm_rows_onepass(x.data_ptr(), _DT[x.dtype], x.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(x16),
+                                            ninst, rows_per_inst, Cch, groups, float(eps), int(bool(silu)), st), "ds_groupnorm_rows_onepass")
+        return (y, x16) if raw_f16 else y
     if colstats is not None:
         assert colstats.dtype == torch.float32 and colstats.shape[1] >= Cch and colstats.stride(1) == 2 and colstats.stride(2) == 1
         check(lib.ds_groupnorm_rows_colstats(x.data_ptr(), _DT[x.dtype], x.stride(0), colstats.data_ptr(), colstats.stride(0) // 2,

@@ -32,6 +32,16 @@ def select_prompt_from_multi_prompt_dict_by_factor(prompt_dict, factor):
 # relative error of the CFG-combined eps (guidance 7.5) at t = 999 -- where it is largest -- per residual mode of the fp16-operand
 # UNet, measured against the reference on MI355X (profiles/r4_measured_parity.jsonl, tests/test_gpu_fullsize.py)
 GUIDED_EPS_ERR = {"f16": 1.0e-2, "f32outer": 7.4e-3, "f32": 5.6e-3}
+# The table above was measured on seed-0 synthetic weights (t = 999, CFG 7.5).  Round 6: at set-up the pipelines MEASURE the same quantity
+# on the caller's own UNet and contexts (one wide + one own-mode evaluation pair at the schedule's first timestep, the wide result as the
+# fp32 reference) and use measured / OPERAND_SAFETY instead; the table is what an uncalibrated pipeline (no device yet) falls back to.
+OPERAND_SAFETY = 0.8
+
+
+def _noise_shape(t):
+    """How the guided-eps error falls with the noise level, relative to t = 999 (measured, default mode: 7.4e-3 at 999, 5.0e-3 at 816,
+    3.6e-3 at 612, 2.8e-3 below 200; within 5 %)."""
+    return 0.375 + 0.625 * (float(t) / 999.0) ** 3.5
 
 
 class _ProgressBar:
@@ -112,6 +122,15 @@ class VC2_Pipeline_T2V:
         self.exchange_x0 = os.environ.get("DS_EXCHANGE_X0", "last")
         self.operand_policy = os.environ.get("DS_OPERAND_POLICY", "auto")
         self.operand_budget = 1e-3
+        # "auto" walks a ladder per step: the model's own mode where its predicted error is inside the budget; else the rungs in this
+        # order -- "strict" (the fp32 residual stream, single fp16 operands: +12 % per evaluation) where ITS prediction is inside, "wide"
+        # (3.7x) otherwise.  ("wide",) = round 5's behaviour.
+        self.operand_rungs = tuple(r for r in os.environ.get("DS_OPERAND_RUNGS", "strict,wide").split(",") if r)
+        # "auto": the guided-eps error of a mode is measured on the caller's UNet at set-up (_calibrate_operands; cached on the UNet);
+        # "table": GUIDED_EPS_ERR
+        self.operand_calibration = os.environ.get("DS_OPERAND_CALIBRATION", "auto")
+        self._calibration = {}               # mode -> (t of the measurement, measured guided-eps error)
+        self.strict_steps_run = []
         self.wide_tile_batch = 1
         self._step_precision = None
         self.wide_steps_run = []             # (step i, schedule index) of the steps of the last loop that ran wide
@@ -151,35 +170,110 @@ class VC2_Pipeline_T2V:
             return None
         if pol in (None, "f16"):
             return None
-        if pol == "wide":
-            return "wide"
+        if pol in ("wide", "strict"):
+            return pol
         if pol == "auto":
             unet = self._unet()
-            mode = "f16" if unet.residual_dtype == torch.float16 else ("f32outer" if unet.residual_scope == "outer" else "f32")
+            mode = self._mode_name(unet)
             if getattr(unet, "operand_mode", "f16") == "wide":
                 return None                              # the model itself already evaluates wide
-            # the guided-eps error falls with the noise level (7.4e-3 at t = 999, 5.0e-3 at 816, 3.6e-3 at 612, 2.8e-3 below 200 in the
-            # default mode): 0.375 + 0.625 (t / 999)^3.5 of its t = 999 value fits the measured points within 5 %
-            t = float(self.scheduler.ddim_timesteps[index])
-            r_e = GUIDED_EPS_ERR[mode] * (0.375 + 0.625 * (t / 999.0) ** 3.5)
-            pred = self.scheduler.eps_amplification(index) * r_e * max(1.0, abs(float(guidance_scale))) / 7.5
-            return "wide" if pred > self.operand_budget else None
+            if self.predicted_error(index, guidance_scale, mode) <= self.operand_budget:
+                return None
+            for rung in self.operand_rungs:
+                if rung == "strict":
+                    if mode != "f32" and self.predicted_error(index, guidance_scale, "f32") <= self.operand_budget:
+                        return "strict"
+                elif rung == "wide":
+                    return "wide"
+                else:
+                    raise ValueError(f"operand_rungs={self.operand_rungs!r}: expected 'strict' and / or 'wide'")
+            return None
         if isinstance(pol, str):
-            raise ValueError(f"operand_policy={pol!r}: expected 'auto', 'f16', 'wide' or a collection of schedule indices")
+            raise ValueError(f"operand_policy={pol!r}: expected 'auto', 'f16', 'strict', 'wide' or a collection of schedule indices")
         return "wide" if index in pol else None
+
+    @staticmethod
+    def _mode_name(unet):
+        return "f16" if unet.residual_dtype == torch.float16 else ("f32outer" if unet.residual_scope == "outer" else "f32")
+
+    def guided_eps_error(self, mode, t):
+        """Relative error of the CFG-combined eps of residual mode `mode` at timestep t: measured on this pipeline's UNet where a
+        calibration exists (measured / OPERAND_SAFETY, carried to t along the measured noise-level curve), else the table's."""
+        cal = self._calibration.get(mode)
+        if cal is not None:
+            t0, e0 = cal
+            return e0 / OPERAND_SAFETY * _noise_shape(t) / _noise_shape(t0)
+        return GUIDED_EPS_ERR[mode] * _noise_shape(t)
+
+    def predicted_error(self, index, guidance_scale, mode=None):
+        """Predicted relative error of x_prev (unit-scale latents) of the DDIM step at schedule index `index` evaluated in `mode`."""
+        if mode is None:
+            mode = self._mode_name(self._unet())
+        t = float(self.scheduler.ddim_timesteps[index])
+        return self.scheduler.eps_amplification(index) * self.guided_eps_error(mode, t) * max(1.0, abs(float(guidance_scale))) / 7.5
 
     def _begin_step(self, i, index, guidance_scale):
         """Fix the operand mode of step i (schedule index `index`) for every UNet evaluation until the next call."""
         if i == 0:
-            self.wide_steps_run = []
+            self.wide_steps_run, self.strict_steps_run = [], []
         self._step_precision = self.precision_for(index, guidance_scale)
         if self._step_precision == "wide":
             self.wide_steps_run.append((int(i), int(index)))
+        elif self._step_precision == "strict":
+            self.strict_steps_run.append((int(i), int(index)))
         return self._step_precision
 
     def wide_steps_of(self, num_inference_steps, guidance_scale):
         """Schedule indices the current policy evaluates wide on a schedule of `num_inference_steps` (make_schedule must have run)."""
         return [ix for ix in range(num_inference_steps - 1, -1, -1) if self.precision_for(ix, guidance_scale) == "wide"]
+
+    def strict_steps_of(self, num_inference_steps, guidance_scale):
+        """... and the ones it evaluates on the strict rung (fp32 residual stream, fp16 operands)."""
+        return [ix for ix in range(num_inference_steps - 1, -1, -1) if self.precision_for(ix, guidance_scale) == "strict"]
+
+    @torch.no_grad()
+    def _calibrate_operands(self, x, t, ctx_cond, ctx_uncond, guidance_scale, fps, frames, eval_kwargs):
+        """Measure, on THIS UNet with THESE contexts, the relative error of the guided eps of the model's own residual mode (and of the
+        strict rung) against the wide operand mode's fp32-level result: x [1,C,T,h,w] one tile at the schedule's first noise level,
+        t its timestep.  One evaluation pair per mode (~0.2 s with the wide pair); the result is cached on the UNet per (packed
+        generation, mode, t, guidance, tile shape, context length), so pipelines that share a model measure once."""
+        unet = self._unet()
+        if self.operand_policy != "auto" or self.operand_calibration != "auto" or not hasattr(unet, "twin") or ctx_uncond is None:
+            return
+        if getattr(unet, "operand_mode", "f16") == "wide" or not x.is_cuda:
+            return
+        model = self.pretrained_t2v.model
+        own = self._mode_name(unet)
+        cache = unet.__dict__.setdefault("_operand_calibration", {})
+        g = float(guidance_scale)
+        ctx = torch.cat([ctx_cond.to(x.device), ctx_uncond.to(x.device)], 0)
+        xx = torch.cat([x, x], 0).contiguous()
+        ts = torch.full((2,), int(t), device=x.device, dtype=torch.long)
+        kw = {k: v for k, v in dict(eval_kwargs).items() if k != "precision"}
+
+        def guided(precision):
+            e = model(xx, ts, c_crossattn=[ctx], fps=fps, curr_time_steps=ts, temporal_length=frames, **(dict(kw, precision=precision) if precision else kw)).float()
+            return e[1:] + g * (e[:1] - e[1:])
+
+        ref = None
+        for mode, precision in ((own, None), ("f32", "strict")):
+            if mode == "f32" and (own == "f32" or "strict" not in self.operand_rungs):
+                continue
+            key = (getattr(unet, "_generation", 0), mode, int(t), round(g, 4), tuple(x.shape), int(ctx.shape[1]))
+            if key not in cache:
+                if ref is None:
+                    ref = guided("wide")
+                cache[key] = float((guided(precision) - ref).norm() / ref.norm().clamp_min(1e-30))
+            self._calibration[mode] = (int(t), cache[key])
+
+    def operand_report(self, num_inference_steps, guidance_scale):
+        """What the policy decided and on which figures (bench.py's config.operand_policy)."""
+        return {"policy": self.operand_policy if isinstance(self.operand_policy, str) else sorted(self.operand_policy), "budget": self.operand_budget,
+                "rungs": list(self.operand_rungs), "safety": OPERAND_SAFETY,
+                "guided_eps_err_measured": {m: {"t": t0, "err": e0} for m, (t0, e0) in self._calibration.items()},
+                "guided_eps_err_table": dict(GUIDED_EPS_ERR) if not self._calibration else None,
+                "predicted_first_step_error": self.predicted_error(num_inference_steps - 1, guidance_scale) if hasattr(self._unet(), "twin") else None,
+                "strict_steps": self.strict_steps_of(num_inference_steps, guidance_scale), "wide_steps": self.wide_steps_of(num_inference_steps, guidance_scale)}
 
     # -- conditioning --
     def _encode(self, prompt, prompt_embeds, guidance_scale):
@@ -215,8 +309,8 @@ class VC2_Pipeline_T2V:
         model = self.pretrained_t2v.model
         if cfg_pairs and self.share_cfg_prefix and hasattr(getattr(model, "diffusion_model", None), "c_program_trace"):      # the HIP UNet
             kwargs = dict(kwargs, cfg_pairs=int(cfg_pairs))
-        if self._step_precision == "wide" and hasattr(getattr(model, "diffusion_model", None), "twin"):
-            kwargs = dict(kwargs, precision="wide")
+        if self._step_precision in ("wide", "strict") and hasattr(getattr(model, "diffusion_model", None), "twin"):
+            kwargs = dict(kwargs, precision=self._step_precision)
         # graph replay only for signatures that a key can identify: python scalars in the kwargs (a tensor-valued kwarg would
         # be baked into the graph by pointer), an int fps
         scalar_kw = all(v is None or isinstance(v, (bool, int, float, str)) for v in kwargs.values())
@@ -289,6 +383,8 @@ class VC2_Pipeline_T2V:
         kwargs.update({"clean_cond": True})
         denoised = None
         pano_shape = (1,) + tuple(latents.shape[1:])
+        if uc_emb is not None and hasattr(self._unet(), "twin") and len(timesteps):
+            self._calibrate_operands(latents[:1], timesteps[0], text_emb.to(device), uc_emb.to(device), guidance_scale, fps, frames, kwargs)
         with self.progress_bar(total=len(timesteps)) as bar:
             for i, t in enumerate(timesteps):
                 self._begin_step(i, total_steps - i - 1, guidance_scale)
@@ -505,8 +601,6 @@ class VC2_Pipeline_T2V:
         unet = getattr(getattr(self.pretrained_t2v, "model", None), "diffusion_model", None)
         if unet is not None and hasattr(unet, "prepare"):
             unet.prepare(device)
-            if hasattr(unet, "twin") and any(self.precision_for(len(timesteps) - i - 1, guidance_scale) == "wide" for i in range(len(timesteps))):
-                unet.twin("wide").prepare(device)          # the second packed buffer (hi + lo planes), before any side stream runs
         st = _RingState()
         st.in_device = init_panorama_latent.device    # overwritten with the execution device when the loop drew the latent itself
         st.pano = init_panorama_latent.to(device=device, dtype=self.latent_dtype).contiguous().clone()
@@ -527,7 +621,24 @@ class VC2_Pipeline_T2V:
         kwargs = dict(kwargs)
         kwargs.update({"clean_cond": True})
         st.kwargs = kwargs
+        if unet is not None and hasattr(unet, "twin") and st.uc_emb is not None and len(timesteps):
+            # operand policy on the weights and contexts it runs on: one tile of the panorama at the loop's first timestep (i2v: the
+            # text tokens with the zero-image tokens of the uncond context: the per-window image tokens do not exist yet)
+            ctx_c = st.text_emb
+            if st.uc_emb.shape[1] > ctx_c.shape[1]:
+                ctx_c = torch.cat([ctx_c, st.uc_emb[:, ctx_c.shape[1]:].to(ctx_c.dtype)], 1)
+            tile, _ = ops.ring_gather(st.pano, [(0, 0, 0)], st.tile_fhw, None)
+            self._calibrate_operands(tile, timesteps[0], ctx_c, st.uc_emb, guidance_scale, fps, frames, kwargs)
+            self._prepare_rungs(unet, device, len(timesteps), guidance_scale)
         return st
+
+    def _prepare_rungs(self, unet, device, nsteps, guidance_scale):
+        """The packed buffers of the rungs this loop will use, before any side stream runs (strict: a second fp16 image with its own
+        LayerNorm handling; wide: hi + lo planes)."""
+        need = {self.precision_for(ix, guidance_scale) for ix in range(self.scheduler.ddim_timesteps.shape[0])}     # (a superset for cut schedules)
+        for rung in ("strict", "wide"):
+            if rung in need:
+                unet.twin(rung).prepare(device)
 
     def _finish(self, st, output_type, total_frames, seam_safe):
         """Return tuple of the ring loops.  Like the reference (t2v_sphere_panorama_pipeline.py:636-660) the second element

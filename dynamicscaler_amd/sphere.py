@@ -215,9 +215,17 @@ class ViewMapCache:
     44 views cost 1.6 s of host time per step otherwise -- as much as the step's UNet evaluations -- for the first loop_step_theta
     steps.  The worker only computes host tensors (its uploads would queue behind the step's kernels on the stream); get() uploads."""
 
+    # Maps depend only on the key (view angles, view size, panorama size): gen_pano_360's 44 views x 10 theta offsets are 440 of them.
+    # Uploaded maps are shared by every cache of a device, so a later loop -- the next stage, the next run in the same process -- does
+    # not rebuild them (round 6; bounded: the oldest entries leave when more than SHARED_MAX are held).
+    _SHARED = {}
+    SHARED_MAX = 4096
+
     def __init__(self, device):
         self.device = device
-        self._maps = {}
+        self._maps = ViewMapCache._SHARED.setdefault(str(torch.device(device)), {})
+        while len(self._maps) > ViewMapCache.SHARED_MAX:
+            self._maps.pop(next(iter(self._maps)))
         self._host = {}            # prefetched on the host, not uploaded yet
         self._worker, self._jobs, self._pending, self._error = None, None, None, None
 

@@ -179,17 +179,27 @@ class UNetModel(nn.Module):
         return self.operand_mode == "wide"
 
     def twin(self, operand_mode="wide"):
-        """A module over the SAME parameters (and parameter tree) evaluated in another operand mode, with its own packed buffer and
-        C handle: both stay resident, so single evaluations can be routed to it (forward(..., precision=...))."""
+        """A module over the SAME parameters (and parameter tree) evaluated in another mode, with its own packed buffer and C handle:
+        both stay resident, so single evaluations can be routed to it (forward(..., precision=...)).  "wide": split-fp16 operands, fp32
+        storage (csrc/wide.hip); "strict" (round 6): single fp16 operands with the WHOLE residual stream and every GroupNorm input in
+        fp32 (residual_dtype float32, scope "full": +12 % per evaluation) -- the rung the pipelines' operand policy tries first."""
+        if operand_mode not in ("wide", "strict"):
+            raise ValueError(f"twin({operand_mode!r}): expected 'wide' or 'strict'")
         tw = self._twins.get(operand_mode)
         if tw is None:
             import copy
             tw = copy.copy(self)                 # shallow: _parameters / _modules (the parameter tree) are shared objects; no handle,
             tw._generation = 0                   # packed buffer, twin or lock travels with a copy (__getstate__ / __setstate__)
-            tw.operand_mode = operand_mode
+            if operand_mode == "wide":
+                tw.operand_mode = "wide"
+            else:
+                tw.operand_mode, tw.residual_dtype, tw.residual_scope = "f16", torch.float32, "full"
             tw.gn_from_producer = False
             self._twins[operand_mode] = tw
         return tw
+
+    def _is_strict_mode(self):
+        return self.operand_mode == "f16" and self.residual_dtype == torch.float32 and self.residual_scope == "full"
 
     @torch.no_grad()
     def prepare(self, device=None, force=False):
@@ -365,13 +375,13 @@ class UNetModel(nn.Module):
         the same numbers: the result is bit-identical to the plain 2n forward (a batch equals its separate forwards)."""
         pairs = kwargs.pop("cfg_pairs", None)
         precision = kwargs.pop("precision", None)          # "wide": this evaluation with split-fp16 operands and fp32 storage (twin)
-        if precision not in (None, "f16", "wide"):
-            raise ValueError(f"precision={precision!r}: expected None, 'f16' or 'wide'")
-        if precision == "wide" and not self._wide():
+        if precision not in (None, "f16", "wide", "strict"):
+            raise ValueError(f"precision={precision!r}: expected None, 'f16', 'strict' or 'wide'")
+        if (precision == "wide" and not self._wide()) or (precision == "strict" and not self._wide() and not self._is_strict_mode()):
             if pairs:
                 kwargs["cfg_pairs"] = pairs
-            return self.twin("wide").forward(x, timesteps, context=context, features_adapter=features_adapter, fps=fps,
-                                             timestep_cond=timestep_cond, **kwargs)
+            return self.twin(precision).forward(x, timesteps, context=context, features_adapter=features_adapter, fps=fps,
+                                                timestep_cond=timestep_cond, **kwargs)
         if features_adapter is not None or timestep_cond is not None:
             raise NotImplementedError("features_adapter / timestep_cond are not used by the DynamicScaler pipelines")
         if not x.is_cuda:

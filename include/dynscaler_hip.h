@@ -269,6 +269,15 @@ int ds_groupnorm_f16_strided(const void* x, int ldx, const float* gamma, const f
    strict-precision mode's residual stream (UNetModel.residual_dtype).                                                  */
 int ds_groupnorm_rows(const void* x, int x_dtype, int ldx, const float* gamma, const float* beta, void* y, void* x_f16,
                       float* workspace, int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream);
+/* ds_groupnorm_rows as ONE launch that reads the instance ONCE (round 6): a workgroup owns (instance, slab of whole groups) for all rows
+ * and keeps its slab in registers (+ LDS) between the statistics and the normalisation -- 6 instead of 10 bytes per fp32 element.  Exists
+ * for instances of 257 .. ~5000 rows whose slab fits (ds_groupnorm_onepass_applies: per-frame norms of UNet levels 1-2, joint-T norms of
+ * levels 3-4); needs no workspace.  OPT-IN: measured on MI355X it is 0.6-1.0x of the two-launch form per launch but does not pay in the
+ * step (profiles/r6_notes.md section 4), and its statistics are summed in another order than ds_groupnorm_rows' (results agree to fp32
+ * rounding of mean / rstd).  Replaces GroupNormSpecific / nn.GroupNorm(32, C) like ds_groupnorm_rows (lvdm/basics.py:76-86). */
+int ds_groupnorm_onepass_applies(int rows_per_inst, int C, int groups, int x_dtype);
+int ds_groupnorm_rows_onepass(const void* x, int x_dtype, int ldx, const float* gamma, const float* beta, void* y, void* x_f16,
+                              int ninst, int rows_per_inst, int C, int groups, float eps, int silu, void* stream);
 /* ds_groupnorm_rows with the statistics taken from the producer's colstats table (ds_gemm_f16_stats) instead of a pass over x:
    colstats points at the entry of x's first row block and first column; rows_per_inst % 32 == 0.  Two launches: the table is
    folded into per-chunk group sums (1/8 of the bytes of x), the apply reduces those in fp64 as in ds_groupnorm_rows.            */

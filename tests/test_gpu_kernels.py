@@ -455,8 +455,8 @@ def test_temporal_attention(T):
 
 
 # ------------------------------------------------------------------------------------------------ norms / misc
-# (from (8, 2560, 320) on: the one-launch register-resident form of round 6 -- 52 / 26 / 13 rows per thread, instance counts that are and
-#  are not multiples of 8 (the XCD-aware slab placement), the joint-T shape of level 3)
+# (from (8, 2560, 320) on: shapes of the opt-in one-launch register-resident form of round 6 -- 52 / 26 / 13 rows per thread, instance
+#  counts that are and are not multiples of 8 (the XCD-aware slab placement), the joint-T shape of level 3)
 @pytest.mark.parametrize("ninst,rows,C", [(6, 80, 320), (2, 4 * 80, 64), (3, 40, 2560), (2, 700, 1920), (5, 33, 128),
                                           (8, 2560, 320), (3, 2560, 320), (16, 640, 640), (5, 640, 1280), (4, 2560, 1280), (16, 300, 640), (2, 2551, 640)])
 @pytest.mark.parametrize("silu", [False, True])
@@ -483,6 +483,17 @@ def test_groupnorm(ninst, rows, C, silu):
     wide[:, 24:24 + C] = x.half().to(d)
     y3 = ops.groupnorm(wide[:, 24:24 + C], g.to(d), b.to(d), ninst, rows, C, 1e-5, silu)
     assert y3.is_contiguous() and torch.equal(y3, y)
+    # the opt-in one-launch read-once form (ds_groupnorm_rows_onepass) where it exists: same normalisation to fp32 rounding of the statistics
+    assert ops.groupnorm_onepass_applies(rows, C, torch.float16) == ((rows, C) in {(320, 64), (700, 1920), (2560, 320), (640, 640), (640, 1280), (2560, 1280), (300, 640), (2551, 640)})
+    if ops.groupnorm_onepass_applies(rows, C, torch.float16):
+        y4 = ops.groupnorm(x.half().to(d), g.to(d), b.to(d), ninst, rows, C, 1e-5, silu, onepass=True)
+        assert relerr(y4, ref) < 1e-3 and relerr(y4, y.float().cpu()) < 3e-4
+        assert torch.equal(ops.groupnorm(wide[:, 24:24 + C], g.to(d), b.to(d), ninst, rows, C, 1e-5, silu, onepass=True), y4)
+        part = ops.groupnorm(x.half().to(d)[:rows].contiguous(), g.to(d), b.to(d), 1, rows, C, 1e-5, silu, onepass=True)
+        assert torch.equal(part, y4[:rows])                      # batch-invariant: an instance does not see how many share the launch
+    else:
+        with pytest.raises(Exception):
+            ops.groupnorm(x.half().to(d), g.to(d), b.to(d), ninst, rows, C, 1e-5, silu, onepass=True)
 
 
 @pytest.mark.parametrize("rows,C", [(40, 1280), (160, 1280), (640, 640), (2560, 320), (16 * 160, 1280)])
@@ -586,6 +597,14 @@ def test_groupnorm_fp32_input(ninst, rows, C, silu):
     # fp16 input through the same entry point stays what it was
     yh = ops.groupnorm(x.half().to(d), g.to(d), b.to(d), ninst, rows, C, 1e-5, silu)
     assert relerr(yh, ref) < 1.5e-3
+    # the opt-in one-launch read-once form on fp32 rows: statistics in fp64 over fp32 partial sums, the raw-copy output, strided input
+    if ops.groupnorm_onepass_applies(rows, C, torch.float32):
+        y5, x16b = ops.groupnorm(x.to(d), g.to(d), b.to(d), ninst, rows, C, 1e-5, silu, raw_f16=True, onepass=True)
+        assert relerr(y5, ref) < 4e-4 and torch.equal(x16b.cpu(), x.half())
+        assert float((y5.float().cpu() - ref.half().float()).abs().max()) <= 2 * float(torch.finfo(torch.float16).eps) * float(ref.abs().max())
+        assert torch.equal(ops.groupnorm(wide[:, 24:24 + C], g.to(d), b.to(d), ninst, rows, C, 1e-5, silu, onepass=True), y5)
+        part = ops.groupnorm(x.to(d)[-rows:].contiguous(), g.to(d), b.to(d), 1, rows, C, 1e-5, silu, onepass=True)
+        assert torch.equal(part, y5[-rows:])
 
 
 @pytest.mark.parametrize("rows,C", [(1000, 320), (77, 1280), (5, 64), (333, 512), (130, 2048)])

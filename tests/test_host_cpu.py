@@ -672,10 +672,35 @@ def test_operand_policy_selects_the_steps_that_amplify_the_guided_eps_error():
     sched = lvdm_DDIM_Scheduler(ld)
     pipe = VC2_Pipeline_T2V(ld, sched, None)
     assert pipe.operand_policy == "auto" and set(GUIDED_EPS_ERR) == {"f16", "f32outer", "f32"}
+    # round 5's ladder (own mode -> wide), on the table's constants
+    pipe.operand_rungs = ("wide",)
     want = {4: [3, 2, 1], 10: [9, 8, 7, 6], 25: [24, 23, 22, 21], 40: [39], 50: []}
     for n, idx in want.items():
         sched.make_schedule(n, verbose=False)
-        assert pipe.wide_steps_of(n, 7.5) == idx, (n, pipe.wide_steps_of(n, 7.5))
+        assert pipe.wide_steps_of(n, 7.5) == idx and pipe.strict_steps_of(n, 7.5) == [], (n, pipe.wide_steps_of(n, 7.5))
+    # round 6: the strict rung (fp32 residual stream, +12 %) is tried before the wide one (3.7x): it takes the steps whose predicted error
+    # it brings inside the budget -- together the two rungs cover exactly the steps the wide rung alone covered
+    pipe.operand_rungs = ("strict", "wide")
+    for n, idx in want.items():
+        sched.make_schedule(n, verbose=False)
+        w, st_ = pipe.wide_steps_of(n, 7.5), pipe.strict_steps_of(n, 7.5)
+        assert sorted(w + st_, reverse=True) == idx and not set(w) & set(st_), (n, w, st_)
+        assert all(pipe.predicted_error(ix, 7.5, "f32") <= 1e-3 < pipe.predicted_error(ix, 7.5) for ix in st_)
+        assert all(pipe.predicted_error(ix, 7.5, "f32") > 1e-3 for ix in w)
+    sched.make_schedule(40, verbose=False)
+    assert pipe.strict_steps_of(40, 7.5) == [39] and pipe.wide_steps_of(40, 7.5) == []
+    # a calibration (measured on the caller's UNet at the schedule's first timestep) replaces the table, with the 0.8 safety factor
+    sched.make_schedule(50, verbose=False)
+    pipe._calibration = {"f32outer": (999, 7.4e-3), "f32": (999, 5.6e-3)}
+    assert abs(pipe.guided_eps_error("f32outer", 999) - 7.4e-3 / 0.8) < 1e-9 and pipe.guided_eps_error("f16", 999) == GUIDED_EPS_ERR["f16"]
+    assert pipe.strict_steps_of(50, 7.5) == [49, 48] and pipe.wide_steps_of(50, 7.5) == []   # 0.113 x 9.25e-3 = 1.05e-3: the first two steps take the strict rung
+    pipe._calibration = {"f32outer": (999, 2.0e-3), "f32": (999, 1.5e-3)}                       # a model whose guided eps is 3.7x more accurate
+    sched.make_schedule(25, verbose=False)
+    assert pipe.wide_steps_of(25, 7.5) == [] and pipe.strict_steps_of(25, 7.5) == []
+    rep = pipe.operand_report(25, 7.5)
+    assert rep["guided_eps_err_measured"]["f32outer"] == {"t": 999, "err": 2.0e-3} and rep["safety"] == 0.8 and rep["wide_steps"] == []
+    pipe._calibration = {}
+    pipe.operand_rungs = ("wide",)
     sched.make_schedule(4, verbose=False)
     a3, a0 = sched.eps_amplification(3), sched.eps_amplification(0)
     assert 0.75 < a3 < 0.85 and a0 == 0.0 and abs(sched.eps_amplification(3, relative=False) - 3.79) < 0.02
@@ -870,6 +895,7 @@ def test_view_map_prefetch_equals_direct_build():
     import torch
     from dynamicscaler_amd.sphere import ViewMapCache, ViewMaps
     reqs = [(120, 30 * k, ph, 16, 8, 64, 32, False) for k in range(4) for ph in (60, 0, -45)] + [(120, 12, 0, 64, 40, 256, 128, True)]
+    ViewMapCache._SHARED.clear()                                  # (uploaded maps are shared by the caches of a device: start from none)
     c = ViewMapCache("cpu")
     c.prefetch(reqs)
     c.wait()
@@ -887,3 +913,8 @@ def test_view_map_prefetch_equals_direct_build():
     with pytest.raises((TypeError, ValueError)):
         c.wait()
     c.wait()                                                     # ... is raised once
+    # a second cache of the same device (the next stage / the next run in the process) finds the maps the first one built or fetched
+    c2 = ViewMapCache("cpu")
+    assert c2._maps is c._maps and c2.get(120, 30, 60, 16, 8, 64, 32) is c.get(120, 30, 60, 16, 8, 64, 32)
+    c2.prefetch(reqs[:3])
+    assert c2._pending is None                                   # nothing to compute
