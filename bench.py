@@ -18,7 +18,13 @@ region; nothing is skipped.  N > 1 shards the tiles of the SAME panorama over th
 Defaults: the tile batches of a dependency level run on two HIP streams (4 + 4 tiles at N = 1) as hipGraph replays of
 the batched UNet evaluation (`--streams 1 --graph 0` = plain eager loop, same results bit for bit).
 
-One JSON line on rank 0 with the driver's fields plus
+Operand policy (round 6): at set-up the pipeline measures, on this UNet, how far the guided eps of its own mode is from the wide operand
+mode's fp32-level result and predicts each step's error from it; the schedule's first steps may then run on another rung (the strict
+residual mode, +12 %: on these synthetic weights the first TWO of the 50).  Those leading steps are executed in their own modes before
+the warm-up; the W warm-up + K timed steps are own-mode steps (48 of the 50); `sec_per_50_step_panorama` is one complete loop with
+every step in the mode the policy gives it; `config.strict_step_ms / wide_step_ms / own_mode_step_eager_ms` time one step per rung.
+
+stdout carries exactly ONE line, the JSON record (everything else goes to stderr), with the driver's fields plus
   "roofline":     the dominant kernel family (implicit-GEMM MFMA kernel): algorithmic FLOPs of every launch of one
                   step / sum of their HIP-event durations, against the dense fp16 MFMA peak (2.5 PFLOP/s)
   "cpu_baseline": the CPU oracle (oracle/, torch fp32) timed on this host on a bounded sample (one UNet evaluation
@@ -105,7 +111,7 @@ def self_launch(argv, n, timeout_s):
     if timed_out:
         raise SystemExit(124)
     if line is not None:
-        print(line, flush=True)
+        print(line, file=sys.__stdout__, flush=True)
     if rc != 0 or line is None:
         sys.stderr.write(f"bench.py: the {n}-rank child exited with code {rc}" + ("" if line else " and printed no result line") + "\n")
         raise SystemExit(rc if rc != 0 else 1)
@@ -126,6 +132,9 @@ def usable_cpus():
 
 
 def main():
+    # stdout carries ONE line, the JSON record: whatever the libraries underneath print goes to stderr
+    real_stdout = sys.__stdout__
+    sys.stdout = sys.stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -351,6 +360,8 @@ def main():
 
     nsched = GEOM["num_inference_steps"] - 1      # steps 0..48 re-noise the overlaps; the last step of a schedule does not,
     phase[0] = "warm-up + timed steps"            # so a run longer than one panorama wraps around before it
+    for k in range(lead_steps):                  # the schedule's leading steps, each in the mode the policy gives it (untimed here: timed
+        pipe.ring_step(st, k)                    # per rung further down, and inside the complete 50-step panorama)
     elapsed, step_idx = timed_steps(pipe, st, lead_steps, args.warmup, args.steps, nsched)
     assert bool(torch.isfinite(st.pano.float()).all()), "non-finite latent after the timed steps"
     if pipe.operand_policy == "auto":         # every warm-up / timed step ran in the model's own mode
@@ -632,11 +643,14 @@ def main():
             pp, begin_o, _shape = make_pipe(name)
             so = begin_o()
             g_ = CONFIGS[name]["geom"]
-            t_o, _k = timed_steps(pp, so, 0, 1, 2, g_["num_inference_steps"] - 1)
+            lead_o = 0                              # (own-mode steps, like the headline's timed region)
+            while lead_o < g_["num_inference_steps"] - 1 and pp.precision_for(g_["num_inference_steps"] - 1 - lead_o, 7.5) is not None:
+                lead_o += 1
+            t_o, _k = timed_steps(pp, so, lead_o, 1, 2, g_["num_inference_steps"] - 1)
             assert bool(torch.isfinite(so.pano.float()).all()), name
             other_configs[name] = {"workload": CONFIGS[name]["label"], "ms_per_step": round(1e3 * t_o / 2, 2), "value": round(2 / t_o, 4),
                                    "unit": "denoising-steps/sec", "steps": 2, "warmup": 1, "tiles_per_step": g_["num_windows_w"] * g_["num_windows_h"],
-                                   "residual_mode": timed_mode, "setup_s": round(time.time() - t_setup - t_o, 1),
+                                   "residual_mode": timed_mode, "timed_region_starts_at_step": lead_o, "setup_s": round(time.time() - t_setup - t_o, 1),
                                    "result_sha256": _hl.sha256(so.pano.float().cpu().numpy().tobytes()).hexdigest()[:16]}
             del pp, so, begin_o
             torch.cuda.empty_cache()
@@ -660,18 +674,21 @@ def main():
             t_s0 = time.perf_counter()
             fin_s, _den_s = sp.basic_sample_shift_shpere_panorama(
                 prompt="a synthetic prompt", fps=8, guidance_scale=7.5, output_type="latent", height=320, width=512, frames=16, total_f=16,
-                equirect_width=2048, equirect_height=1024, view_fov=120, loop_step_theta=10, num_inference_steps=48, denoise_to_step=3,
+                equirect_width=2048, equirect_height=1024, view_fov=120, loop_step_theta=10, num_inference_steps=48, denoise_to_step=5,
                 phi_theta_dict={90: [0], -90: [0], 75: ring_, -75: ring_, 60: ring_, -60: ring_, 45: ring_, -45: ring_, 0: ring_},
                 merge_renoised_overlap_latent_ratio=1, overlap_ratio_list_f=[0.75] * 24 + [0.5] * 24, loop_step_frame=8, paste_on_static=True,
                 merge_prev_denoised_ratio_list=[0.5 * (1 - t / 10) for t in range(10)] + [0] * 38,
                 init_sphere_latent=synth_normal((1, 4, 16, 128, 256), 2333333), pano_image_tensor=synth_normal((3, 1024, 2048), 77).clamp(-1, 1),
                 static_frame_latent=synth_normal((1, 4, 1, 128, 256), 78), step_callback=sphere_cb)
-            t_timed = stamps[2][0] - stamps[0][0]
+            # steps 0-2 untimed (the operand policy puts the 48-step schedule's first two on the strict rung), steps 3 and 4 timed
+            t_timed = stamps[4][0] - stamps[2][0]
+            assert sp.precision_for(48 - 1 - 3, 7.5) is None and sp.precision_for(48 - 1 - 4, 7.5) is None
             assert bool(torch.isfinite(fin_s.float()).all()), "sphere_stage1"
             other_configs["sphere_stage1"] = {
                 "workload": "gen_pano_360.py stage 1: i2v sphere loop, 2048x1024 equirect, 44 views of 512x320x16f per step (fov 120), per-view "
                             "image tokens, paste_on_static, merge-prev, CFG 7.5, 48-step schedule",
-                "ms_per_step": round(1e3 * t_timed / 2, 2), "value": round(2 / t_timed, 4), "unit": "denoising-steps/sec", "steps": 2, "warmup": 1,
+                "ms_per_step": round(1e3 * t_timed / 2, 2), "value": round(2 / t_timed, 4), "unit": "denoising-steps/sec", "steps": 2, "warmup": 3,
+                "strict_steps_of_schedule": sp.strict_steps_of(48, 7.5), "strict_step_ms": round(1e3 * (stamps[1][0] - stamps[0][0]), 1),
                 "views_per_step": stamps[0][1], "unet_evals_per_step": 2 * stamps[0][1], "first_step_ms": round(1e3 * (stamps[0][0] - t_s0), 1),
                 "residual_mode": timed_mode, "setup_s": round(t_s0 - t_setup, 1),
                 "note": "the views of a step overlap: 31 dependency levels of 1-2 views, so an evaluation runs at the small-batch rate",
@@ -723,7 +740,7 @@ def main():
             torch.cuda.synchronize(); t_h = time.perf_counter()
             up = resize_video_latent(lat2.clone(), target_height=128, target_width=256, mode="bicubic")
             sch_ = lvdm_DDIM_Scheduler(ld_s, rng_mode="device")
-            sch_.make_schedule(NSCHED)
+            sch_.make_schedule(NSCHED, verbose=False)
             mixed = sch_.re_noise(up, 0, NSCHED - D2S)
             torch.cuda.synchronize(); t_resize2 = time.perf_counter() - t_h
             s3_step, pp3, st3_ = ring_stage(2048, 1024, 4, 4, mixed, 92)
@@ -863,7 +880,7 @@ def main():
             "other_configs": other_configs,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), file=real_stdout, flush=True)
     phase[0] = "teardown"
     if world > 1:
         torch.distributed.destroy_process_group()

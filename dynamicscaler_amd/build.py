@@ -56,6 +56,8 @@ VARIANTS = {"barebarrier": ["-DDS_EXP_BARE_BARRIER"],
             "gemmstats": ["-DDS_GEMM_STATS=1", "-DDS_PERSIST=0"],   # (with the persistent tile loop one of its kernels spills)
             # round 6: GEMM kernels held to fewer registers than two waves per SIMD allow (room for co-resident waves of other kernels)
             "regcap208": ["-DDS_GEMM_VGPR_CAP=208", "-DDS_TUNING_ENV=1"], "regcap192": ["-DDS_GEMM_VGPR_CAP=192", "-DDS_TUNING_ENV=1"],
+            # round 6 A/B: 16-row epilogue strips of the wave's whole width on the 256 x 320 tile (320-byte store pieces) instead of 32 rows x two tiles
+            "epihalf": ["-DDS_EPI_HALF=1", "-DDS_TUNING_ENV=1"],
             "m16p1": ["-DDS_M16_PSPAN4=1"], "m16p3": ["-DDS_M16_PSPAN4=3"], "m16p4": ["-DDS_M16_PSPAN4=4"], "m16a3": ["-DDS_M16_AHEAD=3"], "m16a1": ["-DDS_M16_AHEAD=1"]}
 
 

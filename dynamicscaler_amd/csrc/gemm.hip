@@ -158,9 +158,19 @@ struct TileCfg {
     // bid, bid + grid, ... -- and the FIRST K-step of its next tile is issued into stage 0 before the epilogue of the current one,
     // whose strips therefore live BEHIND stage 0 (in stage 1 and the tail of the allocation), two tiles per column group at most
     static constexpr bool OVERLAP = WG_PER_CU == 1 && NS == 2 && DS_PERSIST != 0;
-    static constexpr int NG = OVERLAP && NG0 > 2 ? 2 : NG0;
+    // HALF (round 6, build variant "epihalf"; the 256 x 320 persistent tile): strips of SIXTEEN rows x ALL the wave's columns instead of
+    // 32 rows x two tiles -- the same bytes behind stage 0, but a wave then stores its whole 160-column width at once: 320-byte row pieces
+    // instead of 128 + 128 + 64.  A copy kernel with this tile's patterns moves the launch's bytes 7-10 % faster with 320-byte pieces
+    // (profiles/r6_notes.md section 1); in the GEMM it measured NO gain (every K = 320 ... 1280 launch within -1 ... +3.6 %, the step
+    // 463.8 +- 1 ms with against 463.3 +- 1.5 without: 60 of 64 lanes active, six sweeps of 3 rows instead of four of 8), same bits.  OFF.
+#ifndef DS_EPI_HALF
+#define DS_EPI_HALF 0
+#endif
+    static constexpr bool HALF = OVERLAP && NG0 > 2 && TN <= 5 && DS_MFMA16 != 0 && DS_GEMM_STATS == 0 && DS_EPI_HALF != 0;
+    static constexpr int NG = HALF ? TN : (OVERLAP && NG0 > 2 ? 2 : NG0);
+    static constexpr int SROWS = HALF ? 16 : 32;               // rows of a strip
     static constexpr int STR = 32 * NG + 4;                    // floats per strip row
-    static constexpr size_t EPI = (size_t)(NT / 64) * 32 * STR * sizeof(float);
+    static constexpr size_t EPI = (size_t)(NT / 64) * SROWS * STR * sizeof(float);
     static constexpr size_t STRIP_OFF = OVERLAP ? STAGE1 : 0;
     static constexpr size_t LDS = STAGE > STRIP_OFF + EPI ? STAGE : STRIP_OFF + EPI;
     // fragment scheduling: all four k-slices of a K-step up front when that is <= 16 fragments, else one k-slice
@@ -267,7 +277,7 @@ gemm_f16_kernel(GemmArgs) {
     const int tid = tid_;              // per tile instead of being hoisted out of the tile loop and held in ~25 registers around it
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    float* sW = reinterpret_cast<float*>(smem + Cfg::STRIP_OFF) + (size_t)wave * 32 * Cfg::STR;   // this wave's epilogue strip
+    float* sW = reinterpret_cast<float*>(smem + Cfg::STRIP_OFF) + (size_t)wave * Cfg::SROWS * Cfg::STR;   // this wave's epilogue strip
     const int ld_row = tid >> 3;   // 0..LROWS-1
     const int ld_chunk = tid & 7;  // 16-byte chunk within the 64-half K-step
     // LDS-DMA writes lane l of a wave-instruction at LDS offset 16*l (8 rows x 128 B per instruction), so the physical
@@ -999,8 +1009,9 @@ gemm_f16_kernel(GemmArgs) {
         if constexpr (!RES && !PIB) {
             if (fast && !out_f32 && (!bias || GE || bias_done)) {
                 constexpr int NGH_ = TNE < 2 * NG ? TNE : 2 * NG;      // tiles per group in the same strip bytes,
-                constexpr int NGH = NGH_ < 4 ? NGH_ : 4;               // at most 4: 16 chunks per row, 8 sweeps of 4 rows
+                constexpr int NGH = Cfg::HALF ? NGH_ : (NGH_ < 4 ? NGH_ : 4);   // at most 4: 16 chunks per row, 8 sweeps of 4 rows (HALF: 16-row strips, 20 chunks, 6 sweeps of 3)
                 constexpr int STRH = 32 * NGH + 8;                     // halfs per strip row (16-byte aligned chunks)
+                constexpr int SR = Cfg::SROWS, NH = 32 / SR;           // strip rows; strips per 32-row block
                 static_assert(STRH <= 2 * STR, "fp16 strip must fit the fp32 strip");
                 f16* const sH = reinterpret_cast<f16*>(sW);
 #pragma unroll
@@ -1013,15 +1024,18 @@ gemm_f16_kernel(GemmArgs) {
                                         : n0 + wn * WN + c0 * 32 + ch * 8;
                     const long ocol = GE ? (long)tile_n * (BN / 2) + wn * (WN / 2) + c0 * 32 + ch * 8 : (long)ncol;
                     const bool col_on = lane_on && (GE ? ncol + 32 < d.N : ncol < d.N);
-                    const int nsw = (32 + rps - 1) / rps;
+                    const int nsw = (SR + rps - 1) / rps;
+                    static_assert(NGH <= 4 || SR == 16, "8 sweeps hold a whole strip");
 #pragma unroll
-                    for (int mi = 0; mi < TM; ++mi) {
-                        const int mrow0 = m0 + wm * WM + mi * 32;
+                    for (int mi0 = 0; mi0 < TM * NH; ++mi0) {
+                        const int mi = mi0 / NH, hb = mi0 % NH;         // 32-row block, 16-row half of it (HALF strips)
+                        const int mrow0 = m0 + wm * WM + mi * 32 + hb * SR;
 #pragma unroll
                         for (int t = 0; t < NGH; ++t) {
                             if (t < gw) {
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
+                                    if (NH == 2 && qrq(g) != hb) continue;
                                     f32x4 v = {ACC(c0 + t, mi, g, 0), ACC(c0 + t, mi, g, 1), ACC(c0 + t, mi, g, 2), ACC(c0 + t, mi, g, 3)};
                                     if constexpr (!GE) {
                                         if (silu) {
@@ -1030,7 +1044,7 @@ gemm_f16_kernel(GemmArgs) {
                                         }
                                     }
                                     const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                                    *reinterpret_cast<f16x4*>(sH + qrow(g) * STRH + t * 32 + qcol(g)) = h;
+                                    *reinterpret_cast<f16x4*>(sH + (qrow(g) - hb * SR) * STRH + t * 32 + qcol(g)) = h;
                                 }
                             }
                         }
@@ -1040,7 +1054,7 @@ gemm_f16_kernel(GemmArgs) {
                         u32x4 hv[8];
 #pragma unroll
                         for (int sw = 0; sw < 8; ++sw)
-                            if (sw < nsw) hv[sw] = *reinterpret_cast<const u32x4*>(sH + min(sw * rps + r0, 31) * STRH + ch * 8);
+                            if (sw < nsw) hv[sw] = *reinterpret_cast<const u32x4*>(sH + min(sw * rps + r0, SR - 1) * STRH + ch * 8);
 #pragma unroll
                         for (int sw = 0; sw < 8; ++sw) {
                             if (sw < nsw) {
@@ -1048,7 +1062,7 @@ gemm_f16_kernel(GemmArgs) {
 #ifdef DS_EXP_NOSTORE
                                 asm volatile("" ::"v"(hv[sw]));
 #else
-                                if (col_on && row < 32 && mrow0 + row < d.M) DS_OUT_STORE_H(reinterpret_cast<u32x4*>(out_base + sw * out_step), hv[sw]);
+                                if (col_on && row < SR && mrow0 + row < d.M) DS_OUT_STORE_H(reinterpret_cast<u32x4*>(out_base + sw * out_step), hv[sw]);
 #endif
                             }
                         }
@@ -1059,7 +1073,7 @@ gemm_f16_kernel(GemmArgs) {
                                 for (int sw = 0; sw < 8; ++sw) {
                                     if (sw < nsw) {
                                         const int row = sw * rps + r0;
-                                        const bool on = col_on && row < 32 && mrow0 + row < d.M;
+                                        const bool on = col_on && row < SR && mrow0 + row < d.M;
                                         const f16x8 hh = __builtin_bit_cast(f16x8, hv[sw]);
 #pragma unroll
                                         for (int j = 0; j < 8; ++j) {
@@ -1113,17 +1127,20 @@ gemm_f16_kernel(GemmArgs) {
                     bx[4] = b1[0]; bx[5] = b1[1]; bx[6] = b1[2]; bx[7] = b1[3];
                 }
             }
+            constexpr int SR = Cfg::SROWS, NH = 32 / SR;           // strip rows; strips per 32-row block (HALF: two 16-row strips)
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const int mrow0 = m0 + wm * WM + mi * 32;
+            for (int mi0 = 0; mi0 < TM * NH; ++mi0) {
+                const int mi = mi0 / NH, hb = mi0 % NH;
+                const int mrow0 = m0 + wm * WM + mi * 32 + hb * SR;
                 // accumulators -> strip
 #pragma unroll
                 for (int t = 0; t < NG; ++t) {
                     if (t < gw) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
+                            if (NH == 2 && qrq(g) != hb) continue;
                             f32x4 v = {ACC(c0 + t, mi, g, 0), ACC(c0 + t, mi, g, 1), ACC(c0 + t, mi, g, 2), ACC(c0 + t, mi, g, 3)};
-                            *reinterpret_cast<f32x4*>(sW + qrow(g) * STR + t * 32 + qcol(g)) = v;
+                            *reinterpret_cast<f32x4*>(sW + (qrow(g) - hb * SR) * STR + t * 32 + qcol(g)) = v;
                         }
                     }
                 }
@@ -1134,7 +1151,7 @@ gemm_f16_kernel(GemmArgs) {
                     // the batch, then the arithmetic and the stores -- straight-line code (RES / PIB are compile-time),
                     // so the LDS and memory latencies of a batch overlap instead of adding up per sweep.
                     constexpr int SB = TM * TN > 8 ? 2 : 4;   // 160 accumulator registers leave room for two sweeps
-                    const int nsw = (32 + rps - 1) / rps;
+                    const int nsw = (SR + rps - 1) / rps;
                     const long out_step = (long)rps * d.ldc, res_step = (long)rps * d.ldr;
                     f16* const out_base = reinterpret_cast<f16*>(out) + (long)(mrow0 + r0) * d.ldc + ocol;
                     const f16* const res_base = (RES && !RES32) ? residual + (long)(mrow0 + r0) * d.ldr + ocol : nullptr;
@@ -1149,8 +1166,8 @@ gemm_f16_kernel(GemmArgs) {
 #pragma unroll
                             for (int u = 0; u < SB; ++u) {
                                 const int row = (sb + u) * rps + r0;
-                                ok[u] = col_on && row < 32 && mrow0 + row < d.M;
-                                okb[u] = col_onB && row < 32 && mrow0 + row < d.M;
+                                ok[u] = col_on && row < SR && mrow0 + row < d.M;
+                                okb[u] = col_onB && row < SR && mrow0 + row < d.M;
                                 if constexpr (RES32) {
                                     const float* rp = res32_base + (sb + u) * res_step;
                                     rs0[u] = DS_RES_LOAD(reinterpret_cast<const f32x4*>(ok[u] ? rp : reinterpret_cast<const float*>(residual)));
@@ -1167,7 +1184,7 @@ gemm_f16_kernel(GemmArgs) {
                             }
 #pragma unroll
                             for (int u = 0; u < SB; ++u) {
-                                const int row = min((sb + u) * rps + r0, 31);
+                                const int row = min((sb + u) * rps + r0, SR - 1);
                                 p0[u] = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * (W4 ? 4 : 8));
                                 p1[u] = *reinterpret_cast<const f32x4*>(sW + row * STR + ch * (W4 ? 4 : 8) + dB);
                             }
@@ -1233,7 +1250,7 @@ gemm_f16_kernel(GemmArgs) {
                     }
                 } else {
                     // generic (rare, tiny layers): scalar stores, any N, fp32 or fp16 out; GEGLU not supported here
-                    for (int idx = lane; idx < 32 * gw * 32; idx += 64) {
+                    for (int idx = lane; idx < SR * gw * 32; idx += 64) {
                         const int row = idx / (gw * 32), col = idx - row * (gw * 32);
                         const int m = mrow0 + row, n = n0 + wn * WN + c0 * 32 + col;
                         if (m >= d.M || n >= d.N) continue;

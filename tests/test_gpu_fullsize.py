@@ -615,7 +615,7 @@ def test_ring_loops_real_unet_on_the_50_step_schedule_vs_reference(model, residu
         extra = dict(pano_image_tensor=synth_normal((3, 512, 1024), int(z["pano_img_seed"])).clamp(-1, 1))
     unet = ld.model.diffusion_model
     _set_mode(unet, residual)
-    out = {}
+    out, stats_all = {}, {}
     try:
         for end in ("first", "last"):
             geom = rec["geom"] if model == "t2v" else rec["geoms"][end]
@@ -645,10 +645,11 @@ def test_ring_loops_real_unet_on_the_50_step_schedule_vs_reference(model, residu
             if den is not None:
                 assert torch.equal(den.float().cpu(), snaps[-1][1])
             out[end] = errs
+            stats_all[end] = {str(k): loop_err_stats(snaps[k][0], T(z[f"{end}_pano_{k}"]), trace[k][2]) for k in range(nrec) if f"{end}_pano_{k}" in z.files}
     finally:
         _reset_mode(unet)
     r = dict(test="ring50_real_unet", model=model, residual=residual, first={str(k): v for k, v in out["first"].items()},
-             last={str(k): v for k, v in out["last"].items()})
+             last={str(k): v for k, v in out["last"].items()}, stats=stats_all)
     print(r)
     record(**r)
     for end in ("first", "last"):
@@ -699,7 +700,8 @@ def test_ring_loop_real_unet_mid_schedule_on_the_headline_window_grid_vs_referen
     assert any(w[1] > W for _, _, wins in trace[1:] for w in wins), "no window of the recorded steps crosses the W seam"
     errs = {k: relerr(snaps[k][0], T(z[f"pano_{k}"])) for k in range(nrec) if f"pano_{k}" in z.files}
     errs["x0"] = relerr(snaps[-1][1], T(z[f"x0_{nrec - 1}"]))
-    r = dict(test="ring50_mid_real_unet", residual="outer", errs={str(k): v for k, v in errs.items()})
+    r = dict(test="ring50_mid_real_unet", residual="outer", errs={str(k): v for k, v in errs.items()},
+             stats={str(k): loop_err_stats(snaps[k][0], T(z[f"pano_{k}"]), trace[k][2]) for k in range(nrec) if f"pano_{k}" in z.files})
     print(r)
     record(**r)
     # the LATENT panorama -- what the loop carries forward -- at the north star after every recorded step.  The pred-x0 panorama at
@@ -881,7 +883,7 @@ def test_cfg4_geometry_one_step_with_the_real_i2v_unet_vs_reference():
         out[mode] = snaps[0]
     assert torch.equal(out["bench"][0], out["plain"][0]) and torch.equal(out["bench"][1], out["plain"][1])
     errs = {"0": relerr(out["bench"][0], T(z["pano_0"])), "x0": relerr(out["bench"][1], T(z["x0_0"]))}
-    r = dict(test="cfg4_real_unet_one_step", residual="outer", errs=errs)
+    r = dict(test="cfg4_real_unet_one_step", residual="outer", errs=errs, stats={"0": loop_err_stats(out["bench"][0], T(z["pano_0"]), trace[0][2])})
     print(r)
     record(**r)
     assert errs["0"] < NORTH_STAR, r
@@ -1057,7 +1059,8 @@ def test_i2v_ring_loop_real_unet_mid_schedule_vs_reference():
         assert i == ref["i"] and t == ref["t"] and wins == ref["windows"], (i, t, wins, ref)
     errs = {k: relerr(snaps[k][0], T(z[f"pano_{k}"])) for k in range(nrec) if f"pano_{k}" in z.files}
     errs["x0"] = relerr(snaps[-1][1], T(z[f"x0_{nrec - 1}"]))
-    r = dict(test="i2v_ring50_mid_real_unet", residual="outer", errs={str(k): v for k, v in errs.items()})
+    r = dict(test="i2v_ring50_mid_real_unet", residual="outer", errs={str(k): v for k, v in errs.items()},
+             stats={str(k): loop_err_stats(snaps[k][0], T(z[f"pano_{k}"]), trace[k][2]) for k in range(nrec) if f"pano_{k}" in z.files})
     print(r)
     record(**r)
     assert len(errs) == 4 and all(e < RING50_TOL for k, e in errs.items() if k != "x0"), r      # the latent panorama: north star

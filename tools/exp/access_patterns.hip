@@ -61,6 +61,26 @@ __global__ void __launch_bounds__(512, 1) copy_kernel(const char* __restrict__ x
                 u32x4* p = reinterpret_cast<u32x4*>(o + (long)row * 640 + 256 + ch * 16);
                 if (NT_STORE) __builtin_nontemporal_store(v[16 + s], p); else *p = v[16 + s];
             }
+        } else if (WR == 2) {
+            // the wave's whole width at once: 320-byte pieces, 3.2 rows per wave-instruction (per-wave strips of 16 rows x 160 columns)
+            const int wm = wave >> 1, wn = wave & 1;
+            char* o = y + base + (long)(wm * 64) * 640 + wn * 320;
+#pragma unroll
+            for (int i = 0; i < 20; ++i) {
+                const int f = i * 64 + lane, row = f / 20, ch = f % 20;
+                u32x4* p = reinterpret_cast<u32x4*>(o + (long)row * 640 + ch * 16);
+                if (NT_STORE) __builtin_nontemporal_store(v[i], p); else *p = v[i];
+            }
+        } else if (WR == 3) {
+            // pair-cooperative whole rows: per 16-row block a wave stores 8 full 640-byte rows (5 KB contiguous, 1 KB per instruction)
+            const int wm = wave >> 1, half = wave & 1;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    u32x4* p = reinterpret_cast<u32x4*>(y + base + (long)(wm * 64 + b * 16 + half * 8) * 640 + (i * 64 + lane) * 16);
+                    if (NT_STORE) __builtin_nontemporal_store(v[b * 5 + i], p); else *p = v[b * 5 + i];
+                }
         } else {
 #pragma unroll
             for (int j = 0; j < 20; ++j) {
@@ -103,6 +123,9 @@ int main(int argc, char** argv) {
             const float c = run<1, 0, 1>(x, y, tiles, delay, grid), d = run<1, 1, 1>(x, y, tiles, delay, grid);
             const float e = run<0, 0, 0>(x, y, tiles, delay, grid), f = run<1, 1, 0>(x, y, tiles, delay, grid);
             auto tb = [&](float ms) { return 2.0 * bytes / (ms * 1e-3) / 1e12; };
+            const float g2 = run<0, 2, 1>(x, y, tiles, delay, grid), g3 = run<0, 3, 1>(x, y, tiles, delay, grid);
+            printf("grid %4d delay %5d | rd strided + wr 320-byte wave pieces %.3f ms %.2f TB/s | rd strided + wr pair-cooperative whole rows %.3f ms %.2f TB/s\n",
+                   grid, delay, g2, tb(g2), g3, tb(g3));
             printf("grid %4d delay %5d | rd strided + wr segments %.3f ms %.2f TB/s | strided + contiguous %.3f ms %.2f | contiguous + segments %.3f ms %.2f | "
                    "contiguous + contiguous %.3f ms %.2f | plain stores: strided + segments %.3f ms %.2f, contiguous %.3f ms %.2f\n",
                    grid, delay, a, tb(a), b, tb(b), c, tb(c), d, tb(d), e, tb(e), f, tb(f));
