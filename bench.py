@@ -345,15 +345,19 @@ def main():
         return x
 
     def timed_steps(pp, state, first, warmup, steps, nsched_):
-        """W untimed + K timed steps from step index `first`, bracketed by barrier + synchronize, max over ranks -> (seconds, next index)."""
+        """W untimed + K timed steps from step index `first`, bracketed by barrier + synchronize, max over ranks -> (seconds, next index).
+        A run longer than the schedule wraps around inside [first, nsched_): never back into the leading steps the operand policy gives
+        another rung (they lie in front of `first`)."""
+        span = max(1, nsched_ - first)
+        wrap = lambda k_: first + (k_ - first) % span
         k = first
         for _ in range(warmup):
-            pp.ring_step(state, k % nsched_)
+            pp.ring_step(state, wrap(k))
             k += 1
         barrier()
         t_ = time.perf_counter()
         for _ in range(steps):
-            pp.ring_step(state, k % nsched_)
+            pp.ring_step(state, wrap(k))
             k += 1
         barrier()
         return max_over_ranks(time.perf_counter() - t_), k
@@ -362,10 +366,11 @@ def main():
     phase[0] = "warm-up + timed steps"            # so a run longer than one panorama wraps around before it
     for k in range(lead_steps):                  # the schedule's leading steps, each in the mode the policy gives it (untimed here: timed
         pipe.ring_step(st, k)                    # per rung further down, and inside the complete 50-step panorama)
+    own_step = lambda k_: lead_steps + (k_ - lead_steps) % max(1, nsched - lead_steps)     # a later step index, kept among the own-mode steps
     elapsed, step_idx = timed_steps(pipe, st, lead_steps, args.warmup, args.steps, nsched)
     assert bool(torch.isfinite(st.pano.float()).all()), "non-finite latent after the timed steps"
     if pipe.operand_policy == "auto":         # every warm-up / timed step ran in the model's own mode
-        assert all(pipe.precision_for(NSTEPS_ - 1 - (k % nsched), 7.5) is None for k in range(lead_steps, step_idx)), (lead_steps, step_idx)
+        assert all(pipe.precision_for(NSTEPS_ - 1 - k, 7.5) is None for k in range(lead_steps, min(step_idx, nsched))), (lead_steps, step_idx)
     # what the job computed, so that runs can be compared: the panorama latent after warmup + timed steps is a function of
     # (config, warmup, steps, latents, residual mode) only -- not of --gpus, --tile-batch, --streams or --graph (rank sharding
     # and batching are bit-exact: tests/test_gpu_fullsize.py, test_gpu_multirank.py)
@@ -381,7 +386,7 @@ def main():
     barrier()
     prof = parallel.profile_begin()
     t_ = time.perf_counter()
-    pipe.ring_step(st, step_idx % nsched)
+    pipe.ring_step(st, own_step(step_idx))
     torch.cuda.synchronize()
     t_rank = time.perf_counter() - t_
     parallel.profile_end()
@@ -458,7 +463,7 @@ def main():
         unet.launch_hook = unet_hook
         pipe.num_streams = 1               # per-launch durations are taken with one kernel on the GPU at a time
         pipe.use_graph = False             # ... and launch by launch
-        pipe.ring_step(st, step_idx % nsched)
+        pipe.ring_step(st, own_step(step_idx))
         torch.cuda.synchronize()
         ops.set_timing_hook(None)
         unet.launch_hook = None
