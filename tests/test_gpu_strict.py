@@ -128,3 +128,55 @@ def test_unet_full_size_strict_vs_reference_golden():
     assert s["eps_cond"] < EPS_TOL_STRICT and s["eps_uncond"] < EPS_TOL_STRICT
     assert s["eps_cond"] < 0.8 * out[torch.float16]["eps_cond"]
     assert s["x_prev_25"] < 1e-3
+
+
+def test_strict_twin_equals_a_model_in_the_strict_mode_and_the_policy_calibrates():
+    """Round 6: `UNetModel.twin("strict")` / `forward(..., precision="strict")` -- the operand policy's first rung -- is the strict residual
+    mode over the SAME parameters: bit for bit the eps of a model built in that mode, for a plain batch and for a CFG pair batch; the
+    model's own forward is untouched by the twin's existence.  And the pipelines' calibration (one wide + one own-mode + one strict
+    evaluation pair on the caller's UNet) measures what a direct comparison measures, caches it on the UNet, and orders the modes."""
+    from dynamicscaler_amd.host_model import LatentDiffusionHost, SyntheticConditioner
+    from dynamicscaler_amd.pipelines import VC2_Pipeline_T2V_SpherePano, OPERAND_SAFETY
+    from dynamicscaler_amd.scheduler import lvdm_DDIM_Scheduler
+    from dynamicscaler_amd.unet_spec import param_shapes
+    from dynamicscaler_amd.synth import synth_state_dict, synth_normal
+    d = dev()
+    z = np.load(os.path.join(G, "unet_tiny_t2v.npz"))
+    params = json.loads(bytes(z["params_json"]).decode())
+    own = build_unet(params, 5, d, torch.float32)
+    own.residual_scope = "outer"                       # the library default mode
+    strict = build_unet(params, 5, d, torch.float32)   # scope "full" = strict
+    x = T(z["x_0"]).to(d, torch.float16)
+    t, ctx, fps = T(z["t_0"]).to(d), T(z["ctx_0"]).to(d), int(z["fps_0"])
+    e_own = own(x, t, context=ctx, fps=fps).clone()
+    e_tw = own(x, t, context=ctx, fps=fps, precision="strict")
+    assert torch.equal(e_tw, strict(x, t, context=ctx, fps=fps)) and not torch.equal(e_tw, e_own)
+    assert torch.equal(own(x, t, context=ctx, fps=fps), e_own)            # the own mode is what it was
+    x2, t2, c2 = torch.cat([x, x]), torch.cat([t, t]), torch.cat([ctx, ctx.flip(1)])
+    assert torch.equal(own(x2, t2, context=c2, fps=fps, cfg_pairs=1, precision="strict"), strict(x2, t2, context=c2, fps=fps, cfg_pairs=1))
+    assert torch.equal(strict(x, t, context=ctx, fps=fps, precision="strict"), strict(x, t, context=ctx, fps=fps))   # already strict: itself
+    with pytest.raises(ValueError):
+        own(x, t, context=ctx, fps=fps, precision="bf16")
+    # the pipeline's calibration on this UNet
+    ld = LatentDiffusionHost({"params": params}, conditioner=SyntheticConditioner(77, params["context_dim"]))
+    ld.model.diffusion_model.load_state_dict(synth_state_dict(param_shapes(params), 5), strict=True)
+    ld = ld.to(d)
+    pipe = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="device"), {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+    geom = dict(height=64, width=128, frames=4, total_w=256, total_h=96, num_windows_w=2, num_windows_h=2, num_windows_f=1, loop_step=4)
+    st = pipe.ring_begin(prompt="a prompt", fps=8, guidance_scale=7.5, init_panorama_latent=synth_normal((1, 4, 4, 12, 32), 3).to(d),
+                         num_inference_steps=10, **geom)
+    cal = dict(pipe._calibration)
+    assert set(cal) == {"f32outer", "f32"} and cal["f32outer"][0] == int(st.timesteps[0])
+    assert 0 < cal["f32"][1] < cal["f32outer"][1] < 5e-2, cal             # the strict stream is closer to the wide result than the default one
+    assert abs(pipe.guided_eps_error("f32outer", cal["f32outer"][0]) - cal["f32outer"][1] / OPERAND_SAFETY) < 1e-12
+    rep = pipe.operand_report(10, 7.5)
+    assert rep["guided_eps_err_measured"]["f32outer"]["err"] == cal["f32outer"][1] and rep["guided_eps_err_table"] is None
+    assert not set(rep["strict_steps"]) & set(rep["wide_steps"])
+    # a second pipeline over the same UNet finds the figures on it: no evaluation is repeated
+    u = ld.model.diffusion_model
+    n_cached = len(u._operand_calibration)
+    pipe2 = VC2_Pipeline_T2V_SpherePano(ld, lvdm_DDIM_Scheduler(ld, rng_mode="device"), {"params": {"unet_config": {"params": params}}}).to(d, torch.float32)
+    pipe2.ring_begin(prompt="a prompt", fps=8, guidance_scale=7.5, init_panorama_latent=synth_normal((1, 4, 4, 12, 32), 3).to(d),
+                     num_inference_steps=10, **geom)
+    assert len(u._operand_calibration) == n_cached and pipe2._calibration == cal
+    record(test="operand_calibration_toy", measured={k: v[1] for k, v in cal.items()}, strict_steps=rep["strict_steps"], wide_steps=rep["wide_steps"])
