@@ -596,20 +596,41 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
             assert tuple(init_sphere_latent.shape) == shape, \
                 f"[basic_sample_shift_multi_windows] init_panorama_latent shape {tuple(init_sphere_latent.shape)} does not match desired shape {shape}"
         assert W == 2 * H                                          # RingPanoramaTensor (:12)
+        # the view-map caches, and step 0's maps on their way (worker thread, host tensors) BEFORE the set-up below -- weight repack, the
+        # operand calibration's evaluations -- instead of in front of the first step (round 6: the first step waited 1.6 s for them)
+        Himg, Wimg = image.shape[-2:]
+        cache, img_cache = ViewMapCache(self._execution_device), ViewMapCache(self._execution_device)
+        emb_cache = {}
+
+        def step_views(i):
+            off = (i % loop_step_theta) * (view_fov // loop_step_theta)
+            return [(ph, th + off) for ph in list(phi_theta_dict.keys()) for th in phi_theta_dict[ph]]
+
+        def prefetch_maps(i):
+            """the index maps step i needs (latent views at the tile / get / set sizes, image crops), on the worker thread"""
+            lat, img = [], []
+            for (ph, th) in step_views(i):
+                for g in sorted({1, gsf, ssf}):
+                    lat.append((view_fov, th, ph, lat_w * g, lat_h * g, W, H, False))
+                if (ph, th) not in emb_cache:
+                    img.append((view_fov, th, ph, width, height, Wimg, Himg, True))
+            cache.prefetch(lat)
+            img_cache.prefetch(img)
+
+        if len(timesteps):
+            prefetch_maps(0)
         st = self._new_state(init_sphere_latent, shape, timesteps, frames, fps, lat_h, lat_w, guidance_scale, text_emb,
                              uc_emb, merge_renoised_overlap_latent_ratio, kwargs)
         st.total_steps = total_steps
         device, sched = st.device, self.scheduler
         mask = torch.zeros((total_f, H, W), dtype=torch.uint8, device=device)   # one byte per (frame, pixel)
-        Himg, Wimg = image.shape[-2:]
         assert Wimg == 2 * Himg                                    # PanoramaTensor of the image (:223)
         image5 = image.to(device=device, dtype=torch.float32).reshape(1, 3, 1, Himg, Wimg).contiguous()
         static = None
         if paste_on_static and static_frame_latent is not None:
             static = static_frame_latent.to(device=device, dtype=st.pano.dtype)
             assert tuple(static.shape) == (1, shape[1], 1, H, W)
-        cache, img_cache = ViewMapCache(device), ViewMapCache(device)
-        emb_cache, prompt_cache, conflict_cache, sub_cache = {}, {}, {}, {}
+        prompt_cache, conflict_cache, sub_cache = {}, {}, {}
         P = lat_h * lat_w
 
         def lat_map(ph, th):
@@ -636,21 +657,6 @@ class VC2_Pipeline_I2V_SpherePano(_I2VRingPipe):
                 wa, wb = set_map(ka[0], ka[1]).write_set, set_map(kb[0], kb[1]).write_set
                 r = conflict_cache[(ka, kb)] = bool((wa & (rb | wb)).any() or (ra & wb).any())
             return r
-
-        def step_views(i):
-            off = (i % loop_step_theta) * (view_fov // loop_step_theta)
-            return [(ph, th + off) for ph in list(phi_theta_dict.keys()) for th in phi_theta_dict[ph]]
-
-        def prefetch_maps(i):
-            """the index maps step i needs (latent views at the tile / get / set sizes, image crops), on the worker thread"""
-            lat, img = [], []
-            for (ph, th) in step_views(i):
-                for g in sorted({1, gsf, ssf}):
-                    lat.append((view_fov, th, ph, lat_w * g, lat_h * g, W, H, False))
-                if (ph, th) not in emb_cache:
-                    img.append((view_fov, th, ph, width, height, Wimg, Himg, True))
-            cache.prefetch(lat)
-            img_cache.prefetch(img)
 
         for i in range(len(timesteps)):
             t = timesteps[i]
